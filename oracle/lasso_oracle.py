@@ -1,0 +1,360 @@
+"""CPU oracle for the ISTA/FISTA sparse-encode + dictionary-learning hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``pytorch-lasso_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker / the timed CPU baseline.
+
+This is a *restatement* (not a copy) of the algorithm of rfeinman/pytorch-lasso
+for the path named by BASELINE.json, written from SURVEY.md section 8a.  Every
+function cites the reference file:line whose arithmetic it follows.  The
+arithmetic itself lives in third-party code (PyTorch ATen CPU kernels and
+SciPy/ARPACK; the reference pins no versions -- this container has torch
+2.10.0, scipy 1.15.3), so this restatement issues the *same ATen ops in the same
+order*: with an explicit float ``lr`` it is bitwise identical to the reference
+on CPU, which is how it is pinned (tests/golden/generate_golden.py ran the real
+reference in the build container and stored its outputs; tests/test_oracle.py
+checks this module against those files).  Parity status: PINNED against outputs
+of the reference itself (the reference ships no tests or golden vectors).
+
+Shapes: x [n,d], weight [d,k] (atoms are columns),
+z [n,k]; all row-major.
+"""
+import math
+import warnings
+
+import torch
+
+__all__ = [
+    "soft_threshold", "lipschitz_constant", "momentum_schedule",
+    "backtracking_step", "fista", "initial_code", "sparse_encode",
+    "lasso_objective", "dict_evaluate", "update_dict", "update_dict_gram",
+    "update_dict_ridge", "dict_learning", "FistaTrace",
+]
+
+
+# --------------------------------------------------------------------------
+# elementwise pieces
+# --------------------------------------------------------------------------
+def soft_threshold(v, lam):
+    """S_lam(v): the proximal map of lam*|.|_1.
+
+    The reference calls ``F.softshrink`` (ista.py:40,52,90), whose ATen CPU
+    kernel is ``v-lam if v>lam; v+lam if v<-lam; else 0``.  We call the same
+    ATen op so that rounding is identical.
+    """
+    return torch.nn.functional.softshrink(v, lam)
+
+
+def momentum_schedule(n_iter):
+    """Nesterov coefficients (t_i - 1)/t_{i+1}, t_0 = 1, as python floats.
+
+    Follows ista.py:78 (t starts at the int 1) and ista.py:98-101
+    (t_next = (1+sqrt(1+4t^2))/2).  The schedule does not depend on the data,
+    which is what lets the HIP engine precompute it on the host.
+    """
+    coeffs, t = [], 1
+    for _ in range(n_iter):
+        t_next = (1 + math.sqrt(1 + 4 * t ** 2)) / 2
+        coeffs.append((t - 1) / t_next)
+        t = t_next
+    return coeffs
+
+
+# --------------------------------------------------------------------------
+# Lipschitz constant  (ista.py:8-14)
+# --------------------------------------------------------------------------
+def lipschitz_constant(weight, method="arpack"):
+    """lambda_max(W^T W), the Lipschitz constant of the RSS gradient.
+
+    method='arpack' follows ista.py:8-14 exactly: fp32 Gram [k,k] on the
+    tensor's device, copied to host, ARPACK ``eigsh(k=1, which='LM')``.  That
+    path is not run-to-run reproducible (~1e-6 relative jitter, SURVEY.md
+    section 0).  method='exact' is the deterministic fp64 value (eigvalsh of
+    the smaller of W W^T / W^T W) used as ground truth for the device-side
+    estimator.
+    """
+    if method == "arpack":
+        from scipy.sparse.linalg import eigsh
+        gram = torch.matmul(weight.t(), weight)
+        return eigsh(gram.detach().cpu().numpy(), k=1, which="LM",
+                     return_eigenvectors=False).item()
+    if method == "exact":
+        w = weight.detach().to("cpu", torch.float64)
+        gram = w @ w.t() if w.shape[0] <= w.shape[1] else w.t() @ w
+        return torch.linalg.eigvalsh(gram)[-1].item()
+    raise ValueError("unknown method %r" % (method,))
+
+
+# --------------------------------------------------------------------------
+# backtracking line search  (ista.py:17-54)
+# --------------------------------------------------------------------------
+def backtracking_step(p, x, weight, alpha, lr0, eta=1.5, max_trials=1000,
+                      trace=None):
+    """One Beck-Teboulle backtracking proximal step from the point ``p``.
+
+    Follows ista.py:17-54.  All sums run over the WHOLE batch, i.e. one step
+    size is chosen for all samples (ista.py:23,28,33-35).  Returns
+    ``(z_next, lr_accepted)``.  On failure after ``max_trials`` trials it
+    warns and reverts to lr0 (ista.py:48-52).
+    """
+    if eta <= 1:
+        raise ValueError("eta must be > 1.")                      # ista.py:18-19
+
+    resid0 = torch.matmul(p, weight.T) - x                        # ista.py:22
+    f0 = 0.5 * resid0.pow(2).sum()                                # ista.py:23
+    g0 = torch.matmul(resid0, weight)                             # ista.py:24
+
+    lr, trials, accepted = lr0, 0, False
+    z_next = None
+    while trials < max_trials:
+        z_next = soft_threshold(p - lr * g0, alpha * lr)          # ista.py:40
+        resid1 = torch.matmul(z_next, weight.T) - x               # ista.py:27
+        l1 = z_next.abs().sum()
+        big_f = 0.5 * resid1.pow(2).sum() + alpha * l1            # ista.py:28
+        dz = z_next - p                                           # ista.py:31
+        big_q = (f0 + (dz * g0).sum()                             # ista.py:32-35
+                 + (0.5 / lr) * dz.pow(2).sum()
+                 + alpha * z_next.abs().sum())
+        trials += 1
+        if big_f <= big_q:                                        # ista.py:45
+            accepted = True
+            break
+        lr = lr / eta                                             # ista.py:47
+    if not accepted:
+        warnings.warn("backtracking line search failed. Reverting to initial "
+                      "step size")                                # ista.py:49-50
+        lr = lr0
+        z_next = soft_threshold(p - lr * g0, alpha * lr)          # ista.py:51-52
+    if trace is not None:
+        trace.trials.append(trials)
+        trace.accepted_lr.append(lr)
+    return z_next, lr
+
+
+class FistaTrace:
+    """Optional per-iteration record (not in the reference; test aid)."""
+
+    def __init__(self):
+        self.objective = []      # mean objective of z BEFORE each iteration
+        self.delta = []          # sum|z - z_next| of each iteration
+        self.trials = []         # line-search trials per iteration
+        self.accepted_lr = []
+        self.iterations = 0
+        self.stopped = False
+
+
+# --------------------------------------------------------------------------
+# ISTA / FISTA  (ista.py:57-104)
+# --------------------------------------------------------------------------
+def fista(x, z0, weight, alpha=1.0, fast=True, lr="auto", maxiter=10,
+          tol=1e-5, backtrack=False, eta_backtrack=1.5, trace=None):
+    """min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 by (accelerated) proximal
+    gradient.  Follows ista.py:57-104 (same defaults, same op order).
+
+    * lr='auto' -> 1/lipschitz_constant(weight)               (ista.py:59-63)
+    * absolute stop budget = z0.numel()*tol                    (ista.py:64)
+    * the stop test compares z (not y) with z_next and runs BEFORE the
+      momentum update; on stop the returned code is z_next     (ista.py:93-95)
+    * with backtracking the accepted step size is discarded, every outer
+      iteration restarts from lr                               (ista.py:87)
+    * maxiter=0 returns z0 itself                              (ista.py:76,104)
+    """
+    if lr == "auto":
+        lr = 1 / lipschitz_constant(weight)
+    budget = z0.numel() * tol
+
+    def mean_objective(zk):                                       # ista.py:66-69
+        resid = torch.matmul(zk, weight.T) - x
+        return (0.5 * resid.pow(2).sum() + alpha * zk.abs().sum()) / x.size(0)
+
+    z = z0
+    y, t = z0, 1                                                  # ista.py:76-78
+    for _ in range(maxiter):
+        if trace is not None:
+            trace.objective.append(float(mean_objective(z)))
+        p = y if fast else z                                      # ista.py:84
+        if backtrack:
+            z_next, _ = backtracking_step(p, x, weight, alpha, lr,
+                                          eta_backtrack, trace=trace)
+        else:
+            resid = torch.matmul(p, weight.T) - x                 # ista.py:72
+            grad = torch.matmul(resid, weight)                    # ista.py:73
+            z_next = soft_threshold(p - lr * grad, alpha * lr)    # ista.py:90
+        delta = (z - z_next).abs().sum()                          # ista.py:93
+        if trace is not None:
+            trace.delta.append(float(delta))
+            trace.iterations += 1
+        if delta <= budget:
+            z = z_next
+            if trace is not None:
+                trace.stopped = True
+            break
+        if fast:                                                  # ista.py:98-101
+            t_next = (1 + math.sqrt(1 + 4 * t ** 2)) / 2
+            y = z_next + ((t - 1) / t_next) * (z_next - z)
+            t = t_next
+        z = z_next                                                # ista.py:102
+    return z
+
+
+# --------------------------------------------------------------------------
+# sparse_encode boundary  (sparse_encode.py:8-51, 62-63)
+# --------------------------------------------------------------------------
+_DEFAULT_INIT = {"ista": "zero"}                                  # sparse_encode.py:8-16
+
+
+def initial_code(x, weight, alpha, mode):
+    """z0 initialisation, sparse_encode.py:19-35.  Modes on the hot path:
+    'zero' (:22-23), plus the GEMM-only modes 'transpose' (:30-31) and 'unif'
+    (:24-25).  'lstsq'/'ridge' (:26-29) depend on lasso/linear/utils.py and
+    are outside the hot path."""
+    n, k = x.size(0), weight.size(1)
+    if mode == "zero":
+        return x.new_zeros(n, k)
+    if mode == "unif":
+        return x.new(n, k).uniform_(-0.1, 0.1)
+    if mode == "transpose":
+        return torch.matmul(x, weight)
+    if mode in ("lstsq", "ridge"):
+        raise NotImplementedError("init=%r is outside the hot path" % mode)
+    raise ValueError("invalid init parameter '{}'.".format(mode))  # :33
+
+
+def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm="ista", init=None,
+                  **kwargs):
+    """sparse_encode.py:38-73 restricted to the 'ista' arm (:62-63)."""
+    n, k = x.size(0), weight.size(1)
+    if z0 is not None:
+        assert z0.shape == (n, k)                                 # :44-45
+    else:
+        if init is None:
+            init = _DEFAULT_INIT.get(algorithm, "zero")           # :47-48
+        z0 = initial_code(x, weight, alpha, init)                 # :51
+    if algorithm == "ista":
+        return fista(x, z0, weight, alpha, **kwargs)              # :62-63
+    if algorithm in ("cd", "gpsr", "iter-ridge", "interior-point",
+                     "split-bregman", "own"):
+        raise NotImplementedError("algorithm=%r is outside the hot path"
+                                  % algorithm)
+    raise ValueError("invalid algorithm parameter '{}'.".format(algorithm))  # :71
+
+
+# --------------------------------------------------------------------------
+# objective + M-steps + EM driver  (dict_learning.py)
+# --------------------------------------------------------------------------
+def lasso_objective(X, Z, weight, alpha=1.0):
+    """(0.5*||X - Z W^T||^2 + alpha*||Z||_1)/n, dict_learning.py:10-13."""
+    recon = torch.matmul(Z, weight.T)
+    return (0.5 * (X - recon).pow(2).sum() + alpha * Z.abs().sum()) / X.size(0)
+
+
+def dict_evaluate(X, weight, alpha, **kwargs):
+    """dict_learning.py:16-20."""
+    X = X.to(weight.device)
+    Z = sparse_encode(X, weight, alpha, **kwargs)
+    return lasso_objective(X, Z, weight, alpha)
+
+
+def update_dict(dictionary, X, Z, random_seed=None, positive=False, eps=1e-10):
+    """Constrained M-step: Gauss-Seidel sweep over atoms with unit-norm
+    projection, dict_learning.py:56-103.  Mutates ``dictionary`` AND ``Z`` in
+    place (:86,98) and returns ``dictionary`` (:103)."""
+    k = dictionary.size(1)
+    if random_seed is not None:
+        torch.manual_seed(random_seed)                            # :78-79
+    resid = X - torch.matmul(Z, dictionary.T)                     # :82
+    for j in range(k):
+        code_j = Z[:, j]
+        resid += torch.outer(code_j, dictionary[:, j])            # :85
+        dictionary[:, j] = torch.matmul(code_j, resid)            # :86
+        if positive:
+            dictionary[:, j].clamp_(0, None)                      # :87-88
+        nrm = dictionary[:, j].norm()                             # :91
+        if nrm < eps:                                             # :92
+            dictionary[:, j].normal_()                            # :93
+            if positive:
+                dictionary[:, j].clamp_(0, None)
+            dictionary[:, j] /= dictionary[:, j].norm()           # :96
+            Z[:, j].zero_()                                       # :98
+        else:
+            dictionary[:, j] /= nrm                               # :100
+            resid -= torch.outer(code_j, dictionary[:, j])        # :101
+    return dictionary
+
+
+def update_dict_gram(dictionary, gram_zz, gram_zx, positive=False, eps=1e-10,
+                     fresh_atom=None):
+    """The same sweep in Gram form: with
+    A = Z^T Z [k,k] and B = Z^T X [k,d],
+        u_j = B_j - A_j . D^T + A_jj d_j      (using the CURRENT D),
+    which equals ``Z[:,j] @ R`` of dict_learning.py:85-86 because
+    R = X - Z D^T at every point of the sweep.  This is the form the HIP
+    M-step implements (it needs one all-reduce of A,B instead of passes over
+    the row-sharded residual).  Returns (dictionary, degenerate_mask); the
+    caller zeroes Z[:, j] for degenerate atoms (dict_learning.py:98).
+    ``fresh_atom(j) -> [d]`` supplies the replacement direction for a
+    degenerate atom (the reference draws it from torch's global RNG, :93).
+    A/B are modified in place the way zeroing Z[:,j] would modify them."""
+    k = dictionary.size(1)
+    degenerate = torch.zeros(k, dtype=torch.bool)
+    for j in range(k):
+        d_j = dictionary[:, j]
+        u = gram_zx[j] - torch.mv(dictionary, gram_zz[j]) + gram_zz[j, j] * d_j
+        if positive:
+            u = u.clamp(0, None)
+        nrm = u.norm()
+        if nrm < eps:
+            u = fresh_atom(j) if fresh_atom is not None else torch.randn_like(u)
+            if positive:
+                u = u.clamp(0, None)
+            dictionary[:, j] = u / u.norm()
+            gram_zz[j, :] = 0
+            gram_zz[:, j] = 0
+            gram_zx[j, :] = 0
+            degenerate[j] = True
+        else:
+            dictionary[:, j] = u / nrm
+    return dictionary, degenerate
+
+
+def update_dict_ridge(x, z, lambd=1e-4):
+    """Unconstrained M-step V = ((Z^T Z + lambd*n*I)^-1 Z^T X)^T via Cholesky,
+    dict_learning.py:106-123."""
+    rhs = torch.mm(z.T, x)                                        # :117
+    gram = torch.mm(z.T, z)                                       # :118
+    gram.diagonal().add_(lambd * x.size(0))                       # :119
+    chol = torch.linalg.cholesky(gram)                            # :120
+    return torch.cholesky_solve(rhs, chol).T                      # :121
+
+
+def dict_learning(X, n_components, alpha=1.0, constrained=True, persist=False,
+                  lambd=1e-2, steps=60, device="cpu", progbar=False,
+                  init_weight=None, **solver_kwargs):
+    """EM dictionary learning, dict_learning.py:23-53.
+
+    Same order of operations: orthogonal init (+ column normalisation when
+    constrained) :28-31; per step E-step :38, objective BEFORE the M-step :39,
+    optional warm start that aliases Z :40-41, then the M-step :44-47.
+    ``init_weight`` (extension, for parity runs) replaces the RNG-dependent
+    initial dictionary.  The tqdm bar of :35,50-51 is omitted."""
+    n, d = X.shape
+    X = X.to(device)
+    if init_weight is None:
+        weight = torch.empty(d, n_components, device=device)      # :28
+        torch.nn.init.orthogonal_(weight)                         # :29
+        if constrained:
+            weight = torch.nn.functional.normalize(weight, dim=0)  # :30-31
+    else:
+        weight = init_weight.clone().to(device)
+    Z0 = None
+    losses = torch.zeros(steps, device=device)                    # :34
+    for i in range(steps):
+        Z = sparse_encode(X, weight, alpha, Z0, **solver_kwargs)  # :38
+        losses[i] = lasso_objective(X, Z, weight, alpha)          # :39
+        if persist:
+            Z0 = Z                                                # :40-41
+        if constrained:
+            weight = update_dict(weight, X, Z)                    # :44-45
+        else:
+            weight = update_dict_ridge(X, Z, lambd=lambd)         # :46-47
+    return weight, losses
