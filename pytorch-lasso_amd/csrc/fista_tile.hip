@@ -1,0 +1,379 @@
+// Fused persistent FISTA/ISTA kernel for gfx950 (MI355X), fp32.
+//
+// Replaces the hot loop of lasso/linear/solvers/ista.py:79-102 (fixed step):
+//     r      = p W^T - x                      (ista.py:72)   GEMM-1  [16 x K] x [K x D]
+//     g      = r W                            (ista.py:73)   GEMM-2  [16 x D] x [D x K]
+//     z_next = softshrink(p - lr*g, alpha*lr) (ista.py:90)
+//     delta  = sum |z - z_next|               (ista.py:93)   -> per-tile partial
+//     y      = z_next + c_i (z_next - z)      (ista.py:98-100)
+// One workgroup (8 waves) owns a 16-row tile of the batch and runs ALL
+// requested iterations for it without touching HBM for state:
+//   * y tile   [16][K]  fp32 lives in LDS (A operand of GEMM-1, XOR-swizzled)
+//   * z tile            lives in VGPRs in MFMA C-layout (K/32 regs per lane)
+//   * r tile   [16][D]  is exchanged through LDS once per iteration
+//   * W / W^T are streamed from L2 by LDS-DMA (global_load_lds_dwordx4) into a
+//     private 2-slot ring per wave -> no workgroup barrier in the GEMM loops,
+//     two s_barrier per iteration (r exchange, y complete).
+// Both GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).
+//
+// MFMA operand mapping used throughout (lane l, n=l&15, q=l>>4):
+//   one ds_read_b128 gives 4 consecutive K-values {4q..4q+3} of a 16-wide
+//   K-group; MFMA number j of the group consumes element j, i.e. it contracts
+//   over k = kbase + 4q + j, q=0..3.  A and B use the same convention, so the
+//   sum over j,q covers the 16 K-values exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+#include "lasso_kernels.h"
+
+namespace lasso {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using lds_void_ptr = __attribute__((address_space(3))) void*;
+using lds_char = __attribute__((address_space(3))) char;
+using lds_f32 = __attribute__((address_space(3))) float;
+using lds_f32x4 = __attribute__((address_space(3))) f32x4;
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
+#define LASSO_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#define LASSO_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+
+namespace {
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr int kStepBytes = 4096;               // 32 rows x 128 B
+constexpr int kRingBytesPerWave = 2 * kStepBytes;
+
+// byte offset of element (row, col) inside a swizzled [16][LD] fp32 LDS tile:
+// 16-byte chunk index is XORed with the row in its low 4 bits.
+template <int LD>
+__device__ __forceinline__ int tile_off(int row, int col) {
+  const int chunk = col >> 2;
+  return row * (LD * 4) + ((chunk ^ row) << 4) + ((col & 3) << 2);
+}
+
+// One ring step = 4 LDS-DMA instructions (1 KiB each, lane-linear in LDS), issued
+// from inline asm so the address form is exactly  saddr(SGPR pair) + voffset(VGPR,
+// unsigned bytes) + imm  and nothing 64-bit is precomputed per step.  hipcc does not
+// count these in its own s_waitcnt bookkeeping; every consumer below waits with an
+// explicit counted vmcnt (DMA returns in issue order).  M0 (the LDS destination) is
+// saved/restored inside the statement.
+template <int IMM>
+__device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff)[4],
+                                         lds_char* slot) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)slot;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %5 offset:%c7\n\t"
+      "s_add_u32 m0, %6, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5 offset:%c7\n\t"
+      "s_add_u32 m0, %6, 0x800\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %5 offset:%c7\n\t"
+      "s_add_u32 m0, %6, 0xc00\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, %5 offset:%c7\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(src), "s"(lds_addr), "i"(IMM)
+      : "memory", "scc");
+}
+
+__device__ __forceinline__ float soft_threshold(float v, float lam) {
+  // ATen softshrink: v>lam ? v-lam : (v<-lam ? v+lam : 0)
+  return v > lam ? v - lam : (v < -lam ? v + lam : 0.0f);
+}
+
+}  // namespace
+
+template <int K>
+__global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const FistaTileParams p) {
+  constexpr int D = kFistaD;
+  constexpr int NW = kFistaWaves;
+  constexpr int S1 = K / 32;        // GEMM-1 steps (32 k-values each)
+  constexpr int KW = K / NW;        // GEMM-2 output columns per wave
+  constexpr int NP = KW / 32;       // GEMM-2 passes (2 col-blocks each)
+  constexpr int T2 = D / 32;        // GEMM-2 steps per pass
+  constexpr int YT_BYTES = kTileM * K * 4;
+  constexpr int RT_BYTES = kTileM * D * 4;
+  static_assert(D == 32 * NW, "each wave owns two GEMM-1 column blocks");
+  static_assert(S1 % 2 == 0 && (NP * T2) % 2 == 0, "ring parity");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const yt = (lds_char*)smem;
+  lds_char* const rt = yt + YT_BYTES;
+  lds_char* const rings = yt + YT_BYTES + RT_BYTES;
+  lds_f32* const red = (lds_f32*)(rings + NW * kRingBytesPerWave);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15;
+  const int q = lane >> 4;
+  lds_char* const ring = rings + wid * kRingBytesPerWave;
+
+  // ---- per-lane DMA source offsets (floats).  DMA instruction j writes LDS
+  // bytes [j*1024, j*1024+1024) lane-linearly = rows 8j..8j+7 of the step tile,
+  // 8 lanes per 128-B row; the XOR swizzle is applied on the SOURCE chunk.
+  unsigned voff1[4], voff2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voff1[j] = (unsigned)(row * K + 4 * c) * 4u;
+    voff2[j] = (unsigned)(row * D + 4 * c) * 4u;
+  }
+  const float* const w1 = p.Wp + (size_t)(32 * wid) * K;    // rows of W   [D][K]
+  const float* const w2 = p.Wtp + (size_t)(KW * wid) * D;   // rows of W^T [K][D]
+
+  // fragment read offsets inside a ring slot (B operand) ...
+  int boff[2];
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) boff[ss] = n * 128 + (((4 * ss + q) ^ ((n >> 1) & 7)) << 4);
+  // ... and inside the y / r tiles (A operand): chunk = 8*s + 4*ss + q
+  int aoff[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) aoff[par][ss] = ((8 * par + 4 * ss + q) ^ n) << 4;
+
+  // prologue: first two W steps of GEMM-1 are always in flight on entry
+  dma_step<0>(w1, voff1, ring);
+  dma_step<128>(w1, voff1, ring + kStepBytes);
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+
+    // ---- load state -------------------------------------------------------
+    // y tile -> LDS (swizzled).  y_in == nullptr means y = z_in; z_in == nullptr means 0.
+    {
+      const float* ysrc = p.y_in ? p.y_in : p.z_in;
+      const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
+      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+        const int r = idx / K, c = idx - r * K;
+        float v = 0.0f;
+        if (ysrc && (row0 + r) < p.n && c < p.k) v = ysrc[(int64_t)(row0 + r) * ldy + c];
+        *(lds_f32*)(yt + tile_off<K>(r, c)) = v;
+      }
+    }
+    // z in C-layout registers: zreg[pass][cb][reg] <-> row 4q+reg, col wid*KW+32*pass+16*cb+n
+    f32x4 zreg[NP][2];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 4 * q + rg, c = wid * KW + 32 * ps + 16 * cb + n;
+          float v = 0.0f;
+          if (p.z_in && (row0 + r) < p.n && c < p.k)
+            v = (p.z_in + (int64_t)row0 * p.ldz_in)[r * (int)p.ldz_in + c];
+          zreg[ps][cb][rg] = v;
+        }
+    // -x in the C layout of GEMM-1's output (cols 32*wid + 16*cb + n)
+    f32x4 xneg[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, c = 32 * wid + 16 * cb + n;
+        float v = 0.0f;
+        if ((row0 + r) < p.n && c < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + c];
+        xneg[cb][rg] = -v;
+      }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+
+    for (int it = 0; it < p.iters; ++it) {
+      const float coef = p.coef[it];
+      float dsum = 0.0f;
+      // opaque copies of the lane coordinates: keeps the (cheap) epilogue address
+      // arithmetic inside the iteration instead of 32 hoisted-and-spilled addresses
+      int no = n, qo = q;
+      asm volatile("" : "+v"(no), "+v"(qo));
+
+      // ================= GEMM-1: r = y W^T - x ==========================
+      f32x4 acc[2] = {xneg[0], xneg[1]};
+      // one step: wait for its ring slot, pull fragments, refill the slot two steps
+      // ahead, 16 MFMAs.  `pf_src`/`pf_voff`: where the refill comes from.
+      auto gemm1_step = [&](int s2, auto par_c, const float* pf_src, const unsigned (&pf_voff)[4]) {
+        constexpr int par = decltype(par_c)::value;
+        lds_char* const slot = ring + par * kStepBytes;
+        LASSO_WAIT_VMCNT(4);  // this step's 4 DMA pieces have landed
+        f32x4 b[2][2], a[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss)
+            b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + boff[ss]);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+          a[ss] = *(const lds_f32x4*)(yt + n * (K * 4) + s2 * 256 + aoff[par][ss]);
+        LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
+        dma_step<0>(pf_src, pf_voff, slot);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[0][ss][j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[1][ss][j], acc[1], 0, 0, 0);
+          }
+      };
+      using P0 = std::integral_constant<int, 0>;
+      using P1 = std::integral_constant<int, 1>;
+#pragma unroll 1
+      for (int s2 = 0; s2 < S1 / 2 - 1; ++s2) {
+        gemm1_step(s2, P0{}, w1 + 64 * s2 + 64, voff1);
+        gemm1_step(s2, P1{}, w1 + 64 * s2 + 96, voff1);
+      }
+      // last two steps refill the ring with GEMM-2's first two steps (W^T stream)
+      gemm1_step(S1 / 2 - 1, P0{}, w2, voff2);
+      gemm1_step(S1 / 2 - 1, P1{}, w2 + 32, voff2);
+      // r tile -> LDS (C layout -> swizzled row-major), then everyone reads all of it
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      f32x4 rf[T2][2];
+#pragma unroll
+      for (int t = 0; t < T2; ++t)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+          rf[t][ss] = *(const lds_f32x4*)(rt + n * (D * 4) + (t >> 1) * 256 + aoff[t & 1][ss]);
+
+      // ================= GEMM-2 + prox/momentum epilogue ================
+      static_for<NP>([&](auto ps_c) {
+        constexpr int ps = decltype(ps_c)::value;
+        f32x4 g2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        static_for<T2>([&](auto t_c) {
+          constexpr int t = decltype(t_c)::value;
+          constexpr int U = ps * T2 + t;            // step index inside GEMM-2
+          lds_char* const slot = ring + (U & 1) * kStepBytes;
+          LASSO_WAIT_VMCNT(4);
+          f32x4 b[2][2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+              b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + boff[ss]);
+          LASSO_WAIT_LGKM0();
+          if constexpr (U + 2 < NP * T2) {
+            constexpr int pn = (U + 2) / T2, tn = (U + 2) % T2;
+            dma_step<tn * 128>(w2 + (size_t)(32 * pn) * D, voff2, slot);
+          } else {
+            dma_step<(U + 2 - NP * T2) * 128>(w1, voff1, slot);   // next iteration's GEMM-1
+          }
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              g2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[0][ss][j], g2[0], 0, 0, 0);
+              g2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[1][ss][j], g2[1], 0, 0, 0);
+            }
+        });
+        // epilogue for the 2 finished column blocks (in-place y update is safe:
+        // GEMM-1 of this iteration is complete for every wave)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            lds_f32* const yp = (lds_f32*)(
+                yt + tile_off<K>(4 * qo + rg, wid * KW + 32 * ps + 16 * cb + no));
+            const float yv = *yp;
+            const float zo = zreg[ps][cb][rg];
+            const float step = __fmul_rn(p.lr, g2[cb][rg]);           // lr * grad
+            const float zn = soft_threshold(__fsub_rn(yv, step), p.lam);
+            dsum += __builtin_fabsf(__fsub_rn(zo, zn));                // |z - z_next|
+            const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));      // c (z_next - z)
+            *yp = __fadd_rn(zn, mom);
+            zreg[ps][cb][rg] = zn;
+          }
+      });
+
+      // ---- per-tile sum |z - z_next| (deterministic order) ---------------
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+      if (lane == 0) red[wid] = dsum;
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete
+      if (p.partials && tid == 0) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += red[w];
+        p.partials[(int64_t)it * p.ntiles + tile] = tsum;
+      }
+    }
+
+    // ---- store state --------------------------------------------------------
+    {
+      int no = n, qo = q;
+      asm volatile("" : "+v"(no), "+v"(qo));
+      float* const zo_base = p.z_out + (int64_t)row0 * p.ldz_out;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 4 * qo + rg, c = wid * KW + 32 * ps + 16 * cb + no;
+            if ((row0 + r) < p.n && c < p.k) zo_base[r * (int)p.ldz_out + c] = zreg[ps][cb][rg];
+          }
+    }
+    if (p.y_out) {
+      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+        const int r = idx / K, c = idx - r * K;
+        if ((row0 + r) < p.n && c < p.k)
+          p.y_out[(int64_t)(row0 + r) * p.ldy_out + c] = *(const lds_f32*)(yt + tile_off<K>(r, c));
+      }
+    }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();   // tile LDS may be overwritten by the next tile
+  }
+  LASSO_WAIT_VMCNT(0);  // drain the prefetched DMA before the LDS is released
+}
+
+size_t fista_tile_lds_bytes(int K) {
+  return (size_t)kTileM * K * 4 + (size_t)kTileM * kFistaD * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
+}
+
+template <int K>
+static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
+  const size_t lds = fista_tile_lds_bytes(K);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fista_tile_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream) {
+  switch (kpad) {
+    case 256: return launch_k<256>(p, grid, stream);
+    case 512: return launch_k<512>(p, grid, stream);
+    case 1024: return launch_k<1024>(p, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace lasso

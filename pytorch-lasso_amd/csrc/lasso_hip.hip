@@ -1,0 +1,380 @@
+// C-ABI layer of the MI355X FISTA engine (include/lasso_hip.h) plus the small
+// support kernels (W packing, momentum table, per-iteration delta reduction).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/lasso_hip.h"
+#include "lasso_kernels.h"
+
+namespace lasso {
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+#define LASSO_HIP_TRY(expr)                                                         \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess)                                                           \
+      return fail(LASSO_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+int pad_k(int64_t k) {
+  if (k <= 256) return 256;
+  if (k <= 512) return 512;
+  if (k <= 1024) return 1024;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------
+constexpr int kChunkMax = 64;     // iterations per launch when deltas are recorded
+
+struct Workspace {
+  float* wp;        // [256][Kp]
+  float* wtp;       // [Kp][256]
+  float* coef;      // [coef_cap]  FISTA momentum coefficients
+  float* zeros;     // [coef_cap]  ISTA "coefficients"
+  float* partials;  // [kChunkMax][ntiles]
+  float* delta;     // [kChunkMax]
+  float* state[4];  // zA, yA, zB, yB  [n][k]   (stop rule only)
+  size_t bytes;
+};
+
+Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool with_state) {
+  Workspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes);
+    return reinterpret_cast<float*>(r);
+  };
+  const int64_t ntiles = (n + kTileM - 1) / kTileM;
+  w.wp = take((size_t)kFistaD * kp * 4);
+  w.wtp = take((size_t)kp * kFistaD * 4);
+  w.coef = take((size_t)std::max(coef_cap, 1) * 4);
+  w.zeros = take((size_t)std::max(coef_cap, 1) * 4);
+  w.partials = take((size_t)kChunkMax * ntiles * 4);
+  w.delta = take((size_t)kChunkMax * 4);
+  for (int i = 0; i < 4; ++i) w.state[i] = with_state ? take((size_t)n * k * 4) : nullptr;
+  w.bytes = off;
+  return w;
+}
+
+// ---------------------------------------------------------------------------
+// support kernels
+// ---------------------------------------------------------------------------
+// Wp[r][c] = W[r][c] (zero padded to [256][Kp]); Wtp[c][r] = W[r][c].
+__global__ void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int d, int k, int kp,
+                              float* __restrict__ wp, float* __restrict__ wtp) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < d && c < k) ? W[(int64_t)r * ldw + c] : 0.0f;
+    tile[i][tx] = v;
+    wp[(size_t)r * kp + c] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    wtp[(size_t)c * kFistaD + r] = tile[tx][i];
+  }
+}
+
+// Momentum table (ista.py:78,98-100): t_0 = 1, t_{i+1} = (1+sqrt(1+4 t_i^2))/2,
+// coef_i = (float)((t_i - 1)/t_{i+1}).  Evaluated in IEEE double without
+// contraction so it reproduces the reference's python-float arithmetic.
+__global__ void momentum_table_kernel(float* __restrict__ coef, float* __restrict__ zeros, int count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t = 1.0;
+  for (int i = 0; i < count; ++i) {
+    const double tt = __dmul_rn(t, t);
+    const double s = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(4.0, tt)));
+    const double tn = __ddiv_rn(__dadd_rn(1.0, s), 2.0);
+    coef[i] = (float)__ddiv_rn(__dsub_rn(t, 1.0), tn);
+    zeros[i] = 0.0f;
+    t = tn;
+  }
+}
+
+// delta[i] = sum_t partials[i][t], fixed summation order (deterministic).
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles,
+                                       float* __restrict__ delta) {
+  __shared__ float sh[256];
+  const float* row = partials + (size_t)blockIdx.x * ntiles;
+  float acc = 0.0f;
+  for (int t = threadIdx.x; t < ntiles; t += 256) acc += row[t];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) delta[blockIdx.x] = sh[0];
+}
+
+int device_cus() {
+  static int cached = -1;
+  if (cached > 0) return cached;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  cached = prop.multiProcessorCount;
+  return cached;
+}
+
+int check_common(int64_t n, int64_t d, int64_t k, int dtype) {
+  if (dtype != LASSO_F32)
+    return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
+  if (n < 0 || d <= 0 || k <= 0) return fail(LASSO_ERR_BAD_ARG, "bad shape n=%lld d=%lld k=%lld",
+                                              (long long)n, (long long)d, (long long)k);
+  if (d > kFistaD || k > kFistaMaxK)
+    return fail(LASSO_ERR_UNSUPPORTED,
+                "shape d=%lld k=%lld exceeds the fused kernel (d<=%d, k<=%d)", (long long)d,
+                (long long)k, kFistaD, kFistaMaxK);
+  if (n > (int64_t)INT32_MAX - kTileM) return fail(LASSO_ERR_UNSUPPORTED, "n too large");
+  return LASSO_OK;
+}
+
+int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
+             int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
+             float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
+             int fast, int it0, int iters, float* delta, hipStream_t stream) {
+  if (n == 0) return LASSO_OK;
+  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  FistaTileParams p;
+  p.X = x; p.ldx = ldx;
+  p.Wp = ws.wp; p.Wtp = ws.wtp;
+  p.z_in = z_in; p.ldz_in = ldz_in;
+  p.y_in = y_in; p.ldy_in = ldy_in;
+  p.z_out = z_out; p.ldz_out = ldz_out;
+  p.y_out = y_out; p.ldy_out = ldy_out;
+  p.coef = (fast ? ws.coef : ws.zeros) + it0;
+  p.partials = delta ? ws.partials : nullptr;
+  p.n = (int)n; p.d = (int)d; p.k = (int)k;
+  p.ntiles = ntiles; p.iters = iters;
+  p.lr = (float)lr;                 // ATen casts the python scalar to the tensor dtype
+  p.lam = (float)(alpha * lr);      // softshrink(lambd = alpha*lr), product in double (ista.py:90)
+  const int cus = device_cus();
+  if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
+  const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
+  LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream));
+  if (delta && iters > 0) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
+                       ntiles, delta);
+    LASSO_HIP_TRY(hipGetLastError());
+  }
+  return LASSO_OK;
+}
+
+int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k,
+                 int coef_cap, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, stream, w, ldw,
+                     (int)d, (int)k, kp, ws.wp, ws.wtp);
+  LASSO_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, stream, ws.coef, ws.zeros,
+                     std::max(coef_cap, 1));
+  LASSO_HIP_TRY(hipGetLastError());
+  return LASSO_OK;
+}
+
+}  // namespace
+}  // namespace lasso
+
+using namespace lasso;
+
+extern "C" {
+
+int lasso_hip_abi_version(void) { return LASSO_HIP_ABI_VERSION; }
+
+const char* lasso_hip_status_string(int status) {
+  switch (status) {
+    case LASSO_OK: return "ok";
+    case LASSO_ERR_BAD_ARG: return "bad argument";
+    case LASSO_ERR_UNSUPPORTED: return "unsupported shape or dtype";
+    case LASSO_ERR_WORKSPACE: return "workspace too small";
+    case LASSO_ERR_HIP: return "HIP runtime error";
+    case LASSO_WARN_LINESEARCH: return "backtracking line search failed; reverted to initial step";
+    default: return "unknown status";
+  }
+}
+
+const char* lasso_hip_last_error(void) { return g_err; }
+
+int lasso_hip_device_cus(int* cus_out) {
+  const int c = device_cus();
+  if (cus_out) *cus_out = c;
+  return c > 0 ? LASSO_OK : fail(LASSO_ERR_HIP, "no HIP device visible");
+}
+
+size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
+                                   double tol, int stop_mode) {
+  (void)d; (void)dtype;
+  const int kp = pad_k(k);
+  if (kp < 0 || n < 0) return 0;
+  const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
+  return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
+}
+
+int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype,
+                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+  // coefficient-table capacity is whatever fits: derive it from the workspace size the
+  // caller obtained from lasso_fista_workspace_bytes(n=.., maxiter=..): we cannot know
+  // maxiter here, so prepare() only packs W; lasso_fista_run() (re)builds the table.
+  if (int s = check_common(0, d, k, dtype)) return s;
+  if (!w_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldw < k) return fail(LASSO_ERR_BAD_ARG, "ldw < k");
+  const int kp = pad_k(k);
+  Workspace ws = carve(workspace_dev, 0, k, kp, 0, false);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0,
+                     (hipStream_t)stream, (const float*)w_dev, ldw, (int)d, (int)k, kp, ws.wp, ws.wtp);
+  LASSO_HIP_TRY(hipGetLastError());
+  return LASSO_OK;
+}
+
+int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_t ldz_in,
+                    const void* y_in_dev, int64_t ldy_in, void* z_out_dev, int64_t ldz_out,
+                    void* y_out_dev, int64_t ldy_out, int64_t n, int64_t d, int64_t k, int dtype,
+                    double alpha, double lr, int fast, int it0, int iters, float* delta_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (int s = check_common(n, d, k, dtype)) return s;
+  if (!x_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (it0 < 0 || iters < 0) return fail(LASSO_ERR_BAD_ARG, "negative iteration range");
+  if (delta_dev && iters > kChunkMax)
+    return fail(LASSO_ERR_BAD_ARG, "iters=%d > %d with delta recording", iters, kChunkMax);
+  if (ldx < d || ldz_out < k || (z_in_dev && ldz_in < k) || (y_in_dev && ldy_in < k) ||
+      (y_out_dev && ldy_out < k))
+    return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
+  const int kp = pad_k(k);
+  const int cap = it0 + iters;
+  Workspace ws = carve(workspace_dev, n, k, kp, cap, false);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, st, ws.coef, ws.zeros,
+                     std::max(cap, 1));
+  LASSO_HIP_TRY(hipGetLastError());
+  return run_impl(ws, kp, (const float*)x_dev, ldx, (const float*)z_in_dev, ldz_in,
+                  (const float*)y_in_dev, ldy_in, (float*)z_out_dev, ldz_out, (float*)y_out_dev,
+                  ldy_out, n, d, k, alpha, lr, fast, it0, iters, delta_dev, st);
+}
+
+int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                      const void* z0_dev, int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n,
+                      int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
+                      int maxiter, double tol, int stop_mode, int32_t* iters_out,
+                      float* last_delta_out, void* workspace_dev, size_t workspace_bytes,
+                      void* stream) {
+  if (int s = check_common(n, d, k, dtype)) return s;
+  if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
+  if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k))
+    return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
+  if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (iters_out) *iters_out = 0;
+  if (last_delta_out) *last_delta_out = NAN;
+  const float* x = (const float*)x_dev;
+  const float* z0 = (const float*)z0_dev;
+  float* zout = (float*)z_out_dev;
+
+  if (maxiter == 0 || n == 0) {   // ista.py:76,104: returns z0 itself
+    if (n > 0) {
+      if (z0) {
+        if (z0 != zout)
+          LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+      } else {
+        LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+      }
+    }
+    return LASSO_OK;
+  }
+
+  const bool stop_rule = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL;
+  const int kp = pad_k(k);
+  if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
+  Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
+  if (workspace_bytes < ws.bytes)
+    return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  if (int s = prepare_impl(ws, kp, (const float*)w_dev, ldw, d, k, maxiter, st)) return s;
+
+  if (!stop_rule) {
+    if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
+                         alpha, lr, fast, 0, maxiter, nullptr, st))
+      return s;
+    if (iters_out) *iters_out = maxiter;
+    return LASSO_OK;
+  }
+
+  // ---- exact global stop rule: speculate a chunk, read its per-iteration deltas,
+  // replay the chunk up to the stopping iteration if one fired ----------
+  const float budget = (float)((double)n * (double)k * tol);   // ista.py:64, compared in fp32
+  const float* cur_z = z0;  int64_t cur_ldz = ldz0;
+  const float* cur_y = nullptr; int64_t cur_ldy = 0;
+  if (z0 && z0 == zout) {     // aliasing: keep the initial state intact for a replay
+    LASSO_HIP_TRY(hipMemcpy2DAsync(ws.state[2], k * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+    cur_z = ws.state[2]; cur_ldz = k;
+  }
+  int done = 0, flip = 0;
+  std::vector<float> hdelta(kChunkMax);
+  float last = NAN;
+  while (done < maxiter) {
+    const int c = std::min(kChunkMax, maxiter - done);
+    const bool final_chunk = (done + c == maxiter);
+    float* nz = final_chunk ? zout : ws.state[2 * flip];
+    const int64_t nldz = final_chunk ? ldz : k;
+    float* ny = ws.state[2 * flip + 1];
+    // the aliasing copy above used state[2]; first chunk writes state[0]/[1] (flip = 0)
+    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, nz, nldz, ny, k, n, d, k,
+                         alpha, lr, fast, done, c, ws.delta, st))
+      return s;
+    LASSO_HIP_TRY(hipMemcpyAsync(hdelta.data(), ws.delta, c * sizeof(float), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    int hit = -1;
+    for (int i = 0; i < c; ++i) {
+      last = hdelta[i];
+      if (hdelta[i] <= budget) { hit = i; break; }
+    }
+    if (hit >= 0) {
+      if (hit + 1 < c) {   // replay the chunk from its (intact) input state
+        if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, zout, ldz, nullptr, 0,
+                             n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st))
+          return s;
+      } else if (!final_chunk) {
+        LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, nz, nldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+      }
+      done += hit + 1;
+      if (iters_out) *iters_out = done;
+      if (last_delta_out) *last_delta_out = last;
+      return LASSO_OK;
+    }
+    done += c;
+    cur_z = nz; cur_ldz = nldz; cur_y = ny; cur_ldy = k;
+    flip ^= 1;
+  }
+  if (iters_out) *iters_out = done;
+  if (last_delta_out) *last_delta_out = last;
+  return LASSO_OK;
+}
+
+}  // extern "C"

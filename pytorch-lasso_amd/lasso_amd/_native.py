@@ -1,0 +1,112 @@
+"""ctypes binding of liblasso_hip.so (the C ABI of include/lasso_hip.h).
+
+This is the binding a maintainer of the reference would add next to
+lasso/linear/solvers/ista.py; see INTEGRATION.md.  The library is built in-tree
+by ``__graft_entry__.build()`` / ``make -C pytorch-lasso_amd/csrc``.
+"""
+import ctypes as C
+import os
+import warnings
+
+import torch
+
+LASSO_OK, LASSO_ERR_BAD_ARG, LASSO_ERR_UNSUPPORTED = 0, 1, 2
+LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
+LASSO_F32, LASSO_BF16 = 0, 1
+STOP_GLOBAL, STOP_NONE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class NativeError(RuntimeError):
+    """The HIP extension is missing, or a native call failed."""
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblasso_hip.so")
+
+
+def _declare(lib):
+    i64, i32, dbl, vp, sz = C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_size_t
+    lib.lasso_hip_abi_version.restype = i32
+    lib.lasso_hip_status_string.restype = C.c_char_p
+    lib.lasso_hip_status_string.argtypes = [i32]
+    lib.lasso_hip_last_error.restype = C.c_char_p
+    lib.lasso_hip_device_cus.argtypes = [C.POINTER(i32)]
+    lib.lasso_fista_workspace_bytes.restype = sz
+    lib.lasso_fista_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, dbl, i32]
+    lib.lasso_fista_solve.restype = i32
+    lib.lasso_fista_solve.argtypes = [
+        vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
+        dbl, dbl, i32, i32, dbl, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+        vp, sz, vp]
+    lib.lasso_fista_prepare.restype = i32
+    lib.lasso_fista_prepare.argtypes = [vp, i64, i64, i64, i32, vp, sz, vp]
+    lib.lasso_fista_run.restype = i32
+    lib.lasso_fista_run.argtypes = [
+        vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
+        dbl, dbl, i32, i32, i32, vp, vp, sz, vp]
+
+
+def lib():
+    """Load the shared library; fail loudly if it is not built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise NativeError(
+                "lasso_amd: %s is missing -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (there is no CPU fallback)" % path)
+        try:
+            handle = C.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise NativeError("lasso_amd: cannot load %s: %s" % (path, e))
+        _declare(handle)
+        if handle.lasso_hip_abi_version() != 1:
+            raise NativeError("lasso_amd: ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    if status == LASSO_OK:
+        return
+    L = lib()
+    msg = "%s: %s" % (L.lasso_hip_status_string(status).decode(),
+                      L.lasso_hip_last_error().decode())
+    if status == LASSO_WARN_LINESEARCH:
+        warnings.warn("backtracking line search failed. Reverting to initial step size")
+        return
+    if status == LASSO_ERR_BAD_ARG:
+        raise ValueError(msg)
+    if status == LASSO_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise NativeError(msg)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise NativeError("lasso_amd: no HIP device visible (torch.cuda.is_available() is "
+                          "False); this package has no CPU fallback")
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_WS = {}
+
+
+def workspace(device, nbytes):
+    """A cached device scratch buffer (caller-owned memory of the C ABI)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

@@ -1,0 +1,79 @@
+"""HIP-backed ISTA/FISTA: same signature, defaults and error behaviour as
+``lasso.linear.solvers.ista.ista`` (reference ista.py:57-104)."""
+import ctypes as C
+
+import torch
+
+from ... import _native as nat
+
+_DT = {torch.float32: nat.LASSO_F32}
+
+
+def _to_device(t, device):
+    return t if t.device == device else t.to(device)
+
+
+def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
+         tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
+         return_info=False):
+    """Solve min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 on the GPU.
+
+    x [n,d], z0 [n,k], weight [d,k]; returns a NEW tensor z [n,k] with the
+    dtype/device of z0 (``maxiter=0`` returns ``z0`` itself, ista.py:76,104).
+    Inputs are never modified.  ``return_info`` (extension) additionally
+    returns ``dict(iterations=..., last_delta=...)``.
+    Tensors that live on the CPU are staged through the current HIP device
+    (the arithmetic still runs in the HIP kernels; there is no CPU fallback).
+    """
+    nat.require_gpu()
+    if backtrack and eta_backtrack <= 1:
+        raise ValueError('eta must be > 1.')                       # ista.py:18-19
+    if x.dim() != 2 or weight.dim() != 2 or z0.dim() != 2:
+        raise RuntimeError("ista expects 2-D x, z0, weight")
+    n, d = x.shape
+    k = weight.shape[1]
+    if weight.shape[0] != d or tuple(z0.shape) != (n, k):
+        raise RuntimeError("shape mismatch: x %s, weight %s, z0 %s"
+                           % (tuple(x.shape), tuple(weight.shape), tuple(z0.shape)))
+    if not (x.dtype == weight.dtype == z0.dtype):
+        raise RuntimeError("expected x, weight, z0 of one dtype")
+    if x.dtype not in _DT:
+        raise NotImplementedError("lasso_amd: dtype %s is not implemented on the HIP path" % x.dtype)
+    if maxiter == 0:
+        return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
+
+    out_device = z0.device
+    dev = x.device if x.is_cuda else (weight.device if weight.is_cuda else
+                                      (z0.device if z0.is_cuda else torch.device('cuda', torch.cuda.current_device())))
+    xg = _to_device(x.detach(), dev).contiguous()
+    wg = _to_device(weight.detach(), dev).contiguous()
+    zg = _to_device(z0.detach(), dev).contiguous()
+
+    if lr == 'auto':
+        from ..lipschitz import lipschitz_constant
+        lr = 1.0 / lipschitz_constant(wg)                          # ista.py:59-63
+    lr = float(lr)
+    if backtrack:
+        raise NotImplementedError("lasso_amd: backtrack=True is not implemented yet")
+
+    L = nat.lib()
+    z = torch.empty((n, k), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = L.lasso_fista_workspace_bytes(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
+                                               nat.STOP_GLOBAL)
+        ws = nat.workspace(dev, nbytes)
+        iters = C.c_int32(0)
+        last = C.c_float(float('nan'))
+        st = L.lasso_fista_solve(
+            nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
+            nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
+            int(maxiter), float(tol), nat.STOP_GLOBAL, C.byref(iters), C.byref(last),
+            nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
+        nat.check(st)
+    if z.device != out_device:
+        z = z.to(out_device)
+    if verbose:
+        print('iterations: %d' % iters.value)
+    if return_info:
+        return z, dict(iterations=iters.value, last_delta=last.value)
+    return z
