@@ -67,8 +67,9 @@ __device__ __forceinline__ int tile_off(int row, int col) {
 // unsigned bytes) + imm  and nothing 64-bit is precomputed per step.  hipcc does not
 // count these in its own s_waitcnt bookkeeping; every consumer below waits with an
 // explicit counted vmcnt (DMA returns in issue order).  M0 (the LDS destination) is
-// saved/restored inside the statement.
-template <int IMM>
+// saved/restored inside the statement.  NOTE: the instruction's immediate offset is
+// added to the LDS address as well as to the global address, so it stays 0 and the
+// per-step advance goes into the SGPR base.
 __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff)[4],
                                          lds_char* slot) {
   const unsigned lds_addr = (unsigned)(uintptr_t)slot;
@@ -77,19 +78,19 @@ __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %6\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5 offset:%c7\n\t"
+      "global_load_lds_dwordx4 %1, %5 offset:0\n\t"
       "s_add_u32 m0, %6, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5 offset:%c7\n\t"
+      "global_load_lds_dwordx4 %2, %5 offset:0\n\t"
       "s_add_u32 m0, %6, 0x800\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5 offset:%c7\n\t"
+      "global_load_lds_dwordx4 %3, %5 offset:0\n\t"
       "s_add_u32 m0, %6, 0xc00\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5 offset:%c7\n\t"
+      "global_load_lds_dwordx4 %4, %5 offset:0\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(src), "s"(lds_addr), "i"(IMM)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(src), "s"(lds_addr)
       : "memory", "scc");
 }
 
@@ -114,10 +115,12 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
   static_assert(S1 % 2 == 0 && (NP * T2) % 2 == 0, "ring parity");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const yt = (lds_char*)smem;
+  // LDS map: [rings 64 KiB | y tile | r tile | reduction scratch].  The DMA rings sit
+  // in the low 64 KiB so their M0 destination offsets fit 16 bits.
+  lds_char* const rings = (lds_char*)smem;
+  lds_char* const yt = rings + NW * kRingBytesPerWave;
   lds_char* const rt = yt + YT_BYTES;
-  lds_char* const rings = yt + YT_BYTES + RT_BYTES;
-  lds_f32* const red = (lds_f32*)(rings + NW * kRingBytesPerWave);
+  lds_f32* const red = (lds_f32*)(rt + RT_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
     for (int ss = 0; ss < 2; ++ss) aoff[par][ss] = ((8 * par + 4 * ss + q) ^ n) << 4;
 
   // prologue: first two W steps of GEMM-1 are always in flight on entry
-  dma_step<0>(w1, voff1, ring);
-  dma_step<128>(w1, voff1, ring + kStepBytes);
+  dma_step(w1, voff1, ring);
+  dma_step(w1 + 32, voff1, ring + kStepBytes);
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
         for (int ss = 0; ss < 2; ++ss)
           a[ss] = *(const lds_f32x4*)(yt + n * (K * 4) + s2 * 256 + aoff[par][ss]);
         LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
-        dma_step<0>(pf_src, pf_voff, slot);
+        dma_step(pf_src, pf_voff, slot);
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -276,9 +279,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
           LASSO_WAIT_LGKM0();
           if constexpr (U + 2 < NP * T2) {
             constexpr int pn = (U + 2) / T2, tn = (U + 2) % T2;
-            dma_step<tn * 128>(w2 + (size_t)(32 * pn) * D, voff2, slot);
+            dma_step(w2 + (size_t)(32 * pn) * D + 32 * tn, voff2, slot);
           } else {
-            dma_step<(U + 2 - NP * T2) * 128>(w1, voff1, slot);   // next iteration's GEMM-1
+            dma_step(w1 + 32 * (U + 2 - NP * T2), voff1, slot);   // next iteration's GEMM-1
           }
 #pragma unroll
           for (int ss = 0; ss < 2; ++ss)
