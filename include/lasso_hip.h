@@ -102,6 +102,54 @@ int lasso_fista_run(const void* x_dev, int64_t ldx,
                     float* delta_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- Lipschitz constant: replaces _lipschitz_constant, ista.py:8-14 -----------------
+ * L = lambda_max(W^T W), deterministic, fp64, computed on the device (Gram of the
+ * smaller side + repeated squaring; see csrc/lipschitz.hip).  Synchronises `stream`
+ * to return the value through the HOST pointer l_out (the reference returns a python
+ * float the same way).  ((double*)workspace_dev)[0] also holds the value on the device.
+ */
+size_t lasso_lipschitz_workspace_bytes(int64_t d, int64_t k);
+int lasso_lipschitz(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype,
+                    double* l_out, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- objective: replaces lasso_loss, dict_learning.py:10-13 ------------------------
+ * loss = (0.5*||X - Z W^T||^2 + alpha*||Z||_1) / n.  No host synchronisation:
+ * loss_dev (device float, nullable) receives the scalar for THIS shard's n;
+ * sums_dev (device double[2], nullable) receives {sum r^2, sum |z|} of the shard so a
+ * multi-GPU driver can all-reduce them and normalise by the global n.
+ */
+size_t lasso_objective_workspace_bytes(int64_t n, int64_t d, int64_t k);
+int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                    const void* z_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype,
+                    double alpha, float* loss_dev, double* sums_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- constrained M-step in Gram form: replaces update_dict, dict_learning.py:56-103 --
+ * lasso_gram_accumulate: A = Z^T Z [k][k] (ld k), B = Z^T X [k][d] (ld d) of this row
+ *   shard (fp32 MFMA).  The caller all-reduces A and B across GPUs (they may be two
+ *   slices of one buffer).
+ * lasso_dict_sweep: Gauss-Seidel sweep over the atoms on (A, B), updating the
+ *   dictionary D [d][k] (ldd) IN PLACE like the reference (:86,:100).  Atoms with
+ *   ||u|| < eps (:92) are replaced by the next unused row of `pool_dev`
+ *   [pool_rows][d] (ld pool_ld) normalised to unit length -- the reference draws that
+ *   direction from torch's RNG (:93) -- or, if pool_dev is NULL, by a counter-based
+ *   N(0,1) vector keyed by (seed, atom).  degenerate_dev [k] (int32, device) is set to
+ *   1 for those atoms; ndeg_out (HOST, nullable) receives their count and, when
+ *   non-NULL, makes the call synchronise `stream`.
+ * lasso_zero_columns: Z[:, j] = 0 where degenerate_dev[j] != 0 (:98).
+ */
+int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx,
+                          int64_t n, int64_t d, int64_t k, int dtype,
+                          float* a_dev, float* b_dev, void* stream);
+size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k);
+int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd,
+                     int64_t d, int64_t k, int dtype, double eps, int positive,
+                     const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
+                     int32_t* degenerate_dev, int32_t* ndeg_out,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
+                       const int32_t* degenerate_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,98 +21,21 @@
 //   K-group; MFMA number j of the group consumes element j, i.e. it contracts
 //   over k = kbase + 4q + j, q=0..3.  A and B use the same convention, so the
 //   sum over j,q covers the 16 K-values exactly once.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
-#include <utility>
-#include "lasso_kernels.h"
+#include "tile_device.hpp"
 
 namespace lasso {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-using lds_void_ptr = __attribute__((address_space(3))) void*;
-using lds_char = __attribute__((address_space(3))) char;
-using lds_f32 = __attribute__((address_space(3))) float;
-using lds_f32x4 = __attribute__((address_space(3))) f32x4;
-
-// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
-#define LASSO_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
-#define LASSO_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
-
-namespace {
-
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-constexpr int kStepBytes = 4096;               // 32 rows x 128 B
-constexpr int kRingBytesPerWave = 2 * kStepBytes;
-
-// byte offset of element (row, col) inside a swizzled [16][LD] fp32 LDS tile:
-// 16-byte chunk index is XORed with the row in its low 4 bits.
-template <int LD>
-__device__ __forceinline__ int tile_off(int row, int col) {
-  const int chunk = col >> 2;
-  return row * (LD * 4) + ((chunk ^ row) << 4) + ((col & 3) << 2);
-}
-
-// One ring step = 4 LDS-DMA instructions (1 KiB each, lane-linear in LDS), issued
-// from inline asm so the address form is exactly  saddr(SGPR pair) + voffset(VGPR,
-// unsigned bytes) + imm  and nothing 64-bit is precomputed per step.  hipcc does not
-// count these in its own s_waitcnt bookkeeping; every consumer below waits with an
-// explicit counted vmcnt (DMA returns in issue order).  M0 (the LDS destination) is
-// saved/restored inside the statement.  NOTE: the instruction's immediate offset is
-// added to the LDS address as well as to the global address, so it stays 0 and the
-// per-step advance goes into the SGPR base.
-__device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff)[4],
-                                         lds_char* slot) {
-  const unsigned lds_addr = (unsigned)(uintptr_t)slot;
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5 offset:0\n\t"
-      "s_add_u32 m0, %6, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5 offset:0\n\t"
-      "s_add_u32 m0, %6, 0x800\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5 offset:0\n\t"
-      "s_add_u32 m0, %6, 0xc00\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5 offset:0\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(src), "s"(lds_addr)
-      : "memory", "scc");
-}
-
-__device__ __forceinline__ float soft_threshold(float v, float lam) {
-  // ATen softshrink: v>lam ? v-lam : (v<-lam ? v+lam : 0)
-  return v > lam ? v - lam : (v < -lam ? v + lam : 0.0f);
-}
-
-}  // namespace
 
 template <int K>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const FistaTileParams p) {
   constexpr int D = kFistaD;
   constexpr int NW = kFistaWaves;
-  constexpr int S1 = K / 32;        // GEMM-1 steps (32 k-values each)
   constexpr int KW = K / NW;        // GEMM-2 output columns per wave
   constexpr int NP = KW / 32;       // GEMM-2 passes (2 col-blocks each)
   constexpr int T2 = D / 32;        // GEMM-2 steps per pass
   constexpr int YT_BYTES = kTileM * K * 4;
   constexpr int RT_BYTES = kTileM * D * 4;
   static_assert(D == 32 * NW, "each wave owns two GEMM-1 column blocks");
-  static_assert(S1 % 2 == 0 && (NP * T2) % 2 == 0, "ring parity");
+  static_assert((K / 32) % 2 == 0 && (NP * T2) % 2 == 0, "ring parity");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS map: [rings 64 KiB | y tile | r tile | reduction scratch].  The DMA rings sit
@@ -122,41 +45,14 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
   lds_char* const rt = yt + YT_BYTES;
   lds_f32* const red = (lds_f32*)(rt + RT_BYTES);
 
+  TileCtx<K> c;
+  c.init(p.Wp, p.Wtp, rings);
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15;
-  const int q = lane >> 4;
-  lds_char* const ring = rings + wid * kRingBytesPerWave;
-
-  // ---- per-lane DMA source offsets (floats).  DMA instruction j writes LDS
-  // bytes [j*1024, j*1024+1024) lane-linearly = rows 8j..8j+7 of the step tile,
-  // 8 lanes per 128-B row; the XOR swizzle is applied on the SOURCE chunk.
-  unsigned voff1[4], voff2[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 8 * j + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    voff1[j] = (unsigned)(row * K + 4 * c) * 4u;
-    voff2[j] = (unsigned)(row * D + 4 * c) * 4u;
-  }
-  const float* const w1 = p.Wp + (size_t)(32 * wid) * K;    // rows of W   [D][K]
-  const float* const w2 = p.Wtp + (size_t)(KW * wid) * D;   // rows of W^T [K][D]
-
-  // fragment read offsets inside a ring slot (B operand) ...
-  int boff[2];
-#pragma unroll
-  for (int ss = 0; ss < 2; ++ss) boff[ss] = n * 128 + (((4 * ss + q) ^ ((n >> 1) & 7)) << 4);
-  // ... and inside the y / r tiles (A operand): chunk = 8*s + 4*ss + q
-  int aoff[2][2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) aoff[par][ss] = ((8 * par + 4 * ss + q) ^ n) << 4;
+  const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
 
   // prologue: first two W steps of GEMM-1 are always in flight on entry
-  dma_step(w1, voff1, ring);
-  dma_step(w1 + 32, voff1, ring + kStepBytes);
+  dma_step(c.w1, c.voff1, c.ring);
+  dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
@@ -211,41 +107,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
 
       // ================= GEMM-1: r = y W^T - x ==========================
       f32x4 acc[2] = {xneg[0], xneg[1]};
-      // one step: wait for its ring slot, pull fragments, refill the slot two steps
-      // ahead, 16 MFMAs.  `pf_src`/`pf_voff`: where the refill comes from.
-      auto gemm1_step = [&](int s2, auto par_c, const float* pf_src, const unsigned (&pf_voff)[4]) {
-        constexpr int par = decltype(par_c)::value;
-        lds_char* const slot = ring + par * kStepBytes;
-        LASSO_WAIT_VMCNT(4);  // this step's 4 DMA pieces have landed
-        f32x4 b[2][2], a[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-            b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + boff[ss]);
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-          a[ss] = *(const lds_f32x4*)(yt + n * (K * 4) + s2 * 256 + aoff[par][ss]);
-        LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
-        dma_step(pf_src, pf_voff, slot);
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[0][ss][j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[1][ss][j], acc[1], 0, 0, 0);
-          }
-      };
-      using P0 = std::integral_constant<int, 0>;
-      using P1 = std::integral_constant<int, 1>;
-#pragma unroll 1
-      for (int s2 = 0; s2 < S1 / 2 - 1; ++s2) {
-        gemm1_step(s2, P0{}, w1 + 64 * s2 + 64, voff1);
-        gemm1_step(s2, P1{}, w1 + 64 * s2 + 96, voff1);
-      }
-      // last two steps refill the ring with GEMM-2's first two steps (W^T stream)
-      gemm1_step(S1 / 2 - 1, P0{}, w2, voff2);
-      gemm1_step(S1 / 2 - 1, P1{}, w2 + 32, voff2);
+      // (its last two steps refill the ring with GEMM-2's first two W^T steps)
+      gemm1_stream<K>(c, yt, acc, c.w2, c.w2 + 32, c.voff2);
+
       // r tile -> LDS (C layout -> swizzled row-major), then everyone reads all of it
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -259,7 +123,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
       for (int t = 0; t < T2; ++t)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss)
-          rf[t][ss] = *(const lds_f32x4*)(rt + n * (D * 4) + (t >> 1) * 256 + aoff[t & 1][ss]);
+          rf[t][ss] = *(const lds_f32x4*)(rt + n * (D * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
 
       // ================= GEMM-2 + prox/momentum epilogue ================
       static_for<NP>([&](auto ps_c) {
@@ -268,20 +132,20 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
         static_for<T2>([&](auto t_c) {
           constexpr int t = decltype(t_c)::value;
           constexpr int U = ps * T2 + t;            // step index inside GEMM-2
-          lds_char* const slot = ring + (U & 1) * kStepBytes;
+          lds_char* const slot = c.ring + (U & 1) * kStepBytes;
           LASSO_WAIT_VMCNT(4);
           f32x4 b[2][2];
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
-              b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + boff[ss]);
+              b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
           LASSO_WAIT_LGKM0();
           if constexpr (U + 2 < NP * T2) {
             constexpr int pn = (U + 2) / T2, tn = (U + 2) % T2;
-            dma_step(w2 + (size_t)(32 * pn) * D + 32 * tn, voff2, slot);
+            dma_step(c.w2 + (size_t)(32 * pn) * D + 32 * tn, c.voff2, slot);
           } else {
-            dma_step(w1 + 32 * (U + 2 - NP * T2), voff1, slot);   // next iteration's GEMM-1
+            dma_step(c.w1 + 32 * (U + 2 - NP * T2), c.voff1, slot);   // next iteration's GEMM-1
           }
 #pragma unroll
           for (int ss = 0; ss < 2; ++ss)
@@ -311,8 +175,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
       });
 
       // ---- per-tile sum |z - z_next| (deterministic order) ---------------
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+      dsum = wave_sum(dsum);
       if (lane == 0) red[wid] = dsum;
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete

@@ -377,4 +377,136 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   return LASSO_OK;
 }
 
+// ---------------------------------------------------------------------------
+size_t lasso_lipschitz_workspace_bytes(int64_t d, int64_t k) {
+  if (d <= 0 || k <= 0) return 0;
+  return lipschitz_workspace_bytes(d, k);
+}
+
+int lasso_lipschitz(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype, double* l_out,
+                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!w_dev || !workspace_dev || d <= 0 || k <= 0 || ldw < k)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (std::min(d, k) > 2048) return fail(LASSO_ERR_UNSUPPORTED, "min(d,k) > 2048");
+  if (workspace_bytes < lipschitz_workspace_bytes(d, k))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lipschitz_workspace_bytes(d, k));
+  hipStream_t st = (hipStream_t)stream;
+  LASSO_HIP_TRY(launch_lipschitz((const float*)w_dev, ldw, d, k, workspace_dev, 20, st));
+  if (l_out) {
+    LASSO_HIP_TRY(hipMemcpyAsync(l_out, workspace_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return LASSO_OK;
+}
+
+// ---------------------------------------------------------------------------
+size_t lasso_objective_workspace_bytes(int64_t n, int64_t d, int64_t k) {
+  (void)d;
+  const int kp = pad_k(k);
+  if (kp < 0 || n < 0) return 0;
+  const int64_t ntiles = (n + kTileM - 1) / kTileM;
+  return align_up((size_t)kFistaD * kp * 4) + align_up((size_t)kp * kFistaD * 4) +
+         align_up((size_t)std::max<int64_t>(ntiles, 1) * 2 * 4) + 256;
+}
+
+int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* z_dev,
+                    int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype, double alpha,
+                    float* loss_dev, double* sums_dev, void* workspace_dev, size_t workspace_bytes,
+                    void* stream) {
+  if (int s = check_common(n, d, k, dtype)) return s;
+  if (!x_dev || !w_dev || !z_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldx < d || ldw < k || ldz < k) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
+  if (workspace_bytes < lasso_objective_workspace_bytes(n, d, k))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_objective_workspace_bytes(n, d, k));
+  hipStream_t st = (hipStream_t)stream;
+  const int kp = pad_k(k);
+  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  char* base = (char*)workspace_dev;
+  float* wp = (float*)base;
+  float* wtp = (float*)(base + align_up((size_t)kFistaD * kp * 4));
+  float* partials = (float*)((char*)wtp + align_up((size_t)kp * kFistaD * 4));
+  double* sums = (double*)((char*)partials + align_up((size_t)std::max(ntiles, 1) * 2 * 4));
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, st,
+                     (const float*)w_dev, ldw, (int)d, (int)k, kp, wp, wtp);
+  LASSO_HIP_TRY(hipGetLastError());
+  ObjectiveParams p;
+  p.X = (const float*)x_dev; p.ldx = ldx; p.Wp = wp;
+  p.Z = (const float*)z_dev; p.ldz = ldz; p.partials = partials;
+  p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
+  const int cus = device_cus();
+  if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
+  if (n > 0) {
+    LASSO_HIP_TRY(launch_objective(p, kp, std::min(ntiles, cus), alpha, (double)n,
+                                   sums_dev ? sums_dev : sums, loss_dev, st));
+  }
+  return LASSO_OK;
+}
+
+// ---------------------------------------------------------------------------
+int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
+                          int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!z_dev || !x_dev || !a_dev || !b_dev || n < 0 || d <= 0 || k <= 0 || ldz < k || ldx < d)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (n > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "n too large");
+  hipStream_t st = (hipStream_t)stream;
+  const float* Z = (const float*)z_dev;
+  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, st));
+  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, b_dev, d, 0, st));
+  return LASSO_OK;
+}
+
+size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k) {
+  if (d <= 0 || k <= 0 || d > kFistaD) return 0;
+  return align_up((size_t)k * kFistaD * 4) * 2 + align_up((size_t)kSweepBlock * kFistaD * 4) + 256;
+}
+
+int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
+                     int64_t k, int dtype, double eps, int positive, const float* pool_dev,
+                     int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
+                     int32_t* ndeg_out, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!a_dev || !b_dev || !d_dev || !degenerate_dev || !workspace_dev || d <= 0 || k <= 0 || ldd < k)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (d > kFistaD) return fail(LASSO_ERR_UNSUPPORTED, "d > %d", kFistaD);
+  if (pool_dev && (pool_rows <= 0 || pool_ld < d)) return fail(LASSO_ERR_BAD_ARG, "bad pool");
+  if (workspace_bytes < lasso_dict_sweep_workspace_bytes(d, k))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_dict_sweep_workspace_bytes(d, k));
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace_dev;
+  float* U = (float*)base;
+  float* Dt = (float*)(base + align_up((size_t)k * kFistaD * 4));
+  float* dD = (float*)((char*)Dt + align_up((size_t)k * kFistaD * 4));
+  int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * kFistaD * 4));
+  float* D = (float*)d_dev;
+  LASSO_HIP_TRY(hipMemsetAsync(ndeg, 0, sizeof(int), st));
+  // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, padded row stride 256)
+  LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * kFistaD * 4, st));
+  LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, kFistaD, (int)k, (int)d, (int)k, st));
+  // Dt[j][dd] = D[dd][j]  (zero padded to 256 features)
+  LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, kFistaD, (int)k, kFistaD, st));
+  SweepParams p;
+  p.A = a_dev; p.lda = k; p.U = U; p.ldu = kFistaD; p.Dt = Dt; p.dD = dD;
+  p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
+  p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
+  p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
+  LASSO_HIP_TRY(launch_dict_sweep(p, st));
+  // D[dd][j] = Dt[j][dd]
+  LASSO_HIP_TRY(launch_transpose_pad(Dt, kFistaD, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
+  if (ndeg_out) {
+    LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return LASSO_OK;
+}
+
+int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
+                       const int32_t* degenerate_dev, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!z_dev || !degenerate_dev || n < 0 || k <= 0 || ldz < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  LASSO_HIP_TRY(launch_zero_columns((float*)z_dev, ldz, (int)n, (int)k, degenerate_dev, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
 }  // extern "C"

@@ -29,7 +29,49 @@ struct FistaTileParams {
   float lr, lam;                         // step size, alpha*lr
 };
 
+// lasso_loss tile kernel (objective.hip)
+struct ObjectiveParams {
+  const float* X; int64_t ldx;
+  const float* Wp;                       // [kFistaD][Kpad]
+  const float* Z; int64_t ldz;
+  float* partials;                       // [ntiles][2]  (sum r^2, sum |z|)
+  int n, d, k, ntiles;
+};
+
+// constrained M-step (mstep.hip)
+constexpr int kSweepBlock = 32;
+struct SweepParams {
+  const float* A; int64_t lda;           // [k][k]   Z^T Z
+  float* U; int64_t ldu;                 // [k][kFistaD]  B - A D^T, updated in place
+  float* Dt;                             // [k][kFistaD]  atoms as rows (in/out)
+  float* dD;                             // [kSweepBlock][kFistaD] scratch
+  const float* pool; int pool_rows;      // [pool_rows][pool_ld] replacement directions (nullable)
+  int64_t pool_ld; unsigned long long seed;
+  int* degenerate;                       // [k] out: 1 where the atom was re-initialised
+  int* ndeg_in_out;                      // [1] running count of degenerate atoms
+  int k, d;
+  float eps; int positive;
+};
+
 size_t fista_tile_lds_bytes(int kpad);
 hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
+
+hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
+                            double n_total, double* sums, float* loss_out, hipStream_t stream);
+
+size_t lipschitz_workspace_bytes(int64_t d, int64_t k);
+hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,
+                            int squarings, hipStream_t stream);
+
+hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
+                          int n, float* C, int64_t ldc, int sym, hipStream_t stream);
+hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
+                              const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
+                              int kk, hipStream_t stream);
+hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int cols, float* dst,
+                                int64_t ld_dst, int drows, int dcols, hipStream_t stream);
+hipError_t launch_zero_columns(float* Z, int64_t ldz, int n, int k, const int* degenerate,
+                               hipStream_t stream);
 
 }  // namespace lasso

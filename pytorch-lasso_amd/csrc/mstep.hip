@@ -1,0 +1,370 @@
+// M-step kernels: the constrained dictionary update of
+// lasso/linear/dict_learning.py:56-103 in GRAM FORM.
+//
+// With A = Z^T Z [k,k] and B = Z^T X [k,d] (row-shard partial sums, all-reduced by
+// the host across GPUs), the reference's Gauss-Seidel atom sweep
+//     R += z_j d_j^T ; u = z_j^T R ; d_j <- u/||u|| ; R -= z_j d_j^T     (:85-101)
+// is u_j = B_j - sum_i A_ji d_i + A_jj d_j with the CURRENT atoms d_i.  We keep
+// U = B - A D^T (one GEMM) and sweep blocks of 32 atoms:
+//   sweep_block_kernel   one wave, sequential inside the block, U rows in registers;
+//   trailing_update      U[j' > block] -= A[j', block] * dD[block]   (many workgroups).
+// A degenerate atom (||u|| < eps, :92-98) is replaced by a caller-supplied unit vector
+// and removed from the model (its effective new atom is 0, as zeroing Z[:,j] does).
+//
+//   gram_tn_kernel   C = P^T Q     fp32 MFMA, reduce over the n rows of the shard
+//   gemm_nt_kernel   C = C0 - A B^T
+// Rooflines: the two GEMM kernels are MFMA-bound (2nk^2 + 2nkd and 2k^2 d flop); the
+// sweep is a latency-bound dependency chain of k steps (time reported, no roofline).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "lasso_kernels.h"
+#include "static_for.hpp"
+
+namespace lasso {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// C[pc x qc] = P^T Q,  P [n x pc] (ldp), Q [n x qc] (ldq).  64x64 block per workgroup,
+// 4 waves x (32x32), samples in chunks of 32 through LDS (row stride 80 floats:
+// the per-MFMA operand read "16 consecutive floats of 4 consecutive rows" is
+// conflict-free).  sym != 0: P == Q, only blocks bj >= bi are computed and mirrored.
+// ---------------------------------------------------------------------------
+constexpr int kGB = 64, kGS = 32, kGLd = 80;
+
+__global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ P, int64_t ldp, int pc,
+                                                      const float* __restrict__ Q, int64_t ldq, int qc,
+                                                      int n, float* __restrict__ C, int64_t ldc, int sym) {
+  if (sym && blockIdx.x < blockIdx.y) return;
+  __shared__ float sp[2][kGS][kGLd], sq[2][kGS][kGLd];
+  const int i0 = blockIdx.y * kGB, j0 = blockIdx.x * kGB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int l15 = lane & 15, q = lane >> 4;
+  f32x4 acc[2][2] = {};
+  // staging map: thread -> (row = tid/16 [+16], 4 consecutive columns)
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  float stg[2][2][4];   // [P/Q][half][4]
+
+  auto load_chunk = [&](int s0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = s0 + srow + 16 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cp = i0 + scol + e, cq = j0 + scol + e;
+        stg[0][h][e] = (r < n && cp < pc) ? P[(int64_t)r * ldp + cp] : 0.0f;
+        stg[1][h][e] = (r < n && cq < qc) ? Q[(int64_t)r * ldq + cq] : 0.0f;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sp[buf][srow + 16 * h][scol + e] = stg[0][h][e];
+        sq[buf][srow + 16 * h][scol + e] = stg[1][h][e];
+      }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  for (int s0 = 0; s0 < n; s0 += kGS) {
+    const bool more = s0 + kGS < n;
+    if (more) load_chunk(s0 + kGS);
+#pragma unroll
+    for (int ks = 0; ks < kGS / 4; ++ks) {
+      float a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = sp[buf][4 * ks + q][32 * wr + 16 * m + l15];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) b[m] = sq[buf][4 * ks + q][32 * wc + 16 * m + l15];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = i0 + 32 * wr + 16 * mi + 4 * q + rg, cc = j0 + 32 * wc + 16 * nj + l15;
+        if (r < pc && cc < qc) {
+          C[(int64_t)r * ldc + cc] = acc[mi][nj][rg];
+          if (sym && blockIdx.x != blockIdx.y) C[(int64_t)cc * ldc + r] = acc[mi][nj][rg];
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------
+// C[m x nn] = C0 - A B^T,  A [m x kk] (lda), B [nn x kk] (ldb): both K-contiguous.
+// 64x64 block, chunks of 32 along kk, operands staged as [64 rows][32 floats] with the
+// same 16-B-chunk XOR swizzle as the FISTA ring (ds_read_b128 fragments).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int swz_off(int row, int chunk) {   // bytes inside a [rows][128 B] tile
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb,
+                                                          const float* __restrict__ C0, int64_t ldc0,
+                                                          float* __restrict__ C, int64_t ldc, int m,
+                                                          int nn, int kk) {
+  __shared__ __attribute__((aligned(16))) char sa[2][64 * 128], sb[2][64 * 128];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int l15 = lane & 15, q = lane >> 4;
+  f32x4 acc[2][2] = {};
+  // staging: thread -> row = tid/4 (0..63), chunks 2*(tid&3), 2*(tid&3)+1
+  const int srow = tid >> 2, sch = (tid & 3) * 2;
+  float stg[2][8];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kcol = k0 + sch * 4 + e;
+      stg[0][e] = (i0 + srow < m && kcol < kk) ? A[(int64_t)(i0 + srow) * lda + kcol] : 0.0f;
+      stg[1][e] = (j0 + srow < nn && kcol < kk) ? B[(int64_t)(j0 + srow) * ldb + kcol] : 0.0f;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *(f32x4*)(sa[buf] + swz_off(srow, sch + h)) = (f32x4){stg[0][4 * h], stg[0][4 * h + 1], stg[0][4 * h + 2], stg[0][4 * h + 3]};
+      *(f32x4*)(sb[buf] + swz_off(srow, sch + h)) = (f32x4){stg[1][4 * h], stg[1][4 * h + 1], stg[1][4 * h + 2], stg[1][4 * h + 3]};
+    }
+  };
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < kk; k0 += 32) {
+    const bool more = k0 + 32 < kk;
+    if (more) load_chunk(k0 + 32);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(sa[buf] + swz_off(32 * wr + 16 * mi + l15, 4 * ss + q));
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) b[nj] = *(const f32x4*)(sb[buf] + swz_off(32 * wc + 16 * nj + l15, 4 * ss + q));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj)
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[nj][j], acc[mi][nj], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = i0 + 32 * wr + 16 * mi + 4 * q + rg, cc = j0 + 32 * wc + 16 * nj + l15;
+        if (r < m && cc < nn) C[(int64_t)r * ldc + cc] = C0[(int64_t)r * ldc0 + cc] - acc[mi][nj][rg];
+      }
+}
+
+// counter-based standard normal (splitmix-style hash + Box-Muller); used only when the
+// caller supplies no replacement pool for degenerate atoms
+__device__ __forceinline__ float counter_normal(unsigned long long seed, unsigned a, unsigned b) {
+  unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (((unsigned long long)a << 32) | b) + 0xD1B54A32D192ED03ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  const float u1 = ((unsigned)(x >> 40) + 1.0f) * (1.0f / 16777217.0f);
+  const float u2 = (unsigned)((x >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// ---------------------------------------------------------------------------
+// Sequential sweep over the kSweepBlock atoms [j0, j0+JB) -- one wave, lane owns
+// features 4*lane..4*lane+3 (d <= 256).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, int j0) {
+  constexpr int JB = kSweepBlock;
+  __shared__ float sA[JB][JB];          // A[j0+a][j0+b]
+  __shared__ __attribute__((aligned(16))) float sD[JB][kFistaD];   // old atoms of the block (rows of Dt)
+  const int lane = threadIdx.x;
+  const int nb = min(JB, p.k - j0);
+  for (int e = lane; e < JB * JB; e += 64) {
+    const int a = e / JB, b = e % JB;
+    sA[a][b] = (a < nb && b < nb) ? p.A[(int64_t)(j0 + a) * p.lda + j0 + b] : 0.0f;
+  }
+  for (int a = 0; a < JB; ++a) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a < nb) v = *(const f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane);
+    *(f32x4*)(&sD[a][4 * lane]) = v;
+  }
+  float u[JB][4];
+#pragma unroll
+  for (int a = 0; a < JB; ++a)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int dd = 4 * lane + f;
+      u[a][f] = (a < nb && dd < p.d) ? p.U[(int64_t)(j0 + a) * p.ldu + dd] : 0.0f;
+    }
+  __syncthreads();
+  int ndeg = p.ndeg_in_out[0];
+  static_for<JB>([&](auto a_c) {
+    constexpr int a = decltype(a_c)::value;
+    if (a < nb) {   // wave-uniform
+      const float ajj = sA[a][a];
+      float v[4], dcur[4], ss = 0.0f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        dcur[f] = sD[a][4 * lane + f];
+        v[f] = fmaf(ajj, dcur[f], u[a][f]);
+        if (p.positive) v[f] = fmaxf(v[f], 0.0f);              // dict_learning.py:87-88
+        ss = fmaf(v[f], v[f], ss);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+      const float nrm = sqrtf(ss);                               // :91
+      float dnew[4], delta[4];
+      if (nrm < p.eps) {                                         // :92-98 degenerate atom
+        float fs = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int dd = 4 * lane + f;
+          float g = 0.0f;
+          if (dd < p.d) {
+            if (p.pool && p.pool_rows > 0)   // caller-supplied replacement direction #ndeg
+              g = p.pool[(int64_t)min(ndeg, p.pool_rows - 1) * p.pool_ld + dd];
+            else                             // counter-based N(0,1) keyed by (seed, atom, feature)
+              g = counter_normal(p.seed, (unsigned)(j0 + a), (unsigned)dd);
+          }
+          dnew[f] = g;
+          if (p.positive) dnew[f] = fmaxf(dnew[f], 0.0f);
+          fs = fmaf(dnew[f], dnew[f], fs);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) fs += __shfl_xor(fs, off, 64);
+        const float inv = 1.0f / sqrtf(fs);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { dnew[f] *= inv; delta[f] = -dcur[f]; }   // atom leaves the model
+        if (lane == 0) p.degenerate[j0 + a] = 1;
+        ++ndeg;
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { dnew[f] = v[f] / nrm; delta[f] = dnew[f] - dcur[f]; }   // :100
+        if (lane == 0) p.degenerate[j0 + a] = 0;
+      }
+      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane) = (f32x4){dnew[0], dnew[1], dnew[2], dnew[3]};
+      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){delta[0], delta[1], delta[2], delta[3]};
+#pragma unroll
+      for (int b = a + 1; b < JB; ++b) {
+        const float cf = sA[b][a];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf, delta[f], u[b][f]);
+      }
+    }
+  });
+  if (lane == 0) p.ndeg_in_out[0] = ndeg;
+}
+
+// U[j'][:] -= sum_a A[j'][j0+a] * dD[a][:]   for j' >= j0 + JB; one row per wave-iteration
+__global__ __launch_bounds__(256) void trailing_update_kernel(const SweepParams p, int j0) {
+  constexpr int JB = kSweepBlock;
+  const int dd = threadIdx.x;              // feature (kFistaD == 256 threads)
+  float dl[JB];
+#pragma unroll
+  for (int a = 0; a < JB; ++a) dl[a] = p.dD[(int64_t)a * kFistaD + dd];
+  const int nb = min(JB, p.k - j0);
+  for (int r = j0 + JB + blockIdx.x; r < p.k; r += gridDim.x) {
+    const float* arow = p.A + (int64_t)r * p.lda + j0;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < JB; ++a) acc = fmaf((a < nb) ? arow[a] : 0.0f, dl[a], acc);
+    if (dd < p.d) p.U[(int64_t)r * p.ldu + dd] -= acc;
+  }
+}
+
+// dst[c][r] = src[r][c] (zero padded to the dst extents)
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
+                                     float* __restrict__ dst, int64_t ldd, int drows, int dcols) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;     // dst row = c, dst col = r
+    if (c < drows && r < dcols) dst[(int64_t)c * ldd + r] = t[threadIdx.x][i];
+  }
+}
+
+// Z[:, j] = 0 for degenerate atoms (dict_learning.py:98; matters when persist=True)
+__global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, int k,
+                                    const int* __restrict__ degenerate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * k) return;
+  const int c = (int)(idx % k);
+  if (degenerate[c]) Z[(idx / k) * ldz + c] = 0.0f;
+}
+
+}  // namespace
+
+hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
+                          int n, float* C, int64_t ldc, int sym, hipStream_t stream) {
+  const dim3 grid((qc + kGB - 1) / kGB, (pc + kGB - 1) / kGB);
+  hipLaunchKernelGGL(gram_tn_kernel, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
+                              const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
+                              int kk, hipStream_t stream) {
+  const dim3 grid((nn + 63) / 64, (m + 63) / 64);
+  hipLaunchKernelGGL(gemm_nt_sub_kernel, grid, dim3(256), 0, stream, A, lda, B, ldb, C0, ldc0, C, ldc,
+                     m, nn, kk);
+  return hipGetLastError();
+}
+
+hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
+  for (int j0 = 0; j0 < p.k; j0 += kSweepBlock) {
+    hipLaunchKernelGGL(sweep_block_kernel, dim3(1), dim3(64), 0, stream, p, j0);
+    if (j0 + kSweepBlock < p.k) {
+      const int rows = p.k - j0 - kSweepBlock;
+      hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256)), dim3(256), 0, stream, p, j0);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int cols, float* dst,
+                                int64_t ld_dst, int drows, int dcols, hipStream_t stream) {
+  const int gr = std::max(rows, dcols), gc = std::max(cols, drows);
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((gc + 31) / 32, (gr + 31) / 32), dim3(32, 8), 0, stream,
+                     src, ld_src, rows, cols, dst, ld_dst, drows, dcols);
+  return hipGetLastError();
+}
+
+hipError_t launch_zero_columns(float* Z, int64_t ldz, int n, int k, const int* degenerate,
+                               hipStream_t stream) {
+  const int64_t total = (int64_t)n * k;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     Z, ldz, n, k, degenerate);
+  return hipGetLastError();
+}
+
+}  // namespace lasso

@@ -1,0 +1,162 @@
+// Device-side building blocks shared by the tile kernels (fista_tile.hip,
+// objective.hip, backtrack.hip): LDS layouts, the per-wave LDS-DMA ring that streams
+// W / W^T from L2, and the MFMA GEMM-1 loop  acc = A_tile * W^T.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+#include "lasso_kernels.h"
+#include "static_for.hpp"
+
+namespace lasso {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using lds_void_ptr = __attribute__((address_space(3))) void*;
+using lds_char = __attribute__((address_space(3))) char;
+using lds_f32 = __attribute__((address_space(3))) float;
+using lds_f32x4 = __attribute__((address_space(3))) f32x4;
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
+#define LASSO_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#define LASSO_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+
+constexpr int kStepBytes = 4096;               // 32 rows x 128 B
+constexpr int kRingBytesPerWave = 2 * kStepBytes;
+
+// byte offset of element (row, col) inside a swizzled [16][LD] fp32 LDS tile:
+// 16-byte chunk index is XORed with the row in its low 4 bits.
+template <int LD>
+__device__ __forceinline__ int tile_off(int row, int col) {
+  const int chunk = col >> 2;
+  return row * (LD * 4) + ((chunk ^ row) << 4) + ((col & 3) << 2);
+}
+
+// One ring step = 4 LDS-DMA instructions (1 KiB each, lane-linear in LDS), issued
+// from inline asm so the address form is exactly  saddr(SGPR pair) + voffset(VGPR,
+// unsigned bytes) + imm  and nothing 64-bit is precomputed per step.  hipcc does not
+// count these in its own s_waitcnt bookkeeping; every consumer below waits with an
+// explicit counted vmcnt (DMA returns in issue order).  M0 (the LDS destination) is
+// saved/restored inside the statement.  NOTE: the instruction's immediate offset is
+// added to the LDS address as well as to the global address, so it stays 0 and the
+// per-step advance goes into the SGPR base.
+__device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff)[4],
+                                         lds_char* slot) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)slot;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %5 offset:0\n\t"
+      "s_add_u32 m0, %6, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5 offset:0\n\t"
+      "s_add_u32 m0, %6, 0x800\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %5 offset:0\n\t"
+      "s_add_u32 m0, %6, 0xc00\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, %5 offset:0\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(src), "s"(lds_addr)
+      : "memory", "scc");
+}
+
+__device__ __forceinline__ float soft_threshold(float v, float lam) {
+  // ATen softshrink: v>lam ? v-lam : (v<-lam ? v+lam : 0)
+  return v > lam ? v - lam : (v < -lam ? v + lam : 0.0f);
+}
+
+
+// Per-thread constants of the streaming scheme.  Wave w owns rows [32w,32w+32) of
+// Wp (GEMM-1 output columns) and rows [w*K/8, (w+1)*K/8) of Wtp (GEMM-2 output columns).
+template <int K>
+struct TileCtx {
+  int lane, wid, n, q;
+  unsigned voff1[4], voff2[4];   // per-lane DMA source byte offsets (ld = K / ld = 256)
+  int boff[2];                   // B-fragment byte offsets inside a ring slot
+  int aoff[2][2];                // A-fragment byte offsets inside a [16][*] tile row
+  lds_char* ring;                // this wave's 2-slot ring
+  const float* w1;               // Wp  + 32*wid*K
+  const float* w2;               // Wtp + (K/8)*wid*256
+
+  __device__ __forceinline__ void init(const float* Wp, const float* Wtp, lds_char* rings) {
+    const int tid = threadIdx.x;
+    lane = tid & 63;
+    wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    n = lane & 15;
+    q = lane >> 4;
+    // DMA instruction j writes LDS bytes [j*1024, j*1024+1024) lane-linearly = rows
+    // 8j..8j+7 of the step tile, 8 lanes per 128-B row; the XOR swizzle is applied on
+    // the SOURCE chunk.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      voff1[j] = (unsigned)(row * K + 4 * c) * 4u;
+      voff2[j] = (unsigned)(row * kFistaD + 4 * c) * 4u;
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) boff[ss] = n * 128 + (((4 * ss + q) ^ ((n >> 1) & 7)) << 4);
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) aoff[par][ss] = ((8 * par + 4 * ss + q) ^ n) << 4;
+    ring = rings + wid * kRingBytesPerWave;
+    w1 = Wp + (size_t)(32 * wid) * K;
+    w2 = Wtp + (size_t)((K / kFistaWaves) * wid) * kFistaD;
+  }
+};
+
+// GEMM-1:  acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T   (cb = 0,1).
+// Pre:  ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave.
+// Post: ring slots 0/1 have `tail0` / `tail1` (+ tail_voff) in flight.
+template <int K>
+__device__ __forceinline__ void gemm1_stream(const TileCtx<K>& c, lds_char* at, f32x4 (&acc)[2],
+                                             const float* tail0, const float* tail1,
+                                             const unsigned (&tail_voff)[4]) {
+  constexpr int S1 = K / 32;
+  auto step = [&](int s2, auto par_c, const float* pf_src, const unsigned (&pf_voff)[4]) {
+    constexpr int par = decltype(par_c)::value;
+    lds_char* const slot = c.ring + par * kStepBytes;
+    LASSO_WAIT_VMCNT(4);  // this step's 4 DMA pieces have landed
+    f32x4 b[2][2], a[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+        b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      a[ss] = *(const lds_f32x4*)(at + c.n * (K * 4) + s2 * 256 + c.aoff[par][ss]);
+    LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
+    dma_step(pf_src, pf_voff, slot);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[0][ss][j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[1][ss][j], acc[1], 0, 0, 0);
+      }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+#pragma unroll 1
+  for (int s2 = 0; s2 < S1 / 2 - 1; ++s2) {
+    step(s2, P0{}, c.w1 + 64 * s2 + 64, c.voff1);
+    step(s2, P1{}, c.w1 + 64 * s2 + 96, c.voff1);
+  }
+  step(S1 / 2 - 1, P0{}, tail0, tail_voff);
+  step(S1 / 2 - 1, P1{}, tail1, tail_voff);
+}
+
+// wave-wide sum (all lanes get the result), fixed order
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace lasso

@@ -47,6 +47,24 @@ def _declare(lib):
     lib.lasso_fista_run.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
         dbl, dbl, i32, i32, i32, vp, vp, sz, vp]
+    lib.lasso_lipschitz_workspace_bytes.restype = sz
+    lib.lasso_lipschitz_workspace_bytes.argtypes = [i64, i64]
+    lib.lasso_lipschitz.restype = i32
+    lib.lasso_lipschitz.argtypes = [vp, i64, i64, i64, i32, C.POINTER(dbl), vp, sz, vp]
+    lib.lasso_objective_workspace_bytes.restype = sz
+    lib.lasso_objective_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.lasso_objective.restype = i32
+    lib.lasso_objective.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, vp, vp,
+                                    vp, sz, vp]
+    lib.lasso_gram_accumulate.restype = i32
+    lib.lasso_gram_accumulate.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp]
+    lib.lasso_dict_sweep_workspace_bytes.restype = sz
+    lib.lasso_dict_sweep_workspace_bytes.argtypes = [i64, i64]
+    lib.lasso_dict_sweep.restype = i32
+    lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
+                                     C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_zero_columns.restype = i32
+    lib.lasso_zero_columns.argtypes = [vp, i64, i64, i64, i32, vp, vp]
 
 
 def lib():
@@ -102,9 +120,9 @@ def ptr(t):
 _WS = {}
 
 
-def workspace(device, nbytes):
+def workspace(device, nbytes, tag='fista'):
     """A cached device scratch buffer (caller-owned memory of the C ABI)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

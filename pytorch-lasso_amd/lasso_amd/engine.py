@@ -1,0 +1,131 @@
+"""Compute engines behind the EM driver (linear/dict_learning.py, parallel.py).
+
+``HipEngine`` is the product: every method is a call through the C ABI of
+include/lasso_hip.h into the HIP kernels.  The driver only talks to this small
+interface so that its host logic (sharding, collectives, persist/loss ordering)
+can be exercised in CPU unit tests with a stand-in engine defined under tests/
+-- nothing in this package falls back to CPU arithmetic.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self, device=None):
+        nat.require_gpu()
+        self.device = torch.device(device) if device is not None else \
+            torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise nat.NativeError("HipEngine needs a HIP device, got %s" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = nat.lib()
+
+    # -- plumbing ---------------------------------------------------------------
+    def to_device(self, t):
+        return t.detach().to(self.device).contiguous()
+
+    def _ws(self, nbytes, tag):
+        return nat.workspace(self.device, nbytes, tag)
+
+    def _stream(self):
+        return nat.stream_ptr(self.device)
+
+    # -- E-step -------------------------------------------------------------------
+    def encode(self, X, W, alpha, z0, **solver_kwargs):
+        from .linear.sparse_encode import sparse_encode
+        return sparse_encode(X, W, alpha, z0, **solver_kwargs)
+
+    def lipschitz(self, W):
+        from .linear.lipschitz import lipschitz_constant
+        return lipschitz_constant(W)
+
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False):
+        """`iters` iterations from (z_in, y_in); returns (z, y, delta[iters] or None).
+        Building block of the distributed exact-stop E-step (lasso_fista_run)."""
+        n, d = X.shape
+        k = W.shape[1]
+        L = self.lib
+        with torch.cuda.device(self.device):
+            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, it0 + iters, 0.0, nat.STOP_NONE)
+            ws = self._ws(nbytes, "fista")
+            if not prepared:
+                nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32,
+                                                nat.ptr(ws), ws.numel(), self._stream()))
+            z = torch.empty((n, k), dtype=torch.float32, device=self.device)
+            y = torch.empty((n, k), dtype=torch.float32, device=self.device)
+            delta = torch.empty(iters, dtype=torch.float32, device=self.device) if want_delta else None
+            nat.check(L.lasso_fista_run(
+                nat.ptr(X), X.stride(0), nat.ptr(z_in), z_in.stride(0) if z_in is not None else 0,
+                nat.ptr(y_in), y_in.stride(0) if y_in is not None else 0,
+                nat.ptr(z), z.stride(0), nat.ptr(y), y.stride(0), n, d, k, nat.LASSO_F32,
+                float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), nat.ptr(delta),
+                nat.ptr(ws), ws.numel(), self._stream()))
+        return z, y, delta
+
+    # -- objective ---------------------------------------------------------------
+    def objective_sums(self, X, Z, W, alpha):
+        """-> (loss_local 0-d float tensor, sums double[2] = {sum r^2, sum |z|}) on device."""
+        n, d = X.shape
+        k = W.shape[1]
+        L = self.lib
+        with torch.cuda.device(self.device):
+            ws = self._ws(L.lasso_objective_workspace_bytes(n, d, k), "obj")
+            loss = torch.empty((), dtype=torch.float32, device=self.device)
+            sums = torch.empty(2, dtype=torch.float64, device=self.device)
+            nat.check(L.lasso_objective(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0),
+                                        nat.ptr(Z), Z.stride(0), n, d, k, nat.LASSO_F32, float(alpha),
+                                        nat.ptr(loss), nat.ptr(sums), nat.ptr(ws), ws.numel(),
+                                        self._stream()))
+        return loss, sums
+
+    # -- M-step --------------------------------------------------------------------
+    def gram(self, Z, X, out):
+        """out: flat fp32 buffer of k*k + k*d (+extra) floats; A and B are written at its
+        start so one all-reduce covers both."""
+        n, k = Z.shape
+        d = X.shape[1]
+        A = out[:k * k].view(k, k)
+        B = out[k * k:k * k + k * d].view(k, d)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_gram_accumulate(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0),
+                                                     n, d, k, nat.LASSO_F32, nat.ptr(A), nat.ptr(B),
+                                                     self._stream()))
+        return A, B
+
+    def sweep(self, A, B, D, pool, eps, positive, seed=0):
+        """In-place Gauss-Seidel atom sweep on D [d,k].  Returns (mask int32[k] on device,
+        ndeg python int)."""
+        d, k = D.shape
+        L = self.lib
+        with torch.cuda.device(self.device):
+            ws = self._ws(L.lasso_dict_sweep_workspace_bytes(d, k), "sweep")
+            mask = torch.zeros(k, dtype=torch.int32, device=self.device)
+            ndeg = C.c_int32(0)
+            pool_dev = pool.to(self.device).contiguous() if pool is not None else None
+            nat.check(L.lasso_dict_sweep(
+                nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
+                int(bool(positive)), nat.ptr(pool_dev),
+                pool_dev.shape[0] if pool_dev is not None else 0,
+                pool_dev.stride(0) if pool_dev is not None else 0, int(seed) & (2 ** 64 - 1),
+                nat.ptr(mask), C.byref(ndeg), nat.ptr(ws), ws.numel(), self._stream()))
+        return mask, ndeg.value
+
+    def zero_columns(self, Z, mask):
+        n, k = Z.shape
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_zero_columns(nat.ptr(Z), Z.stride(0), n, k, nat.LASSO_F32,
+                                                  nat.ptr(mask), self._stream()))
+
+    def ridge(self, A, B, lam_n):
+        """V = ((A + lam_n I)^-1 B)^T  [d,k] (dict_learning.py:117-121).  k x k Cholesky via
+        torch.linalg (rocSOLVER) -- library call off the FISTA hot path."""
+        M = A.clone()
+        M.diagonal().add_(lam_n)
+        chol = torch.linalg.cholesky(M)
+        return torch.cholesky_solve(B, chol).T.contiguous()

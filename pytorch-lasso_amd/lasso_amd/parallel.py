@@ -1,0 +1,208 @@
+"""EM driver shared by the single-GPU ``dict_learning`` and the batch-sharded
+multi-GPU run (one process per GPU, torch.distributed backend 'nccl' = RCCL).
+
+Sharding: rank r holds a row shard of X (and of Z); the dictionary is
+replicated.  Per EM step:
+  * E-step: local FISTA on the shard.  With the reference's global stop rule active
+    (tol > 0) the per-iteration |z - z_next| sums of a chunk are all-reduced ONCE per
+    chunk and every rank replays to the same stopping iteration (exact global rule);
+  * objective: {sum r^2, sum |z|} all-reduced (2 doubles);
+  * M-step: ONE all-reduce of the fp32 buffer [A = Z^T Z | B = Z^T X], then every rank
+    runs the identical deterministic atom sweep (no broadcast of D).
+The reference has no distributed code; this is the only parallelism strategy the build
+adds (BASELINE.json north_star).
+"""
+import math
+
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+def _world(group):
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _all_reduce(t, group):
+    world, _ = _world(group)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class DegeneratePool:
+    """Replacement directions for degenerate atoms, drawn the way the reference does
+    (``dictionary[:, k].normal_()`` on a CPU tensor, dict_learning.py:93): same generator,
+    same non-contiguous-view code path, and only the directions actually consumed
+    advance the generator."""
+
+    def __init__(self, d, rows=8):
+        self.d, self.rows = d, rows
+
+    def draw(self, rows=None):
+        rows = rows or self.rows
+        state = torch.get_rng_state()
+        buf = torch.empty(self.d, 2)
+        col = buf[:, 0]
+        out = torch.empty(rows, self.d)
+        for i in range(rows):
+            col.normal_()
+            out[i] = col
+        return state, out
+
+    def commit(self, state, used):
+        torch.set_rng_state(state)
+        if used:
+            buf = torch.empty(self.d, 2)
+            col = buf[:, 0]
+            for _ in range(used):
+                col.normal_()
+
+
+def constrained_mstep(engine, A, B, D, pool, eps=1e-10, positive=False, group=None):
+    """Atom sweep on the (already all-reduced) Gram matrices; D updated in place.
+    Returns the degenerate mask (device int32[k]) or None when no atom degenerated."""
+    world, rank = _world(group)
+    rows = pool.rows
+    while True:
+        state, cand = pool.draw(rows)
+        if world > 1:   # every rank must use rank 0's directions
+            cand_dev = cand.to(D.device) if D.is_cuda else cand
+            dist.broadcast(cand_dev, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+            cand = cand_dev
+        D_backup = D.clone() if rows < D.shape[1] else None
+        mask, ndeg = engine.sweep(A, B, D, cand, eps, positive)
+        if ndeg <= rows:
+            pool.commit(state, ndeg)
+            return mask if ndeg > 0 else None
+        # more degenerate atoms than candidates: redo with a larger pool
+        torch.set_rng_state(state)
+        if D_backup is not None:
+            D.copy_(D_backup)
+        rows = min(D.shape[1], max(2 * rows, ndeg))
+
+
+def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
+    """E-step on this rank's shard.  world == 1: plain sparse_encode.  world > 1 with an
+    active stop rule: exact GLOBAL rule through chunked speculation + one all-reduce of
+    the chunk's delta vector (see module docstring)."""
+    world, _ = _world(group)
+    if world == 1:
+        return engine.encode(X, W, alpha, z0, **kw)
+    fast = kw.pop('fast', True)
+    lr = kw.pop('lr', 'auto')
+    maxiter = kw.pop('maxiter', 10)
+    tol = kw.pop('tol', 1e-5)
+    backtrack = kw.pop('backtrack', False)
+    kw.pop('eta_backtrack', None)
+    kw.pop('verbose', None)
+    if kw.get('algorithm', 'ista') != 'ista':
+        raise NotImplementedError("sharded E-step supports algorithm='ista' only")
+    kw.pop('algorithm', None)
+    if kw:
+        raise TypeError("ista() got unexpected keyword arguments %s" % sorted(kw))
+    if backtrack:
+        raise NotImplementedError("sharded E-step: backtrack=True is not implemented")
+    if lr == 'auto':
+        lr = 1.0 / engine.lipschitz(W)
+    n, k = X.shape[0], W.shape[1]
+    if z0 is None:
+        z0 = X.new_zeros(n, k)
+    if maxiter == 0:
+        return z0
+    if not tol > 0:
+        z, _, _ = engine.fista_run(X, W, z0, None, alpha, lr, fast, 0, maxiter, False)
+        return z
+    n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
+    _all_reduce(n_glob, group)
+    budget = torch.tensor(n_glob.item() * k * tol, dtype=torch.float32).item()
+    chunk, done = 64, 0
+    z, y = z0, None
+    while done < maxiter:
+        c = min(chunk, maxiter - done)
+        z2, y2, delta = engine.fista_run(X, W, z, y, alpha, lr, fast, done, c, True)
+        _all_reduce(delta, group)
+        hits = (delta <= budget).nonzero()
+        if hits.numel():
+            i = int(hits[0])
+            if i + 1 < c:
+                z2, _, _ = engine.fista_run(X, W, z, y, alpha, lr, fast, done, i + 1, False)
+            return z2
+        z, y, done = z2, y2, done + c
+    return z
+
+
+def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-2, steps=60,
+            progbar=False, solver_kwargs=None, group=None):
+    """The EM loop of dict_learning.py:35-53 on this rank's row shard ``X`` [n_local, d].
+    ``weight`` [d,k] must be identical on every rank.  Returns (weight, losses[steps])."""
+    solver_kwargs = dict(solver_kwargs or {})
+    world, rank = _world(group)
+    n_local, d = X.shape
+    k = weight.shape[1]
+    n_glob = torch.tensor([float(n_local)], dtype=torch.float64, device=X.device)
+    _all_reduce(n_glob, group)
+    n_total = n_glob.item()
+    losses = torch.zeros(steps, device=X.device)
+    buf = torch.empty(k * k + k * d, dtype=torch.float32, device=X.device)
+    pool = DegeneratePool(d)
+    Z0 = None
+    bar = None
+    if progbar and rank == 0:
+        from tqdm import tqdm
+        bar = tqdm(total=steps)
+    for i in range(steps):
+        Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, **solver_kwargs)   # :38
+        loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
+        if world > 1:
+            _all_reduce(sums, group)
+            losses[i] = ((0.5 * sums[0] + alpha * sums[1]) / n_total).to(torch.float32)
+        else:
+            losses[i] = loss_local
+        if persist:
+            Z0 = Z                                                                        # :40-41
+        A, B = engine.gram(Z, X, buf)
+        _all_reduce(buf, group)
+        if constrained:
+            mask = constrained_mstep(engine, A, B, weight, pool, group=group)             # :44-45
+            if mask is not None:
+                engine.zero_columns(Z, mask)                                              # :98
+        else:
+            weight = engine.ridge(A, B, lambd * n_total)                                  # :46-47
+        if bar is not None:
+            bar.set_postfix(loss=losses[i].item())                                        # :50
+            bar.update(1)
+    if bar is not None:
+        bar.close()
+    return weight, losses
+
+
+def dict_learning_sharded(X_shard, n_components, alpha=1.0, constrained=True, persist=False,
+                          lambd=1e-2, steps=60, progbar=False, init_weight=None, group=None,
+                          engine=None, **solver_kwargs):
+    """Multi-GPU dict_learning: call on every rank with its row shard of X (one process
+    per GPU).  The initial dictionary is drawn on rank 0 exactly like the reference
+    (orthogonal_ + normalisation on the CPU generator) and broadcast."""
+    from .engine import HipEngine
+    engine = engine or HipEngine()
+    world, rank = _world(group)
+    d = X_shard.shape[1]
+    if init_weight is None:
+        weight = torch.empty(d, n_components)
+        torch.nn.init.orthogonal_(weight)
+        if constrained:
+            weight = torch.nn.functional.normalize(weight, dim=0)
+    else:
+        weight = init_weight.detach().clone()
+    Xd = engine.to_device(X_shard)
+    weight = engine.to_device(weight).clone()
+    if world > 1:
+        dist.broadcast(weight, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+    return em_loop(engine, Xd, weight, alpha, constrained=constrained, persist=persist,
+                   lambd=lambd, steps=steps, progbar=progbar, solver_kwargs=solver_kwargs,
+                   group=group)

@@ -1,0 +1,67 @@
+"""CPU stand-in for lasso_amd.engine.HipEngine built on the oracle -- TEST ONLY.
+Lets the host logic of the EM driver (sharding, collectives, persist/loss ordering,
+degenerate-atom RNG protocol) run under gloo on CPU."""
+import torch
+
+from oracle import lasso_oracle as orc
+
+
+class OracleEngine:
+    name = "oracle"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+
+    def to_device(self, t):
+        return t.detach().contiguous()
+
+    def encode(self, X, W, alpha, z0, **kw):
+        return orc.sparse_encode(X, W, alpha, z0, **kw)
+
+    def lipschitz(self, W):
+        return orc.lipschitz_constant(W, "exact")
+
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False):
+        coefs = orc.momentum_schedule(it0 + iters) if fast else [0.0] * (it0 + iters)
+        z = z_in if z_in is not None else X.new_zeros(X.shape[0], W.shape[1])
+        y = y_in if y_in is not None else z
+        deltas = []
+        for i in range(it0, it0 + iters):
+            grad = torch.matmul(torch.matmul(y, W.T) - X, W)
+            zn = orc.soft_threshold(y - lr * grad, alpha * lr)
+            deltas.append((z - zn).abs().sum())
+            y = zn + coefs[i] * (zn - z)
+            z = zn
+        return z, y, (torch.stack(deltas) if want_delta else None)
+
+    def objective_sums(self, X, Z, W, alpha):
+        r = X - Z @ W.T
+        sums = torch.stack([r.double().pow(2).sum(), Z.double().abs().sum()])
+        return orc.lasso_objective(X, Z, W, alpha), sums
+
+    def gram(self, Z, X, out):
+        k, d = Z.shape[1], X.shape[1]
+        A = out[:k * k].view(k, k)
+        B = out[k * k:k * k + k * d].view(k, d)
+        A.copy_(Z.T @ Z)
+        B.copy_(Z.T @ X)
+        return A, B
+
+    def sweep(self, A, B, D, pool, eps, positive, seed=0):
+        used = [0]
+
+        def fresh(j):
+            v = pool[min(used[0], pool.shape[0] - 1)]
+            used[0] += 1
+            return v
+        _, deg = orc.update_dict_gram(D, A.clone(), B.clone(), positive=positive, eps=eps,
+                                      fresh_atom=fresh)
+        return deg.to(torch.int32), int(deg.sum())
+
+    def zero_columns(self, Z, mask):
+        Z[:, mask.bool()] = 0
+
+    def ridge(self, A, B, lam_n):
+        M = A.clone()
+        M.diagonal().add_(lam_n)
+        return torch.cholesky_solve(B, torch.linalg.cholesky(M)).T.contiguous()

@@ -1,0 +1,164 @@
+"""GPU parity of the rows of SURVEY.md 8a beyond the FISTA solve: Lipschitz constant,
+objective, Gram/sweep M-step, ridge M-step and the EM driver -- against the oracle and
+the golden fixtures generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from recipes import recipe_xw, recipe_c4_init, recipe_c5, LAMBDA_MAX_C2, LAMBDA_MAX_C4
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _orc():
+    from oracle import lasso_oracle as orc
+    return orc
+
+
+def test_lipschitz_constant_is_exact_and_deterministic():
+    from lasso_amd.linear.lipschitz import lipschitz_constant
+    _, W = recipe_xw(16)
+    L = lipschitz_constant(W.cuda())
+    assert abs(L - LAMBDA_MAX_C2) <= 1e-9 * LAMBDA_MAX_C2
+    assert lipschitz_constant(W.cuda()) == L                       # bitwise reproducible
+    L4 = lipschitz_constant(recipe_c4_init().cuda())
+    assert abs(L4 - LAMBDA_MAX_C4) <= 1e-9 * LAMBDA_MAX_C4
+    orc = _orc()
+    g = torch.Generator().manual_seed(3)
+    for d, k in [(10, 50), (50, 10), (64, 256), (200, 513), (3, 2), (256, 100)]:
+        W = torch.randn(d, k, generator=g)
+        ref = orc.lipschitz_constant(W, "exact")
+        got = lipschitz_constant(W.cuda())
+        assert abs(got - ref) <= 2e-6 * ref, (d, k, got, ref)      # fp32 input, fp64 math
+    with pytest.raises(TypeError):                                   # like the reference (ista.py:12)
+        lipschitz_constant(W.bfloat16().cuda())
+
+
+def test_lr_auto_matches_reference_within_arpack_jitter(golden):
+    from lasso_amd.linear import sparse_encode
+    orc = _orc()
+    X, W = recipe_xw(256)
+    ref = orc.sparse_encode(X, W, alpha=0.5, maxiter=30, tol=0.0)            # lr='auto' (ARPACK)
+    got = sparse_encode(X.cuda(), W.cuda(), alpha=0.5, maxiter=30, tol=0.0)  # lr='auto' (HIP)
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (100, 48, 200), (1000, 64, 256)])
+def test_lasso_loss(n, d, k):
+    from lasso_amd.linear import lasso_loss
+    orc = _orc()
+    g = torch.Generator().manual_seed(n)
+    X, W = torch.randn(n, d, generator=g), torch.randn(d, k, generator=g)
+    Z = torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)
+    ref = orc.lasso_objective(X, Z, W, 0.7).item()
+    got = lasso_loss(X.cuda(), Z.cuda(), W.cuda(), 0.7)
+    assert got.dim() == 0 and got.is_cuda
+    assert abs(got.item() - ref) <= 2e-6 * abs(ref)
+
+
+def test_update_dict_against_reference_outputs(golden):
+    from lasso_amd.linear import update_dict, update_dict_ridge
+    g = golden("small_cases")
+    for tag in "abcd":
+        X, W = T(g[tag + "_X"]), T(g[tag + "_W"])
+        Z = T(g[tag + "_z_fista"])
+        D, Zc = W.clone().cuda(), Z.clone().cuda()
+        torch.manual_seed(7)
+        out = update_dict(D, X.cuda(), Zc)
+        assert out is D                                               # in place, returns it
+        Dref, Zref = T(g[tag + "_D_bcd"]), T(g[tag + "_Z_after_bcd"])
+        live = (Zref.abs().sum(0) > 0) | (Z.abs().sum(0) == 0)
+        err = (D.cpu() - Dref)[:, Z.abs().sum(0) > 0].abs().max().item()
+        assert err <= 5e-5, (tag, err)
+        assert torch.equal((Zc.cpu() == 0), (Zref == 0)), tag         # zeroed codes match
+        # degenerate atoms: same directions as the reference drew (seed 7, CPU generator)
+        dead = Z.abs().sum(0) == 0
+        if dead.any():
+            assert (D.cpu() - Dref)[:, dead].abs().max().item() <= 1e-6
+        assert (D.norm(dim=0).cpu() - 1).abs().max().item() <= 1e-5
+        V = update_dict_ridge(X.cuda(), Z.cuda(), lambd=1e-2)
+        Vref = T(g[tag + "_D_ridge"])
+        assert (V.cpu() - Vref).abs().max().item() <= 2e-4 * max(1.0, Vref.abs().max().item())
+
+
+def test_update_dict_positive_and_large():
+    from lasso_amd.linear import update_dict
+    orc = _orc()
+    X, W = recipe_xw(2048)
+    Z = orc.sparse_encode(X, W, 0.5, lr=1 / LAMBDA_MAX_C2, maxiter=10, tol=0.0)
+    for positive in (False, True):
+        Dref, Zref = W.clone(), Z.clone()
+        torch.manual_seed(0)
+        orc.update_dict(Dref, X, Zref, positive=positive)
+        D, Zg = W.clone().cuda(), Z.clone().cuda()
+        torch.manual_seed(0)
+        update_dict(D, X.cuda(), Zg, positive=positive)
+        assert (D.cpu() - Dref).abs().max().item() <= 1e-4, positive
+
+
+def test_g1_readme_dict_learning(golden):
+    """BASELINE config 1 through the HIP engine, device='cpu' like the README."""
+    from lasso_amd.linear import dict_learning, sparse_encode
+    g = golden("g1_readme")
+    data = T(g["data"])
+    torch.manual_seed(0)
+    _ = torch.randn(100, 10)
+    D, losses = dict_learning(data, 50, alpha=0.5, algorithm='ista', lr=0.05, progbar=False)
+    assert D.device.type == "cpu" and losses.shape == (60,)
+    assert (losses - T(g["losses_fix"])).abs().max().item() <= 1e-5
+    assert (D - T(g["D_fix"])).abs().max().item() <= 1e-3
+    z = sparse_encode(data, D, alpha=0.2, algorithm='ista', lr=0.05)
+    assert z.device.type == "cpu"
+    assert (z - T(g["z_fix"])).abs().max().item() <= 2e-3
+    # lr='auto' path (native Lipschitz) against the reference's lr='auto' run
+    torch.manual_seed(0)
+    _ = torch.randn(100, 10)
+    Da, la = dict_learning(data, 50, alpha=0.5, algorithm='ista', progbar=False)
+    assert (la - T(g["losses_auto"])).abs().max().item() <= 2e-5
+    np.testing.assert_allclose(la[:3].numpy(), [2.4155431, 2.2525399, 2.1674533], atol=1e-5)
+    np.testing.assert_allclose(la[57:].numpy(), [1.9542167, 1.9540943, 1.9539309], atol=2e-5)
+    # ridge + persist variants
+    torch.manual_seed(0)
+    _ = torch.randn(100, 10)
+    Dr, lr_ = dict_learning(data, 50, alpha=0.5, constrained=False, algorithm='ista', lr=0.05,
+                            progbar=False)
+    assert (lr_ - T(g["losses_ridge"])).abs().max().item() <= 2e-5
+    torch.manual_seed(0)
+    _ = torch.randn(100, 10)
+    Dp, lp = dict_learning(data, 50, alpha=0.5, persist=True, algorithm='ista', lr=0.05,
+                           progbar=False)
+    assert (lp - T(g["losses_persist"])).abs().max().item() <= 2e-5
+
+
+def test_g5_patches(golden):
+    from lasso_amd.linear import dict_learning
+    g = golden("g5_c5_patches")
+    torch.manual_seed(0)
+    X = recipe_c5(8192, reseed=False)
+    D, losses = dict_learning(X.cuda(), 256, alpha=0.1, steps=10, algorithm='ista', progbar=False,
+                              device='cuda', init_weight=T(g["D0"]))
+    assert (losses.cpu() - T(g["losses"])).abs().max().item() <= 1e-4     # SURVEY 8d G5 tolerance
+    assert (D.cpu() - T(g["D"])).abs().max().item() <= 5e-3
+
+
+def test_g4_c4_em_steps(golden):
+    """BASELINE config 4 on one GPU (full n=65536): first EM steps equal the reference's."""
+    from lasso_amd.linear import dict_learning
+    g = golden("g4_c4_em")
+    X, _ = recipe_xw(65536)
+    D0 = recipe_c4_init()
+    assert np.array_equal(D0[0, :3].numpy(), g["check_D0"])
+    Xg = X.cuda()
+    D, losses = dict_learning(Xg, 1024, alpha=0.5, steps=3, algorithm='ista', progbar=False,
+                              device='cuda', init_weight=D0)
+    ref = T(g["c_losses_auto"])
+    assert abs(losses[0].item() - 59.917267) <= 1e-4
+    assert (losses.cpu() - ref).abs().max().item() <= 2e-4
+    assert (D[:, :32].cpu() - T(g["c_D_cols_auto"])).abs().max().item() <= 2e-3
+    Dr, lr_ = dict_learning(Xg, 1024, alpha=0.5, constrained=False, steps=3, algorithm='ista',
+                            progbar=False, device='cuda', init_weight=D0)
+    assert (lr_.cpu() - T(g["r_losses_auto"])).abs().max().item() <= 5e-4
