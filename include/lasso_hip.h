@@ -66,9 +66,15 @@ int lasso_hip_device_cus(int* cus_out);
  *   iters_out / last_delta_out (HOST pointers, nullable): iterations executed and
  *   the last evaluated sum|z - z_next| (only when the stop rule is active).
  *   x, W, z0 are never written; z_out may alias z0.
+ *   backtrack != 0: Beck-Teboulle backtracking line search (ista.py:17-54) from lr
+ *   every outer iteration (the accepted step is discarded, ista.py:87), eta_backtrack
+ *   > 1 (else LASSO_ERR_BAD_ARG, the reference's ValueError :18-19).  Line search and
+ *   stop rule are global over the batch; the call synchronises `stream` once per outer
+ *   iteration.  If no step is accepted within 1000 trials the iteration falls back to lr
+ *   and the call returns LASSO_WARN_LINESEARCH after completing (ista.py:48-52).
  */
 size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
-                                   int maxiter, double tol, int stop_mode);
+                                   int maxiter, double tol, int stop_mode, int backtrack);
 
 int lasso_fista_solve(const void* x_dev, int64_t ldx,
                       const void* w_dev, int64_t ldw,
@@ -77,6 +83,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx,
                       int64_t n, int64_t d, int64_t k, int dtype,
                       double alpha, double lr, int fast, int maxiter,
                       double tol, int stop_mode,
+                      int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 

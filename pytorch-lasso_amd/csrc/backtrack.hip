@@ -1,0 +1,291 @@
+// Backtracking line search (Beck-Teboulle), replaces lasso/linear/solvers/ista.py:17-54.
+// All sums are over the WHOLE batch (one step size for every sample), like the reference.
+// Per outer iteration at the point p (y for FISTA, z for ISTA):
+//   bt_grad_kernel    r0 = p W^T - x, g0 = r0 W -> HBM, rss0 partials        (:22-24)
+//   bt_trial_kernel   z+ = S(p - lr g0) -> HBM candidate, r1 = z+ W^T - x,
+//                     partials {sum r1^2, sum|z+|, sum dz*g0, sum dz^2}         (:40-42)
+//   bt_decide_kernel  F <= Q ?  (fp32, operation order of :26-35,45)  -> accepted flag
+//   bt_finish_kernel  sum|z - z+|, y = z+ + c (z+ - z), z = z+                   (:93-102)
+// Trial kernels launched after an accepted trial exit immediately (they read the flag),
+// so a batch of trials can be enqueued without a host round trip per trial.
+// Rooflines: grad = 4ndk flop, each trial = 2ndk flop (MFMA-bound, same streams as the
+// fused kernel); finish is an HBM-bound elementwise pass (5 n k floats moved).
+#include "tile_device.hpp"
+
+namespace lasso {
+
+template <int K>
+__global__ __launch_bounds__(kFistaThreads, 2) void bt_grad_kernel(const BtParams p) {
+  constexpr int D = kFistaD;
+  constexpr int NW = kFistaWaves;
+  constexpr int KW = K / NW;
+  constexpr int NP = KW / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const rings = (lds_char*)smem;
+  lds_char* const pt = rings + NW * kRingBytesPerWave;
+  lds_char* const rt = pt + kTileM * K * 4;
+  lds_f32* const red = (lds_f32*)(rt + kTileM * D * 4);
+
+  TileCtx<K> c;
+  c.init(p.Wp, p.Wtp, rings);
+  const int tid = threadIdx.x;
+  const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+  dma_step(c.w1, c.voff1, c.ring);
+  dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+    for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+      const int r = idx / K, cc = idx - r * K;
+      float v = 0.0f;
+      if ((row0 + r) < p.n && cc < p.k) v = p.P[(int64_t)(row0 + r) * p.ldp + cc];
+      *(lds_f32*)(pt + tile_off<K>(r, cc)) = v;
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+        float v = 0.0f;
+        if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+        acc[cb][rg] = -v;
+      }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    gemm1_stream<K>(c, pt, acc, c.w2, c.w2 + 32, c.voff2);
+    float rss = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        rss = fmaf(acc[cb][rg], acc[cb][rg], rss);
+        *(lds_f32*)(rt + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = acc[cb][rg];
+      }
+    rss = wave_sum(rss);
+    if (lane == 0) red[wid] = rss;
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+      float a = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += red[w];
+      p.partials[tile] = a;
+    }
+    f32x4 rf[D / 32][2];
+    load_r_frags<K>(c, rt, rf);
+    float* const g_base = p.G + (int64_t)row0 * p.k;
+    static_for<NP>([&](auto ps_c) {
+      constexpr int ps = decltype(ps_c)::value;
+      f32x4 g2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      gemm2_pass<K, ps>(c, rf, g2);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 4 * q + rg, cc = wid * KW + 32 * ps + 16 * cb + n;
+          if ((row0 + r) < p.n && cc < p.k) g_base[r * p.k + cc] = g2[cb][rg];
+        }
+    });
+    __builtin_amdgcn_s_barrier();   // pt / rt / red reuse by the next tile
+  }
+  LASSO_WAIT_VMCNT(0);
+}
+
+template <int K>
+__global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtParams p, float lr,
+                                                                    float lam, int force) {
+  constexpr int NW = kFistaWaves;
+  if (!force && p.flags[0] != 0) return;   // an earlier trial of this iteration was accepted
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const rings = (lds_char*)smem;
+  lds_char* const zt = rings + NW * kRingBytesPerWave;
+  lds_f32* const red = (lds_f32*)(zt + kTileM * K * 4);
+
+  TileCtx<K> c;
+  c.init(p.Wp, p.Wp, rings);
+  const int tid = threadIdx.x;
+  const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+  dma_step(c.w1, c.voff1, c.ring);
+  dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+    float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+    for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+      const int r = idx / K, cc = idx - r * K;
+      float zn = 0.0f;
+      if ((row0 + r) < p.n && cc < p.k) {
+        const float pv = p.P[(int64_t)(row0 + r) * p.ldp + cc];
+        const float g = p.G[(int64_t)(row0 + r) * p.k + cc];
+        zn = soft_threshold(__fsub_rn(pv, __fmul_rn(lr, g)), lam);          // ista.py:40
+        p.C[(int64_t)(row0 + r) * p.k + cc] = zn;
+        const float dz = __fsub_rn(zn, pv);                                   // :31
+        l1 += __builtin_fabsf(zn);
+        dzg = __fadd_rn(dzg, __fmul_rn(dz, g));
+        dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+      }
+      *(lds_f32*)(zt + tile_off<K>(r, cc)) = zn;
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+        float v = 0.0f;
+        if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+        acc[cb][rg] = -v;
+      }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    gemm1_stream<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
+    float rss = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) rss = fmaf(acc[cb][rg], acc[cb][rg], rss);
+    rss = wave_sum(rss); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
+    if (lane == 0) { red[4 * wid] = rss; red[4 * wid + 1] = l1; red[4 * wid + 2] = dzg; red[4 * wid + 3] = dz2; }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    if (tid < 4) {
+      float a = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += red[4 * w + tid];
+      p.partials[(int64_t)p.ntiles * (1 + tid) + tile] = a;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  LASSO_WAIT_VMCNT(0);
+}
+
+// One block.  partials layout: [0][t] rss0, [1][t] rss1, [2][t] l1, [3][t] dz.g0, [4][t] dz^2.
+// flags: [0] accepted, [1] trials evaluated so far this iteration, [2] index of accepted trial.
+// fvals: [0] F, [1] Q of the last evaluated trial (diagnostics), [2] accepted lr
+__global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict__ partials, int ntiles,
+                                                        float alpha, float half_over_lr, float lr,
+                                                        int trial_index, int force,
+                                                        int* __restrict__ flags, float* __restrict__ fvals) {
+  if (!force && flags[0] != 0) return;
+  __shared__ double sh[5][256];
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int t = threadIdx.x; t < ntiles; t += 256)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) acc[s] += partials[(size_t)s * ntiles + t];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) sh[s][threadIdx.x] = acc[s];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+#pragma unroll
+      for (int s = 0; s < 5; ++s) sh[s][threadIdx.x] += sh[s][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float rss0 = (float)sh[0][0], rss1 = (float)sh[1][0], l1 = (float)sh[2][0];
+    const float dzg = (float)sh[3][0], dz2 = (float)sh[4][0];
+    const float f0 = __fmul_rn(0.5f, rss0);                                        // ista.py:23
+    const float al1 = __fmul_rn(alpha, l1);
+    const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                         // :28
+    const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(half_over_lr, dz2)), al1);  // :32-35
+    fvals[0] = F; fvals[1] = Q;
+    flags[1] = trial_index + 1;
+    if (force || F <= Q) { flags[0] = 1; flags[2] = trial_index; fvals[2] = lr; }  // :45
+  }
+}
+
+// z_next = C (accepted candidate): delta partials, momentum, state update.  Grid-stride
+// over n*k with a FIXED grid so the reduction order is deterministic.
+__global__ __launch_bounds__(256) void bt_finish_kernel(float* __restrict__ Z, int64_t ldz,
+                                                        float* __restrict__ Y, const float* __restrict__ Cand,
+                                                        int n, int k, float coef, const int* __restrict__ flags,
+                                                        float* __restrict__ dpart) {
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  if (flags[0] != 0) {
+    const int64_t total = (int64_t)n * k;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+      const int64_t r = idx / k;
+      const int cc = (int)(idx - r * k);
+      const float zo = Z[r * ldz + cc];
+      const float zn = Cand[idx];
+      acc += __builtin_fabsf(__fsub_rn(zo, zn));                                   // ista.py:93
+      Y[idx] = __fadd_rn(zn, __fmul_rn(coef, __fsub_rn(zn, zo)));                  // :99-100
+      Z[r * ldz + cc] = zn;                                                        // :102
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dpart[blockIdx.x] = sh[0];
+}
+
+template <int K>
+static hipError_t set_lds(const void* fn, size_t lds) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int K>
+static hipError_t launch_grad_k(const BtParams& p, int grid, hipStream_t stream) {
+  const size_t lds = fista_tile_lds_bytes(K);
+  static bool done = false;
+  if (!done) {
+    hipError_t e = set_lds<K>(reinterpret_cast<const void*>(&bt_grad_kernel<K>), lds);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL(bt_grad_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_trial_k(const BtParams& p, float lr, float lam, int force, int grid,
+                                 hipStream_t stream) {
+  const size_t lds = (size_t)kFistaWaves * kRingBytesPerWave + (size_t)kTileM * K * 4 + 256;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = set_lds<K>(reinterpret_cast<const void*>(&bt_trial_kernel<K>), lds);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL(bt_trial_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p, lr, lam, force);
+  return hipGetLastError();
+}
+
+hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream) {
+  switch (kpad) {
+    case 256: return launch_grad_k<256>(p, grid, stream);
+    case 512: return launch_grad_k<512>(p, grid, stream);
+    case 1024: return launch_grad_k<1024>(p, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
+                           int trial_index, int force, hipStream_t stream) {
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  hipError_t e;
+  switch (kpad) {
+    case 256: e = launch_trial_k<256>(p, lr_f, lam, force, grid, stream); break;
+    case 512: e = launch_trial_k<512>(p, lr_f, lam, force, grid, stream); break;
+    case 1024: e = launch_trial_k<1024>(p, lr_f, lam, force, grid, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bt_decide_kernel, dim3(1), dim3(256), 0, stream, p.partials, p.ntiles,
+                     (float)alpha, (float)(0.5 / lr), lr_f, trial_index, force, p.flags, p.fvals);
+  return hipGetLastError();
+}
+
+hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
+                            float coef, const int* flags, float* dpart, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(bt_finish_kernel, dim3(grid), dim3(256), 0, stream, Z, ldz, Y, Cand, n, k, coef,
+                     flags, dpart);
+  return hipGetLastError();
+}
+
+}  // namespace lasso

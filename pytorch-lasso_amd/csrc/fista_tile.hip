@@ -119,42 +119,13 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       f32x4 rf[T2][2];
-#pragma unroll
-      for (int t = 0; t < T2; ++t)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-          rf[t][ss] = *(const lds_f32x4*)(rt + n * (D * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
+      load_r_frags<K>(c, rt, rf);
 
       // ================= GEMM-2 + prox/momentum epilogue ================
       static_for<NP>([&](auto ps_c) {
         constexpr int ps = decltype(ps_c)::value;
         f32x4 g2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        static_for<T2>([&](auto t_c) {
-          constexpr int t = decltype(t_c)::value;
-          constexpr int U = ps * T2 + t;            // step index inside GEMM-2
-          lds_char* const slot = c.ring + (U & 1) * kStepBytes;
-          LASSO_WAIT_VMCNT(4);
-          f32x4 b[2][2];
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-              b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
-          LASSO_WAIT_LGKM0();
-          if constexpr (U + 2 < NP * T2) {
-            constexpr int pn = (U + 2) / T2, tn = (U + 2) % T2;
-            dma_step(c.w2 + (size_t)(32 * pn) * D + 32 * tn, c.voff2, slot);
-          } else {
-            dma_step(c.w1 + 32 * (U + 2 - NP * T2), c.voff1, slot);   // next iteration's GEMM-1
-          }
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              g2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[0][ss][j], g2[0], 0, 0, 0);
-              g2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[1][ss][j], g2[1], 0, 0, 0);
-            }
-        });
+        gemm2_pass<K, ps>(c, rf, g2);
         // epilogue for the 2 finished column blocks (in-place y update is safe:
         // GEMM-1 of this iteration is complete for every wave)
 #pragma unroll

@@ -198,6 +198,118 @@ int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64
   return LASSO_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// backtracking driver (ista.py:17-54 + the outer loop :79-102)
+// ---------------------------------------------------------------------------
+constexpr int kBtFinishGrid = 1024;
+constexpr int kBtBatch = 8;          // trials enqueued per host round trip
+constexpr int kBtMaxTrials = 1000;   // ista.py:17 (maxiter=1000)
+
+struct BtWorkspace {
+  float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
+  float* G; float* C; float* Y;
+  size_t bytes;
+};
+
+BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp) {
+  BtWorkspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes);
+    return reinterpret_cast<float*>(r);
+  };
+  const int64_t ntiles = (n + kTileM - 1) / kTileM;
+  w.wp = take((size_t)kFistaD * kp * 4);
+  w.wtp = take((size_t)kp * kFistaD * 4);
+  w.partials = take((size_t)5 * std::max<int64_t>(ntiles, 1) * 4);
+  w.dpart = take((size_t)kBtFinishGrid * 4);
+  w.delta = take(256);
+  w.flags = reinterpret_cast<int*>(take(256));
+  w.fvals = take(256);
+  w.G = take((size_t)n * k * 4);
+  w.C = take((size_t)n * k * 4);
+  w.Y = take((size_t)n * k * 4);
+  w.bytes = off;
+  return w;
+}
+
+int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* z0,
+                       int64_t ldz0, float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, int kp,
+                       double alpha, double lr0, int fast, int maxiter, double tol, double eta,
+                       int32_t* iters_out, float* last_delta_out, void* workspace, size_t ws_bytes,
+                       hipStream_t st) {
+  BtWorkspace ws = carve_bt(workspace, n, k, kp);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  const int cus = device_cus();
+  if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
+  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  const int grid = std::min(ntiles, cus);
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, st, w, ldw, (int)d,
+                     (int)k, kp, ws.wp, ws.wtp);
+  LASSO_HIP_TRY(hipGetLastError());
+  // working state: z lives in zout, y in the workspace (y0 = z0, ista.py:76-78)
+  if (z0) {
+    if (z0 != zout)
+      LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  } else {
+    LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+  }
+  LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+
+  BtParams p;
+  p.X = x; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
+  p.G = ws.G; p.C = ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
+  p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
+  const float budget = (float)((double)n * (double)k * tol);
+  bool warned = false;
+  double t_mom = 1.0;   // ista.py:78 (python int 1; same arithmetic in double)
+  struct { int flags[4]; float delta; } host;
+  int it = 0;
+  float last = NAN;
+  for (; it < maxiter; ++it) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;             // :98
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;                 // :99
+    p.P = fast ? ws.Y : zout;
+    p.ldp = fast ? k : ldz;
+    LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
+    LASSO_HIP_TRY(launch_bt_grad(p, kp, grid, st));
+    double lr = lr0;
+    int t = 0;
+    bool accepted = false;
+    while (!accepted) {
+      const bool give_up = t >= kBtMaxTrials;
+      const int batch = give_up ? 1 : std::min(kBtBatch, kBtMaxTrials - t);
+      for (int b = 0; b < batch; ++b) {
+        if (give_up) {   // ista.py:48-52: warn and revert to the initial step size
+          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr0, t, 1, st));
+          warned = true;
+        } else {
+          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr, t + b, 0, st));
+          lr = lr / eta;                                                               // :47
+        }
+      }
+      t += batch;
+      LASSO_HIP_TRY(launch_bt_finish(zout, ldz, ws.Y, ws.C, (int)n, (int)k, coef, ws.flags, ws.dpart,
+                                     kBtFinishGrid, st));
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kBtFinishGrid, ws.delta);
+      LASSO_HIP_TRY(hipGetLastError());
+      LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipMemcpyAsync(&host.delta, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      accepted = host.flags[0] != 0;
+    }
+    last = host.delta;
+    t_mom = t_next;
+    if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95
+  }
+  if (iters_out) *iters_out = it;
+  if (last_delta_out) *last_delta_out = last;
+  return warned ? fail(LASSO_WARN_LINESEARCH, "backtracking line search failed; reverted to lr0") : LASSO_OK;
+}
+
 }  // namespace
 }  // namespace lasso
 
@@ -228,10 +340,11 @@ int lasso_hip_device_cus(int* cus_out) {
 }
 
 size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
-                                   double tol, int stop_mode) {
+                                   double tol, int stop_mode, int backtrack) {
   (void)d; (void)dtype;
   const int kp = pad_k(k);
   if (kp < 0 || n < 0) return 0;
+  if (backtrack) return carve_bt(nullptr, n, k, kp).bytes;
   const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
 }
@@ -282,15 +395,16 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
 int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
                       const void* z0_dev, int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n,
                       int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
-                      int maxiter, double tol, int stop_mode, int32_t* iters_out,
-                      float* last_delta_out, void* workspace_dev, size_t workspace_bytes,
-                      void* stream) {
+                      int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
+                      int32_t* iters_out, float* last_delta_out, void* workspace_dev,
+                      size_t workspace_bytes, void* stream) {
   if (int s = check_common(n, d, k, dtype)) return s;
   if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
   if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k))
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
+  if (backtrack && !(eta_backtrack > 1.0)) return fail(LASSO_ERR_BAD_ARG, "eta must be > 1.");
   hipStream_t st = (hipStream_t)stream;
   if (iters_out) *iters_out = 0;
   if (last_delta_out) *last_delta_out = NAN;
@@ -313,6 +427,10 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const bool stop_rule = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL;
   const int kp = pad_k(k);
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
+  if (backtrack)
+    return solve_backtracking(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, kp,
+                              alpha, lr, fast, maxiter, stop_rule ? tol : 0.0, eta_backtrack,
+                              iters_out, last_delta_out, workspace_dev, workspace_bytes, st);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
     return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);

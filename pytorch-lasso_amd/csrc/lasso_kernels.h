@@ -53,11 +53,29 @@ struct SweepParams {
   float eps; int positive;
 };
 
+// backtracking line search (backtrack.hip)
+struct BtParams {
+  const float* X; int64_t ldx;
+  const float* Wp; const float* Wtp;
+  const float* P; int64_t ldp;           // the point p (y or z)
+  float* G;                              // [n][k] gradient at p
+  float* C;                              // [n][k] candidate z_next
+  float* partials;                       // [5][ntiles]
+  int* flags; float* fvals;
+  int n, d, k, ntiles;
+};
+
 size_t fista_tile_lds_bytes(int kpad);
 hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);
+
+hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
+hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
+                           int trial_index, int force, hipStream_t stream);
+hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
+                            float coef, const int* flags, float* dpart, int grid, hipStream_t stream);
 
 size_t lipschitz_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,

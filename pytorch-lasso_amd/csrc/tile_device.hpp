@@ -152,6 +152,55 @@ __device__ __forceinline__ void gemm1_stream(const TileCtx<K>& c, lds_char* at, 
   step(S1 / 2 - 1, P1{}, tail1, tail_voff);
 }
 
+
+// GEMM-2, pass PS:  g2[cb] = r_tile[16][256] * Wtp[wid*K/8 + 32*PS + 16*cb .. +16][256]^T.
+// `rf` are the r fragments (A layout) of the whole tile; the ring is refilled two steps
+// ahead from the W^T stream and, past its end, with steps 0/1 of the next GEMM-1.
+template <int K, int PS>
+__device__ __forceinline__ void gemm2_pass(const TileCtx<K>& c, const f32x4 (&rf)[kFistaD / 32][2],
+                                           f32x4 (&g2)[2]) {
+  constexpr int D = kFistaD;
+  constexpr int T2 = D / 32;
+  constexpr int NP = (K / kFistaWaves) / 32;
+  static_for<T2>([&](auto t_c) {
+    constexpr int t = decltype(t_c)::value;
+    constexpr int U = PS * T2 + t;            // step index inside GEMM-2
+    lds_char* const slot = c.ring + (U & 1) * kStepBytes;
+    LASSO_WAIT_VMCNT(4);
+    f32x4 b[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+        b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
+    LASSO_WAIT_LGKM0();
+    if constexpr (U + 2 < NP * T2) {
+      constexpr int pn = (U + 2) / T2, tn = (U + 2) % T2;
+      dma_step(c.w2 + (size_t)(32 * pn) * D + 32 * tn, c.voff2, slot);
+    } else {
+      dma_step(c.w1 + 32 * (U + 2 - NP * T2), c.voff1, slot);   // next GEMM-1, steps 0/1
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[0][ss][j], g2[0], 0, 0, 0);
+        g2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[1][ss][j], g2[1], 0, 0, 0);
+      }
+  });
+}
+
+// load all r fragments (A layout) of a swizzled [16][256] tile
+template <int K>
+__device__ __forceinline__ void load_r_frags(const TileCtx<K>& c, lds_char* rt,
+                                             f32x4 (&rf)[kFistaD / 32][2]) {
+#pragma unroll
+  for (int t = 0; t < kFistaD / 32; ++t)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      rf[t][ss] = *(const lds_f32x4*)(rt + c.n * (kFistaD * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
+}
+
 // wave-wide sum (all lanes get the result), fixed order
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

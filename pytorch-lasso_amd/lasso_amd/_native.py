@@ -35,11 +35,11 @@ def _declare(lib):
     lib.lasso_hip_last_error.restype = C.c_char_p
     lib.lasso_hip_device_cus.argtypes = [C.POINTER(i32)]
     lib.lasso_fista_workspace_bytes.restype = sz
-    lib.lasso_fista_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, dbl, i32]
+    lib.lasso_fista_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, dbl, i32, i32]
     lib.lasso_fista_solve.restype = i32
     lib.lasso_fista_solve.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
-        dbl, dbl, i32, i32, dbl, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+        dbl, dbl, i32, i32, dbl, i32, i32, dbl, C.POINTER(C.c_int32), C.POINTER(C.c_float),
         vp, sz, vp]
     lib.lasso_fista_prepare.restype = i32
     lib.lasso_fista_prepare.argtypes = [vp, i64, i64, i64, i32, vp, sz, vp]

@@ -52,7 +52,7 @@ class HipEngine:
         k = W.shape[1]
         L = self.lib
         with torch.cuda.device(self.device):
-            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, it0 + iters, 0.0, nat.STOP_NONE)
+            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, it0 + iters, 0.0, nat.STOP_NONE, 0)
             ws = self._ws(nbytes, "fista")
             if not prepared:
                 nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32,

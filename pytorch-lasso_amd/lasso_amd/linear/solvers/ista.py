@@ -53,21 +53,20 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         from ..lipschitz import lipschitz_constant
         lr = 1.0 / lipschitz_constant(wg)                          # ista.py:59-63
     lr = float(lr)
-    if backtrack:
-        raise NotImplementedError("lasso_amd: backtrack=True is not implemented yet")
 
     L = nat.lib()
     z = torch.empty((n, k), dtype=x.dtype, device=dev)
     with torch.cuda.device(dev):
         nbytes = L.lasso_fista_workspace_bytes(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
-                                               nat.STOP_GLOBAL)
+                                               nat.STOP_GLOBAL, int(bool(backtrack)))
         ws = nat.workspace(dev, nbytes)
         iters = C.c_int32(0)
         last = C.c_float(float('nan'))
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
-            int(maxiter), float(tol), nat.STOP_GLOBAL, C.byref(iters), C.byref(last),
+            int(maxiter), float(tol), nat.STOP_GLOBAL, int(bool(backtrack)), float(eta_backtrack),
+            C.byref(iters), C.byref(last),
             nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         nat.check(st)
     if z.device != out_device:

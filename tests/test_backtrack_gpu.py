@@ -1,0 +1,88 @@
+"""GPU parity of the backtracking line search (ista.py:17-54): HIP vs oracle on small
+cases, vs the golden z of the reference, and BASELINE config 3 (fp32) at full size."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from recipes import recipe_xw, LAMBDA_MAX_C2
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_small_cases_against_reference_outputs(golden):
+    from lasso_amd.linear import sparse_encode
+    g = golden("small_cases")
+    for tag in "abcd":
+        X, W = T(g[tag + "_X"]), T(g[tag + "_W"])
+        z = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, fast=True, lr=1.0, maxiter=8, tol=0.0,
+                          backtrack=True)
+        assert (z.cpu() - T(g[tag + "_z_bt"])).abs().max().item() <= 5e-5, tag
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_trace_matches_oracle(fast):
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    X, W = recipe_xw(512)
+    z0 = X.new_zeros(512, 1024)
+    tr = orc.FistaTrace()
+    ref = orc.fista(X, z0, W, 0.5, fast=fast, lr=1.0, maxiter=6, tol=0.0, backtrack=True, trace=tr)
+    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.5, fast=fast, lr=1.0, maxiter=6, tol=0.0,
+                     backtrack=True, return_info=True)
+    assert info["iterations"] == 6
+    assert (got.cpu() - ref).abs().max().item() <= 5e-5
+    # with a stop tolerance: same number of outer iterations
+    tr2 = orc.FistaTrace()
+    orc.fista(X, z0, W, 0.5, fast=fast, lr=1.0, maxiter=200, tol=1e-3, backtrack=True, trace=tr2)
+    _, info2 = ista(X.cuda(), z0.cuda(), W.cuda(), 0.5, fast=fast, lr=1.0, maxiter=200, tol=1e-3,
+                    backtrack=True, return_info=True)
+    assert abs(info2["iterations"] - tr2.iterations) <= 1
+    # lr0 already admissible -> one trial per iteration, identical to the fixed-step solve
+    fixed = ista(X.cuda(), z0.cuda(), W.cuda(), 0.5, fast=fast, lr=1 / LAMBDA_MAX_C2, maxiter=6, tol=0.0)
+    bt = ista(X.cuda(), z0.cuda(), W.cuda(), 0.5, fast=fast, lr=1 / LAMBDA_MAX_C2, maxiter=6, tol=0.0,
+              backtrack=True)
+    assert (fixed - bt).abs().max().item() <= 2e-5
+
+
+def test_c3_fp32_full_size(golden):
+    """BASELINE config 3 (fp32 leg): n=16384, lr0=1.0, 10 iterations; SURVEY 8d G3."""
+    from lasso_amd.linear import sparse_encode
+    from oracle import lasso_oracle as orc
+    g = golden("g3_c3_backtrack")
+    X, W = recipe_xw(16384)
+    z = sparse_encode(X.cuda(), W.cuda(), alpha=0.5, lr=1.0, maxiter=10, tol=0.0, backtrack=True).cpu()
+    obj = orc.lasso_objective(X, z, W, 0.5).item()
+    assert abs(obj - 64.142166) <= 1e-5 * 64.142166
+    assert (z[:64, :64] - T(g["fp32_z_block"])).abs().max().item() <= 1e-4
+    st = g["fp32_stats"]
+    assert abs(z.double().abs().sum().item() - st[1]) <= 1e-5 * st[1]
+    z = sparse_encode(X.cuda(), W.cuda(), alpha=0.5, fast=False, lr=1.0, maxiter=5, tol=0.0,
+                      backtrack=True).cpu()
+    obj = orc.lasso_objective(X, z, W, 0.5).item()
+    assert abs(obj - float(g["fp32_ista_bt_obj"])) <= 1e-5 * obj
+
+
+def test_eta_and_failure_semantics():
+    from lasso_amd.linear import sparse_encode
+    from oracle import lasso_oracle as orc
+    X, W = recipe_xw(64)
+    with pytest.raises(ValueError):                                   # ista.py:18-19
+        sparse_encode(X.cuda(), W.cuda(), lr=1.0, backtrack=True, eta_backtrack=1.0)
+    # eta barely above 1: 1000 trials are not enough to reach 1/L from lr0=1e3 -> warn + revert
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ref = orc.sparse_encode(X, W, alpha=0.5, lr=1e3, maxiter=1, tol=0.0, backtrack=True,
+                                eta_backtrack=1.000001)
+    assert any("backtracking" in str(w.message) for w in rec)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = sparse_encode(X.cuda(), W.cuda(), alpha=0.5, lr=1e3, maxiter=1, tol=0.0, backtrack=True,
+                            eta_backtrack=1.000001)
+    assert any("backtracking" in str(w.message) for w in rec)
+    assert torch.allclose(got.cpu(), ref, atol=1e-2, rtol=1e-4)
