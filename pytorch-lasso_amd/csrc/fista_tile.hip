@@ -117,7 +117,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
         for (int rg = 0; rg < 4; ++rg)
           *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
       LASSO_WAIT_LGKM0();
+#ifndef LASSO_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
       f32x4 rf[T2][2];
       load_r_frags<K>(c, rt, rf);
 
@@ -128,6 +130,10 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
         gemm2_pass<K, ps>(c, rf, g2);
         // epilogue for the 2 finished column blocks (in-place y update is safe:
         // GEMM-1 of this iteration is complete for every wave)
+#ifdef LASSO_ABL_NOEPI   // timing ablation only (results invalid)
+        asm volatile("" :: "v"(g2[0]), "v"(g2[1]));
+        if (false)
+#endif
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -149,7 +155,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_kernel(const Fist
       dsum = wave_sum(dsum);
       if (lane == 0) red[wid] = dsum;
       LASSO_WAIT_LGKM0();
+#ifndef LASSO_ABL_NOBAR
       __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete
+#endif
       if (p.partials && tid == 0) {
         float tsum = 0.0f;
 #pragma unroll

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -143,6 +144,16 @@ int device_cus() {
   return cached;
 }
 
+// Kernel variant: 16 waves per workgroup (default) or 8 (LASSO_FISTA_WAVES=8, kept for A/B).
+int fista_waves() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("LASSO_FISTA_WAVES");
+    v = (e && atoi(e) == 8) ? 8 : 16;
+  }
+  return v;
+}
+
 int check_common(int64_t n, int64_t d, int64_t k, int dtype) {
   if (dtype != LASSO_F32)
     return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
@@ -178,7 +189,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
-  LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream));
+  if (fista_waves() == 16) LASSO_HIP_TRY(launch_fista_tile16(p, kp, grid, stream));
+  else LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream));
   if (delta && iters > 0) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
                        ntiles, delta);

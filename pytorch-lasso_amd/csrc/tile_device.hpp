@@ -18,8 +18,25 @@ using lds_f32 = __attribute__((address_space(3))) float;
 using lds_f32x4 = __attribute__((address_space(3))) f32x4;
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
+#ifdef LASSO_ABL_NOVMWAIT   // timing ablation only (results invalid)
+#define LASSO_WAIT_VMCNT(n)
+#else
 #define LASSO_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#endif
 #define LASSO_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+// Raise the wave's issue priority around an MFMA cluster: the two waves sharing a SIMD
+// then alternate (one bursts MFMAs while the other does its LDS reads / DMA issue)
+// instead of converging to lockstep and idling the matrix pipe together.
+#ifndef LASSO_SETPRIO
+#define LASSO_SETPRIO 1
+#endif
+#if LASSO_SETPRIO
+#define LASSO_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define LASSO_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define LASSO_PRIO_HI()
+#define LASSO_PRIO_LO()
+#endif
 
 constexpr int kStepBytes = 4096;               // 32 rows x 128 B
 constexpr int kRingBytesPerWave = 2 * kStepBytes;
@@ -42,6 +59,9 @@ __device__ __forceinline__ int tile_off(int row, int col) {
 // per-step advance goes into the SGPR base.
 __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff)[4],
                                          lds_char* slot) {
+#ifdef LASSO_ABL_NODMA      // timing ablation only (results invalid)
+  return;
+#endif
   const unsigned lds_addr = (unsigned)(uintptr_t)slot;
   unsigned keep;
   asm volatile(
@@ -133,6 +153,7 @@ __device__ __forceinline__ void gemm1_stream(const TileCtx<K>& c, lds_char* at, 
       a[ss] = *(const lds_f32x4*)(at + c.n * (K * 4) + s2 * 256 + c.aoff[par][ss]);
     LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
     dma_step(pf_src, pf_voff, slot);
+    LASSO_PRIO_HI();
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -140,6 +161,7 @@ __device__ __forceinline__ void gemm1_stream(const TileCtx<K>& c, lds_char* at, 
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[0][ss][j], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[1][ss][j], acc[1], 0, 0, 0);
       }
+    LASSO_PRIO_LO();
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
@@ -180,6 +202,7 @@ __device__ __forceinline__ void gemm2_pass(const TileCtx<K>& c, const f32x4 (&rf
     } else {
       dma_step(c.w1 + 32 * (U + 2 - NP * T2), c.voff1, slot);   // next GEMM-1, steps 0/1
     }
+    LASSO_PRIO_HI();
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -187,6 +210,7 @@ __device__ __forceinline__ void gemm2_pass(const TileCtx<K>& c, const f32x4 (&rf
         g2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[0][ss][j], g2[0], 0, 0, 0);
         g2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rf[t][ss][j], b[1][ss][j], g2[1], 0, 0, 0);
       }
+    LASSO_PRIO_LO();
   });
 }
 

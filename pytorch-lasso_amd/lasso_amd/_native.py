@@ -24,7 +24,8 @@ class NativeError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblasso_hip.so")
+    # LASSO_HIP_LIB: developer override used for A/B builds of the kernels (tools/)
+    return os.environ.get("LASSO_HIP_LIB") or os.path.join(_HERE, "liblasso_hip.so")
 
 
 def _declare(lib):
