@@ -20,6 +20,9 @@ constexpr int kStep = 2048;                // 16 rows x 128 B
 constexpr int kRing = 2 * kStep;
 
 __device__ __forceinline__ void dma2(const float* src, const unsigned (&voff)[2], lds_char* slot) {
+#ifdef LASSO_ABL_NODMA      // timing ablation only (results invalid)
+  return;
+#endif
   const unsigned lds_addr = (unsigned)(uintptr_t)slot;
   unsigned keep;
   asm volatile(
@@ -77,11 +80,16 @@ __device__ __forceinline__ void step(const Ctx<K>& c, const lds_char* atile_row,
   lds_char* const slot = c.ring + PAR * kStep;
   LASSO_WAIT_VMCNT(2);
   f32x4 b[2], a[2];
+#ifdef LASSO_ABL_NOLDS      // timing ablation only (results invalid)
+  b[0] = acc[0]; b[1] = acc[1]; a[0] = acc[1]; a[1] = acc[0];
+  asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]));
+#else
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss) b[ss] = *(const lds_f32x4*)(slot + c.boff[ss]);
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss) a[ss] = *(const lds_f32x4*)(atile_row + c.aoff[PAR][ss]);
   LASSO_WAIT_LGKM0();
+#endif
   dma2(pf_src, pf_voff, slot);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -186,6 +194,10 @@ __global__ __launch_bounds__(kThreads, 4) void fista_tile16_kernel(const FistaTi
             step<K, (U & 1)>(c, rrow + (t >> 1) * 256, g2, c.w1 + 32 * (U + 2 - NP * T2), c.voff1);
           }
         });
+#ifdef LASSO_ABL_NOEPI   // timing ablation only (results invalid)
+        asm volatile("" :: "v"(g2[0]), "v"(g2[1]));
+        if (false)
+#endif
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           lds_f32* const yp = (lds_f32*)(yt + tile_off<K>(4 * qo + rg, wid * KW + 16 * ps + no));

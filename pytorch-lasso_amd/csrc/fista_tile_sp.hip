@@ -1,0 +1,367 @@
+// Software-pipelined 8-wave variant of the fused persistent FISTA kernel.
+// Algorithm, LDS layouts, W streaming and MFMA operand convention: see fista_tile.hip.
+//
+// Why: all waves of a workgroup run the same instruction stream in near lockstep (the
+// two barriers per iteration re-align them), so any stretch in which a wave is NOT
+// issuing MFMAs -- waiting for its ds_read fragments, issuing LDS-DMA, running the prox
+// epilogue -- is a stretch in which EVERY wave on the SIMD is idle and the matrix pipe
+// drains (ablations on MI355X: epilogue 7 %, DMA issue 5 %, fragment waits ~10 %).
+// Here each wave hides those stretches behind its OWN MFMAs:
+//   * B/A fragments of step g+1 are read into a second register set while the MFMAs of
+//     step g run (the ring slot is released -- and refilled by LDS-DMA with step g+3 --
+//     as soon as those reads have returned, a few MFMAs into step g);
+//   * the prox/momentum epilogue of GEMM-2 pass p runs between the MFMAs of the first
+//     step of pass p+1 (two alternating accumulator sets).
+#include "tile_device.hpp"
+
+namespace lasso {
+namespace sp {
+
+struct Frag {
+  f32x4 b[2][2];   // [col-block][k-half]
+  f32x4 a[2];      // [k-half]       (GEMM-1 only; GEMM-2 uses the r fragments)
+};
+
+template <int K>
+__device__ __forceinline__ void load_b(const TileCtx<K>& c, Frag& f, const lds_char* slot) {
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) f.b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
+}
+
+template <int K>
+__device__ __forceinline__ void load_a(const TileCtx<K>& c, Frag& f, const lds_char* row_chunk, int par) {
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) f.a[ss] = *(const lds_f32x4*)(row_chunk + c.aoff[par][ss]);
+}
+
+// MFMAs number [LO, HI) of the 16 of a step (order: k-half, j, col-block)
+template <int LO, int HI>
+__device__ __forceinline__ void mfma_range(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f) {
+  static_for<HI - LO>([&](auto i_c) {
+    constexpr int i = LO + decltype(i_c)::value;
+    constexpr int ss = i / 8, j = (i % 8) / 2, cb = i % 2;
+    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], f.b[cb][ss][j], acc[cb], 0, 0, 0);
+  });
+}
+
+// one LDS-DMA instruction (1 KiB = rows 8j..8j+7 of a step tile); see dma_step()
+__device__ __forceinline__ void dma_piece(const float* src, unsigned voff, lds_char* dst) {
+#ifdef LASSO_ABL_NODMA      // timing ablation only (results invalid)
+  return;
+#endif
+  const unsigned lds_addr = (unsigned)(uintptr_t)dst;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:0\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(src), "s"(lds_addr)
+      : "memory");
+}
+
+// pin the issue order at this point (hipcc otherwise sinks the prefetching ds_reads down
+// to their first use and re-exposes the LDS latency the pipeline is there to hide)
+#define LASSO_PIN() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int kHead = 4;   // MFMAs issued before the mid-step "slot free -> DMA refill" point
+
+// MFMAs 0..15 of one step on fragments `f` with the refill of `slot` (4 LDS-DMA pieces)
+// spread between them; e0..e3 are optional epilogue stages run in the four gaps.
+template <typename E0, typename E1, typename E2, typename E3>
+__device__ __forceinline__ void step_body(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f,
+                                          const float* src, const unsigned (&voff)[4], lds_char* slot,
+                                          E0&& e0, E1&& e1, E2&& e2, E3&& e3) {
+  LASSO_PIN();
+  mfma_range<0, kHead>(acc, a, f);
+  LASSO_PIN();
+  LASSO_WAIT_LGKM0();                 // the prefetching ds_reads have returned: slot is free
+  dma_piece(src, voff[0], slot);
+  LASSO_PIN();
+  e0();
+  mfma_range<4, 7>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[1], slot + 1024);
+  LASSO_PIN();
+  e1();
+  mfma_range<7, 10>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[2], slot + 2048);
+  LASSO_PIN();
+  e2();
+  mfma_range<10, 13>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[3], slot + 3072);
+  LASSO_PIN();
+  e3();
+  mfma_range<13, 16>(acc, a, f);
+  LASSO_PIN();
+}
+__device__ __forceinline__ void no_stage() {}
+
+template <int K>
+__global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
+  constexpr int D = kFistaD;
+  constexpr int NW = kFistaWaves;
+  constexpr int S1 = K / 32;
+  constexpr int KW = K / NW;
+  constexpr int NP = KW / 32;
+  constexpr int T2 = D / 32;
+  constexpr int S2 = NP * T2;
+  constexpr int YT_BYTES = kTileM * K * 4;
+  constexpr int RT_BYTES = kTileM * D * 4;
+  static_assert(D == 32 * NW && S1 % 2 == 0 && S2 % 2 == 0 && S1 >= 6 && S2 >= 4, "geometry");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const rings = (lds_char*)smem;
+  lds_char* const yt = rings + NW * kRingBytesPerWave;
+  lds_char* const rt = yt + YT_BYTES;
+  lds_f32* const red = (lds_f32*)(rt + RT_BYTES);
+
+  TileCtx<K> c;
+  c.init(p.Wp, p.Wtp, rings);
+  const int tid = threadIdx.x;
+  const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+  lds_char* const slot0 = c.ring;
+  lds_char* const slot1 = c.ring + kStepBytes;
+
+  // Ring invariant on entry of GEMM-1 (every iteration, every tile):
+  //   X.b holds the B fragments of step 0; slot1 <- step 1, slot0 <- step 2 in flight.
+  Frag X, Y;
+  dma_step(c.w1, c.voff1, slot0);
+  dma_step(c.w1 + 32, c.voff1, slot1);
+  LASSO_WAIT_VMCNT(4);
+  load_b<K>(c, X, slot0);
+  LASSO_WAIT_LGKM0();
+  dma_step(c.w1 + 64, c.voff1, slot0);
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+    {
+      const float* ysrc = p.y_in ? p.y_in : p.z_in;
+      const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
+      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+        const int r = idx / K, cc = idx - r * K;
+        float v = 0.0f;
+        if (ysrc && (row0 + r) < p.n && cc < p.k) v = ysrc[(int64_t)(row0 + r) * ldy + cc];
+        *(lds_f32*)(yt + tile_off<K>(r, cc)) = v;
+      }
+    }
+    f32x4 zreg[NP][2];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 4 * q + rg, cc = wid * KW + 32 * ps + 16 * cb + n;
+          float v = 0.0f;
+          if (p.z_in && (row0 + r) < p.n && cc < p.k)
+            v = (p.z_in + (int64_t)row0 * p.ldz_in)[r * (int)p.ldz_in + cc];
+          zreg[ps][cb][rg] = v;
+        }
+    f32x4 xneg[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+        float v = 0.0f;
+        if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+        xneg[cb][rg] = -v;
+      }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+
+    for (int it = 0; it < p.iters; ++it) {
+      const float coef = p.coef[it];
+      float dsum = 0.0f;
+      int no = n, qo = q;
+      asm volatile("" : "+v"(no), "+v"(qo));
+      const lds_char* const yrow = yt + n * (K * 4);
+
+      // ======================= GEMM-1: r = y W^T - x =========================
+      f32x4 acc[2] = {xneg[0], xneg[1]};
+      load_a<K>(c, X, yrow, 0);                       // A fragments of step 0 (y is final now)
+      // one trip = steps s = 2*s2 (on X) and s+1 (on Y).  srcE/srcO: DMA refills issued
+      // in the even/odd step (steps s+3 / s+4 of the stream).
+      auto trip = [&](int s2, const float* srcE, const unsigned (&voffE)[4], const float* srcO,
+                      const unsigned (&voffO)[4], auto last_c) {
+        constexpr bool last = decltype(last_c)::value;
+        // ---- even step: compute X, fetch step s+1 -> Y
+        LASSO_WAIT_VMCNT(4);
+        load_b<K>(c, Y, slot1);
+        load_a<K>(c, Y, yrow + s2 * 256, 1);
+        step_body(acc, X.a, X, srcE, voffE, slot1, no_stage, no_stage, no_stage, no_stage);
+        // ---- odd step: compute Y, fetch step s+2 -> X (B only when it is GEMM-2's step 0)
+        LASSO_WAIT_VMCNT(4);
+        load_b<K>(c, X, slot0);
+        if constexpr (!last) load_a<K>(c, X, yrow + (s2 + 1) * 256, 0);
+        step_body(acc, Y.a, Y, srcO, voffO, slot0, no_stage, no_stage, no_stage, no_stage);
+      };
+      using F = std::false_type;
+      using T = std::true_type;
+#pragma unroll 1
+      for (int s2 = 0; s2 < S1 / 2 - 2; ++s2)
+        trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
+      // steps S1-4, S1-3: refills are W step S1-1 and W^T step 0
+      trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, c.w2, c.voff2, F{});
+      // steps S1-2, S1-1: refills are W^T steps 1 and 2
+      trip(S1 / 2 - 1, c.w2 + 32, c.voff2, c.w2 + 64, c.voff2, T{});
+      // now X.b = B fragments of GEMM-2 step 0; slot1 <- W^T step 1, slot0 <- W^T step 2
+
+      // r tile -> LDS, everyone reads all of it
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      f32x4 rf[T2][2];
+      load_r_frags<K>(c, rt, rf);
+
+      // ================= GEMM-2 + pipelined prox/momentum epilogue ==============
+      f32x4 g2[2][2];   // [pass parity][col-block]
+      f32x4 yv[2], yn[2];   // epilogue temporaries: y read from / written to the LDS tile
+      // The prox/momentum epilogue of pass ps, cut into four stages that are issued in
+      // the gaps between the MFMAs of the NEXT pass's first step.
+      auto ep_addr = [&](auto ps_c, int cb, int rg) {
+        constexpr int ps = decltype(ps_c)::value;
+        return (lds_f32*)(yt + tile_off<K>(4 * qo + rg, wid * KW + 32 * ps + 16 * cb + no));
+      };
+      auto ep_read = [&](auto ps_c) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) yv[cb][rg] = *ep_addr(ps_c, cb, rg);
+      };
+      auto ep_math = [&](auto ps_c, auto cb_c) {
+        constexpr int ps = decltype(ps_c)::value;
+        constexpr int cb = decltype(cb_c)::value;
+#ifdef LASSO_ABL_NOEPI   // timing ablation only (results invalid)
+        asm volatile("" :: "v"(g2[ps & 1][cb]));
+        if (false)
+#endif
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float zo = zreg[ps][cb][rg];
+          const float stp = __fmul_rn(p.lr, g2[ps & 1][cb][rg]);              // lr * grad
+          const float zn = soft_threshold(__fsub_rn(yv[cb][rg], stp), p.lam);
+          dsum += __builtin_fabsf(__fsub_rn(zo, zn));                          // |z - z_next|
+          const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));                // c (z_next - z)
+          yn[cb][rg] = __fadd_rn(zn, mom);
+          zreg[ps][cb][rg] = zn;
+        }
+      };
+      auto ep_write = [&](auto ps_c) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) *ep_addr(ps_c, cb, rg) = yn[cb][rg];
+      };
+      using CB0 = std::integral_constant<int, 0>;
+      using CB1 = std::integral_constant<int, 1>;
+      static_for<S2>([&](auto u_c) {
+        constexpr int U = decltype(u_c)::value;
+        constexpr int ps = U / T2, t = U % T2;
+        Frag& cur = (U & 1) ? Y : X;
+        Frag& nxt = (U & 1) ? X : Y;
+        lds_char* const nslot = (U & 1) ? slot0 : slot1;     // slot of step U+1
+        if constexpr (t == 0) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) g2[ps & 1][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        LASSO_WAIT_VMCNT(4);
+        load_b<K>(c, nxt, nslot);            // step U+1 (for U = S2-1: next iteration's GEMM-1 step 0)
+        const float* src;
+        if constexpr (U + 3 < S2) {
+          constexpr int pn = (U + 3) / T2, tn = (U + 3) % T2;
+          src = c.w2 + (size_t)(32 * pn) * D + 32 * tn;
+        } else {
+          src = c.w1 + 32 * (U + 3 - S2);    // next GEMM-1, steps 0..2
+        }
+        const unsigned (&voff)[4] = (U + 3 < S2) ? c.voff2 : c.voff1;
+        if constexpr (t == 0 && ps > 0) {
+          using PP = std::integral_constant<int, ps - 1>;
+          step_body(g2[ps & 1], rf[t], cur, src, voff, nslot,
+                    [&] { ep_read(PP{}); }, [&] { ep_math(PP{}, CB0{}); },
+                    [&] { ep_math(PP{}, CB1{}); }, [&] { ep_write(PP{}); });
+        } else {
+          step_body(g2[ps & 1], rf[t], cur, src, voff, nslot, no_stage, no_stage, no_stage, no_stage);
+        }
+      });
+      {   // last pass: nothing left to hide behind
+        using PL = std::integral_constant<int, NP - 1>;
+        ep_read(PL{}); ep_math(PL{}, CB0{}); ep_math(PL{}, CB1{}); ep_write(PL{});
+      }
+
+      dsum = wave_sum(dsum);
+      if (lane == 0) red[wid] = dsum;
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete
+      if (p.partials && tid == 0) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += red[w];
+        p.partials[(int64_t)it * p.ntiles + tile] = tsum;
+      }
+    }
+
+    {
+      int no = n, qo = q;
+      asm volatile("" : "+v"(no), "+v"(qo));
+      float* const zo_base = p.z_out + (int64_t)row0 * p.ldz_out;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 4 * qo + rg, cc = wid * KW + 32 * ps + 16 * cb + no;
+            if ((row0 + r) < p.n && cc < p.k) zo_base[r * (int)p.ldz_out + cc] = zreg[ps][cb][rg];
+          }
+    }
+    if (p.y_out) {
+      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
+        const int r = idx / K, cc = idx - r * K;
+        if ((row0 + r) < p.n && cc < p.k)
+          p.y_out[(int64_t)(row0 + r) * p.ldy_out + cc] = *(const lds_f32*)(yt + tile_off<K>(r, cc));
+      }
+    }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+  }
+  LASSO_WAIT_VMCNT(0);
+}
+
+template <int K>
+static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
+  const size_t lds = fista_tile_lds_bytes(K);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fista_tile_sp_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace sp
+
+hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int grid, hipStream_t stream) {
+  switch (kpad) {
+    case 256: return sp::launch_k<256>(p, grid, stream);
+    case 512: return sp::launch_k<512>(p, grid, stream);
+    case 1024: return sp::launch_k<1024>(p, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace lasso

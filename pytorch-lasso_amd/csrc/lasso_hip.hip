@@ -144,12 +144,15 @@ int device_cus() {
   return cached;
 }
 
-// Kernel variant: 16 waves per workgroup (default) or 8 (LASSO_FISTA_WAVES=8, kept for A/B).
-int fista_waves() {
+// Kernel variant (developer A/B switch): LASSO_FISTA_VARIANT = w8 | w16 | w8p (default:
+// w8p, the software-pipelined 8-wave kernel).
+int fista_variant() {
   static int v = 0;
   if (!v) {
-    const char* e = getenv("LASSO_FISTA_WAVES");
-    v = (e && atoi(e) == 8) ? 8 : 16;
+    const char* e = getenv("LASSO_FISTA_VARIANT");
+    if (e && !strcmp(e, "w8")) v = 8;
+    else if (e && !strcmp(e, "w16")) v = 16;
+    else v = 1;
   }
   return v;
 }
@@ -189,8 +192,11 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
-  if (fista_waves() == 16) LASSO_HIP_TRY(launch_fista_tile16(p, kp, grid, stream));
-  else LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream));
+  switch (fista_variant()) {
+    case 8: LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream)); break;
+    case 16: LASSO_HIP_TRY(launch_fista_tile16(p, kp, grid, stream)); break;
+    default: LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, grid, stream)); break;
+  }
   if (delta && iters > 0) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
                        ntiles, delta);

@@ -4,7 +4,7 @@ set -e
 NAME=$1; shift
 SRC=/root/repo/pytorch-lasso_amd/csrc
 OUT=/root/repo/variants; mkdir -p $OUT/obj_$NAME
-for f in lasso_hip fista_tile lipschitz objective mstep backtrack; do
+for f in $(cd $SRC && ls *.hip | sed "s/[.]hip\$//"); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 "$@" -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
