@@ -68,6 +68,17 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned voff, lds_c
 // to their first use and re-exposes the LDS latency the pipeline is there to hide)
 #define LASSO_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Waves w and w+4 share a SIMD and leave every barrier in lockstep, so their non-MFMA
+// gaps coincide; delaying the second half by a fraction of a step staggers them.
+#ifndef LASSO_DESYNC_SLEEP
+#define LASSO_DESYNC_SLEEP 0
+#endif
+#if LASSO_DESYNC_SLEEP > 0
+#define LASSO_DESYNC() do { if (wid >= 4) __builtin_amdgcn_s_sleep(LASSO_DESYNC_SLEEP); } while (0)
+#else
+#define LASSO_DESYNC()
+#endif
+
 constexpr int kHead = 4;   // MFMAs issued before the mid-step "slot free -> DMA refill" point
 
 // MFMAs 0..15 of one step on fragments `f` with the refill of `slot` (4 LDS-DMA pieces)
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
           *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
+      LASSO_DESYNC();
       f32x4 rf[T2][2];
       load_r_frags<K>(c, rt, rf);
 
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       if (lane == 0) red[wid] = dsum;
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete
+      LASSO_DESYNC();
       if (p.partials && tid == 0) {
         float tsum = 0.0f;
 #pragma unroll

@@ -86,3 +86,22 @@ def test_eta_and_failure_semantics():
                             eta_backtrack=1.000001)
     assert any("backtracking" in str(w.message) for w in rec)
     assert torch.allclose(got.cpu(), ref, atol=1e-2, rtol=1e-4)
+
+
+def test_c3_bf16_leg(golden):
+    """BASELINE config 3, bf16 tensors: objective (evaluated in fp32) within rtol 2e-3 of the
+    reference's bf16 run; lr='auto' raises TypeError like the reference."""
+    from lasso_amd.linear import sparse_encode
+    from oracle import lasso_oracle as orc
+    g = golden("g3_c3_backtrack")
+    X, W = recipe_xw(16384)
+    Xb, Wb = X.bfloat16(), W.bfloat16()
+    z = sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5, lr=1.0, maxiter=10, tol=0.0, backtrack=True)
+    assert z.dtype == torch.bfloat16 and z.is_cuda
+    obj = orc.lasso_objective(Xb.float(), z.float().cpu(), Wb.float(), 0.5).item()
+    assert abs(obj - float(g["bf16_obj_fp32eval"])) <= 2e-3 * obj
+    z = sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5, lr=1.0 / LAMBDA_MAX_C2, maxiter=10, tol=0.0)
+    obj = orc.lasso_objective(Xb.float(), z.float().cpu(), Wb.float(), 0.5).item()
+    assert abs(obj - float(g["bf16_fixed_obj_fp32eval"])) <= 2e-3 * obj
+    with pytest.raises(TypeError):
+        sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5)
