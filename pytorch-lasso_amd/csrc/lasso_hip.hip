@@ -474,8 +474,9 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   int done = 0, flip = 0;
   std::vector<float> hdelta(kChunkMax);
   float last = NAN;
+  int next_chunk = kChunkMax;
   while (done < maxiter) {
-    const int c = std::min(kChunkMax, maxiter - done);
+    const int c = std::min(next_chunk, maxiter - done);
     const bool final_chunk = (done + c == maxiter);
     float* nz = final_chunk ? zout : ws.state[2 * flip];
     const int64_t nldz = final_chunk ? ldz : k;
@@ -507,6 +508,27 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     done += c;
     cur_z = nz; cur_ldz = nldz; cur_y = ny; cur_ldy = k;
     flip ^= 1;
+    // Size the next speculative chunk from the decay of the deltas seen so far (purely a
+    // scheduling heuristic -- the stop decision itself stays exact): estimate the
+    // iterations left until delta <= budget from the geometric decay over the chunk and
+    // approach the predicted stop with short chunks so that little work is wasted or replayed.
+    next_chunk = kChunkMax;
+    if (c >= 8 && budget > 0.0f) {
+      const int h = c / 2;
+      float hi = 0.0f, lo = 0.0f;
+      for (int i = 0; i < h; ++i) hi = std::max(hi, hdelta[i]);
+      for (int i = h; i < c; ++i) lo = std::max(lo, hdelta[i]);
+      if (lo > budget && hi > lo) {
+        const double rate = log((double)hi / lo) / h;              // per-iteration log decay
+        const double left = log((double)lo / budget) / rate;       // iterations still needed
+        if (left < 2.0 * kChunkMax) {
+          const int guess = (int)left - 6;
+          next_chunk = guess >= kChunkMax ? kChunkMax : std::max(8, std::min(guess, kChunkMax));
+        }
+      } else if (lo <= budget * 4.0f) {
+        next_chunk = 8;
+      }
+    }
   }
   if (iters_out) *iters_out = done;
   if (last_delta_out) *last_delta_out = last;

@@ -10,7 +10,8 @@
 // which converges to lambda_max from below with relative error <= ~1/(e*N) per
 // eigenvalue clustered at the top (p = 20: ~3.5e-7 worst case, exact to fp64
 // rounding for any realistic gap).  Cost: p+1 small fp64 GEMMs (2 m^3 flop each,
-// 33.5 MFLOP at m = 256) -- launch-latency bound, not on the FISTA hot loop.
+// 33.5 MFLOP at m = 256) on v_mfma_f64_16x16x4_f64 -- launch-latency bound, not on the
+// FISTA hot loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "lasso_kernels.h"
@@ -35,65 +36,43 @@ __device__ double block_trace(const double* __restrict__ A, int m, int ld, doubl
   return t;
 }
 
-// G[i][j] = sum_t w(i,t) w(j,t),  w(i,t) = W[i*si + t*st]  (fp32 in, fp64 accumulate).
-// Output is zero-padded to mp x mp (mp multiple of 32).
-__global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ W, int64_t si,
-                                                       int64_t st, int m, int len, int mp,
-                                                       double* __restrict__ G) {
-  __shared__ double sa[kLipTile][kLipTile + 1], sb[kLipTile][kLipTile + 1];
-  const int i0 = blockIdx.y * kLipTile, j0 = blockIdx.x * kLipTile;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 2x2 outputs each
-  double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-  for (int t0 = 0; t0 < len; t0 += kLipTile) {
-    for (int e = threadIdx.x; e < kLipTile * kLipTile; e += 256) {
-      const int r = e / kLipTile, c = e % kLipTile;   // r: row in tile, c: t index
-      const int t = t0 + c;
-      sa[r][c] = (i0 + r < m && t < len) ? (double)W[(int64_t)(i0 + r) * si + (int64_t)t * st] : 0.0;
-      sb[r][c] = (j0 + r < m && t < len) ? (double)W[(int64_t)(j0 + r) * si + (int64_t)t * st] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int c = 0; c < kLipTile; ++c) {
-      const double a0 = sa[ty][c], a1 = sa[ty + 16][c], b0 = sb[tx][c], b1 = sb[tx + 16][c];
-      c00 = fma(a0, b0, c00); c01 = fma(a0, b1, c01);
-      c10 = fma(a1, b0, c10); c11 = fma(a1, b1, c11);
-    }
-    __syncthreads();
-  }
-  G[(size_t)(i0 + ty) * mp + j0 + tx] = c00;
-  G[(size_t)(i0 + ty) * mp + j0 + tx + 16] = c01;
-  G[(size_t)(i0 + ty + 16) * mp + j0 + tx] = c10;
-  G[(size_t)(i0 + ty + 16) * mp + j0 + tx + 16] = c11;
-}
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// C = (A/s)(A/s)^T with s = tr(A)   (A symmetric => both operands row-contiguous)
-__global__ __launch_bounds__(256) void square_f64_kernel(const double* __restrict__ A, int mp,
-                                                         double* __restrict__ C) {
-  __shared__ double sa[kLipTile][kLipTile + 1], sb[kLipTile][kLipTile + 1];
+// C[mp x mp] = (s A)(s A)^T on v_mfma_f64_16x16x4_f64, A given as elem(i,t) = A[i*si + t*st]
+// (TIn = float for the Gram of W, double for the squarings), rows >= m and t >= len read 0.
+// One workgroup = 4 waves = one 32x32 tile (a 16x16 block per wave); the t-range is staged
+// through LDS in chunks of 32.  SCALE: s = 1/tr(A) (A square, ld = si), else s = 1.
+// MFMA f64 layouts: A/B one double per lane (row l&15, k = l>>4); C/D col = l&15,
+// row = (l>>4) + 4*reg.
+template <typename TIn, bool SCALE>
+__global__ __launch_bounds__(256) void syrk_f64_kernel(const TIn* __restrict__ A, int64_t si, int64_t st,
+                                                       int m, int len, int mp, double* __restrict__ C) {
+  constexpr int RS = 33;                            // padded row stride (doubles)
+  __shared__ double sa[32][RS], sb[32][RS];
   __shared__ double sh[256];
-  const double inv = 1.0 / block_trace(A, mp, mp, sh);
-  const int i0 = blockIdx.y * kLipTile, j0 = blockIdx.x * kLipTile;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-  for (int t0 = 0; t0 < mp; t0 += kLipTile) {
-    for (int e = threadIdx.x; e < kLipTile * kLipTile; e += 256) {
-      const int r = e / kLipTile, c = e % kLipTile;
-      sa[r][c] = A[(size_t)(i0 + r) * mp + t0 + c] * inv;
-      sb[r][c] = A[(size_t)(j0 + r) * mp + t0 + c] * inv;
+  double inv = 1.0;
+  if constexpr (SCALE) inv = 1.0 / block_trace(reinterpret_cast<const double*>(A), m, (int)si, sh);
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int t0 = 0; t0 < len; t0 += 32) {
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int r = e >> 5, cc = e & 31;            // consecutive threads -> consecutive t
+      const int t = t0 + cc;
+      sa[r][cc] = (i0 + r < m && t < len) ? (double)A[(int64_t)(i0 + r) * si + (int64_t)t * st] * inv : 0.0;
+      sb[r][cc] = (j0 + r < m && t < len) ? (double)A[(int64_t)(j0 + r) * si + (int64_t)t * st] * inv : 0.0;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int c = 0; c < kLipTile; ++c) {
-      const double a0 = sa[ty][c], a1 = sa[ty + 16][c], b0 = sb[tx][c], b1 = sb[tx + 16][c];
-      c00 = fma(a0, b0, c00); c01 = fma(a0, b1, c01);
-      c10 = fma(a1, b0, c10); c11 = fma(a1, b1, c11);
-    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[iw + l15][4 * ks + q], sb[jw + l15][4 * ks + q], acc, 0, 0, 0);
     __syncthreads();
   }
-  C[(size_t)(i0 + ty) * mp + j0 + tx] = c00;
-  C[(size_t)(i0 + ty) * mp + j0 + tx + 16] = c01;
-  C[(size_t)(i0 + ty + 16) * mp + j0 + tx] = c10;
-  C[(size_t)(i0 + ty + 16) * mp + j0 + tx + 16] = c11;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+    C[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
 }
 
 // out[0] = <G, P>_F / tr(P)   (single block, fixed summation order)
@@ -132,11 +111,12 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   double* G = out + 32;
   double* P[2] = {G + (size_t)mp * mp, G + 2 * (size_t)mp * mp};
   const dim3 grid(mp / kLipTile, mp / kLipTile);
-  hipLaunchKernelGGL(gram_f64_kernel, grid, dim3(256), 0, stream, W, rows ? ldw : (int64_t)1,
-                     rows ? (int64_t)1 : ldw, m, len, mp, G);
+  hipLaunchKernelGGL((syrk_f64_kernel<float, false>), grid, dim3(256), 0, stream, W,
+                     rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, G);
   const double* src = G;
   for (int p = 0; p < squarings; ++p) {
-    hipLaunchKernelGGL(square_f64_kernel, grid, dim3(256), 0, stream, src, mp, P[p & 1]);
+    hipLaunchKernelGGL((syrk_f64_kernel<double, true>), grid, dim3(256), 0, stream, src, (int64_t)mp,
+                       (int64_t)1, mp, mp, mp, P[p & 1]);
     src = P[p & 1];
   }
   hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, src, mp, out);

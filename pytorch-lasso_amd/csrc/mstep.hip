@@ -32,67 +32,67 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the per-MFMA operand read "16 consecutive floats of 4 consecutive rows" is
 // conflict-free).  sym != 0: P == Q, only blocks bj >= bi are computed and mirrored.
 // ---------------------------------------------------------------------------
-constexpr int kGB = 64, kGS = 32, kGLd = 80;
+constexpr int kGB = 64, kGS = 64, kGLd = 80;
 
+// VEC: every row segment is 16-byte aligned and the column counts are multiples of 4,
+// so the staging loads are float4 (the usual case: k, d, ld multiples of 4).
+template <bool VEC>
 __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ P, int64_t ldp, int pc,
                                                       const float* __restrict__ Q, int64_t ldq, int qc,
                                                       int n, float* __restrict__ C, int64_t ldc, int sym) {
   if (sym && blockIdx.x < blockIdx.y) return;
-  __shared__ float sp[2][kGS][kGLd], sq[2][kGS][kGLd];
+  __shared__ __attribute__((aligned(16))) float sp[kGS][kGLd], sq[kGS][kGLd];
   const int i0 = blockIdx.y * kGB, j0 = blockIdx.x * kGB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int l15 = lane & 15, q = lane >> 4;
   f32x4 acc[2][2] = {};
-  // staging map: thread -> (row = tid/16 [+16], 4 consecutive columns)
+  // staging map: thread -> rows srow + 16h (h = 0..3), 4 consecutive columns
   const int srow = tid >> 4, scol = (tid & 15) * 4;
-  float stg[2][2][4];   // [P/Q][half][4]
+  f32x4 stg[2][4];   // [P/Q][h]
 
   auto load_chunk = [&](int s0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
       const int r = s0 + srow + 16 * h;
+      if constexpr (VEC) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        stg[0][h] = (r < n && i0 + scol < pc) ? *(const f32x4*)(P + (int64_t)r * ldp + i0 + scol) : z;
+        stg[1][h] = (r < n && j0 + scol < qc) ? *(const f32x4*)(Q + (int64_t)r * ldq + j0 + scol) : z;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int cp = i0 + scol + e, cq = j0 + scol + e;
-        stg[0][h][e] = (r < n && cp < pc) ? P[(int64_t)r * ldp + cp] : 0.0f;
-        stg[1][h][e] = (r < n && cq < qc) ? Q[(int64_t)r * ldq + cq] : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+          const int cp = i0 + scol + e, cq = j0 + scol + e;
+          stg[0][h][e] = (r < n && cp < pc) ? P[(int64_t)r * ldp + cp] : 0.0f;
+          stg[1][h][e] = (r < n && cq < qc) ? Q[(int64_t)r * ldq + cq] : 0.0f;
+        }
       }
     }
   };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sp[buf][srow + 16 * h][scol + e] = stg[0][h][e];
-        sq[buf][srow + 16 * h][scol + e] = stg[1][h][e];
-      }
-  };
 
   load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  int buf = 0;
   for (int s0 = 0; s0 < n; s0 += kGS) {
-    const bool more = s0 + kGS < n;
-    if (more) load_chunk(s0 + kGS);
+    __syncthreads();                       // previous chunk's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      *(f32x4*)(&sp[srow + 16 * h][scol]) = stg[0][h];
+      *(f32x4*)(&sq[srow + 16 * h][scol]) = stg[1][h];
+    }
+    __syncthreads();
+    if (s0 + kGS < n) load_chunk(s0 + kGS);   // global loads fly under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < kGS / 4; ++ks) {
       float a[2], b[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = sp[buf][4 * ks + q][32 * wr + 16 * m + l15];
+      for (int m = 0; m < 2; ++m) a[m] = sp[4 * ks + q][32 * wr + 16 * m + l15];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) b[m] = sq[buf][4 * ks + q][32 * wc + 16 * m + l15];
+      for (int m = 0; m < 2; ++m) b[m] = sq[4 * ks + q][32 * wc + 16 * m + l15];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
           acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
     }
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -183,6 +183,26 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restric
       }
 }
 
+// Wave-wide sum on the ALU path (no LDS crossbar): DPP row_shr 1,2,4,8 leaves each
+// 16-lane row's total in its last lane; four readlanes + scalar-operand adds give the
+// wave total in a fixed order.  Result is wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  int v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = __float_as_int(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(v, 15));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(v, 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(v, 47));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(v, 63));
+  return (r0 + r1) + (r2 + r3);
+}
+
 // counter-based standard normal (splitmix-style hash + Box-Muller); used only when the
 // caller supplies no replacement pool for degenerate atoms
 __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigned a, unsigned b) {
@@ -199,7 +219,7 @@ __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigne
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, int j0) {
   constexpr int JB = kSweepBlock;
-  __shared__ float sA[JB][JB];          // A[j0+a][j0+b]
+  __shared__ __attribute__((aligned(16))) float sA[JB][JB];   // A[j0+a][j0+b] (symmetric)
   __shared__ __attribute__((aligned(16))) float sD[JB][kFistaD];   // old atoms of the block (rows of Dt)
   const int lane = threadIdx.x;
   const int nb = min(JB, p.k - j0);
@@ -225,7 +245,15 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
   static_for<JB>([&](auto a_c) {
     constexpr int a = decltype(a_c)::value;
     if (a < nb) {   // wave-uniform
-      const float ajj = sA[a][a];
+      // the block's coefficients of atom a, A[j0+b][j0+a] = sA[a][b] by symmetry: one
+      // batch of broadcast ds_read_b128 instead of a dependent read per later atom
+      float cf[JB];
+#pragma unroll
+      for (int b4 = 0; b4 < JB / 4; ++b4) {
+        const f32x4 t4 = *(const f32x4*)(&sA[a][4 * b4]);
+        cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
+      }
+      const float ajj = cf[a];
       float v[4], dcur[4], ss = 0.0f;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
@@ -234,8 +262,7 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
         if (p.positive) v[f] = fmaxf(v[f], 0.0f);              // dict_learning.py:87-88
         ss = fmaf(v[f], v[f], ss);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+      ss = wave_sum_dpp(ss);
       const float nrm = sqrtf(ss);                               // :91
       float dnew[4], delta[4];
       if (nrm < p.eps) {                                         // :92-98 degenerate atom
@@ -254,8 +281,7 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
           if (p.positive) dnew[f] = fmaxf(dnew[f], 0.0f);
           fs = fmaf(dnew[f], dnew[f], fs);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) fs += __shfl_xor(fs, off, 64);
+        fs = wave_sum_dpp(fs);
         const float inv = 1.0f / sqrtf(fs);
 #pragma unroll
         for (int f = 0; f < 4; ++f) { dnew[f] *= inv; delta[f] = -dcur[f]; }   // atom leaves the model
@@ -270,9 +296,8 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){delta[0], delta[1], delta[2], delta[3]};
 #pragma unroll
       for (int b = a + 1; b < JB; ++b) {
-        const float cf = sA[b][a];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf, delta[f], u[b][f]);
+        for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
       }
     }
   });
@@ -326,7 +351,12 @@ __global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, i
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
                           int n, float* C, int64_t ldc, int sym, hipStream_t stream) {
   const dim3 grid((qc + kGB - 1) / kGB, (pc + kGB - 1) / kGB);
-  hipLaunchKernelGGL(gram_tn_kernel, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
+  const bool vec = pc % 4 == 0 && qc % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 &&
+                   ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(gram_tn_kernel<true>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
+  else
+    hipLaunchKernelGGL(gram_tn_kernel<false>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
   return hipGetLastError();
 }
 
