@@ -114,7 +114,9 @@ __device__ __forceinline__ void step_body(f32x4 (&acc)[2], const f32x4 (&a)[2], 
 }
 __device__ __forceinline__ void no_stage() {}
 
-template <int K>
+// STOP: compile the in-kernel global stop rule in (separate instantiation so that the
+// fixed-iteration kernel keeps its register allocation).
+template <int K, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
   constexpr int D = kFistaD;
   constexpr int NW = kFistaWaves;
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
 
+    bool stopped = false;
     for (int it = 0; it < p.iters; ++it) {
       const float coef = p.coef[it];
       float dsum = 0.0f;
@@ -216,15 +219,58 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       };
       using F = std::false_type;
       using T = std::true_type;
+      // in-kernel stop rule: wave 0 fetches the previous iteration's per-tile |dz| granules
+      // a quarter into GEMM-1 (every workgroup has published them by then) and looks at
+      // them when GEMM-1 is done -- the L2 round trip hides behind the MFMAs.
+      unsigned long long gr[4] = {0ull, 0ull, 0ull, 0ull};
+      const bool check = STOP && p.stop_on && it > 0;
+      const unsigned long long* const grow =
+          p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * p.ntiles : nullptr;
 #pragma unroll 1
-      for (int s2 = 0; s2 < S1 / 2 - 2; ++s2)
+      for (int s2 = 0; s2 < S1 / 2 - 2; ++s2) {
+        if (STOP && check && wid == 0 && s2 == S1 / 8) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (lane + 64 * e < p.ntiles)
+              gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
+      }
       // steps S1-4, S1-3: refills are W step S1-1 and W^T step 0
       trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, c.w2, c.voff2, F{});
       // steps S1-2, S1-1: refills are W^T steps 1 and 2
       trip(S1 / 2 - 1, c.w2 + 32, c.voff2, c.w2 + 64, c.voff2, T{});
       // now X.b = B fragments of GEMM-2 step 0; slot1 <- W^T step 1, slot0 <- W^T step 2
 
+      if (STOP && check && wid == 0) {
+        // every granule must carry tag == it (iteration it-1 published as it-1+1); re-poll the
+        // (rare) late ones.  Sum in a fixed order: identical decision in every workgroup.
+        const unsigned want = (unsigned)it;
+        float part = 0.0f;
+        int spins = 0;
+        bool ok;
+        do {
+          ok = true;
+          part = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (lane + 64 * e < p.ntiles) {
+              if ((unsigned)(gr[e] >> 32) != want) {
+                gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && ((unsigned)(gr[e] >> 32) == want);
+              }
+              part += __uint_as_float((unsigned)gr[e]);
+            }
+          ok = __all(ok);
+          if (!ok) __builtin_amdgcn_s_sleep(8);
+        } while (!ok && ++spins < (1 << 22));
+        const float total = wave_sum(part);
+        if (lane == 0) {
+          red[NW] = (ok && total <= p.stop_budget) ? 1.0f : 0.0f;        // ista.py:93
+          red[NW + 1] = total;
+          if (!ok && blockIdx.x == 0) p.stop_out[2] = 1;
+        }
+      }
       // r tile -> LDS, everyone reads all of it
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -234,6 +280,14 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       LASSO_DESYNC();
+      if (STOP && check && red[NW] != 0.0f) {      // iteration it-1 met the stop rule: z (registers) is its z_next
+        if (blockIdx.x == 0 && tid == 0) {
+          p.stop_out[0] = it;
+          p.stop_out[1] = __float_as_int(red[NW + 1]);
+        }
+        stopped = true;
+        break;
+      }
       f32x4 rf[T2][2];
       load_r_frags<K>(c, rt, rf);
 
@@ -317,11 +371,40 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();   // y tile complete; red[] complete
       LASSO_DESYNC();
-      if (p.partials && tid == 0) {
+      if ((p.partials || (STOP && p.stop_on)) && tid == 0) {
         float tsum = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += red[w];
-        p.partials[(int64_t)it * p.ntiles + tile] = tsum;
+        if (p.partials) p.partials[(int64_t)it * p.ntiles + tile] = tsum;
+        if (STOP && p.stop_on)   // one 8-byte write-through store {tag = it+1, value}: the data is the flag
+          __hip_atomic_store(p.stop_gran + (size_t)(it & (kStopRing - 1)) * p.ntiles + tile,
+                             ((unsigned long long)(unsigned)(it + 1) << 32) | __float_as_uint(tsum),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (STOP && p.stop_on && !stopped && blockIdx.x == 0 && wid == 0 && p.iters > 0) {
+      // ran to maxiter: report the last iteration's global delta (does not change z)
+      const unsigned want = (unsigned)p.iters;
+      const unsigned long long* const lrow = p.stop_gran + (size_t)((p.iters - 1) & (kStopRing - 1)) * p.ntiles;
+      float part = 0.0f;
+      int spins = 0;
+      bool ok;
+      do {
+        ok = true;
+        part = 0.0f;
+        for (int e = lane; e < p.ntiles; e += 64) {
+          const unsigned long long g = __hip_atomic_load(lrow + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((unsigned)(g >> 32) == want);
+          part += __uint_as_float((unsigned)g);
+        }
+        ok = __all(ok);
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      } while (!ok && ++spins < (1 << 22));
+      const float total = wave_sum(part);
+      if (lane == 0) {
+        p.stop_out[0] = p.iters;
+        p.stop_out[1] = __float_as_int(total);
+        if (!ok) p.stop_out[2] = 1;
       }
     }
 
@@ -352,18 +435,23 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   LASSO_WAIT_VMCNT(0);
 }
 
-template <int K>
-static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
+template <int K, bool STOP>
+static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stream) {
   const size_t lds = fista_tile_lds_bytes(K);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, STOP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(fista_tile_sp_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  hipLaunchKernelGGL((fista_tile_sp_kernel<K, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
+  return p.stop_on ? launch_ks<K, true>(p, grid, stream) : launch_ks<K, false>(p, grid, stream);
 }
 
 }  // namespace sp

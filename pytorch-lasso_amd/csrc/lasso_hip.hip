@@ -54,6 +54,8 @@ struct Workspace {
   float* zeros;     // [coef_cap]  ISTA "coefficients"
   float* partials;  // [kChunkMax][ntiles]
   float* delta;     // [kChunkMax]
+  unsigned long long* gran;  // [kStopRing][ntiles] in-kernel stop-rule granules
+  int* stop_out;    // [4]
   float* state[4];  // zA, yA, zB, yB  [n][k]   (stop rule only)
   size_t bytes;
 };
@@ -74,6 +76,8 @@ Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool wit
   w.zeros = take((size_t)std::max(coef_cap, 1) * 4);
   w.partials = take((size_t)kChunkMax * ntiles * 4);
   w.delta = take((size_t)kChunkMax * 4);
+  w.gran = reinterpret_cast<unsigned long long*>(take((size_t)kStopRing * std::max<int64_t>(ntiles, 1) * 8));
+  w.stop_out = reinterpret_cast<int*>(take(256));
   for (int i = 0; i < 4; ++i) w.state[i] = with_state ? take((size_t)n * k * 4) : nullptr;
   w.bytes = off;
   return w;
@@ -173,7 +177,7 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype) {
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
              int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
-             int fast, int it0, int iters, float* delta, hipStream_t stream) {
+             int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f) {
   if (n == 0) return LASSO_OK;
   const int ntiles = (int)((n + kTileM - 1) / kTileM);
   FistaTileParams p;
@@ -189,6 +193,10 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.ntiles = ntiles; p.iters = iters;
   p.lr = (float)lr;                 // ATen casts the python scalar to the tensor dtype
   p.lam = (float)(alpha * lr);      // softshrink(lambd = alpha*lr), product in double (ista.py:90)
+  p.stop_on = stop_budget >= 0.0f;
+  p.stop_budget = stop_budget;
+  p.stop_gran = ws.gran;
+  p.stop_out = ws.stop_out;
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
@@ -462,9 +470,32 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return LASSO_OK;
   }
 
-  // ---- exact global stop rule: speculate a chunk, read its per-iteration deltas,
-  // replay the chunk up to the stopping iteration if one fired (DESIGN.md) ----------
   const float budget = (float)((double)n * (double)k * tol);   // ista.py:64, compared in fp32
+  // ---- exact global stop rule, in-kernel: when every tile has its own resident workgroup
+  // the persistent kernel evaluates the rule itself (one-iteration lag) and a
+  // single launch runs to the stopping iteration -- one host sync, at the end. ------------
+  {
+    const int ntiles = (int)((n + kTileM - 1) / kTileM);
+    const int cus = device_cus();
+    if (fista_variant() == 1 && ntiles <= cus && !getenv("LASSO_STOP_CHUNKED")) {
+      LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * ntiles * 8, st));
+      LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
+      if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
+                           alpha, lr, fast, 0, maxiter, nullptr, st, budget))
+        return s;
+      int hout[4] = {0, 0, 0, 0};
+      LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      if (hout[2]) return fail(LASSO_ERR_HIP, "in-kernel stop rule: granule handshake timed out");
+      float lastf;
+      memcpy(&lastf, &hout[1], sizeof(float));
+      if (iters_out) *iters_out = hout[0];
+      if (last_delta_out) *last_delta_out = lastf;
+      return LASSO_OK;
+    }
+  }
+  // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
+  // replay the chunk up to the stopping iteration if one fired (DESIGN.md) ----------
   const float* cur_z = z0;  int64_t cur_ldz = ldz0;
   const float* cur_y = nullptr; int64_t cur_ldy = 0;
   if (z0 && z0 == zout) {     // aliasing: keep the initial state intact for a replay

@@ -27,7 +27,13 @@ struct FistaTileParams {
   int n, d, k;                           // real sizes
   int ntiles, iters;
   float lr, lam;                         // step size, alpha*lr
+  // in-kernel exact global stop rule (fista_tile_sp.hip; needs gridDim.x == ntiles):
+  unsigned long long* stop_gran;         // [kStopRing][ntiles] {tag = it+1, |dz| partial} granules, zeroed per solve
+  int* stop_out;                         // [0] iterations executed, [1] last delta (float bits), [2] error
+  float stop_budget;                     // n*k*tol (ista.py:64)
+  int stop_on;
 };
+constexpr int kStopRing = 64;
 
 // lasso_loss tile kernel (objective.hip)
 struct ObjectiveParams {
