@@ -141,6 +141,12 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
   lds_char* const slot0 = c.ring;
   lds_char* const slot1 = c.ring + kStepBytes;
+  // y-tile byte offset of this lane's C-layout element (row 4q+rg, column colbase+n), see
+  // tile_off():  ep_rg[rg] + (((colbase>>4)&3) ^ q) << 6) + (colbase>>6)*256
+  int ep_rg[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+    ep_rg[rg] = (4 * q + rg) * (K * 4) + (((n >> 2) ^ rg) << 4) + ((n & 3) << 2);
 
   // Ring invariant on entry of GEMM-1 (every iteration, every tile):
   //   X.b holds the B fragments of step 0; slot1 <- step 1, slot0 <- step 2 in flight.
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       // the gaps between the MFMAs of the NEXT pass's first step.
       auto ep_addr = [&](auto ps_c, int cb, int rg) {
         constexpr int ps = decltype(ps_c)::value;
-        return (lds_f32*)(yt + tile_off<K>(4 * qo + rg, wid * KW + 32 * ps + 16 * cb + no));
+        const int colbase = wid * KW + 32 * ps + 16 * cb;          // wave-uniform
+        return (lds_f32*)(yt + ep_rg[rg] + ((((colbase >> 4) & 3) ^ qo) << 6) + (colbase >> 6) * 256);
       };
       auto ep_read = [&](auto ps_c) {
 #pragma unroll

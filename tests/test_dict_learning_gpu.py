@@ -165,3 +165,34 @@ def test_g4_c4_em_steps(golden):
     Dr, lr_ = dict_learning(Xg, 1024, alpha=0.5, constrained=False, steps=3, algorithm='ista',
                             progbar=False, device='cuda', init_weight=D0)
     assert (lr_.cpu() - T(g["r_losses_auto"])).abs().max().item() <= 5e-4
+
+
+def test_sharded_driver_world1_equals_single_gpu(golden):
+    """The batch-sharded driver (lasso_amd.parallel) with one rank and the nccl (RCCL)
+    process group initialised is the same computation as dict_learning."""
+    import os
+    import torch.distributed as dist
+    from lasso_amd.linear import dict_learning
+    from lasso_amd.parallel import dict_learning_sharded
+    X, _ = recipe_xw(2048)
+    D0 = recipe_c4_init()
+    Xg = X.cuda()
+    torch.manual_seed(3)
+    Dref, lref = dict_learning(Xg, 1024, alpha=0.5, steps=3, algorithm='ista', progbar=False,
+                               device='cuda', init_weight=D0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        torch.manual_seed(3)
+        D, losses = dict_learning_sharded(Xg, 1024, alpha=0.5, steps=3, init_weight=D0, algorithm='ista')
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)                                   # the collective itself works
+        assert t.sum().item() == 4.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(losses, lref) and torch.equal(D, Dref)
