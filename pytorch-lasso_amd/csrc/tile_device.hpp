@@ -227,11 +227,24 @@ __device__ __forceinline__ void load_r_frags(const TileCtx<K>& c, lds_char* rt,
       rf[t][ss] = *(const lds_f32x4*)(rt + c.n * (kFistaD * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
 }
 
-// wave-wide sum (all lanes get the result), fixed order
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// wave-wide sum (wave-uniform result), fixed order, on the ALU path: DPP row_shr 1,2,4,8
+// leaves each 16-lane row's total in its last lane; four readlanes finish the job (the
+// ds_bpermute route of __shfl_xor costs ~6 LDS round trips instead).
+__device__ __forceinline__ float wave_sum(float x) {
+  int v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = __float_as_int(x);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(v, 15));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(v, 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(v, 47));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(v, 63));
+  return (r0 + r1) + (r2 + r3);
 }
 
 }  // namespace lasso
