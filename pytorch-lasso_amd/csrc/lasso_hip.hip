@@ -161,12 +161,14 @@ int fista_variant() {
   return v;
 }
 
-int check_common(int64_t n, int64_t d, int64_t k, int dtype) {
+bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
+
+int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = false) {
   if (dtype != LASSO_F32)
     return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
   if (n < 0 || d <= 0 || k <= 0) return fail(LASSO_ERR_BAD_ARG, "bad shape n=%lld d=%lld k=%lld",
                                               (long long)n, (long long)d, (long long)k);
-  if (d > kFistaD || k > kFistaMaxK)
+  if (!allow_large && !fused_shape(d, k))
     return fail(LASSO_ERR_UNSUPPORTED,
                 "shape d=%lld k=%lld exceeds the fused kernel (d<=%d, k<=%d)", (long long)d,
                 (long long)k, kFistaD, kFistaMaxK);
@@ -336,6 +338,77 @@ int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw,
   return warned ? fail(LASSO_WARN_LINESEARCH, "backtracking line search failed; reverted to lr0") : LASSO_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Unfused path for shapes beyond the fused kernel (d > 256 or k > 1024): two MFMA GEMM
+// launches + one elementwise launch per iteration, state in HBM.  Same arithmetic
+// (ista.py:72-73,90,93,98-102); the stop rule is evaluated on the host every iteration
+// like the reference does.  Correctness path, not tuned.
+// ---------------------------------------------------------------------------
+constexpr int kGenGrid = 1024;
+struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; float* delta; size_t bytes; };
+
+GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k) {
+  GenWorkspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes);
+    return reinterpret_cast<float*>(r);
+  };
+  w.Wt = take((size_t)k * d * 4);
+  w.Y = take((size_t)n * k * 4);
+  w.NR = take((size_t)n * d * 4);
+  w.G = take((size_t)n * k * 4);
+  w.dpart = take((size_t)kGenGrid * 4);
+  w.delta = take(256);
+  w.bytes = off;
+  return w;
+}
+
+int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* z0, int64_t ldz0,
+                  float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, double alpha, double lr,
+                  int fast, int maxiter, double tol, int32_t* iters_out, float* last_delta_out,
+                  void* workspace, size_t ws_bytes, hipStream_t st) {
+  GenWorkspace ws = carve_generic(workspace, n, d, k);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  if (n > INT32_MAX || d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+  LASSO_HIP_TRY(launch_transpose_pad(w, ldw, (int)d, (int)k, ws.Wt, d, (int)k, (int)d, st));
+  if (z0) {
+    if (z0 != zout)
+      LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  } else {
+    LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+  }
+  LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  const float budget = (float)((double)n * (double)k * tol);
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  double t_mom = 1.0;
+  float last = NAN;
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
+    // NR = x - y W^T  (= -r);   G = 0 - NR Wt^T = r W
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Y, k, w, ldw, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.NR, d, ws.Wt, d, nullptr, 0, ws.G, k, (int)n, (int)k, (int)d, st));
+    LASSO_HIP_TRY(launch_generic_prox(zout, ldz, ws.Y, ws.G, (int)n, (int)k, lr_f, lam, coef, ws.dpart,
+                                      kGenGrid, st));
+    t_mom = t_next;
+    if (tol > 0.0) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, ws.delta);
+      LASSO_HIP_TRY(hipGetLastError());
+      LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      if (last <= budget) { ++it; break; }
+    }
+  }
+  if (iters_out) *iters_out = it;
+  if (last_delta_out) *last_delta_out = last;
+  return LASSO_OK;
+}
+
 }  // namespace
 }  // namespace lasso
 
@@ -367,9 +440,11 @@ int lasso_hip_device_cus(int* cus_out) {
 
 size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
                                    double tol, int stop_mode, int backtrack) {
-  (void)d; (void)dtype;
+  (void)dtype;
+  if (n < 0 || d <= 0 || k <= 0) return 0;
+  if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
-  if (kp < 0 || n < 0) return 0;
+  if (kp < 0) return 0;
   if (backtrack) return carve_bt(nullptr, n, k, kp).bytes;
   const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
@@ -424,9 +499,11 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
-  if (int s = check_common(n, d, k, dtype)) return s;
+  if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
+  if (!fused_shape(d, k) && backtrack)
+    return fail(LASSO_ERR_UNSUPPORTED, "backtrack=1 needs d<=%d, k<=%d", kFistaD, kFistaMaxK);
   if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k))
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
@@ -451,8 +528,12 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   }
 
   const bool stop_rule = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL;
-  const int kp = pad_k(k);
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
+  if (!fused_shape(d, k))
+    return solve_generic(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
+                         maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
+                         workspace_bytes, st);
+  const int kp = pad_k(k);
   if (backtrack)
     return solve_backtracking(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, kp,
                               alpha, lr, fast, maxiter, stop_rule ? tol : 0.0, eta_backtrack,

@@ -97,6 +97,8 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
 hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int cols, float* dst,
                                 int64_t ld_dst, int drows, int dcols, hipStream_t stream);
+hipError_t launch_generic_prox(float* Z, int64_t ldz, float* Y, const float* G, int n, int k, float lr,
+                               float lam, float coef, float* dpart, int grid, hipStream_t stream);
 hipError_t launch_zero_columns(float* Z, int64_t ldz, int n, int k, const int* degenerate,
                                hipStream_t stream);
 

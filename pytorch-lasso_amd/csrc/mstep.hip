@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restric
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int r = i0 + 32 * wr + 16 * mi + 4 * q + rg, cc = j0 + 32 * wc + 16 * nj + l15;
-        if (r < m && cc < nn) C[(int64_t)r * ldc + cc] = C0[(int64_t)r * ldc0 + cc] - acc[mi][nj][rg];
+        if (r < m && cc < nn) C[(int64_t)r * ldc + cc] = (C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f) - acc[mi][nj][rg];
       }
 }
 
@@ -337,6 +337,35 @@ __global__ void transpose_pad_kernel(const float* __restrict__ src, int64_t lds_
   }
 }
 
+// Elementwise tail of one FISTA iteration for the unfused large-shape path:
+//   z_next = softshrink(y - lr*g, lam); dpart = sum|z - z_next|; y = z_next + c (z_next - z); z = z_next
+// (ista.py:90,93,98-102).  Fixed grid => deterministic partial sums.
+__global__ __launch_bounds__(256) void generic_prox_kernel(float* __restrict__ Z, int64_t ldz,
+                                                           float* __restrict__ Y, const float* __restrict__ G,
+                                                           int n, int k, float lr, float lam, float coef,
+                                                           float* __restrict__ dpart) {
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  const int64_t total = (int64_t)n * k;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / k;
+    const int cc = (int)(idx - r * k);
+    const float zo = Z[r * ldz + cc];
+    const float v = __fsub_rn(Y[idx], __fmul_rn(lr, G[idx]));
+    const float zn = __fsub_rn(v, __builtin_amdgcn_fmed3f(v, -lam, lam));
+    acc += __builtin_fabsf(__fsub_rn(zo, zn));
+    Y[idx] = __fadd_rn(zn, __fmul_rn(coef, __fsub_rn(zn, zo)));
+    Z[r * ldz + cc] = zn;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dpart[blockIdx.x] = sh[0];
+}
+
 // Z[:, j] = 0 for degenerate atoms (dict_learning.py:98; matters when persist=True)
 __global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, int k,
                                     const int* __restrict__ degenerate) {
@@ -385,6 +414,13 @@ hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int 
   const int gr = std::max(rows, dcols), gc = std::max(cols, drows);
   hipLaunchKernelGGL(transpose_pad_kernel, dim3((gc + 31) / 32, (gr + 31) / 32), dim3(32, 8), 0, stream,
                      src, ld_src, rows, cols, dst, ld_dst, drows, dcols);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic_prox(float* Z, int64_t ldz, float* Y, const float* G, int n, int k, float lr,
+                               float lam, float coef, float* dpart, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(generic_prox_kernel, dim3(grid), dim3(256), 0, stream, Z, ldz, Y, G, n, k, lr, lam,
+                     coef, dpart);
   return hipGetLastError();
 }
 

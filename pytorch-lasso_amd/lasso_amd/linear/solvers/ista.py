@@ -57,6 +57,9 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         raise NotImplementedError("lasso_amd: dtype %s is not implemented on the HIP path" % x.dtype)
     if maxiter == 0:
         return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
+    if n == 0:      # empty batch: nothing to solve (the reference's loop stops at once: 0 <= 0)
+        z = z0.clone()
+        return (z, dict(iterations=1, last_delta=0.0)) if return_info else z
 
     out_device = z0.device
     dev = x.device if x.is_cuda else (weight.device if weight.is_cuda else

@@ -148,5 +148,26 @@ def test_errors_and_unsupported():
         sparse_encode(x, w, z0=torch.zeros(4, 4).cuda())
     with pytest.raises(TypeError):
         sparse_encode(x, w, bogus=1)
-    with pytest.raises(NotImplementedError):
-        sparse_encode(torch.randn(4, 300).cuda(), torch.randn(300, 5).cuda(), lr=0.1)
+    with pytest.raises(NotImplementedError):      # line search is fused-kernel only
+        sparse_encode(torch.randn(4, 300).cuda(), torch.randn(300, 5).cuda(), lr=0.1, backtrack=True)
+
+
+@pytest.mark.parametrize("n,d,k", [(50, 300, 40), (33, 64, 1500), (20, 784, 1100), (0, 10, 50)])
+def test_large_and_empty_shapes(n, d, k):
+    """Shapes beyond the fused kernel (d > 256 or k > 1024) take the unfused HIP path; an
+    empty batch returns an empty code."""
+    sparse_encode, ista, orc = _mods()
+    X, W = _case(n, d, k, seed=11)
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    ref = orc.sparse_encode(X, W, alpha=0.2, lr=lr, maxiter=12, tol=0.0)
+    got = sparse_encode(X.cuda(), W.cuda(), alpha=0.2, lr=lr, maxiter=12, tol=0.0)
+    assert got.shape == (n, k)
+    if n:
+        assert (got.cpu() - ref).abs().max().item() <= Z_ATOL
+        tr = orc.FistaTrace()
+        z0 = X.new_zeros(n, k)
+        orc.fista(X, z0, W, 0.2, lr=lr, maxiter=300, tol=1e-4, trace=tr)
+        _, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.2, lr=lr, maxiter=300, tol=1e-4, return_info=True)
+        assert abs(info["iterations"] - tr.iterations) <= 1
+        assert abs(sparse_encode(X.cuda(), W.cuda(), alpha=0.2, maxiter=3).cpu()
+                   - orc.sparse_encode(X, W, alpha=0.2, maxiter=3)).max().item() <= 1e-4   # lr='auto'
