@@ -35,12 +35,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_grad_kernel(const BtParam
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
-    for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
-      const int r = idx / K, cc = idx - r * K;
-      float v = 0.0f;
-      if ((row0 + r) < p.n && cc < p.k) v = p.P[(int64_t)(row0 + r) * p.ldp + cc];
-      *(lds_f32*)(pt + tile_off<K>(r, cc)) = v;
-    }
+    visit_tile4<K, kFistaThreads>(p.P, p.ldp, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+      *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = v;
+    });
     f32x4 acc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -53,7 +50,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_grad_kernel(const BtParam
       }
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
-    gemm1_stream<K>(c, pt, acc, c.w2, c.w2 + 32, c.voff2);
+    gemm1_stream_sp<K>(c, pt, acc, c.w2, c.w2 + 32, c.voff2);
     float rss = 0.0f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -112,21 +109,30 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
     float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
-    for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
-      const int r = idx / K, cc = idx - r * K;
-      float zn = 0.0f;
+    const bool gvec = vec4_ok(p.G, p.k, p.k);   // G and C are internal [n][k] buffers
+    visit_tile4<K, kFistaThreads>(p.P, p.ldp, row0, p.n, p.k, [&](int r, int cc, const f32x4& pv) {
+      f32x4 zn = {0.f, 0.f, 0.f, 0.f};
       if ((row0 + r) < p.n && cc < p.k) {
-        const float pv = p.P[(int64_t)(row0 + r) * p.ldp + cc];
-        const float g = p.G[(int64_t)(row0 + r) * p.k + cc];
-        zn = soft_threshold(__fsub_rn(pv, __fmul_rn(lr, g)), lam);          // ista.py:40
-        p.C[(int64_t)(row0 + r) * p.k + cc] = zn;
-        const float dz = __fsub_rn(zn, pv);                                   // :31
-        l1 += __builtin_fabsf(zn);
-        dzg = __fadd_rn(dzg, __fmul_rn(dz, g));
-        dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        const float* gp = p.G + (int64_t)(row0 + r) * p.k + cc;
+        if (gvec) g = *reinterpret_cast<const f32x4*>(gp);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (cc + e < p.k) g[e] = gp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cc + e < p.k) {
+            zn[e] = soft_threshold(__fsub_rn(pv[e], __fmul_rn(lr, g[e])), lam);     // ista.py:40
+            const float dz = __fsub_rn(zn[e], pv[e]);                                 // :31
+            l1 += __builtin_fabsf(zn[e]);
+            dzg = __fadd_rn(dzg, __fmul_rn(dz, g[e]));
+            dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+          }
+        store_row4(p.C, p.k, row0 + r, p.n, p.k, cc, zn, gvec);
       }
-      *(lds_f32*)(zt + tile_off<K>(r, cc)) = zn;
-    }
+      *(lds_f32x4*)(zt + tile_chunk_off<K>(r, cc)) = zn;
+    });
     f32x4 acc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
       }
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
-    gemm1_stream<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
+    gemm1_stream_sp<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
     float rss = 0.0f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)

@@ -17,57 +17,6 @@
 namespace lasso {
 namespace sp {
 
-struct Frag {
-  f32x4 b[2][2];   // [col-block][k-half]
-  f32x4 a[2];      // [k-half]       (GEMM-1 only; GEMM-2 uses the r fragments)
-};
-
-template <int K>
-__device__ __forceinline__ void load_b(const TileCtx<K>& c, Frag& f, const lds_char* slot) {
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) f.b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
-}
-
-template <int K>
-__device__ __forceinline__ void load_a(const TileCtx<K>& c, Frag& f, const lds_char* row_chunk, int par) {
-#pragma unroll
-  for (int ss = 0; ss < 2; ++ss) f.a[ss] = *(const lds_f32x4*)(row_chunk + c.aoff[par][ss]);
-}
-
-// MFMAs number [LO, HI) of the 16 of a step (order: k-half, j, col-block)
-template <int LO, int HI>
-__device__ __forceinline__ void mfma_range(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f) {
-  static_for<HI - LO>([&](auto i_c) {
-    constexpr int i = LO + decltype(i_c)::value;
-    constexpr int ss = i / 8, j = (i % 8) / 2, cb = i % 2;
-    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], f.b[cb][ss][j], acc[cb], 0, 0, 0);
-  });
-}
-
-// one LDS-DMA instruction (1 KiB = rows 8j..8j+7 of a step tile); see dma_step()
-__device__ __forceinline__ void dma_piece(const float* src, unsigned voff, lds_char* dst) {
-#ifdef LASSO_ABL_NODMA      // timing ablation only (results invalid)
-  return;
-#endif
-  const unsigned lds_addr = (unsigned)(uintptr_t)dst;
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:0\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(src), "s"(lds_addr)
-      : "memory");
-}
-
-// pin the issue order at this point (hipcc otherwise sinks the prefetching ds_reads down
-// to their first use and re-exposes the LDS latency the pipeline is there to hide)
-#define LASSO_PIN() __builtin_amdgcn_sched_barrier(0)
-
 // Waves w and w+4 share a SIMD and leave every barrier in lockstep, so their non-MFMA
 // gaps coincide; delaying the second half by a fraction of a step staggers them.
 #ifndef LASSO_DESYNC_SLEEP
@@ -78,41 +27,6 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned voff, lds_c
 #else
 #define LASSO_DESYNC()
 #endif
-
-constexpr int kHead = 4;   // MFMAs issued before the mid-step "slot free -> DMA refill" point
-
-// MFMAs 0..15 of one step on fragments `f` with the refill of `slot` (4 LDS-DMA pieces)
-// spread between them; e0..e3 are optional epilogue stages run in the four gaps.
-template <typename E0, typename E1, typename E2, typename E3>
-__device__ __forceinline__ void step_body(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f,
-                                          const float* src, const unsigned (&voff)[4], lds_char* slot,
-                                          E0&& e0, E1&& e1, E2&& e2, E3&& e3) {
-  LASSO_PIN();
-  mfma_range<0, kHead>(acc, a, f);
-  LASSO_PIN();
-  LASSO_WAIT_LGKM0();                 // the prefetching ds_reads have returned: slot is free
-  dma_piece(src, voff[0], slot);
-  LASSO_PIN();
-  e0();
-  mfma_range<4, 7>(acc, a, f);
-  LASSO_PIN();
-  dma_piece(src, voff[1], slot + 1024);
-  LASSO_PIN();
-  e1();
-  mfma_range<7, 10>(acc, a, f);
-  LASSO_PIN();
-  dma_piece(src, voff[2], slot + 2048);
-  LASSO_PIN();
-  e2();
-  mfma_range<10, 13>(acc, a, f);
-  LASSO_PIN();
-  dma_piece(src, voff[3], slot + 3072);
-  LASSO_PIN();
-  e3();
-  mfma_range<13, 16>(acc, a, f);
-  LASSO_PIN();
-}
-__device__ __forceinline__ void no_stage() {}
 
 // STOP: compile the in-kernel global stop rule in (separate instantiation so that the
 // fixed-iteration kernel keeps its register allocation).
@@ -163,12 +77,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     {
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
-      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
-        const int r = idx / K, cc = idx - r * K;
-        float v = 0.0f;
-        if (ysrc && (row0 + r) < p.n && cc < p.k) v = ysrc[(int64_t)(row0 + r) * ldy + cc];
-        *(lds_f32*)(yt + tile_off<K>(r, cc)) = v;
-      }
+      visit_tile4<K, kFistaThreads>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+        *(lds_f32x4*)(yt + tile_chunk_off<K>(r, cc)) = v;
+      });
     }
     f32x4 zreg[NP][2];
 #pragma unroll
@@ -430,10 +341,11 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
           }
     }
     if (p.y_out) {
-      for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
-        const int r = idx / K, cc = idx - r * K;
-        if ((row0 + r) < p.n && cc < p.k)
-          p.y_out[(int64_t)(row0 + r) * p.ldy_out + cc] = *(const lds_f32*)(yt + tile_off<K>(r, cc));
+      const bool yvec = vec4_ok(p.y_out, p.ldy_out, p.k);
+      for (int idx = tid; idx < kTileM * (K / 4); idx += kFistaThreads) {
+        const int r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
+        const f32x4 v = *(const lds_f32x4*)(yt + tile_chunk_off<K>(r, cc));
+        store_row4(p.y_out, p.ldy_out, row0 + r, p.n, p.k, cc, v, yvec);
       }
     }
     LASSO_WAIT_LGKM0();

@@ -27,13 +27,10 @@ __global__ __launch_bounds__(kFistaThreads, 2) void objective_tile_kernel(const 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
     float l1 = 0.0f;
-    for (int idx = tid; idx < kTileM * K; idx += kFistaThreads) {
-      const int r = idx / K, cc = idx - r * K;
-      float v = 0.0f;
-      if ((row0 + r) < p.n && cc < p.k) v = p.Z[(int64_t)(row0 + r) * p.ldz + cc];
-      l1 += __builtin_fabsf(v);
-      *(lds_f32*)(zt + tile_off<K>(r, cc)) = v;
-    }
+    visit_tile4<K, kFistaThreads>(p.Z, p.ldz, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+      l1 += (__builtin_fabsf(v[0]) + __builtin_fabsf(v[1])) + (__builtin_fabsf(v[2]) + __builtin_fabsf(v[3]));
+      *(lds_f32x4*)(zt + tile_chunk_off<K>(r, cc)) = v;
+    });
     f32x4 acc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -47,7 +44,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void objective_tile_kernel(const 
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
     // tail refill = steps 0/1 of the next tile (W is tile independent)
-    gemm1_stream<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
+    gemm1_stream_sp<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
     float rss = 0.0f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)

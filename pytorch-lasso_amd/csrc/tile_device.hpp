@@ -84,6 +84,54 @@ __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff
       : "memory", "scc");
 }
 
+// Visit a 16-row tile of a row-major [n][k] matrix in groups of 4 consecutive columns:
+// f(r, c, v) with c a multiple of 4 and v = src[row0+r][c..c+3] (0 beyond n / k).  Uses
+// 16-byte loads when the layout allows (k, ld multiples of 4 and a 16-B aligned base),
+// else masked scalar loads.  K is the padded tile width, NT the workgroup size.
+template <int K, int NT, typename F>
+__device__ __forceinline__ void visit_tile4(const float* __restrict__ src, int64_t ld, int row0, int n,
+                                            int k, F&& f) {
+  const bool vec = src && (k & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)src) & 15) == 0;
+  for (int idx = threadIdx.x; idx < kTileM * (K / 4); idx += NT) {
+    const int r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src && (row0 + r) < n) {
+      const float* rp = src + (int64_t)(row0 + r) * ld;
+      if (vec) {
+        if (c < k) v = *reinterpret_cast<const f32x4*>(rp + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < k) v[e] = rp[c + e];
+      }
+    }
+    f(r, c, v);
+  }
+}
+
+// store 4 consecutive columns of a row (masked), 16-B store when allowed
+__device__ __forceinline__ void store_row4(float* __restrict__ dst, int64_t ld, int row, int n, int k,
+                                           int c, const f32x4& v, bool vec) {
+  if (row >= n) return;
+  float* rp = dst + (int64_t)row * ld;
+  if (vec) {
+    if (c < k) *reinterpret_cast<f32x4*>(rp + c) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < k) rp[c + e] = v[e];
+  }
+}
+__device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int k) {
+  return p && (k & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)p) & 15) == 0;
+}
+
+// LDS address of the 16-byte chunk holding columns c..c+3 (c % 4 == 0) of row r
+template <int LD>
+__device__ __forceinline__ int tile_chunk_off(int row, int c) {
+  return row * (LD * 4) + (((c >> 2) ^ row) << 4);
+}
+
 __device__ __forceinline__ float soft_threshold(float v, float lam) {
   // ATen softshrink: v>lam ? v-lam : (v<-lam ? v+lam : 0).  Evaluated as v - clamp(v,-lam,lam)
   // (v_med3_f32 + v_sub_f32): bit-identical for every non-NaN v -- v-lam and v-(-lam) are the
@@ -225,6 +273,153 @@ __device__ __forceinline__ void load_r_frags(const TileCtx<K>& c, lds_char* rt,
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
       rf[t][ss] = *(const lds_f32x4*)(rt + c.n * (kFistaD * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
+}
+
+
+// ---------------------------------------------------------------------------
+// Software-pipelined step machinery (see fista_tile_sp.hip for the rationale)
+// ---------------------------------------------------------------------------
+namespace sp {
+
+
+struct Frag {
+  f32x4 b[2][2];   // [col-block][k-half]
+  f32x4 a[2];      // [k-half]       (GEMM-1 only; GEMM-2 uses the r fragments)
+};
+
+template <int K>
+__device__ __forceinline__ void load_b(const TileCtx<K>& c, Frag& f, const lds_char* slot) {
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) f.b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
+}
+
+template <int K>
+__device__ __forceinline__ void load_a(const TileCtx<K>& c, Frag& f, const lds_char* row_chunk, int par) {
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) f.a[ss] = *(const lds_f32x4*)(row_chunk + c.aoff[par][ss]);
+}
+
+// MFMAs number [LO, HI) of the 16 of a step (order: k-half, j, col-block)
+template <int LO, int HI>
+__device__ __forceinline__ void mfma_range(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f) {
+  static_for<HI - LO>([&](auto i_c) {
+    constexpr int i = LO + decltype(i_c)::value;
+    constexpr int ss = i / 8, j = (i % 8) / 2, cb = i % 2;
+    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], f.b[cb][ss][j], acc[cb], 0, 0, 0);
+  });
+}
+
+// one LDS-DMA instruction (1 KiB = rows 8j..8j+7 of a step tile); see dma_step()
+__device__ __forceinline__ void dma_piece(const float* src, unsigned voff, lds_char* dst) {
+#ifdef LASSO_ABL_NODMA      // timing ablation only (results invalid)
+  return;
+#endif
+  const unsigned lds_addr = (unsigned)(uintptr_t)dst;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:0\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(src), "s"(lds_addr)
+      : "memory");
+}
+
+// pin the issue order at this point (hipcc otherwise sinks the prefetching ds_reads down
+// to their first use and re-exposes the LDS latency the pipeline is there to hide)
+#define LASSO_PIN() __builtin_amdgcn_sched_barrier(0)
+
+
+constexpr int kHead = 4;   // MFMAs issued before the mid-step "slot free -> DMA refill" point
+
+// MFMAs 0..15 of one step on fragments `f` with the refill of `slot` (4 LDS-DMA pieces)
+// spread between them; e0..e3 are optional epilogue stages run in the four gaps.
+template <typename E0, typename E1, typename E2, typename E3>
+__device__ __forceinline__ void step_body(f32x4 (&acc)[2], const f32x4 (&a)[2], const Frag& f,
+                                          const float* src, const unsigned (&voff)[4], lds_char* slot,
+                                          E0&& e0, E1&& e1, E2&& e2, E3&& e3) {
+  LASSO_PIN();
+  mfma_range<0, kHead>(acc, a, f);
+  LASSO_PIN();
+  LASSO_WAIT_LGKM0();                 // the prefetching ds_reads have returned: slot is free
+  dma_piece(src, voff[0], slot);
+  LASSO_PIN();
+  e0();
+  mfma_range<4, 7>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[1], slot + 1024);
+  LASSO_PIN();
+  e1();
+  mfma_range<7, 10>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[2], slot + 2048);
+  LASSO_PIN();
+  e2();
+  mfma_range<10, 13>(acc, a, f);
+  LASSO_PIN();
+  dma_piece(src, voff[3], slot + 3072);
+  LASSO_PIN();
+  e3();
+  mfma_range<13, 16>(acc, a, f);
+  LASSO_PIN();
+}
+__device__ __forceinline__ void no_stage() {}
+
+
+}  // namespace sp
+
+// Pipelined GEMM-1 with the same contract as gemm1_stream():
+//   acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T
+// Pre:  ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave.
+// Post: ring slots 0/1 have `tail0` / `tail1` (+ tail_voff) in flight.
+template <int K>
+__device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* at, f32x4 (&acc)[2],
+                                                const float* tail0, const float* tail1,
+                                                const unsigned (&tail_voff)[4]) {
+  constexpr int S1 = K / 32;
+  static_assert(S1 % 2 == 0 && S1 >= 6, "geometry");
+  lds_char* const slot0 = c.ring;
+  lds_char* const slot1 = c.ring + kStepBytes;
+  const lds_char* const arow = at + c.n * (K * 4);
+  sp::Frag X, Y;
+  // prologue: fragments of step 0 into X, slot0 refilled with step 2
+  LASSO_WAIT_VMCNT(4);
+  sp::load_b<K>(c, X, slot0);
+  sp::load_a<K>(c, X, arow, 0);
+  LASSO_WAIT_LGKM0();
+  dma_step(c.w1 + 64, c.voff1, slot0);
+  auto nothing = [] {};
+  // MODE 0: both refills from given sources; 1: only the even step refills (odd = last step)
+  auto trip = [&](int s2, const float* srcE, const unsigned (&voffE)[4], const float* srcO,
+                  const unsigned (&voffO)[4], auto last_c) {
+    constexpr bool last = decltype(last_c)::value;
+    LASSO_WAIT_VMCNT(4);
+    sp::load_b<K>(c, Y, slot1);
+    sp::load_a<K>(c, Y, arow + s2 * 256, 1);
+    sp::step_body(acc, X.a, X, srcE, voffE, slot1, nothing, nothing, nothing, nothing);
+    if constexpr (!last) {
+      LASSO_WAIT_VMCNT(4);
+      sp::load_b<K>(c, X, slot0);
+      sp::load_a<K>(c, X, arow + (s2 + 1) * 256, 0);
+      sp::step_body(acc, Y.a, Y, srcO, voffO, slot0, nothing, nothing, nothing, nothing);
+    } else {
+      LASSO_PIN();
+      sp::mfma_range<0, 16>(acc, Y.a, Y);
+      LASSO_PIN();
+    }
+  };
+  using F = std::false_type;
+  using T = std::true_type;
+#pragma unroll 1
+  for (int s2 = 0; s2 < S1 / 2 - 2; ++s2)
+    trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
+  // steps S1-4 / S1-3: refills = W step S1-1 and tail0;  steps S1-2 / S1-1: refill = tail1 / none
+  trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, tail0, tail_voff, F{});
+  trip(S1 / 2 - 1, tail1, tail_voff, tail1, tail_voff, T{});
 }
 
 // wave-wide sum (wave-uniform result), fixed order, on the ALU path: DPP row_shr 1,2,4,8
