@@ -16,6 +16,7 @@
 // Rooflines: the two GEMM kernels are MFMA-bound (2nk^2 + 2nkd and 2k^2 d flop); the
 // sweep is a latency-bound dependency chain of k steps (time reported, no roofline).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <algorithm>
 #include "lasso_kernels.h"
@@ -217,12 +218,17 @@ __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigne
 // Sequential sweep over the kSweepBlock atoms [j0, j0+JB) -- one wave, lane owns
 // features 4*lane..4*lane+3 (d <= 256).
 // ---------------------------------------------------------------------------
+// FULL: all kSweepBlock atoms of the block exist (no per-atom branch at all, so hipcc can
+// overlap the deferred row updates of atom a with the reduction chain of atom a+1).
+// A degenerate atom (||u|| < eps, :92) leaves the model here (new atom = 0, dD = -old);
+// its replacement direction is written afterwards by degenerate_fixup_kernel.
+template <bool FULL>
 __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, int j0) {
   constexpr int JB = kSweepBlock;
   __shared__ __attribute__((aligned(16))) float sA[JB][JB];   // A[j0+a][j0+b] (symmetric)
   __shared__ __attribute__((aligned(16))) float sD[JB][kFistaD];   // old atoms of the block (rows of Dt)
   const int lane = threadIdx.x;
-  const int nb = min(JB, p.k - j0);
+  const int nb = FULL ? JB : min(JB, p.k - j0);
   for (int e = lane; e < JB * JB; e += 64) {
     const int a = e / JB, b = e % JB;
     sA[a][b] = (a < nb && b < nb) ? p.A[(int64_t)(j0 + a) * p.lda + j0 + b] : 0.0f;
@@ -234,74 +240,88 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
   }
   float u[JB][4];
 #pragma unroll
-  for (int a = 0; a < JB; ++a)
+  for (int a = 0; a < JB; ++a) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a < nb) v = *(const f32x4*)(p.U + (int64_t)(j0 + a) * p.ldu + 4 * lane);   // ldu = 256, padded cols are 0
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int dd = 4 * lane + f;
-      u[a][f] = (a < nb && dd < p.d) ? p.U[(int64_t)(j0 + a) * p.ldu + dd] : 0.0f;
-    }
+    for (int f = 0; f < 4; ++f) u[a][f] = v[f];
+  }
   __syncthreads();
-  int ndeg = p.ndeg_in_out[0];
+  const float lo = p.positive ? 0.0f : -INFINITY;                 // dict_learning.py:87-88
   static_for<JB>([&](auto a_c) {
     constexpr int a = decltype(a_c)::value;
-    if (a < nb) {   // wave-uniform
-      // the block's coefficients of atom a, A[j0+b][j0+a] = sA[a][b] by symmetry: one
-      // batch of broadcast ds_read_b128 instead of a dependent read per later atom
-      float cf[JB];
+    // the block's coefficients of atom a, A[j0+b][j0+a] = sA[a][b] by symmetry: one batch of
+    // broadcast ds_read_b128 instead of a dependent read per later atom
+    float cf[JB];
 #pragma unroll
-      for (int b4 = 0; b4 < JB / 4; ++b4) {
-        const f32x4 t4 = *(const f32x4*)(&sA[a][4 * b4]);
-        cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
-      }
-      const float ajj = cf[a];
-      float v[4], dcur[4], ss = 0.0f;
+    for (int b4 = 0; b4 < JB / 4; ++b4) {
+      const f32x4 t4 = *(const f32x4*)(&sA[a][4 * b4]);
+      cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
+    }
+    const f32x4 dc4 = *(const f32x4*)(&sD[a][4 * lane]);
+    float v[4], dcur[4], ss = 0.0f;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        dcur[f] = sD[a][4 * lane + f];
-        v[f] = fmaf(ajj, dcur[f], u[a][f]);
-        if (p.positive) v[f] = fmaxf(v[f], 0.0f);              // dict_learning.py:87-88
-        ss = fmaf(v[f], v[f], ss);
-      }
-      ss = wave_sum_dpp(ss);
-      const float nrm = sqrtf(ss);                               // :91
-      float dnew[4], delta[4];
-      if (nrm < p.eps) {                                         // :92-98 degenerate atom
-        float fs = 0.0f;
+    for (int f = 0; f < 4; ++f) {
+      dcur[f] = dc4[f];
+      v[f] = fmaxf(fmaf(cf[a], dcur[f], u[a][f]), lo);            // u_j = U_j + A_jj d_j   (:85-88)
+      ss = fmaf(v[f], v[f], ss);
+    }
+    ss = wave_sum_dpp(ss);
+    const float nrm = sqrtf(ss);                                    // :91
+    const bool deg = nrm < p.eps;                                   // :92 (wave-uniform)
+    const float inv = deg ? 0.0f : 1.0f / nrm;                      // :100 (atom / its norm)
+    f32x4 dnew, delta;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const int dd = 4 * lane + f;
-          float g = 0.0f;
-          if (dd < p.d) {
-            if (p.pool && p.pool_rows > 0)   // caller-supplied replacement direction #ndeg
-              g = p.pool[(int64_t)min(ndeg, p.pool_rows - 1) * p.pool_ld + dd];
-            else                             // counter-based N(0,1) keyed by (seed, atom, feature)
-              g = counter_normal(p.seed, (unsigned)(j0 + a), (unsigned)dd);
-          }
-          dnew[f] = g;
-          if (p.positive) dnew[f] = fmaxf(dnew[f], 0.0f);
-          fs = fmaf(dnew[f], dnew[f], fs);
-        }
-        fs = wave_sum_dpp(fs);
-        const float inv = 1.0f / sqrtf(fs);
+    for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dcur[f]; }
+    if (FULL || a < nb) {
+      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane) = dnew;
+      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = delta;
+      if (lane == 0) p.degenerate[j0 + a] = deg ? 1 : 0;
+    } else {
+      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { dnew[f] *= inv; delta[f] = -dcur[f]; }   // atom leaves the model
-        if (lane == 0) p.degenerate[j0 + a] = 1;
-        ++ndeg;
-      } else {
+    for (int b = a + 1; b < JB; ++b) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { dnew[f] = v[f] / nrm; delta[f] = dnew[f] - dcur[f]; }   // :100
-        if (lane == 0) p.degenerate[j0 + a] = 0;
-      }
-      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane) = (f32x4){dnew[0], dnew[1], dnew[2], dnew[3]};
-      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){delta[0], delta[1], delta[2], delta[3]};
-#pragma unroll
-      for (int b = a + 1; b < JB; ++b) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
-      }
+      for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
     }
   });
-  if (lane == 0) p.ndeg_in_out[0] = ndeg;
+}
+
+// Replacement directions for the degenerate atoms, in atom order: the i-th degenerate atom
+// takes pool row i (normalised; dict_learning.py:93-96) or a counter-based N(0,1) vector.
+__global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams p) {
+  __shared__ int s_idx[1024];
+  __shared__ int s_count;
+  __shared__ float sh[256];
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int j = 0; j < p.k; ++j)
+      if (p.degenerate[j]) { if (c < 1024) s_idx[c] = j; ++c; }
+    s_count = c;
+    p.ndeg_in_out[0] = c;
+  }
+  __syncthreads();
+  const int cnt = min(s_count, 1024);
+  const int dd = threadIdx.x;
+  for (int i = 0; i < cnt; ++i) {
+    const int j = s_idx[i];
+    float g = 0.0f;
+    if (dd < p.d) {
+      if (p.pool && p.pool_rows > 0) g = p.pool[(int64_t)min(i, p.pool_rows - 1) * p.pool_ld + dd];
+      else g = counter_normal(p.seed, (unsigned)j, (unsigned)dd);
+      if (p.positive) g = fmaxf(g, 0.0f);
+    }
+    sh[dd] = g * g;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (dd < s) sh[dd] += sh[dd + s];
+      __syncthreads();
+    }
+    const float inv = 1.0f / sqrtf(sh[0]);
+    __syncthreads();
+    p.Dt[(int64_t)j * kFistaD + dd] = g * inv;
+  }
 }
 
 // U[j'][:] -= sum_a A[j'][j0+a] * dD[a][:]   for j' >= j0 + JB; one row per wave-iteration
@@ -400,12 +420,16 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
 
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
   for (int j0 = 0; j0 < p.k; j0 += kSweepBlock) {
-    hipLaunchKernelGGL(sweep_block_kernel, dim3(1), dim3(64), 0, stream, p, j0);
+    if (j0 + kSweepBlock <= p.k)
+      hipLaunchKernelGGL(sweep_block_kernel<true>, dim3(1), dim3(64), 0, stream, p, j0);
+    else
+      hipLaunchKernelGGL(sweep_block_kernel<false>, dim3(1), dim3(64), 0, stream, p, j0);
     if (j0 + kSweepBlock < p.k) {
       const int rows = p.k - j0 - kSweepBlock;
       hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256)), dim3(256), 0, stream, p, j0);
     }
   }
+  hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 
