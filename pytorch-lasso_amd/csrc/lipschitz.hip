@@ -57,18 +57,32 @@ __global__ __launch_bounds__(256) void syrk_f64_kernel(const TIn* __restrict__ A
   const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
   const int l15 = lane & 15, q = lane >> 4;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int t0 = 0; t0 < len; t0 += 32) {
-    for (int e = tid; e < 32 * 32; e += 256) {
+  // register-prefetched staging: the global loads of chunk t+1 fly under the MFMAs of chunk t
+  double ra[4], rb[4];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int e = tid + 256 * h;
       const int r = e >> 5, cc = e & 31;            // consecutive threads -> consecutive t
       const int t = t0 + cc;
-      sa[r][cc] = (i0 + r < m && t < len) ? (double)A[(int64_t)(i0 + r) * si + (int64_t)t * st] * inv : 0.0;
-      sb[r][cc] = (j0 + r < m && t < len) ? (double)A[(int64_t)(j0 + r) * si + (int64_t)t * st] * inv : 0.0;
+      ra[h] = (i0 + r < m && t < len) ? (double)A[(int64_t)(i0 + r) * si + (int64_t)t * st] : 0.0;
+      rb[h] = (j0 + r < m && t < len) ? (double)A[(int64_t)(j0 + r) * si + (int64_t)t * st] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < len; t0 += 32) {
+    __syncthreads();                               // previous chunk's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int e = tid + 256 * h;
+      sa[e >> 5][e & 31] = ra[h] * inv;
+      sb[e >> 5][e & 31] = rb[h] * inv;
     }
     __syncthreads();
+    if (t0 + 32 < len) fetch(t0 + 32);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[iw + l15][4 * ks + q], sb[jw + l15][4 * ks + q], acc, 0, 0, 0);
-    __syncthreads();
   }
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg)
