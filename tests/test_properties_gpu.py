@@ -1,0 +1,82 @@
+"""Size-independent properties of the HIP FISTA path at BASELINE's full config-2 size
+(n=4096, d=256, k=1024) and ragged sizes: determinism, row-shard invariance (the basis of
+the multi-GPU sharding), positive homogeneity, ISTA descent, stop-rule consistency."""
+import pytest
+import torch
+
+from recipes import recipe_xw, LAMBDA_MAX_C2
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc():
+    from lasso_amd.linear import sparse_encode
+    return sparse_encode
+
+
+def test_bitwise_reproducible_and_row_shard_invariant():
+    enc = _enc()
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / LAMBDA_MAX_C2
+    z1 = enc(Xg, Wg, alpha=0.5, lr=lr, maxiter=40, tol=0.0)
+    z2 = enc(Xg, Wg, alpha=0.5, lr=lr, maxiter=40, tol=0.0)
+    assert torch.equal(z1, z2)                                     # run-to-run bitwise
+    # rows are independent problems: any row shard gives bitwise the same rows
+    for lo, hi in [(0, 512), (512, 4096), (1000, 1037), (4080, 4096)]:
+        zs = enc(Xg[lo:hi].contiguous(), Wg, alpha=0.5, lr=lr, maxiter=40, tol=0.0)
+        assert torch.equal(zs, z1[lo:hi]), (lo, hi)
+    # ... also through a strided (non-contiguous) view
+    zs = enc(Xg[::2], Wg, alpha=0.5, lr=lr, maxiter=40, tol=0.0)
+    assert torch.equal(zs, z1[::2])
+
+
+def test_positive_homogeneity():
+    """S_{c*lam}(c*v) = c*S_lam(v): scaling X and alpha by a power of two scales z exactly."""
+    enc = _enc()
+    X, W = recipe_xw(1024)
+    lr = 1.0 / LAMBDA_MAX_C2
+    z = enc(X.cuda(), W.cuda(), alpha=0.5, lr=lr, maxiter=25, tol=0.0)
+    z4 = enc((4 * X).cuda(), W.cuda(), alpha=2.0, lr=lr, maxiter=25, tol=0.0)
+    assert torch.equal(z4, 4 * z)
+
+
+def test_ista_objective_is_monotone_and_fista_converges_to_it():
+    from lasso_amd.linear import lasso_loss
+    enc = _enc()
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / LAMBDA_MAX_C2
+    prev = float("inf")
+    z = None
+    for _ in range(12):                                           # 12 x 5 ISTA iterations, warm started
+        z = enc(Xg, Wg, alpha=0.5, z0=z, fast=False, lr=lr, maxiter=5, tol=0.0)
+        obj = lasso_loss(Xg, z, Wg, 0.5).item()
+        assert obj <= prev * (1 + 1e-7)
+        prev = obj
+    zf = enc(Xg, Wg, alpha=0.5, lr=lr, maxiter=300, tol=0.0)
+    assert lasso_loss(Xg, zf, Wg, 0.5).item() <= prev
+    assert abs(lasso_loss(Xg, zf, Wg, 0.5).item() - 63.608994) <= 2e-5 * 63.6   # SURVEY 8d G2 (M=263)
+
+
+def test_stop_rule_paths_agree():
+    """The in-kernel stop rule (n <= 16*CUs), the chunked speculate-and-replay path and a
+    fixed-iteration run to the reported count give the same code."""
+    import os
+    from lasso_amd.linear.solvers import ista
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(4096, 1024, device="cuda")
+    lr = 1.0 / LAMBDA_MAX_C2
+    z_in, info = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=1000, tol=1e-4, return_info=True)
+    z_fix = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=info["iterations"], tol=0.0)
+    assert torch.equal(z_in, z_fix)
+    # more rows than resident workgroups -> chunked path; its first 4096 rows see a different
+    # GLOBAL sum, so compare against a fixed-iteration run of the same problem instead
+    X2, _ = recipe_xw(4096 + 4096 * 2)
+    X2g = X2.cuda()
+    z02 = torch.zeros(X2g.shape[0], 1024, device="cuda")
+    z_ch, info2 = ista(X2g, z02, Wg, 0.5, lr=lr, maxiter=1000, tol=1e-4, return_info=True)
+    z_fix2 = ista(X2g, z02, Wg, 0.5, lr=lr, maxiter=info2["iterations"], tol=0.0)
+    assert torch.equal(z_ch, z_fix2)
+    assert abs(info2["iterations"] - info["iterations"]) <= 3
