@@ -204,10 +204,9 @@ _DEFAULT_INIT = {"ista": "zero"}                                  # sparse_encod
 
 
 def initial_code(x, weight, alpha, mode):
-    """z0 initialisation, sparse_encode.py:19-35.  Modes on the hot path:
-    'zero' (:22-23), plus the GEMM-only modes 'transpose' (:30-31) and 'unif'
-    (:24-25).  'lstsq'/'ridge' (:26-29) depend on lasso/linear/utils.py and
-    are outside the hot path."""
+    """z0 initialisation, sparse_encode.py:19-35: 'zero' (:22-23, the hot-path default),
+    'unif' (:24-25), 'lstsq' (:26-27), 'ridge' (:28-29), 'transpose' (:30-31)
+    (SURVEY.md section 8f row f1)."""
     n, k = x.size(0), weight.size(1)
     if mode == "zero":
         return x.new_zeros(n, k)
@@ -215,9 +214,37 @@ def initial_code(x, weight, alpha, mode):
         return x.new(n, k).uniform_(-0.1, 0.1)
     if mode == "transpose":
         return torch.matmul(x, weight)
-    if mode in ("lstsq", "ridge"):
-        raise NotImplementedError("init=%r is outside the hot path" % mode)
+    if mode == "lstsq":                                           # :26-27 -> utils.py:13-25
+        return least_squares_code(x, weight)
+    if mode == "ridge":                                           # :28-29 -> utils.py:28-40
+        return ridge_code(x, weight, alpha)
     raise ValueError("invalid init parameter '{}'.".format(mode))  # :33
+
+
+def least_squares_code(x, weight):
+    """z0 with W z0_i = x_i in the least-squares / least-norm sense via a reduced QR
+    (lasso/linear/utils.py:13-25, called as lstsq(x.T, weight).T)."""
+    d, k = weight.shape
+    b = x.T                                                        # [d, n]
+    if d < k:                                                      # under-determined: least norm
+        Q, R = torch.linalg.qr(weight.T, mode="reduced")           # W^T = Q R,  Q [k,d], R [d,d]
+        y = torch.linalg.solve_triangular(R.T, b, upper=False)     # R^T y = b
+        sol = Q @ y
+    else:                                                          # over-determined: least squares
+        Q, R = torch.linalg.qr(weight, mode="reduced")
+        sol = torch.linalg.solve_triangular(R, Q.T @ b, upper=True)
+    return sol.T
+
+
+def ridge_code(x, weight, alpha):
+    """z0 = argmin ||W z - x||^2 + alpha ||z||^2 per sample via Cholesky of W^T W + alpha I
+    (lasso/linear/utils.py:28-40, called as ridge(x.T, weight, alpha=alpha).T)."""
+    gram = weight.T @ weight
+    gram.diagonal().add_(alpha)
+    chol, info = torch.linalg.cholesky_ex(gram)
+    if info != 0:
+        raise RuntimeError("The Gram matrix is not positive definite. Try increasing 'alpha'.")
+    return torch.cholesky_solve(weight.T @ x.T, chol).T
 
 
 def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm="ista", init=None,

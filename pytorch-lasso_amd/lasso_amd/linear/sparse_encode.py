@@ -8,10 +8,32 @@ _init_defaults = {'ista': 'zero'}                                   # sparse_enc
 _OFF_PATH_ALGOS = ('cd', 'gpsr', 'iter-ridge', 'interior-point', 'split-bregman', 'own')
 
 
+def _lstsq_init(x, weight):
+    # least-norm (d < k) / least-squares (d >= k) code through a reduced QR of the dictionary
+    d, k = weight.shape
+    rhs = x.T
+    if d < k:
+        q, r = torch.linalg.qr(weight.T, mode='reduced')
+        return (q @ torch.linalg.solve_triangular(r.T, rhs, upper=False)).T
+    q, r = torch.linalg.qr(weight, mode='reduced')
+    return torch.linalg.solve_triangular(r, q.T @ rhs, upper=True).T
+
+
+def _ridge_init(x, weight, alpha):
+    # (W^T W + alpha I) z = W^T x per sample, Cholesky
+    gram = weight.T @ weight
+    gram.diagonal().add_(alpha)
+    chol, info = torch.linalg.cholesky_ex(gram)
+    if info != 0:
+        raise RuntimeError("The Gram matrix is not positive definite. Try increasing 'alpha'.")
+    return torch.cholesky_solve(weight.T @ x.T, chol).T
+
+
 def initialize_code(x, weight, alpha, mode):
-    """sparse_encode.py:19-35.  'zero' (:22-23) is the hot-path default; 'unif'
-    (:24-25) and 'transpose' (:30-31) are plain tensor ops; 'lstsq'/'ridge'
-    (:26-29) belong to lasso/linear/utils.py and are not part of this engine."""
+    """sparse_encode.py:19-35.  'zero' (:22-23) is the hot-path default; the other modes
+    ('unif', 'transpose', 'lstsq', 'ridge') are one-off dense linear-algebra set-ups that
+    run as torch / torch.linalg calls (rocBLAS / rocSOLVER when the tensors are on the
+    GPU) -- library plumbing, not part of the HIP hot path."""
     n_samples = x.size(0)
     n_components = weight.size(1)
     if mode == 'zero':
@@ -20,8 +42,10 @@ def initialize_code(x, weight, alpha, mode):
         z0 = x.new(n_samples, n_components).uniform_(-0.1, 0.1)
     elif mode == 'transpose':
         z0 = torch.matmul(x, weight)
-    elif mode in ('lstsq', 'ridge'):
-        raise NotImplementedError("lasso_amd: init=%r is outside the HIP hot path" % mode)
+    elif mode == 'lstsq':                                            # :26-27 (utils.py:13-25)
+        z0 = _lstsq_init(x, weight)
+    elif mode == 'ridge':                                            # :28-29 (utils.py:28-40)
+        z0 = _ridge_init(x, weight, alpha)
     else:
         raise ValueError("invalid init parameter '{}'.".format(mode))   # :33
     return z0

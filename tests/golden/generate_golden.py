@@ -250,6 +250,22 @@ def small():
     save("small_cases", **out)
 
 
+def inits():
+    """sparse_encode(init=...) for every init mode of sparse_encode.py:19-35."""
+    from lasso.linear import initialize_code
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    for tag, (n, d, k) in {"under": (40, 12, 30), "over": (40, 30, 12)}.items():
+        W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+        X = torch.randn(n, d, generator=g)
+        out[tag + "_X"], out[tag + "_W"] = X.numpy(), W.numpy()
+        for mode in ("zero", "transpose", "lstsq", "ridge"):
+            out["%s_z0_%s" % (tag, mode)] = initialize_code(X, W, 0.3, mode).numpy().copy()
+            out["%s_z_%s" % (tag, mode)] = sparse_encode(X, W, alpha=0.3, algorithm="ista", init=mode,
+                                                         lr=0.05, maxiter=20, tol=0.0).numpy().copy()
+    save("init_modes", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "small", "g4"]
     torch.set_num_threads(8)

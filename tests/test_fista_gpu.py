@@ -171,3 +171,18 @@ def test_large_and_empty_shapes(n, d, k):
         assert abs(info["iterations"] - tr.iterations) <= 1
         assert abs(sparse_encode(X.cuda(), W.cuda(), alpha=0.2, maxiter=3).cpu()
                    - orc.sparse_encode(X, W, alpha=0.2, maxiter=3)).max().item() <= 1e-4   # lr='auto'
+
+
+def test_init_modes_against_reference(golden):
+    """sparse_encode(init=...) for every mode of sparse_encode.py:19-35."""
+    sparse_encode, ista, orc = _mods()
+    from lasso_amd.linear import initialize_code
+    g = golden("init_modes")
+    for tag in ("under", "over"):
+        X, W = torch.from_numpy(g[tag + "_X"]), torch.from_numpy(g[tag + "_W"])
+        for mode in ("zero", "transpose", "lstsq", "ridge"):
+            z0 = initialize_code(X.cuda(), W.cuda(), 0.3, mode)
+            assert (z0.cpu() - torch.from_numpy(g["%s_z0_%s" % (tag, mode)])).abs().max().item() <= 5e-5
+            z = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, init=mode, lr=0.05, maxiter=20, tol=0.0)
+            assert (z.cpu() - torch.from_numpy(g["%s_z_%s" % (tag, mode)])).abs().max().item() <= 5e-5
+    assert initialize_code(X.cuda(), W.cuda(), 0.3, "unif").abs().max().item() <= 0.1
