@@ -18,6 +18,25 @@ def _to_device(t, device):
     return t if t.device == device else t.to(device)
 
 
+def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
+    """verbose=True: the reference prints the mean objective of z before every iteration
+    (ista.py:80-81, 'loss: %0.4f').  Same here, one HIP iteration at a time (the state
+    round-trips through HBM each step -- a debugging mode, not the fast path)."""
+    from ...engine import HipEngine
+    eng = HipEngine(dev)
+    n, k = z0.shape
+    budget = torch.tensor(float(n * k) * tol, dtype=torch.float32).item()
+    z, y, done, last = z0, None, 0, float('nan')
+    for it in range(maxiter):
+        loss, _ = eng.objective_sums(x, z, weight, alpha)
+        print('loss: %0.4f' % loss.item())
+        z, y, delta = eng.fista_run(x, weight, z, y, alpha, lr, fast, it, 1, True, prepared=False)
+        done, last = it + 1, delta[0].item()
+        if last <= budget:
+            break
+    return z, dict(iterations=done, last_delta=last)
+
+
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
          return_info=False):
@@ -72,6 +91,11 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         from ..lipschitz import lipschitz_constant
         lr = 1.0 / lipschitz_constant(wg)                          # ista.py:59-63
     lr = float(lr)
+
+    if verbose and not backtrack:
+        z, info = _ista_verbose(xg, zg, wg, alpha, fast, lr, maxiter, tol, dev)
+        z = z if z.device == out_device else z.to(out_device)
+        return (z, info) if return_info else z
 
     L = nat.lib()
     z = torch.empty((n, k), dtype=x.dtype, device=dev)

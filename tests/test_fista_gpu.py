@@ -186,3 +186,19 @@ def test_init_modes_against_reference(golden):
             z = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, init=mode, lr=0.05, maxiter=20, tol=0.0)
             assert (z.cpu() - torch.from_numpy(g["%s_z_%s" % (tag, mode)])).abs().max().item() <= 5e-5
     assert initialize_code(X.cuda(), W.cuda(), 0.3, "unif").abs().max().item() <= 0.1
+
+
+def test_verbose_prints_reference_loss_lines(capsys):
+    """verbose=True prints 'loss: %0.4f' of z before each iteration like ista.py:80-81 and
+    returns the same code as the silent path."""
+    sparse_encode, ista, orc = _mods()
+    X, W = _case(40, 20, 60, seed=2)
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    z_ref = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, lr=lr, maxiter=6, tol=0.0)
+    capsys.readouterr()
+    z = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, lr=lr, maxiter=6, tol=0.0, verbose=True)
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("loss:")]
+    tr = orc.FistaTrace()
+    orc.fista(X, X.new_zeros(40, 60), W, 0.3, lr=lr, maxiter=6, tol=0.0, trace=tr)
+    assert out == ["loss: %0.4f" % v for v in tr.objective]
+    assert torch.equal(z, z_ref)
