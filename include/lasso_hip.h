@@ -134,7 +134,9 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
 /* ---- constrained M-step in Gram form: replaces update_dict, dict_learning.py:56-103 --
  * lasso_gram_accumulate: A = Z^T Z [k][k] (ld k), B = Z^T X [k][d] (ld d) of this row
  *   shard (fp32 MFMA).  The caller all-reduces A and B across GPUs (they may be two
- *   slices of one buffer).
+ *   slices of one buffer).  The workspace (optional, may be NULL) holds the partial
+ *   products of the sample splits that keep all CUs busy; they are summed in a fixed
+ *   order, so the result is deterministic either way.
  * lasso_dict_sweep: Gauss-Seidel sweep over the atoms on (A, B), updating the
  *   dictionary D [d][k] (ldd) IN PLACE like the reference (:86,:100).  Atoms with
  *   ||u|| < eps (:92) are replaced by the next unused row of `pool_dev`
@@ -145,9 +147,11 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
  *   non-NULL, makes the call synchronise `stream`.
  * lasso_zero_columns: Z[:, j] = 0 where degenerate_dev[j] != 0 (:98).
  */
+size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k);
 int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx,
                           int64_t n, int64_t d, int64_t k, int dtype,
-                          float* a_dev, float* b_dev, void* stream);
+                          float* a_dev, float* b_dev,
+                          void* workspace_dev, size_t workspace_bytes, void* stream);
 size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k);
 int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd,
                      int64_t d, int64_t k, int dtype, double eps, int positive,

@@ -714,16 +714,28 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
 }
 
 // ---------------------------------------------------------------------------
+size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k) {
+  if (n < 0 || d <= 0 || k <= 0) return 0;
+  return (size_t)16 * (size_t)k * (size_t)std::max(k, d) * 4 + 256;   // up to 16 sample splits
+}
+
 int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
-                          int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev, void* stream) {
+                          int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
+                          void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!z_dev || !x_dev || !a_dev || !b_dev || n < 0 || d <= 0 || k <= 0 || ldz < k || ldx < d)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
   if (n > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "n too large");
   hipStream_t st = (hipStream_t)stream;
   const float* Z = (const float*)z_dev;
-  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, st));
-  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, b_dev, d, 0, st));
+  // optional scratch for the split-n partial products (NULL = single pass)
+  float* scratch = (workspace_dev && workspace_bytes >= lasso_gram_workspace_bytes(n, d, k))
+                       ? (float*)workspace_dev : nullptr;
+  const int cus = device_cus();
+  const int sa = gram_splits((int)k, (int)k, (int)n, 1, cus), sb = gram_splits((int)k, (int)d, (int)n, 0, cus);
+  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, scratch, sa, st));
+  LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, b_dev, d, 0,
+                               scratch, sb, st));
   return LASSO_OK;
 }
 

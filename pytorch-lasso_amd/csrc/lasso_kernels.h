@@ -89,8 +89,10 @@ size_t lipschitz_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,
                             int squarings, hipStream_t stream);
 
+int gram_splits(int pc, int qc, int n, int sym, int cus);
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
-                          int n, float* C, int64_t ldc, int sym, hipStream_t stream);
+                          int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
+                          hipStream_t stream);
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
                               const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
                               int kk, hipStream_t stream);

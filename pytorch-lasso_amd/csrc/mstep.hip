@@ -40,8 +40,16 @@ constexpr int kGB = 64, kGS = 64, kGLd = 80;
 template <bool VEC>
 __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ P, int64_t ldp, int pc,
                                                       const float* __restrict__ Q, int64_t ldq, int qc,
-                                                      int n, float* __restrict__ C, int64_t ldc, int sym) {
+                                                      int n, float* __restrict__ C, int64_t ldc, int sym,
+                                                      int rows_per_split, int64_t split_stride) {
   if (sym && blockIdx.x < blockIdx.y) return;
+  // split-n: blockIdx.z handles samples [z*rows_per_split, (z+1)*rows_per_split) and
+  // writes its partial product to C + z*split_stride (summed in fixed order afterwards)
+  const int n_lo = blockIdx.z * rows_per_split;
+  P += (int64_t)n_lo * ldp;
+  Q += (int64_t)n_lo * ldq;
+  n = min(rows_per_split, n - n_lo);
+  C += (int64_t)blockIdx.z * split_stride;
   __shared__ __attribute__((aligned(16))) float sp[kGS][kGLd], sq[kGS][kGLd];
   const int i0 = blockIdx.y * kGB, j0 = blockIdx.x * kGB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -107,6 +115,17 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
           if (sym && blockIdx.x != blockIdx.y) C[(int64_t)cc * ldc + r] = acc[mi][nj][rg];
         }
       }
+}
+
+// C[r][c] = sum_s part[s][r][c]  (fixed order)
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, int splits,
+                                                         int64_t split_stride, int rows, int cols,
+                                                         float* __restrict__ C, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  float acc = 0.0f;
+  for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + idx];
+  C[(idx / cols) * ldc + idx % cols] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -397,15 +416,39 @@ __global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, i
 
 }  // namespace
 
+// Number of sample splits that gives the chip ~3 workgroups per CU (the output has only
+// (pc/64)*(qc/64) blocks), each split keeping at least 512 samples.
+int gram_splits(int pc, int qc, int n, int sym, int cus) {
+  int blocks = ((qc + kGB - 1) / kGB) * ((pc + kGB - 1) / kGB);
+  if (sym) blocks = blocks / 2 + (pc + kGB - 1) / kGB / 2 + 1;
+  int s = (3 * cus + blocks - 1) / std::max(blocks, 1);
+  s = std::min(s, std::max(n / 512, 1));
+  return std::max(1, std::min(s, 16));
+}
+
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
-                          int n, float* C, int64_t ldc, int sym, hipStream_t stream) {
-  const dim3 grid((qc + kGB - 1) / kGB, (pc + kGB - 1) / kGB);
+                          int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
+                          hipStream_t stream) {
+  if (!scratch) splits = 1;
+  const int rows_per_split = ((n + splits - 1) / splits + kGS - 1) / kGS * kGS;
+  splits = std::max(1, (n + rows_per_split - 1) / std::max(rows_per_split, 1));
+  const dim3 grid((qc + kGB - 1) / kGB, (pc + kGB - 1) / kGB, splits);
   const bool vec = pc % 4 == 0 && qc % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 &&
                    ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
+  float* dst = splits > 1 ? scratch : C;
+  const int64_t dld = splits > 1 ? qc : ldc;
+  const int64_t stride = (int64_t)pc * qc;
   if (vec)
-    hipLaunchKernelGGL(gram_tn_kernel<true>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
+    hipLaunchKernelGGL(gram_tn_kernel<true>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, dst,
+                       dld, sym, rows_per_split, stride);
   else
-    hipLaunchKernelGGL(gram_tn_kernel<false>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, C, ldc, sym);
+    hipLaunchKernelGGL(gram_tn_kernel<false>, grid, dim3(256), 0, stream, P, ldp, pc, Q, ldq, qc, n, dst,
+                       dld, sym, rows_per_split, stride);
+  if (splits > 1) {
+    const int64_t total = (int64_t)pc * qc;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       scratch, splits, stride, pc, qc, C, ldc);
+  }
   return hipGetLastError();
 }
 

@@ -58,7 +58,9 @@ def _declare(lib):
     lib.lasso_objective.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, vp, vp,
                                     vp, sz, vp]
     lib.lasso_gram_accumulate.restype = i32
-    lib.lasso_gram_accumulate.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp]
+    lib.lasso_gram_workspace_bytes.restype = sz
+    lib.lasso_gram_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.lasso_gram_accumulate.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]
     lib.lasso_dict_sweep_workspace_bytes.restype = sz
     lib.lasso_dict_sweep_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_dict_sweep.restype = i32

@@ -93,9 +93,10 @@ class HipEngine:
         A = out[:k * k].view(k, k)
         B = out[k * k:k * k + k * d].view(k, d)
         with torch.cuda.device(self.device):
+            ws = self._ws(self.lib.lasso_gram_workspace_bytes(n, d, k), "gram")
             nat.check(self.lib.lasso_gram_accumulate(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0),
                                                      n, d, k, nat.LASSO_F32, nat.ptr(A), nat.ptr(B),
-                                                     self._stream()))
+                                                     nat.ptr(ws), ws.numel(), self._stream()))
         return A, B
 
     def sweep(self, A, B, D, pool, eps, positive, seed=0):
