@@ -267,6 +267,8 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
   }
   __syncthreads();
   const float lo = p.positive ? 0.0f : -INFINITY;                 // dict_learning.py:87-88
+  const float eps2 = p.eps * p.eps;
+  unsigned degmask = 0;
   static_for<JB>([&](auto a_c) {
     constexpr int a = decltype(a_c)::value;
     // the block's coefficients of atom a, A[j0+b][j0+a] = sA[a][b] by symmetry: one batch of
@@ -286,16 +288,17 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       ss = fmaf(v[f], v[f], ss);
     }
     ss = wave_sum_dpp(ss);
-    const float nrm = sqrtf(ss);                                    // :91
-    const bool deg = nrm < p.eps;                                   // :92 (wave-uniform)
-    const float inv = deg ? 0.0f : 1.0f / nrm;                      // :100 (atom / its norm)
+    // ||u|| < eps  <=>  ||u||^2 < eps^2 (:91-92); 1/||u|| by v_rsq_f32 (1 ulp) -- the
+    // sqrt + divide pair of :91,:100 would put ~25 dependent instructions on the chain
+    const bool deg = ss < eps2;                                     // wave-uniform
+    const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
     f32x4 dnew, delta;
 #pragma unroll
     for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dcur[f]; }
     if (FULL || a < nb) {
       *(f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane) = dnew;
       *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = delta;
-      if (lane == 0) p.degenerate[j0 + a] = deg ? 1 : 0;
+      degmask |= (deg ? 1u : 0u) << a;
     } else {
       *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
     }
   });
+  if (lane < nb) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);   // one store, no per-atom branch
 }
 
 // Replacement directions for the degenerate atoms, in atom order: the i-th degenerate atom
