@@ -30,18 +30,22 @@ namespace sp {
 
 // STOP: compile the in-kernel global stop rule in (separate instantiation so that the
 // fixed-iteration kernel keeps its register allocation).
-template <int K, bool STOP>
+// M: rows per tile; the padded feature count is D = 4096 / M (M = 16 / D = 256 is the flagship
+// shape; M = 32 / 64 serve dictionaries with d <= 128 / 64 without padding d up to 256).
+template <int K, int M, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
-  constexpr int D = kFistaD;
+  constexpr int D = 4096 / M;
   constexpr int NW = kFistaWaves;
   constexpr int S1 = K / 32;
-  constexpr int KW = K / NW;
+  constexpr int KW = TileCtx<K, D>::KW;
   constexpr int NP = KW / 32;
   constexpr int T2 = D / 32;
   constexpr int S2 = NP * T2;
-  constexpr int YT_BYTES = kTileM * K * 4;
-  constexpr int RT_BYTES = kTileM * D * 4;
-  static_assert(D == 32 * NW && S1 % 2 == 0 && S2 % 2 == 0 && S1 >= 6 && S2 >= 4, "geometry");
+  constexpr int YT_BYTES = M * K * 4;
+  constexpr int RT_BYTES = M * D * 4;
+  static_assert(M * D == 4096 && M % 16 == 0 && D % 32 == 0, "tile shape");
+  static_assert(S1 % 2 == 0 && S2 % 2 == 0 && S1 >= 6 && S2 >= 4 && NP >= 1, "geometry");
+  static_assert(YT_BYTES <= 65536, "y tile must fit beside the rings");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const rings = (lds_char*)smem;
@@ -49,10 +53,12 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   lds_char* const rt = yt + YT_BYTES;
   lds_f32* const red = (lds_f32*)(rt + RT_BYTES);
 
-  TileCtx<K> c;
+  TileCtx<K, D> c;
   c.init(p.Wp, p.Wtp, rings);
   const int tid = threadIdx.x;
   const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+  const int rbase = 16 * c.rb;          // first tile row of this wave's row block
+  const int cw = c.cw;                  // column index of the wave inside its row block
   lds_char* const slot0 = c.ring;
   lds_char* const slot1 = c.ring + kStepBytes;
   // y-tile byte offset of this lane's C-layout element (row 4q+rg, column colbase+n), see
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   int ep_rg[4];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg)
-    ep_rg[rg] = (4 * q + rg) * (K * 4) + (((n >> 2) ^ rg) << 4) + ((n & 3) << 2);
+    ep_rg[rg] = (rbase + 4 * q + rg) * (K * 4) + (((n >> 2) ^ rg) << 4) + ((n & 3) << 2);
 
   // Ring invariant on entry of GEMM-1 (every iteration, every tile):
   //   X.b holds the B fragments of step 0; slot1 <- step 1, slot0 <- step 2 in flight.
@@ -68,16 +74,16 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   dma_step(c.w1, c.voff1, slot0);
   dma_step(c.w1 + 32, c.voff1, slot1);
   LASSO_WAIT_VMCNT(4);
-  load_b<K>(c, X, slot0);
+  load_b(c, X, slot0);
   LASSO_WAIT_LGKM0();
   dma_step(c.w1 + 64, c.voff1, slot0);
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int row0 = tile * kTileM;
+    const int row0 = tile * M;
     {
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
-      visit_tile4<K, kFistaThreads>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+      visit_tile4<K, kFistaThreads, M>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
         *(lds_f32x4*)(yt + tile_chunk_off<K>(r, cc)) = v;
       });
     }
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int r = 4 * q + rg, cc = wid * KW + 32 * ps + 16 * cb + n;
+          const int r = rbase + 4 * q + rg, cc = cw * KW + 32 * ps + 16 * cb + n;
           float v = 0.0f;
           if (p.z_in && (row0 + r) < p.n && cc < p.k)
             v = (p.z_in + (int64_t)row0 * p.ldz_in)[r * (int)p.ldz_in + cc];
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+        const int r = rbase + 4 * q + rg, cc = 32 * cw + 16 * cb + n;
         float v = 0.0f;
         if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
         xneg[cb][rg] = -v;
@@ -113,11 +119,11 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       float dsum = 0.0f;
       int no = n, qo = q;
       asm volatile("" : "+v"(no), "+v"(qo));
-      const lds_char* const yrow = yt + n * (K * 4);
+      const lds_char* const yrow = yt + (rbase + n) * (K * 4);
 
       // ======================= GEMM-1: r = y W^T - x =========================
       f32x4 acc[2] = {xneg[0], xneg[1]};
-      load_a<K>(c, X, yrow, 0);                       // A fragments of step 0 (y is final now)
+      load_a(c, X, yrow, 0);                       // A fragments of step 0 (y is final now)
       // one trip = steps s = 2*s2 (on X) and s+1 (on Y).  srcE/srcO: DMA refills issued
       // in the even/odd step (steps s+3 / s+4 of the stream).
       auto trip = [&](int s2, const float* srcE, const unsigned (&voffE)[4], const float* srcO,
@@ -125,13 +131,13 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         constexpr bool last = decltype(last_c)::value;
         // ---- even step: compute X, fetch step s+1 -> Y
         LASSO_WAIT_VMCNT(4);
-        load_b<K>(c, Y, slot1);
-        load_a<K>(c, Y, yrow + s2 * 256, 1);
+        load_b(c, Y, slot1);
+        load_a(c, Y, yrow + s2 * 256, 1);
         step_body(acc, X.a, X, srcE, voffE, slot1, no_stage, no_stage, no_stage, no_stage);
         // ---- odd step: compute Y, fetch step s+2 -> X (B only when it is GEMM-2's step 0)
         LASSO_WAIT_VMCNT(4);
-        load_b<K>(c, X, slot0);
-        if constexpr (!last) load_a<K>(c, X, yrow + (s2 + 1) * 256, 0);
+        load_b(c, X, slot0);
+        if constexpr (!last) load_a(c, X, yrow + (s2 + 1) * 256, 0);
         step_body(acc, Y.a, Y, srcO, voffO, slot0, no_stage, no_stage, no_stage, no_stage);
       };
       using F = std::false_type;
@@ -155,8 +161,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       }
       // steps S1-4, S1-3: refills are W step S1-1 and W^T step 0
       trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, c.w2, c.voff2, F{});
-      // steps S1-2, S1-1: refills are W^T steps 1 and 2
-      trip(S1 / 2 - 1, c.w2 + 32, c.voff2, c.w2 + 64, c.voff2, T{});
+      // steps S1-2, S1-1: refills are W^T steps 1 and 2 (step U = pass U/T2, d-chunk U%T2)
+      trip(S1 / 2 - 1, c.w2 + (size_t)(32 * (1 / T2)) * D + 32 * (1 % T2), c.voff2,
+           c.w2 + (size_t)(32 * (2 / T2)) * D + 32 * (2 % T2), c.voff2, T{});
       // now X.b = B fragments of GEMM-2 step 0; slot1 <- W^T step 1, slot0 <- W^T step 2
 
       if (STOP && check && wid == 0) {
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
+          *(lds_f32*)(rt + tile_off<D>(rbase + 4 * qo + rg, 32 * cw + 16 * cb + no)) = acc[cb][rg];
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       LASSO_DESYNC();
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         break;
       }
       f32x4 rf[T2][2];
-      load_r_frags<K>(c, rt, rf);
+      load_r_frags<K, D>(c, rt, rf);
 
       // ================= GEMM-2 + pipelined prox/momentum epilogue ==============
       f32x4 g2[2][2];   // [pass parity][col-block]
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       // the gaps between the MFMAs of the NEXT pass's first step.
       auto ep_addr = [&](auto ps_c, int cb, int rg) {
         constexpr int ps = decltype(ps_c)::value;
-        const int colbase = wid * KW + 32 * ps + 16 * cb;          // wave-uniform
+        const int colbase = cw * KW + 32 * ps + 16 * cb;           // wave-uniform
         return (lds_f32*)(yt + ep_rg[rg] + ((((colbase >> 4) & 3) ^ qo) << 6) + (colbase >> 6) * 256);
       };
       auto ep_read = [&](auto ps_c) {
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
           for (int cb = 0; cb < 2; ++cb) g2[ps & 1][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         LASSO_WAIT_VMCNT(4);
-        load_b<K>(c, nxt, nslot);            // step U+1 (for U = S2-1: next iteration's GEMM-1 step 0)
+        load_b(c, nxt, nslot);            // step U+1 (for U = S2-1: next iteration's GEMM-1 step 0)
         const float* src;
         if constexpr (U + 3 < S2) {
           constexpr int pn = (U + 3) / T2, tn = (U + 3) % T2;
@@ -336,13 +343,13 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int r = 4 * qo + rg, cc = wid * KW + 32 * ps + 16 * cb + no;
+            const int r = rbase + 4 * qo + rg, cc = cw * KW + 32 * ps + 16 * cb + no;
             if ((row0 + r) < p.n && cc < p.k) zo_base[r * (int)p.ldz_out + cc] = zreg[ps][cb][rg];
           }
     }
     if (p.y_out) {
       const bool yvec = vec4_ok(p.y_out, p.ldy_out, p.k);
-      for (int idx = tid; idx < kTileM * (K / 4); idx += kFistaThreads) {
+      for (int idx = tid; idx < M * (K / 4); idx += kFistaThreads) {
         const int r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
         const f32x4 v = *(const lds_f32x4*)(yt + tile_chunk_off<K>(r, cc));
         store_row4(p.y_out, p.ldy_out, row0 + r, p.n, p.k, cc, v, yvec);
@@ -354,34 +361,44 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   LASSO_WAIT_VMCNT(0);
 }
 
-template <int K, bool STOP>
+template <int K, int M, bool STOP>
 static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stream) {
-  const size_t lds = fista_tile_lds_bytes(K);
+  const size_t lds = (size_t)M * K * 4 + (size_t)M * (4096 / M) * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, STOP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((fista_tile_sp_kernel<K, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
 }
 
-template <int K>
+template <int K, int M>
 static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
-  return p.stop_on ? launch_ks<K, true>(p, grid, stream) : launch_ks<K, false>(p, grid, stream);
+  return p.stop_on ? launch_ks<K, M, true>(p, grid, stream) : launch_ks<K, M, false>(p, grid, stream);
 }
 
 }  // namespace sp
 
-hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int grid, hipStream_t stream) {
-  switch (kpad) {
-    case 256: return sp::launch_k<256>(p, grid, stream);
-    case 512: return sp::launch_k<512>(p, grid, stream);
-    case 1024: return sp::launch_k<1024>(p, grid, stream);
-    default: return hipErrorInvalidValue;
+// rows per tile for a padded feature count (256 -> 16, 128 -> 32, 64 -> 64)
+hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream) {
+  if (dpad == 256) {
+    switch (kpad) {
+      case 256: return sp::launch_k<256, 16>(p, grid, stream);
+      case 512: return sp::launch_k<512, 16>(p, grid, stream);
+      case 1024: return sp::launch_k<1024, 16>(p, grid, stream);
+    }
+  } else if (dpad == 128) {
+    switch (kpad) {
+      case 256: return sp::launch_k<256, 32>(p, grid, stream);
+      case 512: return sp::launch_k<512, 32>(p, grid, stream);
+    }
+  } else if (dpad == 64) {
+    if (kpad == 256) return sp::launch_k<256, 64>(p, grid, stream);
   }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace lasso

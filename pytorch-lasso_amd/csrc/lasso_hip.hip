@@ -42,6 +42,10 @@ int pad_k(int64_t k) {
   return -1;
 }
 
+// Padded feature count of the fused FISTA kernel: tiles are M x D with M*D = 4096, and the
+// y tile (M x Kp fp32) must fit 64 KiB of LDS, so small dictionaries get taller tiles.
+int pad_d(int64_t d, int kp);
+
 // ---------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------
@@ -88,7 +92,7 @@ Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool wit
 // ---------------------------------------------------------------------------
 // Wp[r][c] = W[r][c] (zero padded to [256][Kp]); Wtp[c][r] = W[r][c].
 __global__ void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int d, int k, int kp,
-                              float* __restrict__ wp, float* __restrict__ wtp) {
+                              float* __restrict__ wp, float* __restrict__ wtp, int dpad = kFistaD) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
@@ -101,7 +105,7 @@ __global__ void pack_w_kernel(const float* __restrict__ W, int64_t ldw, int d, i
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, r = r0 + tx;
-    wtp[(size_t)c * kFistaD + r] = tile[tx][i];
+    wtp[(size_t)c * dpad + r] = tile[tx][i];
   }
 }
 
@@ -163,6 +167,13 @@ int fista_variant() {
 
 bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
 
+int pad_d(int64_t d, int kp) {
+  if (fista_variant() != 1) return kFistaD;          // legacy variants: 16 x 256 tiles only
+  if (d <= 64 && kp <= 256) return 64;
+  if (d <= 128 && kp <= 512) return 128;
+  return kFistaD;
+}
+
 int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = false) {
   if (dtype != LASSO_F32)
     return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
@@ -181,7 +192,9 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
              int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f) {
   if (n == 0) return LASSO_OK;
-  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  const int dpad = pad_d(d, kp);
+  const int tile_rows = 4096 / dpad;
+  const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
   FistaTileParams p;
   p.X = x; p.ldx = ldx;
   p.Wp = ws.wp; p.Wtp = ws.wtp;
@@ -205,7 +218,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   switch (fista_variant()) {
     case 8: LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream)); break;
     case 16: LASSO_HIP_TRY(launch_fista_tile16(p, kp, grid, stream)); break;
-    default: LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, grid, stream)); break;
+    default: LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream)); break;
   }
   if (delta && iters > 0) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
@@ -217,8 +230,9 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
 
 int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k,
                  int coef_cap, hipStream_t stream) {
-  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, stream, w, ldw,
-                     (int)d, (int)k, kp, ws.wp, ws.wtp);
+  const int dpad = pad_d(d, kp);
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0, stream, w, ldw,
+                     (int)d, (int)k, kp, ws.wp, ws.wtp, dpad);
   LASSO_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, stream, ws.coef, ws.zeros,
                      std::max(coef_cap, 1));
@@ -461,8 +475,9 @@ int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, in
   const int kp = pad_k(k);
   Workspace ws = carve(workspace_dev, 0, k, kp, 0, false);
   if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
-  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0,
-                     (hipStream_t)stream, (const float*)w_dev, ldw, (int)d, (int)k, kp, ws.wp, ws.wtp);
+  const int dpad = pad_d(d, kp);
+  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0,
+                     (hipStream_t)stream, (const float*)w_dev, ldw, (int)d, (int)k, kp, ws.wp, ws.wtp, dpad);
   LASSO_HIP_TRY(hipGetLastError());
   return LASSO_OK;
 }
@@ -556,7 +571,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // the persistent kernel evaluates the rule itself (one-iteration lag) and a
   // single launch runs to the stopping iteration -- one host sync, at the end. ------------
   {
-    const int ntiles = (int)((n + kTileM - 1) / kTileM);
+    const int tile_rows = 4096 / pad_d(d, kp);
+    const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
     const int cus = device_cus();
     if (fista_variant() == 1 && ntiles <= cus && !getenv("LASSO_STOP_CHUNKED")) {
       LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * ntiles * 8, st));

@@ -74,7 +74,7 @@ struct BtParams {
 size_t fista_tile_lds_bytes(int kpad);
 hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_fista_tile16(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
-hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
+hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);

@@ -46,7 +46,7 @@ constexpr int kRingBytesPerWave = 2 * kStepBytes;
 template <int LD>
 __device__ __forceinline__ int tile_off(int row, int col) {
   const int chunk = col >> 2;
-  return row * (LD * 4) + ((chunk ^ row) << 4) + ((col & 3) << 2);
+  return row * (LD * 4) + ((chunk ^ (row & 15)) << 4) + ((col & 3) << 2);
 }
 
 // One ring step = 4 LDS-DMA instructions (1 KiB each, lane-linear in LDS), issued
@@ -88,11 +88,11 @@ __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff
 // f(r, c, v) with c a multiple of 4 and v = src[row0+r][c..c+3] (0 beyond n / k).  Uses
 // 16-byte loads when the layout allows (k, ld multiples of 4 and a 16-B aligned base),
 // else masked scalar loads.  K is the padded tile width, NT the workgroup size.
-template <int K, int NT, typename F>
+template <int K, int NT, int ROWS = kTileM, typename F>
 __device__ __forceinline__ void visit_tile4(const float* __restrict__ src, int64_t ld, int row0, int n,
                                             int k, F&& f) {
   const bool vec = src && (k & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)src) & 15) == 0;
-  for (int idx = threadIdx.x; idx < kTileM * (K / 4); idx += NT) {
+  for (int idx = threadIdx.x; idx < ROWS * (K / 4); idx += NT) {
     const int r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (src && (row0 + r) < n) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int k) {
 // LDS address of the 16-byte chunk holding columns c..c+3 (c % 4 == 0) of row r
 template <int LD>
 __device__ __forceinline__ int tile_chunk_off(int row, int c) {
-  return row * (LD * 4) + (((c >> 2) ^ row) << 4);
+  return row * (LD * 4) + (((c >> 2) ^ (row & 15)) << 4);
 }
 
 __device__ __forceinline__ float soft_threshold(float v, float lam) {
@@ -140,11 +140,18 @@ __device__ __forceinline__ float soft_threshold(float v, float lam) {
 }
 
 
-// Per-thread constants of the streaming scheme.  Wave w owns rows [32w,32w+32) of
-// Wp (GEMM-1 output columns) and rows [w*K/8, (w+1)*K/8) of Wtp (GEMM-2 output columns).
-template <int K>
+// Per-thread constants of the streaming scheme for a tile of M = 4096/D rows x D padded
+// features (D = 256: 16 rows, the flagship shape; D = 128 / 64: 32 / 64 rows for small
+// feature counts).  The 16 output blocks of GEMM-1 (M/16 row blocks x D/16 column blocks)
+// are dealt two per wave: wave w works on row block rb = w / (D/32) and on the column
+// pair cw = w % (D/32), i.e. it streams rows [32cw, 32cw+32) of Wp and -- for GEMM-2, same
+// row block -- rows [cw*KW, (cw+1)*KW) of Wtp with KW = K/(D/32).
+template <int K, int D = kFistaD>
 struct TileCtx {
+  static constexpr int WPR = D / 32;          // waves per row block
+  static constexpr int KW = K / WPR;          // GEMM-2 output columns per wave
   int lane, wid, n, q;
+  int rb, cw;                    // row block, column index inside the row block
   unsigned voff1[4], voff2[4];   // per-lane DMA source byte offsets (ld = K / ld = 256)
   int boff[2];                   // B-fragment byte offsets inside a ring slot
   int aoff[2][2];                // A-fragment byte offsets inside a [16][*] tile row
@@ -166,7 +173,7 @@ struct TileCtx {
       const int row = 8 * j + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       voff1[j] = (unsigned)(row * K + 4 * c) * 4u;
-      voff2[j] = (unsigned)(row * kFistaD + 4 * c) * 4u;
+      voff2[j] = (unsigned)(row * D + 4 * c) * 4u;
     }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) boff[ss] = n * 128 + (((4 * ss + q) ^ ((n >> 1) & 7)) << 4);
@@ -175,8 +182,10 @@ struct TileCtx {
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) aoff[par][ss] = ((8 * par + 4 * ss + q) ^ n) << 4;
     ring = rings + wid * kRingBytesPerWave;
-    w1 = Wp + (size_t)(32 * wid) * K;
-    w2 = Wtp + (size_t)((K / kFistaWaves) * wid) * kFistaD;
+    rb = wid / WPR;
+    cw = wid - rb * WPR;
+    w1 = Wp + (size_t)(32 * cw) * K;
+    w2 = Wtp + (size_t)(KW * cw) * D;
   }
 };
 
@@ -265,14 +274,14 @@ __device__ __forceinline__ void gemm2_pass(const TileCtx<K>& c, const f32x4 (&rf
 }
 
 // load all r fragments (A layout) of a swizzled [16][256] tile
-template <int K>
-__device__ __forceinline__ void load_r_frags(const TileCtx<K>& c, lds_char* rt,
-                                             f32x4 (&rf)[kFistaD / 32][2]) {
+template <int K, int D = kFistaD>
+__device__ __forceinline__ void load_r_frags(const TileCtx<K, D>& c, lds_char* rt,
+                                             f32x4 (&rf)[D / 32][2]) {
 #pragma unroll
-  for (int t = 0; t < kFistaD / 32; ++t)
+  for (int t = 0; t < D / 32; ++t)
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
-      rf[t][ss] = *(const lds_f32x4*)(rt + c.n * (kFistaD * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
+      rf[t][ss] = *(const lds_f32x4*)(rt + (16 * c.rb + c.n) * (D * 4) + (t >> 1) * 256 + c.aoff[t & 1][ss]);
 }
 
 
@@ -287,16 +296,16 @@ struct Frag {
   f32x4 a[2];      // [k-half]       (GEMM-1 only; GEMM-2 uses the r fragments)
 };
 
-template <int K>
-__device__ __forceinline__ void load_b(const TileCtx<K>& c, Frag& f, const lds_char* slot) {
+template <class Ctx>
+__device__ __forceinline__ void load_b(const Ctx& c, Frag& f, const lds_char* slot) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) f.b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
 }
 
-template <int K>
-__device__ __forceinline__ void load_a(const TileCtx<K>& c, Frag& f, const lds_char* row_chunk, int par) {
+template <class Ctx>
+__device__ __forceinline__ void load_a(const Ctx& c, Frag& f, const lds_char* row_chunk, int par) {
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss) f.a[ss] = *(const lds_f32x4*)(row_chunk + c.aoff[par][ss]);
 }
@@ -388,8 +397,8 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
   sp::Frag X, Y;
   // prologue: fragments of step 0 into X, slot0 refilled with step 2
   LASSO_WAIT_VMCNT(4);
-  sp::load_b<K>(c, X, slot0);
-  sp::load_a<K>(c, X, arow, 0);
+  sp::load_b(c, X, slot0);
+  sp::load_a(c, X, arow, 0);
   LASSO_WAIT_LGKM0();
   dma_step(c.w1 + 64, c.voff1, slot0);
   auto nothing = [] {};
@@ -398,13 +407,13 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
                   const unsigned (&voffO)[4], auto last_c) {
     constexpr bool last = decltype(last_c)::value;
     LASSO_WAIT_VMCNT(4);
-    sp::load_b<K>(c, Y, slot1);
-    sp::load_a<K>(c, Y, arow + s2 * 256, 1);
+    sp::load_b(c, Y, slot1);
+    sp::load_a(c, Y, arow + s2 * 256, 1);
     sp::step_body(acc, X.a, X, srcE, voffE, slot1, nothing, nothing, nothing, nothing);
     if constexpr (!last) {
       LASSO_WAIT_VMCNT(4);
-      sp::load_b<K>(c, X, slot0);
-      sp::load_a<K>(c, X, arow + (s2 + 1) * 256, 0);
+      sp::load_b(c, X, slot0);
+      sp::load_a(c, X, arow + (s2 + 1) * 256, 0);
       sp::step_body(acc, Y.a, Y, srcO, voffO, slot0, nothing, nothing, nothing, nothing);
     } else {
       LASSO_PIN();

@@ -29,7 +29,8 @@ def _case(n, d, k, seed=1):
 
 
 @pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (100, 48, 200),
-                                   (16, 64, 256), (1, 3, 2), (257, 256, 1000), (33, 200, 513)])
+                                   (16, 64, 256), (1, 3, 2), (257, 256, 1000), (33, 200, 513),
+                                   (70, 100, 300), (130, 128, 512), (200, 64, 256), (65, 65, 256)])
 @pytest.mark.parametrize("fast", [True, False])
 def test_fixed_step_matches_oracle(n, d, k, fast):
     sparse_encode, ista, orc = _mods()
