@@ -161,6 +161,39 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
 int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
                        const int32_t* degenerate_dev, void* stream);
 
+/* ---- greedy coordinate descent: replaces coord_descent(),
+ *      lasso/linear/solvers/coordinate_descent.py:5-54 (sparse_encode.py:54-55) --------
+ * Per row: b = x W (:19, independent of z0), tracked z = z0 or 0 (:10-14); per step
+ * propose S_alpha(b), commit the coordinate with the largest |proposal - z| (first index
+ * on ties), b += (I - W^T W)[:, j] * change (:31-39); the row stops once its committed
+ * change is <= tol*k (:9,45-48) or after maxiter steps.  z_out = S_alpha(b) (:52).
+ *   lasso_cd_prepare : S, b and the per-row state into the workspace.
+ *   lasso_cd_run     : up to `iters` further steps for every still-active row
+ *                      (tol_abs is already tol*k).  n_active_out / max_steps_out are HOST
+ *                      pointers (nullable); when either is given the call synchronises.
+ *   lasso_cd_finish  : z_out = S_alpha(b); z_track_out (nullable) receives the tracked z
+ *                      (the reference updates a caller-supplied z0 IN PLACE, :14,47).
+ *   lasso_cd_solve   : prepare + run(maxiter) + finish; z0_inout may be NULL (zero init),
+ *                      otherwise it is overwritten with the tracked z like the reference.
+ * The workspace carries the state between the calls and must not be touched in between.
+ * k <= 4096; any d.  Rows are independent: a row shard needs no collective.
+ */
+size_t lasso_cd_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype);
+int lasso_cd_prepare(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                     const void* z0_dev, int64_t ldz0, int64_t n, int64_t d, int64_t k, int dtype,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_cd_run(int64_t n, int64_t d, int64_t k, double alpha, double tol_abs, int iters,
+                 int32_t* n_active_out, int32_t* max_steps_out,
+                 void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_cd_finish(void* z_out_dev, int64_t ldz, void* z_track_out_dev, int64_t ldzt,
+                    int64_t n, int64_t d, int64_t k, double alpha,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_cd_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                   void* z0_inout_dev, int64_t ldz0, void* z_out_dev, int64_t ldz,
+                   int64_t n, int64_t d, int64_t k, int dtype, double alpha, int maxiter, double tol,
+                   int32_t* n_active_out, int32_t* max_steps_out,
+                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

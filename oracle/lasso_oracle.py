@@ -28,7 +28,7 @@ __all__ = [
     "soft_threshold", "lipschitz_constant", "momentum_schedule",
     "backtracking_step", "fista", "initial_code", "sparse_encode",
     "lasso_objective", "dict_evaluate", "update_dict", "update_dict_gram",
-    "update_dict_ridge", "dict_learning", "FistaTrace",
+    "update_dict_ridge", "dict_learning", "FistaTrace", "coordinate_descent",
 ]
 
 
@@ -249,7 +249,7 @@ def ridge_code(x, weight, alpha):
 
 def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm="ista", init=None,
                   **kwargs):
-    """sparse_encode.py:38-73 restricted to the 'ista' arm (:62-63)."""
+    """sparse_encode.py:38-73 restricted to the 'ista' (:62-63) and 'cd' (:54-55) arms."""
     n, k = x.size(0), weight.size(1)
     if z0 is not None:
         assert z0.shape == (n, k)                                 # :44-45
@@ -259,11 +259,66 @@ def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm="ista", init=None,
         z0 = initial_code(x, weight, alpha, init)                 # :51
     if algorithm == "ista":
         return fista(x, z0, weight, alpha, **kwargs)              # :62-63
-    if algorithm in ("cd", "gpsr", "iter-ridge", "interior-point",
+    if algorithm == "cd":
+        return coordinate_descent(x, weight, z0, alpha, **kwargs)  # :54-55
+    if algorithm in ("gpsr", "iter-ridge", "interior-point",
                      "split-bregman", "own"):
         raise NotImplementedError("algorithm=%r is outside the hot path"
                                   % algorithm)
     raise ValueError("invalid algorithm parameter '{}'.".format(algorithm))  # :71
+
+
+# --------------------------------------------------------------------------
+# greedy coordinate descent  (coordinate_descent.py:5-54)
+# --------------------------------------------------------------------------
+def coordinate_descent(x, weight, z0=None, alpha=1.0, maxiter=1000, tol=1e-6,
+                       return_info=False):
+    """Greedy (largest-update-first) lasso coordinate descent.
+
+    coordinate_descent.py:5-54.  State per sample row: the correlation vector
+    b (starts at x W regardless of z0, :19) and the tracked code z (starts at
+    z0 or 0, :10-14).  One step per row (:31-39): propose S_alpha(b), pick the
+    coordinate j whose proposal moved furthest from z (first index on ties --
+    torch.argmax), commit z_j, and correct b by column j of S = I - W^T W
+    (:22-23) times the committed change.  A row leaves the active set for good
+    once its committed change is <= tol*k (:9,45,47); rows never interact, so
+    the batch loop of the reference is n independent per-row loops.  Returns
+    S_alpha(b) (:52), NOT the tracked z.  Like the reference (:14,47) a
+    caller-supplied z0 is updated in place and ends up holding the tracked z.
+    """
+    d, k = weight.shape
+    n = x.shape[0]
+    assert x.shape[1] == d                                        # :8
+    thresh = tol * k                                              # :9
+    if z0 is None:
+        z = x.new_zeros(n, k)                                     # :11
+    else:
+        assert z0.shape == (n, k)                                 # :13
+        z = z0                                                    # :14 (aliases)
+    b = torch.mm(x, weight)                                       # :19
+    S = -torch.mm(weight.T, weight)                               # :22
+    S.diagonal().add_(1.0)                                        # :23
+    rows = torch.arange(n, device=weight.device)                  # :41
+    row_steps = torch.zeros(n, dtype=torch.int64)
+    for _ in range(maxiter):                                      # :42
+        if rows.numel() == 0:                                     # :43
+            break
+        z_act, b_act = z[rows], b[rows]
+        prop = soft_threshold(b_act, alpha)                       # :32
+        move = prop - z_act                                       # :33
+        j = move.abs().argmax(1)                                  # :34
+        jj = j.unsqueeze(1)
+        b[rows] = b_act + S[:, j].T * move.gather(1, jj)          # :36
+        z_new = z_act.scatter(1, jj, prop.gather(1, jj))          # :37
+        change = (z_new - z_act).abs().sum(1)                     # :46
+        z[rows] = z_new                                           # :47
+        row_steps[rows] += 1
+        rows = rows[change > thresh]                              # :48
+    out = soft_threshold(b, alpha)                                # :52
+    if return_info:
+        return out, dict(row_steps=row_steps, n_active=int(rows.numel()), z_track=z)
+    return out
+
 
 
 # --------------------------------------------------------------------------

@@ -423,6 +423,46 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
   return LASSO_OK;
 }
 
+// ---------------------------------------------------------------------------
+// greedy coordinate descent (cd.hip): workspace = persistent per-row state
+// ---------------------------------------------------------------------------
+int pad_k_cd(int64_t k) {
+  for (int kp = 256; kp <= 4096; kp *= 2)
+    if (k <= kp) return kp;
+  return -1;
+}
+struct CdWorkspace { float* S; float* Wt; float* B; float* Zt; int* active; int* row_steps; int* counter; int* info; size_t bytes; };
+
+CdWorkspace carve_cd(void* base, int64_t n, int64_t d, int kp) {
+  CdWorkspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes);
+    return r;
+  };
+  w.S = (float*)take((size_t)kp * kp * 4);
+  w.Wt = (float*)take((size_t)kp * d * 4);
+  w.B = (float*)take((size_t)n * kp * 4);
+  w.Zt = (float*)take((size_t)n * kp * 4);
+  w.active = (int*)take((size_t)n * 4);
+  w.row_steps = (int*)take((size_t)n * 4);
+  w.counter = (int*)take(256);
+  w.info = (int*)take(256);
+  w.bytes = off;
+  return w;
+}
+
+int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
+  if (n < 0 || d <= 0 || k <= 0) return fail(LASSO_ERR_BAD_ARG, "bad shape n=%lld d=%lld k=%lld",
+                                              (long long)n, (long long)d, (long long)k);
+  if (pad_k_cd(k) < 0) return fail(LASSO_ERR_UNSUPPORTED, "coordinate descent: k=%lld > 4096", (long long)k);
+  if (n > INT32_MAX / 2 || d > INT32_MAX / 2) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+  return LASSO_OK;
+}
+
 }  // namespace
 }  // namespace lasso
 
@@ -805,6 +845,94 @@ int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype
   if (!z_dev || !degenerate_dev || n < 0 || k <= 0 || ldz < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
   LASSO_HIP_TRY(launch_zero_columns((float*)z_dev, ldz, (int)n, (int)k, degenerate_dev, (hipStream_t)stream));
   return LASSO_OK;
+}
+
+// ---- greedy coordinate descent: coordinate_descent.py:5-54 -------------------------
+size_t lasso_cd_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype) {
+  (void)dtype;
+  const int kp = pad_k_cd(k);
+  if (kp < 0 || n < 0 || d <= 0) return 0;
+  return carve_cd(nullptr, n, d, kp).bytes;
+}
+
+int lasso_cd_prepare(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* z0_dev,
+                     int64_t ldz0, int64_t n, int64_t d, int64_t k, int dtype, void* workspace_dev,
+                     size_t workspace_bytes, void* stream) {
+  if (int s = check_cd(n, d, k, dtype)) return s;
+  if (!w_dev || (n > 0 && !x_dev) || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldx < d || ldw < k || (z0_dev && ldz0 < k)) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
+  const int kp = pad_k_cd(k);
+  CdWorkspace ws = carve_cd(workspace_dev, n, d, kp);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // Wt [kp][d] (zero rows past k);  S = -Wt Wt^T (:22), +1 on the first k diagonal entries
+  // (:23);  b = x Wt^T (:19).  Padded columns of b and S are exact zeros.
+  LASSO_HIP_TRY(launch_transpose_pad((const float*)w_dev, ldw, (int)d, (int)k, ws.Wt, d, kp, (int)d, st));
+  LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Wt, d, ws.Wt, d, nullptr, 0, ws.S, kp, kp, kp, (int)d, st));
+  LASSO_HIP_TRY(launch_cd_init((const float*)z0_dev, ldz0, ws.Zt, kp, (int)n, (int)k, ws.active,
+                               ws.row_steps, ws.S, st));
+  if (n > 0)
+    LASSO_HIP_TRY(launch_gemm_nt_sub((const float*)x_dev, ldx, ws.Wt, d, nullptr, 0, ws.B, kp, (int)n, kp,
+                                     (int)d, st, /*add=*/1));
+  return LASSO_OK;
+}
+
+int lasso_cd_run(int64_t n, int64_t d, int64_t k, double alpha, double tol_abs, int iters,
+                 int32_t* n_active_out, int32_t* max_steps_out, void* workspace_dev,
+                 size_t workspace_bytes, void* stream) {
+  if (int s = check_cd(n, d, k, LASSO_F32)) return s;
+  if (!workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null workspace");
+  if (iters < 0 || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "iters=%d alpha=%g", iters, alpha);
+  const int kp = pad_k_cd(k);
+  CdWorkspace ws = carve_cd(workspace_dev, n, d, kp);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool want_info = n_active_out || max_steps_out;
+  int info[2] = {0, 0};
+  if (n > 0) {
+    CdParams p;
+    p.B = ws.B; p.Zt = ws.Zt; p.S = ws.S; p.active = ws.active; p.row_steps = ws.row_steps;
+    p.counter = ws.counter; p.n = (int)n; p.iters = iters;
+    p.alpha = (float)alpha; p.tol = (float)tol_abs;
+    LASSO_HIP_TRY(launch_cd_rows(p, kp, device_cus(), want_info ? ws.info : nullptr, st));
+    if (want_info) {
+      LASSO_HIP_TRY(hipMemcpyAsync(info, ws.info, sizeof(info), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+  if (n_active_out) *n_active_out = info[0];
+  if (max_steps_out) *max_steps_out = info[1];
+  return LASSO_OK;
+}
+
+int lasso_cd_finish(void* z_out_dev, int64_t ldz, void* z_track_out_dev, int64_t ldzt, int64_t n,
+                    int64_t d, int64_t k, double alpha, void* workspace_dev, size_t workspace_bytes,
+                    void* stream) {
+  if (int s = check_cd(n, d, k, LASSO_F32)) return s;
+  if (!workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null workspace");
+  if ((z_out_dev && ldz < k) || (z_track_out_dev && ldzt < k)) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
+  const int kp = pad_k_cd(k);
+  CdWorkspace ws = carve_cd(workspace_dev, n, d, kp);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  LASSO_HIP_TRY(launch_cd_finish(ws.B, ws.Zt, kp, (float*)z_out_dev, ldz, (float*)z_track_out_dev, ldzt,
+                                 (int)n, (int)k, (float)alpha, static_cast<hipStream_t>(stream)));
+  return LASSO_OK;
+}
+
+int lasso_cd_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, void* z0_inout_dev,
+                   int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype,
+                   double alpha, int maxiter, double tol, int32_t* n_active_out, int32_t* max_steps_out,
+                   void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!z_out_dev && n > 0) return fail(LASSO_ERR_BAD_ARG, "null z_out");
+  if (int s = lasso_cd_prepare(x_dev, ldx, w_dev, ldw, z0_inout_dev, ldz0, n, d, k, dtype, workspace_dev,
+                               workspace_bytes, stream))
+    return s;
+  // :9  tol = tol * code_dim
+  if (int s = lasso_cd_run(n, d, k, alpha, tol * (double)k, maxiter, n_active_out, max_steps_out,
+                           workspace_dev, workspace_bytes, stream))
+    return s;
+  return lasso_cd_finish(z_out_dev, ldz, z0_inout_dev, ldz0, n, d, k, alpha, workspace_dev,
+                         workspace_bytes, stream);
 }
 
 }  // extern "C"

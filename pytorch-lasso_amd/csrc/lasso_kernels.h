@@ -71,6 +71,18 @@ struct BtParams {
   int n, d, k, ntiles;
 };
 
+// greedy coordinate descent (cd.hip): per-row state padded to kp = 256*NC columns
+struct CdParams {
+  float* B;                // [n][kp] correlation vectors b
+  float* Zt;               // [n][kp] tracked code z
+  const float* S;          // [kp][kp] I - W^T W (zero padded)
+  int* active;             // [n] 1 = row still in the active set
+  int* row_steps;          // [n] steps taken so far
+  int* counter;            // row hand-out counter
+  int n, iters;
+  float alpha, tol;        // tol = absolute per-row threshold (reference: tol*k)
+};
+
 size_t fista_tile_lds_bytes(int kpad);
 hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_fista_tile16(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
@@ -95,7 +107,12 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
                           hipStream_t stream);
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
                               const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
-                              int kk, hipStream_t stream);
+                              int kk, hipStream_t stream, int add = 0);
+hipError_t launch_cd_init(const float* z0, int64_t ldz0, float* Zt, int kp, int n, int k, int* active,
+                          int* row_steps, float* S, hipStream_t stream);
+hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStream_t stream);
+hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
+                            float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
 hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int cols, float* dst,
                                 int64_t ld_dst, int drows, int dcols, hipStream_t stream);

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// C[m x nn] = C0 - A B^T,  A [m x kk] (lda), B [nn x kk] (ldb): both K-contiguous.
+// C[m x nn] = C0 - A B^T  (add != 0: C0 + A B^T),  A [m x kk] (lda), B [nn x kk] (ldb):
+// both K-contiguous.
 // 64x64 block, chunks of 32 along kk, operands staged as [64 rows][32 floats] with the
 // same 16-B-chunk XOR swizzle as the FISTA ring (ds_read_b128 fragments).
 // ---------------------------------------------------------------------------
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restric
                                                           const float* __restrict__ B, int64_t ldb,
                                                           const float* __restrict__ C0, int64_t ldc0,
                                                           float* __restrict__ C, int64_t ldc, int m,
-                                                          int nn, int kk) {
+                                                          int nn, int kk, int add) {
   __shared__ __attribute__((aligned(16))) char sa[2][64 * 128], sb[2][64 * 128];
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -199,7 +200,10 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restric
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int r = i0 + 32 * wr + 16 * mi + 4 * q + rg, cc = j0 + 32 * wc + 16 * nj + l15;
-        if (r < m && cc < nn) C[(int64_t)r * ldc + cc] = (C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f) - acc[mi][nj][rg];
+        if (r < m && cc < nn) {
+          const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
+          C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
+        }
       }
 }
 
@@ -458,10 +462,10 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
 
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
                               const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
-                              int kk, hipStream_t stream) {
+                              int kk, hipStream_t stream, int add) {
   const dim3 grid((nn + 63) / 64, (m + 63) / 64);
   hipLaunchKernelGGL(gemm_nt_sub_kernel, grid, dim3(256), 0, stream, A, lda, B, ldb, C0, ldc0, C, ldc,
-                     m, nn, kk);
+                     m, nn, kk, add);
   return hipGetLastError();
 }
 

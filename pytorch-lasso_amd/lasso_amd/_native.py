@@ -68,6 +68,18 @@ def _declare(lib):
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
     lib.lasso_zero_columns.restype = i32
     lib.lasso_zero_columns.argtypes = [vp, i64, i64, i64, i32, vp, vp]
+    pi32 = C.POINTER(C.c_int32)
+    lib.lasso_cd_workspace_bytes.restype = sz
+    lib.lasso_cd_workspace_bytes.argtypes = [i64, i64, i64, i32]
+    lib.lasso_cd_prepare.restype = i32
+    lib.lasso_cd_prepare.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]
+    lib.lasso_cd_run.restype = i32
+    lib.lasso_cd_run.argtypes = [i64, i64, i64, dbl, dbl, i32, pi32, pi32, vp, sz, vp]
+    lib.lasso_cd_finish.restype = i32
+    lib.lasso_cd_finish.argtypes = [vp, i64, vp, i64, i64, i64, i64, dbl, vp, sz, vp]
+    lib.lasso_cd_solve.restype = i32
+    lib.lasso_cd_solve.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32,
+                                   dbl, pi32, pi32, vp, sz, vp]
 
 
 def lib():

@@ -1,11 +1,11 @@
 """Mirror of lasso/linear/sparse_encode.py:8-73 for the 'ista' arm."""
 import torch
 
-from .solvers import ista
+from .solvers import ista, coord_descent
 
 _init_defaults = {'ista': 'zero'}                                   # sparse_encode.py:8-16
 
-_OFF_PATH_ALGOS = ('cd', 'gpsr', 'iter-ridge', 'interior-point', 'split-bregman', 'own')
+_OFF_PATH_ALGOS = ('gpsr', 'iter-ridge', 'interior-point', 'split-bregman', 'own')
 
 
 def _lstsq_init(x, weight):
@@ -54,7 +54,7 @@ def initialize_code(x, weight, alpha, mode):
 def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm='ista', init=None,
                   **kwargs):
     """Same call surface as lasso.linear.sparse_encode (sparse_encode.py:38-73);
-    ``algorithm='ista'`` runs on the HIP engine, the other solver names raise
+    ``algorithm='ista'`` and ``'cd'`` run on the HIP engine, the other solver names raise
     NotImplementedError (they are outside the accelerated path), anything else
     raises ValueError like the reference (:71)."""
     n_samples = x.size(0)
@@ -67,9 +67,11 @@ def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm='ista', init=None,
         z0 = initialize_code(x, weight, alpha, mode=init)            # :51
     if algorithm == 'ista':
         z = ista(x, z0, weight, alpha, **kwargs)                     # :62-63
+    elif algorithm == 'cd':
+        z = coord_descent(x, weight, z0, alpha, **kwargs)            # :54-55
     elif algorithm in _OFF_PATH_ALGOS:
         raise NotImplementedError(
-            "lasso_amd accelerates algorithm='ista' only; %r is not on the HIP path" % algorithm)
+            "lasso_amd accelerates algorithm='ista' and 'cd'; %r is not on the HIP path" % algorithm)
     else:
         raise ValueError("invalid algorithm parameter '{}'.".format(algorithm))  # :71
     return z

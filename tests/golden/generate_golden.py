@@ -12,7 +12,7 @@ The reference does not import as-is under scipy 1.15 (iterative_ridge.py:5
 imports a private scipy symbol); the 3-line shim below aliases that symbol
 BEFORE importing -- no reference file is edited or copied.
 
-Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g4 g5 small]
+Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g4 g5 small inits cd]
 """
 import os
 import sys
@@ -264,6 +264,40 @@ def inits():
             out["%s_z_%s" % (tag, mode)] = sparse_encode(X, W, alpha=0.3, algorithm="ista", init=mode,
                                                          lr=0.05, maxiter=20, tol=0.0).numpy().copy()
     save("init_modes", **out)
+
+
+def cd():
+    """Greedy coordinate descent (coordinate_descent.py:5-54):
+    full outputs on small ragged shapes, statistics + a corner at the C2 shape."""
+    from lasso.linear.solvers import coord_descent
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    for tag, (n, d, k, alpha) in {"a": (37, 10, 50, 0.2), "b": (48, 256, 1024, 0.5),
+                                  "c": (100, 48, 200, 0.3), "d": (16, 64, 256, 0.1)}.items():
+        W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+        X = torch.randn(n, d, generator=g)
+        out[tag + "_X"], out[tag + "_W"], out[tag + "_alpha"] = X.numpy(), W.numpy(), alpha
+        for mi in (1, 7, 60, 1000):
+            out["%s_z_%d" % (tag, mi)] = coord_descent(X, W, None, alpha, maxiter=mi).numpy().copy()
+        # warm start: z0 is updated in place by the reference (:14,47)
+        z0 = torch.nn.functional.softshrink(X @ W, alpha)
+        out[tag + "_z0"] = z0.numpy().copy()
+        out[tag + "_z_warm"] = coord_descent(X, W, z0, alpha, maxiter=40, tol=1e-4).numpy().copy()
+        out[tag + "_z0_after"] = z0.numpy().copy()
+        out[tag + "_z_sparse_encode"] = sparse_encode(X, W, alpha=alpha, algorithm="cd",
+                                                      maxiter=25).numpy().copy()
+    # C2 shape (n reduced to 512 rows of the recipe: rows are independent)
+    X, W = recipe_xw(512, 256, 1024)
+    for mi in (100, 1000):
+        t = time.time()
+        z = coord_descent(X, W, None, 0.5, maxiter=mi)
+        print("cd C2[:512] maxiter", mi, "%.1fs" % (time.time() - t))
+        obj = (0.5 * (z @ W.T - X).pow(2).sum(1) + 0.5 * z.abs().sum(1))
+        out["c2_obj_rows_%d" % mi] = obj.numpy().copy()
+        out["c2_corner_%d" % mi] = z[:64, :64].numpy().copy()
+        st = zstats(z)
+        out["c2_stats_%d" % mi] = np.array([st["sum"], st["abssum"], st["nnz"]])
+    save("cd_cases", **out)
 
 
 if __name__ == "__main__":

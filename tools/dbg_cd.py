@@ -1,0 +1,38 @@
+"""Developer probe: HIP coordinate descent vs oracle/golden, and timing at the C2 shape."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+from lasso_amd.linear.solvers import coord_descent
+from oracle import lasso_oracle as orc
+from recipes import recipe_xw
+
+g = np.load(os.path.join(ROOT, "tests/golden/cd_cases.npz"))
+for tag in "abcd":
+    X, W, a = torch.from_numpy(g[tag + "_X"]), torch.from_numpy(g[tag + "_W"]), float(g[tag + "_alpha"])
+    for mi in (1, 7, 60, 1000):
+        ref = torch.from_numpy(g["%s_z_%d" % (tag, mi)])
+        got, info = coord_descent(X.cuda(), W.cuda(), None, a, maxiter=mi, return_info=True)
+        got = got.cpu()
+        rowerr = (got - ref).abs().max(1)[0]
+        print(tag, mi, "max err %.3g rows>1e-4: %d/%d" % (rowerr.max().item(), int((rowerr > 1e-4).sum()), len(rowerr)), info)
+    z0 = torch.from_numpy(g[tag + "_z0"].copy()).cuda()
+    got = coord_descent(X.cuda(), W.cuda(), z0, a, maxiter=40, tol=1e-4).cpu()
+    print(tag, "warm", (got - torch.from_numpy(g[tag + "_z_warm"])).abs().max().item(),
+          (z0.cpu() - torch.from_numpy(g[tag + "_z0_after"])).abs().max().item())
+X, W = recipe_xw(4096, 256, 1024)
+Xg, Wg = X.cuda(), W.cuda()
+for mi in (100, 1000):
+    z = coord_descent(Xg, Wg, None, 0.5, maxiter=mi)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        z, info = coord_descent(Xg, Wg, None, 0.5, maxiter=mi, return_info=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    zc = z[:512].cpu()
+    obj = (0.5 * (zc @ W.T - X[:512]).pow(2).sum(1) + 0.5 * zc.abs().sum(1))
+    ref = torch.from_numpy(g["c2_obj_rows_%d" % mi])
+    print("C2 maxiter", mi, "%.3f ms" % (dt * 1e3), info, "obj rel err max %.3g mean-obj %.6f ref %.6f"
+          % (((obj - ref).abs() / ref).max().item(), obj.mean().item(), ref.mean().item()),
+          "corner err %.3g" % (zc[:64, :64] - torch.from_numpy(g["c2_corner_%d" % mi])).abs().max().item())
