@@ -10,9 +10,10 @@
 //
 // Kernel: ONE WAVE PER ROW, b and z resident in VGPRs for the whole solve (K/64 floats
 // each per lane, lane l owns columns 256c + 4l .. +3: every global access is a coalesced
-// 1 KiB dwordx4 segment).  Per step: 6 VALU per element for propose/compare, two DPP wave
-// reductions (max of |move| as integer bits, then min index among the maxima = first
-// index on ties), two readlanes to broadcast the winner, one coalesced read of row j of
+// 1 KiB dwordx4 segment).  Per step: 4 VALU per element for |S_alpha(b) - z| and its lane
+// maximum, one DPP wave reduction (max of |move| as integer bits), one v_cmp per element
+// whose lane masks give the first column holding the maximum on the SCALAR unit, an indexed
+// register read of the winner's slot, two readlanes, one coalesced read of row j of
 // S (S is bitwise symmetric, so row j is column j) from L2, and K multiply-adds (mul and
 // add rounded separately like the reference's `b + S*dz`).  No LDS, no barriers, no
 // atomics; rows are dealt out statically (wave w: rows w, w + #waves, ...).  The step
@@ -59,9 +60,19 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+// The per-row state lives in ONE vector value per quantity (4*NC floats per lane, split in
+// halves of <= 32 so that it stays a legal register tuple): element 4c+e of the lane is
+// column 256c + 4*lane + e.  A vector -- unlike an array -- can be indexed with the
+// wave-uniform winner slot at run time without leaving the register file (the compiler
+// emits s_set_gpr_idx / v_movrel for it; arrays would be demoted to scratch memory).
+template <int N> using fvec = float __attribute__((ext_vector_type(N)));
+
 template <int NC>
 __global__ __launch_bounds__(256) void cd_rows_kernel(const CdParams p) {
   constexpr int KP = 256 * NC;
+  constexpr int H = NC > 8 ? NC / 8 : 1;       // register tuples per quantity
+  constexpr int HN = 4 * NC / H;               // floats per tuple (<= 32)
+  typedef fvec<HN> vec;
   const int lane = threadIdx.x & 63;
   const float alpha = p.alpha, tol = p.tol;
   // rows are dealt out statically, wave w takes rows w, w + #waves, ...: every branch in
@@ -72,64 +83,83 @@ __global__ __launch_bounds__(256) void cd_rows_kernel(const CdParams p) {
     if (__builtin_amdgcn_readfirstlane(p.active[row]) == 0) continue;
     float* const bp = p.B + (int64_t)row * KP + 4 * lane;
     float* const zp = p.Zt + (int64_t)row * KP + 4 * lane;
-    f32x4 b[NC], z[NC];
+    vec b[H], z[H];
     static_for<NC>([&](auto c) {
-      b[c] = *(const f32x4*)(bp + 256 * c);
-      z[c] = *(const f32x4*)(zp + 256 * c);
+      constexpr int C = decltype(c)::value;
+      const f32x4 tb = *(const f32x4*)(bp + 256 * C), tz = *(const f32x4*)(zp + 256 * C);
+      static_for<4>([&](auto e_) {
+        constexpr int I = 4 * C + decltype(e_)::value;
+        b[I / HN][I % HN] = tb[decltype(e_)::value];
+        z[I / HN][I % HN] = tz[decltype(e_)::value];
+      });
     });
     int steps = 0, still = 1;
     while (steps < p.iters) {
-      // propose + local first-max (ascending column order, strict > keeps the first)
-      float best = -1.0f, bprop = 0.0f, bmove = 0.0f;
-      int bj = 0;
-      static_for<NC>([&](auto c) {
-        static_for<4>([&](auto e_) {
-          constexpr int C = decltype(c)::value, E = decltype(e_)::value;
-          const float pr = shrink(b[C][E], alpha);           // :32
-          const float mv = pr - z[C][E];                     // :33
-          const bool gt = __builtin_fabsf(mv) > best;
-          best = gt ? __builtin_fabsf(mv) : best;
-          bj = gt ? (256 * C + E) : bj;
-          bprop = gt ? pr : bprop;
-          bmove = gt ? mv : bmove;
-        });
+      // pass 1  (:32-33): |S_alpha(b) - z| of every coordinate and the lane's maximum
+      vec a[H];
+      float best = 0.0f;
+      static_for<4 * NC>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        a[I / HN][I % HN] = __builtin_fabsf(shrink(b[I / HN][I % HN], alpha) - z[I / HN][I % HN]);
+        best = __builtin_fmaxf(best, a[I / HN][I % HN]);
       });
-      bj += 4 * lane;
-      // :34  argmax over the row: max |move| (non-negative floats order like their bits),
-      // then the smallest column among the lanes that hold it
+      // :34  argmax over the row.  Non-negative floats order like their bit patterns: wave
+      // max on the integer DPP path; then the smallest column that attains it (torch.argmax
+      // returns the first maximum) -- one v_cmp per coordinate, the rest is scalar work.
       const unsigned mb = wave_max_u32(__float_as_uint(best));
-      const unsigned cand = (__float_as_uint(best) == mb) ? (unsigned)bj : 0x7fffffffu;
-      const int j = (int)wave_min_u32(cand);
-      const int owner = (j & 255) >> 2;
-      const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmove), owner));
-      const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bprop), owner));
+      const float mbf = __uint_as_float(mb);
+      unsigned j = 0x7fffffffu;
+      static_for<4 * NC>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(a[I / HN][I % HN] == mbf);
+        const unsigned cand = m ? (unsigned)(256 * (I / 4) + (I % 4) + 4 * __builtin_ctzll(m)) : 0x7fffffffu;
+        j = min(j, cand);
+      });
+      if (j == 0x7fffffffu) j = 0;        // only if a NaN got in: argmax of all-NaN
       // column j of S == row j (coalesced)
       const float* const sp = p.S + (int64_t)j * KP + 4 * lane;
       f32x4 s[NC];
       static_for<NC>([&](auto c) { s[c] = *(const f32x4*)(sp + 256 * c); });
-      // :37  commit z_j
-      const int slot = ((j >> 8) << 2) | (j & 3);
-      const bool mine = lane == owner;
-      static_for<NC>([&](auto c) {
-        static_for<4>([&](auto e_) {
-          constexpr int C = decltype(c)::value, E = decltype(e_)::value;
-          z[C][E] = (mine && slot == 4 * C + E) ? pz : z[C][E];
-        });
-      });
+      const int owner = (j & 255) >> 2;
+      const int slot = ((j >> 8) << 2) | (j & 3);            // wave-uniform
+      float bs, zs;
+      if constexpr (H == 1) {
+        bs = b[0][slot];
+        zs = z[0][slot];
+      } else {
+        if (slot < HN) { bs = b[0][slot]; zs = z[0][slot]; }
+        else { bs = b[1][slot - HN]; zs = z[1][slot - HN]; }
+      }
+      const float pr = shrink(bs, alpha);
+      const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), owner));
+      const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr - zs), owner));
+      // :37  commit z_j (owner lane only)
+      const float zn = lane == owner ? pz : zs;
+      if constexpr (H == 1) {
+        z[0][slot] = zn;
+      } else {
+        if (slot < HN) z[0][slot] = zn;
+        else z[1][slot - HN] = zn;
+      }
       // :36  b += S[:, j] * dz   (product and sum rounded separately, as ATen does)
-      static_for<NC>([&](auto c) {
-        static_for<4>([&](auto e_) {
-          constexpr int C = decltype(c)::value, E = decltype(e_)::value;
-          const float t = s[C][E] * dz;
-          b[C][E] = b[C][E] + t;
-        });
+      static_for<4 * NC>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        const float t = s[I / 4][I % 4] * dz;
+        b[I / HN][I % HN] = b[I / HN][I % HN] + t;
       });
       ++steps;
-      if (!(__uint_as_float(mb) > tol)) { still = 0; break; }   // :46-48
+      if (!(mbf > tol)) { still = 0; break; }   // :46-48
     }
     static_for<NC>([&](auto c) {
-      *(f32x4*)(bp + 256 * c) = b[c];
-      *(f32x4*)(zp + 256 * c) = z[c];
+      constexpr int C = decltype(c)::value;
+      f32x4 tb, tz;
+      static_for<4>([&](auto e_) {
+        constexpr int I = 4 * C + decltype(e_)::value;
+        tb[decltype(e_)::value] = b[I / HN][I % HN];
+        tz[decltype(e_)::value] = z[I / HN][I % HN];
+      });
+      *(f32x4*)(bp + 256 * C) = tb;
+      *(f32x4*)(zp + 256 * C) = tz;
     });
     // every lane writes the same values to the same two words: no divergent tail
     p.active[row] = still;
