@@ -1,0 +1,157 @@
+// General fp32 MFMA GEMM of the support paths:  C[m x nn] = C0 -/+ A B^T  with
+// A [m x kk] (lda) and B [nn x kk] (ldb), both contiguous along the contraction.
+// Users: the unfused FISTA path for shapes beyond the fused tile kernel (ista.py:72-73:
+// r = y W^T - x and g = r W), U = B - A D^T of the Gram-form M-step (dict_learning.py:82),
+// b = x W and S = I - W^T W of coordinate descent (coordinate_descent.py:19,22-23).
+//
+// BM x BN block per workgroup of 4 waves (2 x 2), each wave a (BM/2) x (BN/2) patch of
+// 16x16 MFMA accumulators; the contraction runs in chunks of 32 floats that are staged
+// global -> registers -> LDS (double buffered: the loads of chunk c+1 are in flight while
+// chunk c feeds the matrix pipe) as [rows][128 B] with the 16-byte-chunk XOR swizzle of the
+// FISTA ring, so every operand fragment is one conflict-free ds_read_b128 that serves four
+// v_mfma_f32_16x16x4_f32.  128 x 128 blocks need 4 flop per byte of L2->LDS traffic less
+// than 64 x 64 ones and are used whenever they still fill the chip.
+// Roofline: MFMA-bound, 2*m*nn*kk flop (measured numbers: DESIGN.md 3.3).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "lasso_kernels.h"
+#include "static_for.hpp"
+
+namespace lasso {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {   // bytes inside a [rows][128 B] tile
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// rows of `src` [rows x kk] (ld) starting at r0, columns k0 + 4*chunk .. +3 -> v (zero outside)
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_chunk4(const float* __restrict__ src, int64_t ld, int row, int rows,
+                                             int kcol, int kk) {
+  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (row < rows) {
+    const float* p = src + (int64_t)row * ld + kcol;
+    if constexpr (VEC) {
+      if (kcol < kk) v = *(const f32x4*)p;          // kk % 4 == 0: the chunk is all in or all out
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (kcol + e < kk) v[e] = p[e];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb,
+                                                         const float* __restrict__ C0, int64_t ldc0,
+                                                         float* __restrict__ C, int64_t ldc, int m, int nn,
+                                                         int kk, int add) {
+  constexpr int MI = BM / 32, NJ = BN / 32;          // 16x16 blocks per wave: MI x NJ
+  constexpr int PA = BM / 32, PB = BN / 32;          // staged 16-byte chunks per thread and operand
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sa = smem;                             // [2][BM * 128]
+  char* const sb = smem + 2 * BM * 128;              // [2][BN * 128]
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int l15 = lane & 15, q = lane >> 4;
+  f32x4 acc[MI][NJ] = {};
+  // staging map: thread -> chunk (tid & 7) of rows (tid >> 3) + 32 h
+  const int srow = tid >> 3, sch = tid & 7;
+  f32x4 ga[PA], gb[PB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < PA; ++h) ga[h] = load_chunk4<VEC>(A, lda, i0 + srow + 32 * h, m, k0 + 4 * sch, kk);
+#pragma unroll
+    for (int h = 0; h < PB; ++h) gb[h] = load_chunk4<VEC>(B, ldb, j0 + srow + 32 * h, nn, k0 + 4 * sch, kk);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < PA; ++h) *(f32x4*)(sa + buf * BM * 128 + swz_off(srow + 32 * h, sch)) = ga[h];
+#pragma unroll
+    for (int h = 0; h < PB; ++h) *(f32x4*)(sb + buf * BN * 128 + swz_off(srow + 32 * h, sch)) = gb[h];
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < kk; k0 += 32) {
+    const bool more = k0 + 32 < kk;
+    if (more) fetch(k0 + 32);
+    const char* const ta = sa + buf * BM * 128;
+    const char* const tb = sb + buf * BN * 128;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      f32x4 a[MI], b[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(ta + swz_off((BM / 2) * wr + 16 * mi + l15, 4 * ss + q));
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[nj] = *(const f32x4*)(tb + swz_off((BN / 2) * wc + 16 * nj + l15, 4 * ss + q));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[nj][j], acc[mi][nj], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+        if (r < m && cc < nn) {
+          const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
+          C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
+        }
+      }
+}
+
+template <int BM, int BN, bool VEC>
+hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
+                       int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk, int add,
+                       hipStream_t stream) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, VEC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const dim3 grid((nn + BN - 1) / BN, (m + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0, ldc0, C,
+                     ldc, m, nn, kk, add);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
+                              int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk,
+                              hipStream_t stream, int add) {
+  if (m <= 0 || nn <= 0) return hipSuccess;
+  const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
+                   ((uintptr_t)B & 15) == 0;
+  // 128 x 128 blocks once they give every CU a workgroup, 64 x 64 below that
+  const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
+  const bool big = big_blocks >= 192;
+  if (big)
+    return vec ? launch_tile<128, 128, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
+               : launch_tile<128, 128, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream);
+  return vec ? launch_tile<64, 64, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
+             : launch_tile<64, 64, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream);
+}
+
+}  // namespace lasso

@@ -12,7 +12,7 @@
 // and removed from the model (its effective new atom is 0, as zeroing Z[:,j] does).
 //
 //   gram_tn_kernel   C = P^T Q     fp32 MFMA, reduce over the n rows of the shard
-//   gemm_nt_kernel   C = C0 - A B^T
+//   (C = C0 - A B^T lives in gemm.hip)
 // Rooflines: the two GEMM kernels are MFMA-bound (2nk^2 + 2nkd and 2k^2 d flop); the
 // sweep is a latency-bound dependency chain of k steps (time reported, no roofline).
 #include <hip/hip_runtime.h>
@@ -126,85 +126,6 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
   float acc = 0.0f;
   for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + idx];
   C[(idx / cols) * ldc + idx % cols] = acc;
-}
-
-// ---------------------------------------------------------------------------
-// C[m x nn] = C0 - A B^T  (add != 0: C0 + A B^T),  A [m x kk] (lda), B [nn x kk] (ldb):
-// both K-contiguous.
-// 64x64 block, chunks of 32 along kk, operands staged as [64 rows][32 floats] with the
-// same 16-B-chunk XOR swizzle as the FISTA ring (ds_read_b128 fragments).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int swz_off(int row, int chunk) {   // bytes inside a [rows][128 B] tile
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-__global__ __launch_bounds__(256) void gemm_nt_sub_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const float* __restrict__ B, int64_t ldb,
-                                                          const float* __restrict__ C0, int64_t ldc0,
-                                                          float* __restrict__ C, int64_t ldc, int m,
-                                                          int nn, int kk, int add) {
-  __shared__ __attribute__((aligned(16))) char sa[2][64 * 128], sb[2][64 * 128];
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1;
-  const int l15 = lane & 15, q = lane >> 4;
-  f32x4 acc[2][2] = {};
-  // staging: thread -> row = tid/4 (0..63), chunks 2*(tid&3), 2*(tid&3)+1
-  const int srow = tid >> 2, sch = (tid & 3) * 2;
-  float stg[2][8];
-  auto load_chunk = [&](int k0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int kcol = k0 + sch * 4 + e;
-      stg[0][e] = (i0 + srow < m && kcol < kk) ? A[(int64_t)(i0 + srow) * lda + kcol] : 0.0f;
-      stg[1][e] = (j0 + srow < nn && kcol < kk) ? B[(int64_t)(j0 + srow) * ldb + kcol] : 0.0f;
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *(f32x4*)(sa[buf] + swz_off(srow, sch + h)) = (f32x4){stg[0][4 * h], stg[0][4 * h + 1], stg[0][4 * h + 2], stg[0][4 * h + 3]};
-      *(f32x4*)(sb[buf] + swz_off(srow, sch + h)) = (f32x4){stg[1][4 * h], stg[1][4 * h + 1], stg[1][4 * h + 2], stg[1][4 * h + 3]};
-    }
-  };
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = 0; k0 < kk; k0 += 32) {
-    const bool more = k0 + 32 < kk;
-    if (more) load_chunk(k0 + 32);
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      f32x4 a[2], b[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(sa[buf] + swz_off(32 * wr + 16 * mi + l15, 4 * ss + q));
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) b[nj] = *(const f32x4*)(sb[buf] + swz_off(32 * wc + 16 * nj + l15, 4 * ss + q));
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int nj = 0; nj < 2; ++nj)
-            acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[nj][j], acc[mi][nj], 0, 0, 0);
-    }
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = i0 + 32 * wr + 16 * mi + 4 * q + rg, cc = j0 + 32 * wc + 16 * nj + l15;
-        if (r < m && cc < nn) {
-          const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
-          C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
-        }
-      }
 }
 
 // Wave-wide sum on the ALU path (no LDS crossbar): DPP row_shr 1,2,4,8 leaves each
@@ -457,15 +378,6 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
     hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        scratch, splits, stride, pc, qc, C, ldc);
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
-                              const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
-                              int kk, hipStream_t stream, int add) {
-  const dim3 grid((nn + 63) / 64, (m + 63) / 64);
-  hipLaunchKernelGGL(gemm_nt_sub_kernel, grid, dim3(256), 0, stream, A, lda, B, ldb, C0, ldc0, C, ldc,
-                     m, nn, kk, add);
   return hipGetLastError();
 }
 
