@@ -727,10 +727,12 @@ int lasso_lipschitz(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dt
 }
 
 // ---------------------------------------------------------------------------
+constexpr int kObjGenGrid = 1024;
 size_t lasso_objective_workspace_bytes(int64_t n, int64_t d, int64_t k) {
-  (void)d;
+  if (n < 0 || d <= 0 || k <= 0) return 0;
+  if (!fused_shape(d, k))     // unfused: residual [n][d] + partial pairs
+    return align_up((size_t)std::max<int64_t>(n, 1) * d * 4) + align_up((size_t)kObjGenGrid * 2 * 4) + 256;
   const int kp = pad_k(k);
-  if (kp < 0 || n < 0) return 0;
   const int64_t ntiles = (n + kTileM - 1) / kTileM;
   return align_up((size_t)kFistaD * kp * 4) + align_up((size_t)kp * kFistaD * 4) +
          align_up((size_t)std::max<int64_t>(ntiles, 1) * 2 * 4) + 256;
@@ -740,15 +742,27 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
                     int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype, double alpha,
                     float* loss_dev, double* sums_dev, void* workspace_dev, size_t workspace_bytes,
                     void* stream) {
-  if (int s = check_common(n, d, k, dtype)) return s;
+  if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !z_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (ldx < d || ldw < k || ldz < k) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
   if (workspace_bytes < lasso_objective_workspace_bytes(n, d, k))
     return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_objective_workspace_bytes(n, d, k));
   hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace_dev;
+  if (!fused_shape(d, k)) {
+    if (d > INT32_MAX / 2 || k > INT32_MAX / 2) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+    float* R = (float*)base;
+    float* partials = (float*)(base + align_up((size_t)std::max<int64_t>(n, 1) * d * 4));
+    double* sums = (double*)((char*)partials + align_up((size_t)kObjGenGrid * 2 * 4));
+    if (n > 0)
+      LASSO_HIP_TRY(launch_objective_generic((const float*)x_dev, ldx, (const float*)w_dev, ldw,
+                                             (const float*)z_dev, ldz, (int)n, (int)d, (int)k, R, partials,
+                                             kObjGenGrid, alpha, (double)n, sums_dev ? sums_dev : sums,
+                                             loss_dev, st));
+    return LASSO_OK;
+  }
   const int kp = pad_k(k);
   const int ntiles = (int)((n + kTileM - 1) / kTileM);
-  char* base = (char*)workspace_dev;
   float* wp = (float*)base;
   float* wtp = (float*)(base + align_up((size_t)kFistaD * kp * 4));
   float* partials = (float*)((char*)wtp + align_up((size_t)kp * kFistaD * 4));
@@ -796,8 +810,9 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
 }
 
 size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k) {
-  if (d <= 0 || k <= 0 || d > kFistaD) return 0;
-  return align_up((size_t)k * kFistaD * 4) * 2 + align_up((size_t)kSweepBlock * kFistaD * 4) + 256;
+  if (d <= 0 || k <= 0 || d > kSweepMaxD || k > kSweepMaxK) return 0;
+  const size_t dp = (size_t)(d + 255) / 256 * 256;
+  return align_up((size_t)k * dp * 4) * 2 + align_up((size_t)kSweepBlock * dp * 4) + 256;
 }
 
 int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
@@ -807,31 +822,34 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!a_dev || !b_dev || !d_dev || !degenerate_dev || !workspace_dev || d <= 0 || k <= 0 || ldd < k)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
-  if (d > kFistaD) return fail(LASSO_ERR_UNSUPPORTED, "d > %d", kFistaD);
+  if (d > kSweepMaxD || k > kSweepMaxK)
+    return fail(LASSO_ERR_UNSUPPORTED, "atom sweep: d=%lld k=%lld (d <= %d, k <= %d)", (long long)d,
+                (long long)k, kSweepMaxD, kSweepMaxK);
   if (pool_dev && (pool_rows <= 0 || pool_ld < d)) return fail(LASSO_ERR_BAD_ARG, "bad pool");
   if (workspace_bytes < lasso_dict_sweep_workspace_bytes(d, k))
     return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_dict_sweep_workspace_bytes(d, k));
   hipStream_t st = (hipStream_t)stream;
+  const int dp = (int)((d + 255) / 256 * 256);     // row stride of U / Dt / dD: whole 256-feature panels
   char* base = (char*)workspace_dev;
   float* U = (float*)base;
-  float* Dt = (float*)(base + align_up((size_t)k * kFistaD * 4));
-  float* dD = (float*)((char*)Dt + align_up((size_t)k * kFistaD * 4));
-  int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * kFistaD * 4));
+  float* Dt = (float*)(base + align_up((size_t)k * dp * 4));
+  float* dD = (float*)((char*)Dt + align_up((size_t)k * dp * 4));
+  int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * dp * 4));
   float* D = (float*)d_dev;
   LASSO_HIP_TRY(hipMemsetAsync(ndeg, 0, sizeof(int), st));
-  // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, padded row stride 256)
-  LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * kFistaD * 4, st));
-  LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, kFistaD, (int)k, (int)d, (int)k, st));
-  // Dt[j][dd] = D[dd][j]  (zero padded to 256 features)
-  LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, kFistaD, (int)k, kFistaD, st));
+  // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, zero padded to dp columns)
+  LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));
+  LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st));
+  // Dt[j][dd] = D[dd][j]  (zero padded to dp features)
+  LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
   SweepParams p;
-  p.A = a_dev; p.lda = k; p.U = U; p.ldu = kFistaD; p.Dt = Dt; p.dD = dD;
+  p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
   p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
   LASSO_HIP_TRY(launch_dict_sweep(p, st));
   // D[dd][j] = Dt[j][dd]
-  LASSO_HIP_TRY(launch_transpose_pad(Dt, kFistaD, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
+  LASSO_HIP_TRY(launch_transpose_pad(Dt, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
   if (ndeg_out) {
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));

@@ -46,11 +46,14 @@ struct ObjectiveParams {
 
 // constrained M-step (mstep.hip)
 constexpr int kSweepBlock = 32;
+constexpr int kSweepMaxD = 1024;   // atom sweep: features per atom (4 waves x 256)
+constexpr int kSweepMaxK = 4096;   // atom sweep: atoms
 struct SweepParams {
   const float* A; int64_t lda;           // [k][k]   Z^T Z
-  float* U; int64_t ldu;                 // [k][kFistaD]  B - A D^T, updated in place
-  float* Dt;                             // [k][kFistaD]  atoms as rows (in/out)
-  float* dD;                             // [kSweepBlock][kFistaD] scratch
+  float* U; int64_t ldu;                 // [k][dp]  B - A D^T, updated in place
+  float* Dt;                             // [k][dp]  atoms as rows (in/out)
+  float* dD;                             // [kSweepBlock][dp] scratch
+  int dp;                                // d rounded up to a multiple of 256 (<= kSweepMaxD)
   const float* pool; int pool_rows;      // [pool_rows][pool_ld] replacement directions (nullable)
   int64_t pool_ld; unsigned long long seed;
   int* degenerate;                       // [k] out: 1 where the atom was re-initialised
@@ -90,6 +93,11 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);
+
+hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* Z,
+                                    int64_t ldz, int n, int d, int k, float* R, float* partials, int grid,
+                                    double alpha, double n_total, double* sums, float* loss_out,
+                                    hipStream_t stream);
 
 hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,

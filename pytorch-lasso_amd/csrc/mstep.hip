@@ -159,34 +159,40 @@ __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigne
 }
 
 // ---------------------------------------------------------------------------
-// Sequential sweep over the kSweepBlock atoms [j0, j0+JB) -- one wave, lane owns
-// features 4*lane..4*lane+3 (d <= 256).
+// Sequential sweep over the kSweepBlock atoms [j0, j0+JB) -- NW waves, wave w owns the
+// feature panel [256w, 256w+256) and lane l its features 256w + 4l .. +3 (d <= 256*NW).
+// NW == 1 (d <= 256, the tuned case) has no barrier at all inside the sweep; for wider
+// rows the squared norm of an atom is the fixed-order sum of the waves' partial sums,
+// exchanged through LDS with one barrier per atom.
 // ---------------------------------------------------------------------------
 // FULL: all kSweepBlock atoms of the block exist (no per-atom branch at all, so hipcc can
 // overlap the deferred row updates of atom a with the reduction chain of atom a+1).
 // A degenerate atom (||u|| < eps, :92) leaves the model here (new atom = 0, dD = -old);
 // its replacement direction is written afterwards by degenerate_fixup_kernel.
-template <bool FULL>
-__global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, int j0) {
+template <bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams p, int j0) {
   constexpr int JB = kSweepBlock;
+  constexpr int DP = 256 * NW;                                     // == p.dp
   __shared__ __attribute__((aligned(16))) float sA[JB][JB];   // A[j0+a][j0+b] (symmetric)
-  __shared__ __attribute__((aligned(16))) float sD[JB][kFistaD];   // old atoms of the block (rows of Dt)
-  const int lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float sD_[];      // [JB][DP] old atoms of the block (rows of Dt)
+  __shared__ float red[JB][NW];
+  const int tid = threadIdx.x;
+  const int fo = 4 * tid;                                           // first feature of this lane
   const int nb = FULL ? JB : min(JB, p.k - j0);
-  for (int e = lane; e < JB * JB; e += 64) {
+  for (int e = tid; e < JB * JB; e += 64 * NW) {
     const int a = e / JB, b = e % JB;
     sA[a][b] = (a < nb && b < nb) ? p.A[(int64_t)(j0 + a) * p.lda + j0 + b] : 0.0f;
   }
   for (int a = 0; a < JB; ++a) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (a < nb) v = *(const f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane);
-    *(f32x4*)(&sD[a][4 * lane]) = v;
+    if (a < nb) v = *(const f32x4*)(p.Dt + (int64_t)(j0 + a) * DP + fo);
+    *(f32x4*)(&sD_[a * DP + fo]) = v;
   }
   float u[JB][4];
 #pragma unroll
   for (int a = 0; a < JB; ++a) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (a < nb) v = *(const f32x4*)(p.U + (int64_t)(j0 + a) * p.ldu + 4 * lane);   // ldu = 256, padded cols are 0
+    if (a < nb) v = *(const f32x4*)(p.U + (int64_t)(j0 + a) * p.ldu + fo);   // padded cols are 0
 #pragma unroll
     for (int f = 0; f < 4; ++f) u[a][f] = v[f];
   }
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       const f32x4 t4 = *(const f32x4*)(&sA[a][4 * b4]);
       cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
     }
-    const f32x4 dc4 = *(const f32x4*)(&sD[a][4 * lane]);
+    const f32x4 dc4 = *(const f32x4*)(&sD_[a * DP + fo]);
     float v[4], dcur[4], ss = 0.0f;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -213,19 +219,26 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       ss = fmaf(v[f], v[f], ss);
     }
     ss = wave_sum_dpp(ss);
+    if constexpr (NW > 1) {
+      if ((tid & 63) == 0) red[a][tid >> 6] = ss;
+      __syncthreads();
+      ss = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) ss += red[a][w];
+    }
     // ||u|| < eps  <=>  ||u||^2 < eps^2 (:91-92); 1/||u|| by v_rsq_f32 (1 ulp) -- the
     // sqrt + divide pair of :91,:100 would put ~25 dependent instructions on the chain
-    const bool deg = ss < eps2;                                     // wave-uniform
+    const bool deg = ss < eps2;                                     // uniform over the workgroup
     const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
     f32x4 dnew, delta;
 #pragma unroll
     for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dcur[f]; }
     if (FULL || a < nb) {
-      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * kFistaD + 4 * lane) = dnew;
-      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = delta;
+      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * DP + fo) = dnew;
+      *(f32x4*)(p.dD + (int64_t)a * DP + fo) = delta;
       degmask |= (deg ? 1u : 0u) << a;
     } else {
-      *(f32x4*)(p.dD + (int64_t)a * kFistaD + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(p.dD + (int64_t)a * DP + fo) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int b = a + 1; b < JB; ++b) {
@@ -233,52 +246,57 @@ __global__ __launch_bounds__(64) void sweep_block_kernel(const SweepParams p, in
       for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
     }
   });
-  if (lane < nb) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);   // one store, no per-atom branch
+  if (tid < nb) p.degenerate[j0 + tid] = (int)((degmask >> tid) & 1u);   // one store, no per-atom branch
 }
 
 // Replacement directions for the degenerate atoms, in atom order: the i-th degenerate atom
 // takes pool row i (normalised; dict_learning.py:93-96) or a counter-based N(0,1) vector.
 __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams p) {
-  __shared__ int s_idx[1024];
+  __shared__ int s_idx[kSweepMaxK];
   __shared__ int s_count;
   __shared__ float sh[256];
   if (threadIdx.x == 0) {
     int c = 0;
     for (int j = 0; j < p.k; ++j)
-      if (p.degenerate[j]) { if (c < 1024) s_idx[c] = j; ++c; }
+      if (p.degenerate[j]) { s_idx[c] = j; ++c; }
     s_count = c;
     p.ndeg_in_out[0] = c;
   }
   __syncthreads();
-  const int cnt = min(s_count, 1024);
-  const int dd = threadIdx.x;
-  for (int i = 0; i < cnt; ++i) {
-    const int j = s_idx[i];
+  const int cnt = s_count;
+  auto direction = [&](int i, int j, int dd) {
     float g = 0.0f;
     if (dd < p.d) {
       if (p.pool && p.pool_rows > 0) g = p.pool[(int64_t)min(i, p.pool_rows - 1) * p.pool_ld + dd];
       else g = counter_normal(p.seed, (unsigned)j, (unsigned)dd);
       if (p.positive) g = fmaxf(g, 0.0f);
     }
-    sh[dd] = g * g;
+    return g;
+  };
+  for (int i = 0; i < cnt; ++i) {
+    const int j = s_idx[i];
+    float part = 0.0f;
+    for (int dd = threadIdx.x; dd < p.dp; dd += 256) { const float g = direction(i, j, dd); part = fmaf(g, g, part); }
+    sh[threadIdx.x] = part;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-      if (dd < s) sh[dd] += sh[dd + s];
+      if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
       __syncthreads();
     }
     const float inv = 1.0f / sqrtf(sh[0]);
     __syncthreads();
-    p.Dt[(int64_t)j * kFistaD + dd] = g * inv;
+    for (int dd = threadIdx.x; dd < p.dp; dd += 256) p.Dt[(int64_t)j * p.dp + dd] = direction(i, j, dd) * inv;
   }
 }
 
-// U[j'][:] -= sum_a A[j'][j0+a] * dD[a][:]   for j' >= j0 + JB; one row per wave-iteration
+// U[j'][:] -= sum_a A[j'][j0+a] * dD[a][:]   for j' >= j0 + JB; one row per workgroup
+// iteration, blockIdx.y = panel of 256 features
 __global__ __launch_bounds__(256) void trailing_update_kernel(const SweepParams p, int j0) {
   constexpr int JB = kSweepBlock;
-  const int dd = threadIdx.x;              // feature (kFistaD == 256 threads)
+  const int dd = 256 * blockIdx.y + threadIdx.x;   // feature
   float dl[JB];
 #pragma unroll
-  for (int a = 0; a < JB; ++a) dl[a] = p.dD[(int64_t)a * kFistaD + dd];
+  for (int a = 0; a < JB; ++a) dl[a] = p.dD[(int64_t)a * p.dp + dd];
   const int nb = min(JB, p.k - j0);
   for (int r = j0 + JB + blockIdx.x; r < p.k; r += gridDim.x) {
     const float* arow = p.A + (int64_t)r * p.lda + j0;
@@ -381,17 +399,42 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
   return hipGetLastError();
 }
 
-hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
+template <int NW>
+static hipError_t sweep_blocks(const SweepParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)kSweepBlock * 256 * NW * 4;
+  static bool attr_set = false;
+  if (!attr_set && lds > 32 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_block_kernel<true, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_block_kernel<false, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   for (int j0 = 0; j0 < p.k; j0 += kSweepBlock) {
     if (j0 + kSweepBlock <= p.k)
-      hipLaunchKernelGGL(sweep_block_kernel<true>, dim3(1), dim3(64), 0, stream, p, j0);
+      hipLaunchKernelGGL((sweep_block_kernel<true, NW>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
     else
-      hipLaunchKernelGGL(sweep_block_kernel<false>, dim3(1), dim3(64), 0, stream, p, j0);
+      hipLaunchKernelGGL((sweep_block_kernel<false, NW>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
     if (j0 + kSweepBlock < p.k) {
       const int rows = p.k - j0 - kSweepBlock;
-      hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256)), dim3(256), 0, stream, p, j0);
+      hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256), NW), dim3(256), 0, stream, p, j0);
     }
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
+  hipError_t e;
+  switch (p.dp) {
+    case 256: e = sweep_blocks<1>(p, stream); break;
+    case 512: e = sweep_blocks<2>(p, stream); break;
+    case 768: e = sweep_blocks<3>(p, stream); break;
+    case 1024: e = sweep_blocks<4>(p, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, p);
   return hipGetLastError();
 }

@@ -118,4 +118,39 @@ hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double
   return hipGetLastError();
 }
 
+// Large shapes (d > 256 or k > 1024): R = X - Z W^T by the general GEMM (gemm.hip), then
+// one pass that folds sum R^2 and sum |Z| into per-workgroup pairs (fixed grid => fixed
+// summation order) for objective_finalize_kernel.
+__global__ __launch_bounds__(256) void objective_reduce_kernel(const float* __restrict__ R, int64_t nd,
+                                                               const float* __restrict__ Z, int64_t ldz,
+                                                               int n, int k, float* __restrict__ partials) {
+  __shared__ float sa[256], sb[256];
+  float a = 0.0f, b = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nd; i += stride) a = fmaf(R[i], R[i], a);
+  const int64_t nk = (int64_t)n * k;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nk; i += stride)
+    b += __builtin_fabsf(Z[(i / k) * ldz + i % k]);
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sa[0]; partials[2 * blockIdx.x + 1] = sb[0]; }
+}
+
+hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* Z,
+                                    int64_t ldz, int n, int d, int k, float* R, float* partials, int grid,
+                                    double alpha, double n_total, double* sums, float* loss_out,
+                                    hipStream_t stream) {
+  hipError_t e = launch_gemm_nt_sub(Z, ldz, W, ldw, X, ldx, R, d, n, d, k, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(objective_reduce_kernel, dim3(grid), dim3(256), 0, stream, R, (int64_t)n * d, Z, ldz, n, k,
+                     partials);
+  hipLaunchKernelGGL(objective_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, alpha, n_total,
+                     sums, loss_out);
+  return hipGetLastError();
+}
+
 }  // namespace lasso

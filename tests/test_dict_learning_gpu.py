@@ -49,7 +49,8 @@ def test_lr_auto_matches_reference_within_arpack_jitter(golden):
     assert (got.cpu() - ref).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (100, 48, 200), (1000, 64, 256)])
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (100, 48, 200), (1000, 64, 256),
+                                   (90, 300, 40), (50, 64, 1500), (130, 784, 1100)])
 def test_lasso_loss(n, d, k):
     from lasso_amd.linear import lasso_loss
     orc = _orc()
@@ -100,6 +101,48 @@ def test_update_dict_positive_and_large():
         torch.manual_seed(0)
         update_dict(D, X.cuda(), Zg, positive=positive)
         assert (D.cpu() - Dref).abs().max().item() <= 1e-4, positive
+
+
+@pytest.mark.parametrize("n,d,k", [(400, 300, 96), (600, 784, 200), (300, 1024, 70), (500, 520, 1100)])
+def test_update_dict_wide_rows(n, d, k):
+    """Shapes beyond the fused tile kernel (d > 256 and/or k > 1024): unfused E-step,
+    multi-wave atom sweep, general GEMM -- same parity bar as the tuned shapes."""
+    from lasso_amd.linear import update_dict, sparse_encode, lasso_loss
+    orc = _orc()
+    g = torch.Generator().manual_seed(d + k)
+    W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+    X = torch.randn(n, d, generator=g)
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    Z = orc.sparse_encode(X, W, 0.6, lr=lr, maxiter=8, tol=0.0)
+    Zg = sparse_encode(X.cuda(), W.cuda(), 0.6, lr=lr, maxiter=8, tol=0.0)
+    assert (Zg.cpu() - Z).abs().max().item() <= 5e-5
+    assert abs(lasso_loss(X.cuda(), Zg, W.cuda(), 0.6).item() - orc.lasso_objective(X, Z, W, 0.6).item()) \
+        <= 2e-6 * orc.lasso_objective(X, Z, W, 0.6).item()
+    for positive in (False, True):
+        Dref, Zref = W.clone(), Z.clone()
+        torch.manual_seed(3)
+        orc.update_dict(Dref, X, Zref, positive=positive)
+        D, Zc = W.clone().cuda(), Z.clone().cuda()
+        torch.manual_seed(3)
+        update_dict(D, X.cuda(), Zc, positive=positive)
+        used = Z.abs().sum(0) > 0
+        assert (D.cpu() - Dref)[:, used].abs().max().item() <= 1e-4, (positive,)
+        if (~used).any():                                                  # re-drawn atoms: same RNG stream
+            assert (D.cpu() - Dref)[:, ~used].abs().max().item() <= 1e-6
+        assert torch.equal(Zc.cpu() == 0, Zref == 0)
+
+
+def test_dict_learning_wide_rows():
+    from lasso_amd.linear import dict_learning
+    orc = _orc()
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(300, 400, generator=g)
+    torch.manual_seed(5)
+    Dref, lref = orc.dict_learning(X, 48, alpha=0.4, steps=4, lr=0.2, progbar=False)
+    torch.manual_seed(5)
+    D, losses = dict_learning(X, 48, alpha=0.4, steps=4, lr=0.2, progbar=False)   # init on the CPU RNG (:28-31)
+    assert (losses.cpu() - lref).abs().max().item() <= 1e-5 * lref.abs().max().item()
+    assert (D.cpu() - Dref).abs().max().item() <= 1e-4
 
 
 def test_g1_readme_dict_learning(golden):
