@@ -199,6 +199,41 @@ int lasso_cd_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ld
                    int32_t* n_active_out, int32_t* max_steps_out,
                    void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- convolutional ISTA/FISTA: replaces ista_conv2d(), lasso/conv2d/ista.py:7-49, and
+ *      lip_bound_conv2d(), lasso/conv2d/lip_const.py:96-135 ---------------------------------
+ * All tensors are contiguous NCHW fp32: x [N][C][H][W], weight [K][C][kh][kw] (the layout
+ * F.conv2d takes: K code channels out, C image channels in), code z [N][K][Hz][Wz] with
+ * H == (Hz-1)*sh - 2*ph + kh (the size conv_transpose2d gives the code; else
+ * LASSO_ERR_BAD_ARG, the reference's shape RuntimeError at ista.py:19).
+ *   lasso_conv_ista_solve: min_z 0.5*||conv_transpose2d(z, W) - x||^2 + alpha*||z||_1 by
+ *     (F)ISTA with the fixed step lr; z0_dev == NULL means zero init; the stop rule
+ *     sum|z - z_next| <= numel(z)*tol is global (ista.py:16,44) and, when tol > 0, costs
+ *     one stream synchronisation per iteration like the reference; tol == 0 runs exactly
+ *     maxiter iterations without any.  iters_out / last_delta_out: HOST, nullable.
+ *   lasso_conv_objective: (0.5*||x - x_hat||^2 + alpha*||z||_1)/N -> loss_dev (ista.py:23-26).
+ *   lasso_conv_lip_bound: the Toeplitz bound on lambda_max of the stride-1 operator on a
+ *     sample x sample frequency grid (sqrt != 0: its square root); ksize odd (else
+ *     LASSO_ERR_BAD_ARG, the reference's ValueError :101-102).  l_out: HOST (synchronises).
+ */
+size_t lasso_conv_ista_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                                       int64_t Hz, int64_t Wz, int kh, int kw,
+                                       int sh, int sw, int ph, int pw);
+int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_dev, void* z_out_dev,
+                          int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz,
+                          int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                          double alpha, double lr, int fast, int maxiter, double tol,
+                          int32_t* iters_out, float* last_delta_out,
+                          void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_conv_objective(const void* x_dev, const void* w_dev, const void* z_dev,
+                         int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz,
+                         int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                         double alpha, float* loss_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+size_t lasso_conv_lip_workspace_bytes(int64_t K, int64_t C, int ksize, int sample);
+int lasso_conv_lip_bound(const void* w_dev, int64_t K, int64_t C, int ksize, int padding, int sample,
+                         int take_sqrt, double* l_out,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

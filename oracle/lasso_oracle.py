@@ -29,6 +29,7 @@ __all__ = [
     "backtracking_step", "fista", "initial_code", "sparse_encode",
     "lasso_objective", "dict_evaluate", "update_dict", "update_dict_gram",
     "update_dict_ridge", "dict_learning", "FistaTrace", "coordinate_descent",
+    "conv_lipschitz_bound", "conv_fista", "conv_objective",
 ]
 
 
@@ -319,6 +320,81 @@ def coordinate_descent(x, weight, z0=None, alpha=1.0, maxiter=1000, tol=1e-6,
         return out, dict(row_steps=row_steps, n_active=int(rows.numel()), z_track=z)
     return out
 
+
+
+# --------------------------------------------------------------------------
+# convolutional ISTA/FISTA  (lasso/conv2d/ista.py:7-49,
+# lasso/conv2d/lip_const.py:96-135)
+# --------------------------------------------------------------------------
+def conv_lipschitz_bound(kernel, padding, stride=1, sample=50, sqrt=False):
+    """Araujo et al. Toeplitz bound on lambda_max(W^T W) of a stride-1 conv2d,
+    lip_const.py:96-135: evaluate the kernel's 2-D Fourier symbol on a
+    sample x sample frequency grid, sum the squared magnitudes over the
+    larger channel dimension, take the maximum over frequencies and sum over
+    the smaller channel dimension."""
+    assert kernel.dim() == 4                                       # :98
+    if kernel.size(-1) != kernel.size(-2):
+        raise ValueError("The last 2 dim of the kernel must be equal.")      # :99-100
+    if kernel.size(-1) % 2 != 1:
+        raise ValueError("The dimension of the kernel must be odd.")         # :101-102
+    if stride != 1:
+        raise NotImplementedError("LipBound not implemented for stride > 1.")  # :103-104
+    ks = kernel.size(-1)
+    if kernel.size(0) > kernel.size(1):
+        kernel = kernel.transpose(0, 1)                            # :106-107
+    freq = torch.linspace(0, 2 * math.pi, sample)                  # :110
+    f0, f1 = torch.meshgrid(freq, freq, indexing="ij")             # :111
+    pos = 1.0 + torch.arange(padding - ks, padding)                # :116
+    h0, h1 = torch.meshgrid(pos, pos, indexing="ij")               # :117
+    phase = (f0.reshape(-1, 1) * h0.reshape(1, -1) + f1.reshape(-1, 1) * h1.reshape(1, -1)).T  # :120
+    taps = kernel.flatten(2)                                       # :125
+    re = torch.matmul(taps, torch.cos(phase))                      # :126
+    im = torch.matmul(taps, torch.sin(phase))                      # :127
+    power = re.square().sum(1) + im.square().sum(1)                # :128-130
+    bound = power.max(-1)[0].sum()                                 # :131
+    return bound.sqrt() if sqrt else bound                         # :132-135
+
+
+def conv_objective(x, z, weight, alpha, stride=1, padding=0):
+    """ista.py:23-26: (0.5*||x - conv_transpose2d(z)||^2 + alpha*||z||_1) / batch."""
+    F = torch.nn.functional
+    x_hat = F.conv_transpose2d(z, weight, stride=stride, padding=padding)
+    return (0.5 * (x - x_hat).pow(2).sum() + alpha * z.abs().sum()) / x.size(0)
+
+
+def conv_fista(x, z0, weight, alpha=1.0, stride=1, padding=0, fast=True,
+               maxiter=10, lr="auto", tol=1e-5, return_info=False):
+    """ista_conv2d, lasso/conv2d/ista.py:7-49: the proximal-gradient loop of
+    fista() with x_hat = conv_transpose2d(z, W) as the synthesis operator and
+    conv2d(. , W) as its adjoint (:18-20).  The momentum update comes before
+    the stop test here (:39-46) -- same iterates, same result."""
+    F = torch.nn.functional
+    if lr == "auto":
+        if stride != 1:
+            raise NotImplementedError("auto lr is only implemented for stride == 1.")  # :10-12
+        lr = 1 / conv_lipschitz_bound(weight, padding)             # :14-15 (a 0-d tensor)
+    budget = z0.numel() * tol                                      # :16
+
+    def step(p):                                                   # :18-20, :28-29
+        resid = F.conv_transpose2d(p, weight, stride=stride, padding=padding) - x
+        return soft_threshold(p - lr * F.conv2d(resid, weight, stride=stride, padding=padding),
+                              alpha * lr)
+
+    z, y, t, done, last = z0, z0, 1, 0, float("nan")
+    for _ in range(maxiter):                                       # :36
+        z_next = step(y) if fast else step(z)                      # :39
+        if fast:
+            t_next = (1 + math.sqrt(1 + 4 * t ** 2)) / 2           # :41
+            y = z_next + ((t - 1) / t_next) * (z_next - z)         # :42
+            t = t_next
+        done += 1
+        last = (z - z_next).abs().sum().item()                     # :44
+        z = z_next
+        if last <= budget:                                         # :44-46
+            break
+    if return_info:
+        return z, dict(iterations=done, last_delta=last)
+    return z
 
 
 # --------------------------------------------------------------------------

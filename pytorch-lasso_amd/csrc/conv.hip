@@ -1,0 +1,201 @@
+// Convolutional ISTA/FISTA (reference lasso/conv2d/ista.py:7-49) and
+// the Toeplitz Lipschitz bound (lasso/conv2d/lip_const.py:96-135).
+//
+//   x_hat = conv_transpose2d(z, W)      (synthesis, ista.py:19)
+//   g     = conv2d(x_hat - x, W)        (its adjoint,  ista.py:20)
+//   z+    = S_{alpha lr}(y - lr g), momentum and global stop rule as in the linear solver.
+//
+// Layout: the code z [N][K][Hz][Wz] is kept as a MATRIX Zm [M = N*Hz*Wz][K] ("one row per
+// code pixel") for the whole solve, so both convolutions become the dense MFMA GEMMs the
+// rest of the library already has, against ONE weight matrix Wt [C*kh*kw][K]:
+//   COLSt [CKK][M] = Wt Ym^T                    (gemm_nt_kernel: every code pixel's patch)
+//   R     [N][C][H][W] = overlap-add(COLSt) - x (conv_residual_kernel, gather form: no atomics)
+//   RCt   [CKK][M]     = patches of R            (conv_patches_kernel, im2col)
+//   G     [M][K]       = RCt^T Wt                (gram_tn_kernel, contraction over CKK)
+//   prox / momentum / sum|z - z+|                (generic_prox_kernel on the matrices)
+// COLSt and RCt are stored tap-major so that neighbouring threads (neighbouring pixels)
+// touch neighbouring addresses in the two data-movement kernels.  Stride and padding live
+// only in the index arithmetic of those two kernels.
+// Rooflines: the GEMMs are MFMA-bound (2*2*M*CKK*K flop per iteration); the two
+// data-movement kernels are HBM-bound (each reads or writes the M*CKK patch matrix once).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <algorithm>
+#include "lasso_kernels.h"
+
+namespace lasso {
+namespace {
+
+// Zm[(n,u,v)][k] <- z[n][k][u][v]   (to_rows != 0)   or the inverse
+__global__ __launch_bounds__(256) void conv_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int N, int K, int P /* Hz*Wz */, int to_rows) {
+  const int64_t total = (int64_t)N * K * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i enumerates the NCHW tensor: ((n*K + k)*P + pix)
+    const int pix = (int)(i % P);
+    const int k = (int)((i / P) % K);
+    const int64_t n = i / ((int64_t)P * K);
+    const int64_t j = (n * P + pix) * K + k;
+    if (to_rows) dst[j] = src[i];
+    else dst[i] = src[j];
+  }
+}
+
+// R[n][c][i][j] = sum_{a,b} COLSt[(c,a,b)][(n,u,v)] - x[n][c][i][j],
+// u = (i + ph - a)/sh, v = (j + pw - b)/sw where they are integers inside the code grid
+__global__ __launch_bounds__(256) void conv_residual_kernel(const float* __restrict__ colst, const float* __restrict__ x,
+                                                            float* __restrict__ r, const ConvGeom g) {
+  const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e % g.W);
+    const int i = (int)((e / g.W) % g.H);
+    const int c = (int)((e / ((int64_t)g.W * g.H)) % g.C);
+    const int n = (int)(e / ((int64_t)g.W * g.H * g.C));
+    float acc = 0.0f;
+    for (int a = 0; a < g.kh; ++a) {
+      const int ii = i + g.ph - a;
+      if (ii < 0 || ii % g.sh != 0) continue;
+      const int u = ii / g.sh;
+      if (u >= g.Hz) continue;
+      for (int b = 0; b < g.kw; ++b) {
+        const int jj = j + g.pw - b;
+        if (jj < 0 || jj % g.sw != 0) continue;
+        const int v = jj / g.sw;
+        if (v >= g.Wz) continue;
+        const int64_t t = ((int64_t)c * g.kh + a) * g.kw + b;
+        acc += colst[t * M + ((int64_t)n * g.Hz + u) * g.Wz + v];
+      }
+    }
+    r[e] = acc - (x ? x[e] : 0.0f);
+  }
+}
+
+// RCt[(c,a,b)][(n,u,v)] = R[n][c][u*sh - ph + a][v*sw - pw + b]   (0 outside the image)
+__global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restrict__ r, float* __restrict__ rct,
+                                                           const ConvGeom g) {
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  const int64_t total = (int64_t)g.C * g.kh * g.kw * M;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e % M;
+    const int t = (int)(e / M);
+    const int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);
+    const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
+    const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
+    const int i = u * g.sh - g.ph + a, j = v * g.sw - g.pw + b;
+    float val = 0.0f;
+    if (i >= 0 && i < g.H && j >= 0 && j < g.W) val = r[(((int64_t)n * g.C + c) * g.H + i) * g.W + j];
+    rct[e] = val;
+  }
+}
+
+// Wt[(c,a,b)][k] = w[k][c][a][b]
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int K,
+                                                          int ckk) {
+  const int total = K * ckk;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int k = e % K, t = e / K;
+    wt[e] = w[(int64_t)k * ckk + t];
+  }
+}
+
+// lip_const.py:96-135.  taps [O][I][T] (T = ksize^2; O <= I after the reference's swap).
+// One workgroup per o: power(o, f) = sum_i (sum_t tap*cos(phase[t][f]))^2 + (... sin ...)^2,
+// out[o] = max_f power.  phase[t][f] = w0[f]*h0[t] + w1[f]*h1[t] (fp32, like the reference).
+__global__ __launch_bounds__(256) void conv_lip_kernel(const float* __restrict__ taps, int64_t so, int64_t si, int I,
+                                                       int ks, int padding, const float* __restrict__ freq,
+                                                       int sample, float* __restrict__ out_max) {
+  extern __shared__ float sh_taps[];          // [I][T]
+  __shared__ float sred[256];
+  const int T = ks * ks, o = blockIdx.x;
+  for (int e = threadIdx.x; e < I * T; e += 256) sh_taps[e] = taps[(int64_t)o * so + (int64_t)(e / T) * si + e % T];
+  __syncthreads();
+  float best = 0.0f;
+  for (int f = threadIdx.x; f < sample * sample; f += 256) {
+    const float w0 = freq[f / sample], w1 = freq[f % sample];
+    float power = 0.0f;
+    for (int i = 0; i < I; ++i) {
+      float re = 0.0f, im = 0.0f;
+      for (int t = 0; t < T; ++t) {
+        const float h0 = 1.0f + (float)(padding - ks + t / ks), h1 = 1.0f + (float)(padding - ks + t % ks);
+        const float a0 = w0 * h0, a1 = w1 * h1;
+        const float ph = a0 + a1;
+        float sn, cs;
+        sincosf(ph, &sn, &cs);
+        re = fmaf(sh_taps[i * T + t], cs, re);
+        im = fmaf(sh_taps[i * T + t], sn, im);
+      }
+      power += re * re + im * im;
+    }
+    best = fmaxf(best, power);
+  }
+  sred[threadIdx.x] = best;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sred[threadIdx.x] = fmaxf(sred[threadIdx.x], sred[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_max[o] = sred[0];
+}
+
+__global__ void conv_lip_sum_kernel(const float* __restrict__ maxes, int O, int take_sqrt, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.0f;
+    for (int o = 0; o < O; ++o) s += maxes[o];
+    out[0] = take_sqrt ? (double)sqrtf(s) : (double)s;
+  }
+}
+
+inline int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 8192); }
+
+}  // namespace
+
+hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream) {
+  const int64_t total = (int64_t)N * K * P;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(conv_relayout_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, N, K, P, to_rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_pack_w(const float* w, float* wt, int K, int ckk, hipStream_t stream) {
+  hipLaunchKernelGGL(conv_pack_w_kernel, dim3(grid_for((int64_t)K * ckk)), dim3(256), 0, stream, w, wt, K, ckk);
+  return hipGetLastError();
+}
+
+// R = conv_transpose2d(rows Ym) - x :  GEMM into COLSt, then the gather
+hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
+                                const ConvGeom& g, hipStream_t stream) {
+  const int ckk = g.C * g.kh * g.kw;
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  hipError_t e = launch_gemm_nt_sub(Wt, g.K, Ym, g.K, nullptr, 0, colst, M, ckk, (int)M, g.K, stream, /*add=*/1);
+  if (e != hipSuccess) return e;
+  const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
+  hipLaunchKernelGGL(conv_residual_kernel, dim3(grid_for(total)), dim3(256), 0, stream, colst, x, r, g);
+  return hipGetLastError();
+}
+
+// G [M][K] = conv2d(R, W) in row layout: patches, then the contraction over the taps
+hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, float* G, float* scratch,
+                                const ConvGeom& g, int cus, hipStream_t stream) {
+  const int ckk = g.C * g.kh * g.kw;
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  hipLaunchKernelGGL(conv_patches_kernel, dim3(grid_for((int64_t)ckk * M)), dim3(256), 0, stream, r, rct, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  (void)scratch; (void)cus;
+  return launch_gram_tn(rct, M, (int)M, Wt, g.K, g.K, ckk, G, g.K, 0, nullptr, 1, stream);
+}
+
+hipError_t launch_conv_lip(const float* taps, int O, int I, int64_t so, int64_t si, int ks, int padding,
+                           const float* freq, int sample, int take_sqrt, float* maxes, double* out,
+                           hipStream_t stream) {
+  const size_t lds = (size_t)I * ks * ks * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv_lip_kernel, dim3(O), dim3(256), lds, stream, taps, so, si, I, ks, padding, freq, sample,
+                     maxes);
+  hipLaunchKernelGGL(conv_lip_sum_kernel, dim3(1), dim3(64), 0, stream, maxes, O, take_sqrt, out);
+  return hipGetLastError();
+}
+
+}  // namespace lasso

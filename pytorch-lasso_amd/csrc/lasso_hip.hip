@@ -463,6 +463,57 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
   return LASSO_OK;
 }
 
+// ---------------------------------------------------------------------------
+// convolutional ISTA (conv.hip)
+// ---------------------------------------------------------------------------
+struct ConvWorkspace { float* Wt; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums; size_t bytes; };
+
+ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
+  ConvWorkspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(std::max<size_t>(bytes, 4));
+    return r;
+  };
+  const size_t ckk = (size_t)g.C * g.kh * g.kw, M = (size_t)g.N * g.Hz * g.Wz;
+  w.Wt = (float*)take(ckk * g.K * 4);
+  w.Zm = (float*)take(M * g.K * 4);
+  w.Ym = (float*)take(M * g.K * 4);
+  w.G = (float*)take(M * g.K * 4);
+  w.PT = (float*)take(ckk * M * 4);
+  w.R = (float*)take((size_t)g.N * g.C * g.H * g.W * 4);
+  w.dpart = (float*)take((size_t)kGenGrid * 2 * 4);
+  w.delta = (float*)take(256);
+  w.sums = (double*)take(256);
+  w.bytes = off;
+  return w;
+}
+
+int check_conv(const ConvGeom& g, int dtype) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d: only LASSO_F32 is implemented", dtype);
+  if (g.N < 0 || g.C <= 0 || g.K <= 0 || g.H <= 0 || g.W <= 0 || g.Hz <= 0 || g.Wz <= 0 || g.kh <= 0 ||
+      g.kw <= 0 || g.sh <= 0 || g.sw <= 0 || g.ph < 0 || g.pw < 0)
+    return fail(LASSO_ERR_BAD_ARG, "bad convolution geometry");
+  // x must have exactly the size conv_transpose2d gives the code (ista.py:19: x_hat - x)
+  if ((int64_t)(g.Hz - 1) * g.sh - 2 * g.ph + g.kh != g.H || (int64_t)(g.Wz - 1) * g.sw - 2 * g.pw + g.kw != g.W)
+    return fail(LASSO_ERR_BAD_ARG, "image %dx%d does not match code %dx%d under kernel %dx%d stride %d,%d padding %d,%d",
+                g.H, g.W, g.Hz, g.Wz, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw);
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz, ckk = (int64_t)g.C * g.kh * g.kw;
+  if (M > INT32_MAX / 2 || ckk > INT32_MAX / 2 || (int64_t)g.N * g.C * g.H * g.W > ((int64_t)1 << 40))
+    return fail(LASSO_ERR_UNSUPPORTED, "convolution problem too large");
+  return LASSO_OK;
+}
+
+ConvGeom make_geom(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz, int kh, int kw,
+                   int sh, int sw, int ph, int pw) {
+  ConvGeom g;
+  g.N = (int)N; g.C = (int)C; g.H = (int)H; g.W = (int)W; g.K = (int)K; g.Hz = (int)Hz; g.Wz = (int)Wz;
+  g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
+  return g;
+}
+
 }  // namespace
 }  // namespace lasso
 
@@ -951,6 +1002,127 @@ int lasso_cd_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ld
     return s;
   return lasso_cd_finish(z_out_dev, ldz, z0_inout_dev, ldz0, n, d, k, alpha, workspace_dev,
                          workspace_bytes, stream);
+}
+
+// ---- convolutional ISTA/FISTA: lasso/conv2d/ista.py:7-49, lip_const.py:96-135 ----------
+size_t lasso_conv_ista_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz,
+                                       int64_t Wz, int kh, int kw, int sh, int sw, int ph, int pw) {
+  const ConvGeom g = make_geom(N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw);
+  if (check_conv(g, LASSO_F32)) return 0;
+  return carve_conv(nullptr, g).bytes;
+}
+
+int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_dev, void* z_out_dev, int64_t N,
+                          int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz, int kh, int kw,
+                          int sh, int sw, int ph, int pw, int dtype, double alpha, double lr, int fast,
+                          int maxiter, double tol, int32_t* iters_out, float* last_delta_out,
+                          void* workspace_dev, size_t workspace_bytes, void* stream) {
+  const ConvGeom g = make_geom(N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw);
+  if (int s = check_conv(g, dtype)) return s;
+  if (!w_dev || !workspace_dev || (N > 0 && (!x_dev || !z_out_dev))) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (maxiter < 0 || !(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "maxiter=%d lr=%g alpha=%g", maxiter, lr, alpha);
+  ConvWorkspace ws = carve_conv(workspace_dev, g);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (iters_out) *iters_out = 0;
+  if (last_delta_out) *last_delta_out = NAN;
+  if (N == 0) return LASSO_OK;
+  const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
+  const int64_t M = (int64_t)g.N * P;
+  const int cus = device_cus();
+  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, g.K, ckk, st));
+  if (z0_dev) LASSO_HIP_TRY(launch_conv_relayout((const float*)z0_dev, ws.Zm, g.N, g.K, P, 1, st));
+  else LASSO_HIP_TRY(hipMemsetAsync(ws.Zm, 0, (size_t)M * g.K * 4, st));
+  LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Zm, (size_t)M * g.K * 4, hipMemcpyDeviceToDevice, st));
+  const float budget = (float)((double)M * (double)g.K * tol);     // ista.py:16, compared in fp32
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  double t_mom = 1.0;
+  float last = NAN;
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
+    LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));   // :19
+    LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wt, ws.PT, ws.G, nullptr, g, cus, st));           // :20
+    LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,
+                                      kGenGrid, st));                                             // :29,:42,:44
+    t_mom = t_next;
+    if (tol > 0.0) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, ws.delta);
+      LASSO_HIP_TRY(hipGetLastError());
+      LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      if (last <= budget) { ++it; break; }                                          // :44-46
+    }
+  }
+  LASSO_HIP_TRY(launch_conv_relayout(ws.Zm, (float*)z_out_dev, g.N, g.K, P, 0, st));
+  if (iters_out) *iters_out = it;
+  if (last_delta_out) *last_delta_out = last;
+  return LASSO_OK;
+}
+
+// (0.5*||x - conv_transpose2d(z)||^2 + alpha*||z||_1) / N   (ista.py:23-26) -> loss_dev
+int lasso_conv_objective(const void* x_dev, const void* w_dev, const void* z_dev, int64_t N, int64_t C, int64_t H,
+                         int64_t W, int64_t K, int64_t Hz, int64_t Wz, int kh, int kw, int sh, int sw, int ph,
+                         int pw, int dtype, double alpha, float* loss_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream) {
+  const ConvGeom g = make_geom(N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw);
+  if (int s = check_conv(g, dtype)) return s;
+  if (!x_dev || !w_dev || !z_dev || !loss_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (N == 0) return fail(LASSO_ERR_BAD_ARG, "empty batch");
+  ConvWorkspace ws = carve_conv(workspace_dev, g);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
+  const int64_t M = (int64_t)g.N * P;
+  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, g.K, ckk, st));
+  LASSO_HIP_TRY(launch_conv_relayout((const float*)z_dev, ws.Zm, g.N, g.K, P, 1, st));
+  LASSO_HIP_TRY(launch_conv_residual(ws.Zm, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));
+  LASSO_HIP_TRY(launch_objective_reduce(ws.R, (int64_t)g.N * g.C * g.H * g.W, ws.Zm, g.K, (int)M, g.K, ws.dpart,
+                                        kGenGrid, alpha, (double)g.N, ws.sums, loss_dev, st));
+  return LASSO_OK;
+}
+
+size_t lasso_conv_lip_workspace_bytes(int64_t K, int64_t C, int ksize, int sample) {
+  (void)ksize;
+  if (K <= 0 || C <= 0 || sample <= 0) return 0;
+  return align_up((size_t)sample * 4) + align_up((size_t)std::min(K, C) * 4) + 256;
+}
+
+int lasso_conv_lip_bound(const void* w_dev, int64_t K, int64_t C, int ksize, int padding, int sample,
+                         int take_sqrt, double* l_out, void* workspace_dev, size_t workspace_bytes,
+                         void* stream) {
+  if (!w_dev || !workspace_dev || K <= 0 || C <= 0 || ksize <= 0 || sample < 2)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (ksize % 2 != 1) return fail(LASSO_ERR_BAD_ARG, "The dimension of the kernel must be odd.");   // :101-102
+  if (workspace_bytes < lasso_conv_lip_workspace_bytes(K, C, ksize, sample))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_conv_lip_workspace_bytes(K, C, ksize, sample));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = (char*)workspace_dev;
+  float* freq = (float*)base;
+  float* maxes = (float*)(base + align_up((size_t)sample * 4));
+  double* out = (double*)((char*)maxes + align_up((size_t)std::min(K, C) * 4));
+  // torch.linspace(0, 2*pi, sample) in fp32 (:110): start + i*step below the midpoint,
+  // end - (sample-1-i)*step above it
+  std::vector<float> f(sample);
+  const float lo = 0.0f, hi = (float)(2.0 * M_PI);
+  const float step = (hi - lo) / (float)(sample - 1);
+  for (int i = 0; i < sample; ++i) f[i] = i < sample / 2 ? lo + step * (float)i : hi - step * (float)(sample - 1 - i);
+  LASSO_HIP_TRY(hipMemcpyAsync(freq, f.data(), (size_t)sample * 4, hipMemcpyHostToDevice, st));
+  LASSO_HIP_TRY(hipStreamSynchronize(st));            // f is a stack-lifetime staging buffer
+  const int T = ksize * ksize;
+  // the smaller channel dimension is summed last (:106-107)
+  const bool swap = K > C;
+  const int O = (int)(swap ? C : K), I = (int)(swap ? K : C);
+  const int64_t so = swap ? T : (int64_t)C * T, si = swap ? (int64_t)C * T : T;
+  if ((size_t)I * T * 4 > 64 * 1024) return fail(LASSO_ERR_UNSUPPORTED, "kernel too large for the bound kernel");
+  LASSO_HIP_TRY(launch_conv_lip((const float*)w_dev, O, I, so, si, ksize, padding, freq, sample, take_sqrt, maxes,
+                                out, st));
+  if (l_out) {
+    LASSO_HIP_TRY(hipMemcpyAsync(l_out, out, sizeof(double), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return LASSO_OK;
 }
 
 }  // extern "C"

@@ -86,6 +86,11 @@ struct CdParams {
   float alpha, tol;        // tol = absolute per-row threshold (reference: tol*k)
 };
 
+// convolutional ISTA (conv.hip): x [N][C][H][W], weight [K][C][kh][kw], code z [N][K][Hz][Wz]
+struct ConvGeom {
+  int N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw;
+};
+
 size_t fista_tile_lds_bytes(int kpad);
 hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_fista_tile16(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
@@ -122,6 +127,18 @@ hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStre
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream);
+hipError_t launch_conv_pack_w(const float* w, float* wt, int K, int ckk, hipStream_t stream);
+hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
+                                const ConvGeom& g, hipStream_t stream);
+hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, float* G, float* scratch,
+                                const ConvGeom& g, int cus, hipStream_t stream);
+hipError_t launch_conv_lip(const float* taps, int O, int I, int64_t so, int64_t si, int ks, int padding,
+                           const float* freq, int sample, int take_sqrt, float* maxes, double* out,
+                           hipStream_t stream);
+hipError_t launch_objective_reduce(const float* R, int64_t nd, const float* Z, int64_t ldz, int n, int k,
+                                   float* partials, int grid, double alpha, double n_total, double* sums,
+                                   float* loss_out, hipStream_t stream);
 hipError_t launch_transpose_pad(const float* src, int64_t ld_src, int rows, int cols, float* dst,
                                 int64_t ld_dst, int drows, int dcols, hipStream_t stream);
 hipError_t launch_generic_prox(float* Z, int64_t ldz, float* Y, const float* G, int n, int k, float lr,

@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void objective_reduce_kernel(const float* __re
   if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sa[0]; partials[2 * blockIdx.x + 1] = sb[0]; }
 }
 
+// sums / loss from a residual that is already in memory (convolutional objective)
+hipError_t launch_objective_reduce(const float* R, int64_t nd, const float* Z, int64_t ldz, int n, int k,
+                                   float* partials, int grid, double alpha, double n_total, double* sums,
+                                   float* loss_out, hipStream_t stream) {
+  hipLaunchKernelGGL(objective_reduce_kernel, dim3(grid), dim3(256), 0, stream, R, nd, Z, ldz, n, k, partials);
+  hipLaunchKernelGGL(objective_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, alpha, n_total,
+                     sums, loss_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* Z,
                                     int64_t ldz, int n, int d, int k, float* R, float* partials, int grid,
                                     double alpha, double n_total, double* sums, float* loss_out,

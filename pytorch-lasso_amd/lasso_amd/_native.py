@@ -77,6 +77,18 @@ def _declare(lib):
     lib.lasso_cd_run.argtypes = [i64, i64, i64, dbl, dbl, i32, pi32, pi32, vp, sz, vp]
     lib.lasso_cd_finish.restype = i32
     lib.lasso_cd_finish.argtypes = [vp, i64, vp, i64, i64, i64, i64, dbl, vp, sz, vp]
+    geom = [i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32]
+    lib.lasso_conv_ista_workspace_bytes.restype = sz
+    lib.lasso_conv_ista_workspace_bytes.argtypes = geom
+    lib.lasso_conv_ista_solve.restype = i32
+    lib.lasso_conv_ista_solve.argtypes = [vp, vp, vp, vp] + geom + [i32, dbl, dbl, i32, i32, dbl, pi32,
+                                                                    C.POINTER(C.c_float), vp, sz, vp]
+    lib.lasso_conv_objective.restype = i32
+    lib.lasso_conv_objective.argtypes = [vp, vp, vp] + geom + [i32, dbl, vp, vp, sz, vp]
+    lib.lasso_conv_lip_workspace_bytes.restype = sz
+    lib.lasso_conv_lip_workspace_bytes.argtypes = [i64, i64, i32, i32]
+    lib.lasso_conv_lip_bound.restype = i32
+    lib.lasso_conv_lip_bound.argtypes = [vp, i64, i64, i32, i32, i32, i32, C.POINTER(dbl), vp, sz, vp]
     lib.lasso_cd_solve.restype = i32
     lib.lasso_cd_solve.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32,
                                    dbl, pi32, pi32, vp, sz, vp]

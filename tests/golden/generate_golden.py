@@ -12,7 +12,7 @@ The reference does not import as-is under scipy 1.15 (iterative_ridge.py:5
 imports a private scipy symbol); the 3-line shim below aliases that symbol
 BEFORE importing -- no reference file is edited or copied.
 
-Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g4 g5 small inits cd]
+Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g4 g5 small inits cd conv]
 """
 import os
 import sys
@@ -298,6 +298,43 @@ def cd():
         st = zstats(z)
         out["c2_stats_%d" % mi] = np.array([st["sum"], st["abssum"], st["nnz"]])
     save("cd_cases", **out)
+
+
+def conv():
+    """Convolutional ISTA/FISTA (lasso/conv2d/ista.py:7-49) and the Toeplitz Lipschitz
+    bound (lasso/conv2d/lip_const.py:96-135), SURVEY 8f row f3."""
+    from lasso.conv2d.ista import ista_conv2d
+    from lasso.conv2d.lip_const import lip_bound_conv2d
+    out = {}
+    g = torch.Generator().manual_seed(2468)
+    # tag: (N, C, K, ksize, stride, padding, Hz, Wz, alpha)
+    cases = {"a": (4, 1, 8, 5, 1, 0, 12, 12, 0.1), "b": (3, 3, 6, 3, 2, 1, 7, 9, 0.05),
+             "c": (2, 2, 5, 7, 1, 3, 9, 11, 0.1), "d": (5, 1, 16, 5, 1, 2, 28, 28, 0.2),
+             "e": (2, 4, 40, 3, 1, 1, 16, 16, 0.02)}
+    for tag, (N, C, K, ks, st, pd, Hz, Wz, alpha) in cases.items():
+        W = torch.randn(K, C, ks, ks, generator=g) * (1.0 / ks)
+        H, Wd = (Hz - 1) * st - 2 * pd + ks, (Wz - 1) * st - 2 * pd + ks
+        x = torch.randn(N, C, H, Wd, generator=g)
+        z0 = torch.zeros(N, K, Hz, Wz)
+        out[tag + "_x"], out[tag + "_w"] = x.numpy(), W.numpy()
+        out[tag + "_cfg"] = np.array([N, C, K, ks, st, pd, Hz, Wz], dtype=np.int64)
+        out[tag + "_alpha"] = alpha
+        lr = 0.5 / (W.pow(2).sum().item())          # a safe explicit step
+        out[tag + "_lr"] = lr
+        for fast in (True, False):
+            for mi in (1, 12):
+                z = ista_conv2d(x, z0, W, alpha, stride=st, padding=pd, fast=fast, maxiter=mi, lr=lr, tol=0.0)
+                out["%s_z_%s_%d" % (tag, "fista" if fast else "ista", mi)] = z.numpy().copy()
+        zw = torch.randn(N, K, Hz, Wz, generator=g) * 0.1
+        out[tag + "_z0_warm"] = zw.numpy().copy()
+        out[tag + "_z_warm"] = ista_conv2d(x, zw, W, alpha, stride=st, padding=pd, maxiter=6, lr=lr,
+                                           tol=0.0).numpy().copy()
+        if st == 1:
+            out[tag + "_lip"] = lip_bound_conv2d(W, pd).item()
+            out[tag + "_lip_sqrt"] = lip_bound_conv2d(W, pd, sqrt=True).item()
+            z = ista_conv2d(x, z0, W, alpha, stride=st, padding=pd, maxiter=200, tol=1e-4)   # lr='auto', stop rule
+            out[tag + "_z_auto_tol"] = z.numpy().copy()
+    save("conv_cases", **out)
 
 
 if __name__ == "__main__":

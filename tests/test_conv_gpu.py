@@ -1,0 +1,157 @@
+"""GPU parity tests for convolutional ISTA/FISTA and the Toeplitz Lipschitz bound
+ against the golden fixtures generated from the reference's
+``ista_conv2d`` / ``lip_bound_conv2d`` (tests/golden/conv_cases.npz) and the CPU oracle.
+fp32 tolerance as for the linear solver: max|dz| <= 5e-5, objective rtol <= 1e-6 with an
+explicit step; lr='auto' goes through the bound (rtol 1e-5: sin/cos differ in the last
+ulp between libm and the device) so those runs are compared at 2e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+Z_ATOL = 5e-5
+TAGS = "abcde"
+
+
+def _mods():
+    from lasso_amd.conv2d import ista_conv2d, lip_bound_conv2d, LipBoundConv2d
+    from lasso_amd.conv2d.ista import conv_loss
+    from oracle import lasso_oracle as orc
+    return ista_conv2d, lip_bound_conv2d, LipBoundConv2d, conv_loss, orc
+
+
+def _case(g, tag):
+    N, C, K, ks, st, pd, Hz, Wz = [int(v) for v in g[tag + "_cfg"]]
+    x, w = torch.from_numpy(g[tag + "_x"]), torch.from_numpy(g[tag + "_w"])
+    return x, w, torch.zeros(N, K, Hz, Wz), float(g[tag + "_alpha"]), float(g[tag + "_lr"]), st, pd
+
+
+def test_golden_fixed_step(golden):
+    ista_conv2d, _, _, conv_loss, orc = _mods()
+    g = golden("conv_cases")
+    for tag in TAGS:
+        x, w, z0, alpha, lr, st, pd = _case(g, tag)
+        for fast in (True, False):
+            for mi in (1, 12):
+                ref = torch.from_numpy(g["%s_z_%s_%d" % (tag, "fista" if fast else "ista", mi)])
+                got = ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), alpha, stride=st, padding=pd, fast=fast,
+                                  maxiter=mi, lr=lr, tol=0.0)
+                assert got.is_cuda and got.shape == ref.shape and got.dtype == ref.dtype
+                assert (got.cpu() - ref).abs().max().item() <= Z_ATOL, (tag, fast, mi)
+                o_ref = orc.conv_objective(x, ref, w, alpha, st, pd).item()
+                o_got = conv_loss(x.cuda(), got, w.cuda(), alpha, st, pd).item()
+                assert abs(o_got - o_ref) <= 2e-6 * abs(o_ref), (tag, fast, mi)
+
+
+def test_golden_warm_start_and_inputs_untouched(golden):
+    ista_conv2d, _, _, _, _ = _mods()
+    g = golden("conv_cases")
+    for tag in TAGS:
+        x, w, _, alpha, lr, st, pd = _case(g, tag)
+        zw = torch.from_numpy(g[tag + "_z0_warm"]).cuda()
+        keep = zw.clone()
+        got = ista_conv2d(x.cuda(), zw, w.cuda(), alpha, stride=st, padding=pd, maxiter=6, lr=lr, tol=0.0)
+        assert (got.cpu() - torch.from_numpy(g[tag + "_z_warm"])).abs().max().item() <= Z_ATOL, tag
+        assert torch.equal(zw, keep) and got.data_ptr() != zw.data_ptr()
+
+
+def test_lipschitz_bound(golden):
+    _, lip_bound_conv2d, LipBoundConv2d, _, orc = _mods()
+    g = golden("conv_cases")
+    for tag in TAGS:
+        x, w, _, alpha, lr, st, pd = _case(g, tag)
+        if st != 1:
+            with pytest.raises(NotImplementedError):
+                lip_bound_conv2d(w.cuda(), pd, stride=st)
+            continue
+        ref = float(g[tag + "_lip"])
+        got = lip_bound_conv2d(w.cuda(), pd)
+        assert got.dim() == 0 and got.is_cuda and got.dtype == torch.float32
+        assert abs(got.item() - ref) <= 1e-5 * ref, tag
+        assert abs(lip_bound_conv2d(w.cuda(), pd, sqrt=True).item() - float(g[tag + "_lip_sqrt"])) <= 1e-5 * ref
+        assert abs(LipBoundConv2d(tuple(w.shape), pd)(w.cuda()).item() - ref) <= 1e-5 * ref
+        # more output than input channels: the reference transposes the kernel first (:106-107)
+        wt = w.transpose(0, 1).contiguous()
+        assert abs(lip_bound_conv2d(wt.cuda(), pd).item() - orc.conv_lipschitz_bound(wt, pd).item()) <= 1e-5 * ref
+    with pytest.raises(ValueError):
+        lip_bound_conv2d(torch.zeros(4, 1, 4, 4, device="cuda"), 0)
+    with pytest.raises(ValueError):
+        lip_bound_conv2d(torch.zeros(4, 1, 3, 5, device="cuda"), 0)
+
+
+def test_auto_step_and_stop_rule(golden):
+    ista_conv2d, _, _, _, orc = _mods()
+    g = golden("conv_cases")
+    for tag in TAGS:
+        x, w, z0, alpha, lr, st, pd = _case(g, tag)
+        if st != 1:
+            with pytest.raises(NotImplementedError):
+                ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), alpha, stride=st, padding=pd)
+            continue
+        ref = torch.from_numpy(g[tag + "_z_auto_tol"])
+        _, rinfo = orc.conv_fista(x, z0, w, alpha, stride=st, padding=pd, maxiter=200, tol=1e-4, return_info=True)
+        got, info = ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), alpha, stride=st, padding=pd, maxiter=200, tol=1e-4,
+                                return_info=True)
+        # The step comes from the bound, which the device evaluates with its own sin/cos
+        # (1e-6-level difference).  How much that matters after up to 200 momentum steps
+        # depends on the problem (the bound is a LOWER bound of L, so 1/bound sits at the edge
+        # of stability): measure the oracle's own sensitivity to a 2e-6 change of the step.
+        L = orc.conv_lipschitz_bound(w, pd).item()
+        sens = max((orc.conv_fista(x, z0, w, alpha, stride=st, padding=pd, maxiter=200, tol=1e-4,
+                                   lr=float(np.float32(1.0 / (L * (1 + rel))))) - ref).abs().max().item()
+                   for rel in (2e-6, -2e-6))
+        assert abs(info["iterations"] - rinfo["iterations"]) <= 1, (tag, info, rinfo)
+        assert (got.cpu() - ref).abs().max().item() <= 2e-4 + 3 * sens, (tag, info, rinfo, sens)
+
+
+@pytest.mark.parametrize("N,C,K,kh,kw,stride,padding,Hz,Wz", [
+    (1, 1, 1, 1, 1, 1, 0, 1, 1), (2, 1, 3, 3, 5, (1, 2), (1, 0), 6, 5), (3, 2, 70, 3, 3, 1, 1, 10, 12),
+    (2, 5, 4, 5, 5, 3, 2, 4, 6), (64, 1, 32, 7, 7, 1, 0, 22, 22), (0, 1, 4, 3, 3, 1, 0, 5, 5)])
+def test_shapes_match_oracle(N, C, K, kh, kw, stride, padding, Hz, Wz):
+    ista_conv2d, _, _, _, orc = _mods()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    g = torch.Generator().manual_seed(N * 100 + K)
+    w = torch.randn(K, C, kh, kw, generator=g) / (kh * kw) ** 0.5
+    x = torch.randn(N, C, (Hz - 1) * sh - 2 * ph + kh, (Wz - 1) * sw - 2 * pw + kw, generator=g)
+    z0 = torch.randn(N, K, Hz, Wz, generator=g) * 0.05
+    lr = 0.3 / max(w.pow(2).sum().item(), 1e-3)
+    for fast in (True, False):
+        ref = orc.conv_fista(x, z0, w, 0.1, stride=stride, padding=padding, fast=fast, maxiter=9, lr=lr, tol=0.0)
+        got = ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), 0.1, stride=stride, padding=padding, fast=fast,
+                          maxiter=9, lr=lr, tol=0.0)
+        assert got.shape == ref.shape
+        if N:
+            assert (got.cpu() - ref).abs().max().item() <= Z_ATOL
+
+
+def test_errors_and_edge_cases():
+    ista_conv2d, _, _, _, _ = _mods()
+    w = torch.randn(4, 2, 3, 3, device="cuda")
+    x = torch.randn(2, 2, 10, 10, device="cuda")
+    z0 = torch.zeros(2, 4, 8, 8, device="cuda")
+    assert ista_conv2d(x, z0, w, maxiter=0, lr=0.1) is z0                      # ista.py:32,49
+    with pytest.raises(RuntimeError):
+        ista_conv2d(x, torch.zeros(2, 4, 7, 8, device="cuda"), w, lr=0.1)      # x_hat - x size mismatch
+    with pytest.raises(RuntimeError):
+        ista_conv2d(x, z0, torch.randn(4, 3, 3, 3, device="cuda"), lr=0.1)     # channel mismatch
+    with pytest.raises(TypeError):
+        ista_conv2d(x, z0, w, backtrack=True)                                  # not an ista_conv2d kwarg
+    # CPU tensors are staged through the device, result comes back on the CPU
+    out = ista_conv2d(x.cpu(), z0.cpu(), w.cpu(), 0.1, lr=0.05, maxiter=3)
+    assert out.device.type == "cpu"
+
+
+def test_verbose_prints_reference_format(capsys):
+    ista_conv2d, _, _, _, orc = _mods()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(4, 1, 3, 3, generator=g) * 0.3
+    x = torch.randn(2, 1, 8, 8, generator=g)
+    z0 = torch.zeros(2, 4, 6, 6)
+    z = ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), 0.1, lr=0.1, maxiter=3, tol=0.0, verbose=True)
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 3 and all(l.startswith("loss: ") for l in lines)
+    assert abs(float(lines[0][6:]) - orc.conv_objective(x, z0, w, 0.1).item()) <= 1e-3
+    ref = orc.conv_fista(x, z0, w, 0.1, lr=0.1, maxiter=3, tol=0.0)
+    assert (z.cpu() - ref).abs().max().item() <= Z_ATOL
