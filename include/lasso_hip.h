@@ -234,6 +234,23 @@ int lasso_conv_lip_bound(const void* w_dev, int64_t K, int64_t C, int ksize, int
                          int take_sqrt, double* l_out,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- reverse-mode derivative of the unrolled fixed-step solve ------------------------
+ * The reference's ista() is ordinary autograd-traceable torch code (ista.py:57-104; the
+ * README advertises back-propagation through the solver).  Given the iterates
+ * z_0 .. z_T of a fixed-step run (trace_dev: [T+1][n][k] contiguous, T = iterations;
+ * produce it with lasso_fista_run, one iteration per call) and dL/dz_T (grad_z_dev
+ * [n][k]), writes dL/dx [n][d], dL/dW [d][k], dL/dz0 [n][k] (each nullable, contiguous).
+ * Same derivative as torch.autograd through the reference loop: softshrink passes the
+ * gradient where |u| > alpha*lr, the step size and the momentum schedule are constants.
+ * Any d, k.  No host synchronisation.
+ */
+size_t lasso_fista_backward_workspace_bytes(int64_t n, int64_t d, int64_t k);
+int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                         const void* trace_dev, const void* grad_z_dev,
+                         int64_t n, int64_t d, int64_t k, int dtype, double lr, int fast, int iterations,
+                         void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1125,4 +1125,99 @@ int lasso_conv_lip_bound(const void* w_dev, int64_t K, int64_t C, int ksize, int
   return LASSO_OK;
 }
 
+// ---- reverse-mode derivative of the unrolled fixed-step solve (autograd.hip) --------------
+namespace {
+struct BwWorkspace { float* Wt; float* zbA; float* zbB; float* yb; float* ub; float* gb; float* y; float* nr; float* rb; float* T1; float* T2; float* scratch; size_t bytes; };
+BwWorkspace carve_bw(void* base, int64_t n, int64_t d, int64_t k) {
+  BwWorkspace w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(std::max<size_t>(bytes, 4));
+    return reinterpret_cast<float*>(r);
+  };
+  const size_t nk = (size_t)n * k * 4, nd = (size_t)n * d * 4, dk = (size_t)d * k * 4;
+  w.Wt = take(dk);
+  w.zbA = take(nk); w.zbB = take(nk); w.yb = take(nk); w.ub = take(nk); w.gb = take(nk); w.y = take(nk);
+  w.nr = take(nd); w.rb = take(nd);
+  w.T1 = take(dk); w.T2 = take(dk);
+  w.scratch = take(16 * dk);
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+size_t lasso_fista_backward_workspace_bytes(int64_t n, int64_t d, int64_t k) {
+  if (n < 0 || d <= 0 || k <= 0) return 0;
+  return carve_bw(nullptr, n, d, k).bytes;
+}
+
+int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* trace_dev,
+                         const void* grad_z_dev, int64_t n, int64_t d, int64_t k, int dtype, double lr, int fast,
+                         int iterations, void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
+  if (!x_dev || !w_dev || !trace_dev || !grad_z_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldx < d || ldw < k || iterations < 0) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (d > INT32_MAX / 2 || k > INT32_MAX / 2) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+  BwWorkspace ws = carve_bw(workspace_dev, n, d, k);
+  if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* X = (const float*)x_dev;
+  const float* W = (const float*)w_dev;
+  const float* trace = (const float*)trace_dev;
+  const int64_t nk = n * k;
+  float* gx = (float*)grad_x_dev;
+  float* gw = (float*)grad_w_dev;
+  float* gz0 = (float*)grad_z0_dev;
+  if (gx && n > 0) LASSO_HIP_TRY(hipMemsetAsync(gx, 0, (size_t)n * d * 4, st));
+  if (gw) LASSO_HIP_TRY(hipMemsetAsync(gw, 0, (size_t)d * k * 4, st));
+  if (n == 0) return LASSO_OK;
+  const int cus = device_cus();
+  // momentum coefficients c_i = (t_i - 1)/t_{i+1}  (ista.py:98-99)
+  std::vector<float> coef((size_t)std::max(iterations, 1));
+  {
+    double t = 1.0;
+    for (int i = 0; i < iterations; ++i) {
+      const double tn = (1.0 + sqrt(1.0 + 4.0 * t * t)) / 2.0;
+      coef[i] = fast ? (float)((t - 1.0) / tn) : 0.0f;
+      t = tn;
+    }
+  }
+  LASSO_HIP_TRY(launch_transpose_pad(W, ldw, (int)d, (int)k, ws.Wt, d, (int)k, (int)d, st));
+  float* zb_next = ws.zbA;
+  float* zb_cur = ws.zbB;
+  LASSO_HIP_TRY(hipMemcpyAsync(zb_next, grad_z_dev, (size_t)nk * 4, hipMemcpyDeviceToDevice, st));
+  LASSO_HIP_TRY(hipMemsetAsync(ws.yb, 0, (size_t)nk * 4, st));
+  const int splits = gram_splits((int)d, (int)k, (int)n, 0, cus);
+  for (int i = iterations - 1; i >= 0; --i) {
+    const float* z_next = trace + (int64_t)(i + 1) * nk;
+    const float* z_i = trace + (int64_t)i * nk;
+    // c_i formed y_{i+1}; for the last iteration y_{i+1} was never used (yb == 0)
+    LASSO_HIP_TRY(launch_bw_prox(zb_next, zb_cur, ws.yb, z_next, ws.ub, ws.gb, nk, coef[i], (float)lr, st));
+    // the point of iteration i:  y_i = z_i + c_{i-1} (z_i - z_{i-1}),  y_0 = z_0
+    LASSO_HIP_TRY(launch_bw_point(z_i, (i > 0 && fast) ? trace + (int64_t)(i - 1) * nk : nullptr, ws.y, nk,
+                                  i > 0 ? coef[i - 1] : 0.0f, st));
+    // nr = x - y W^T (= -r_i);  rb = gb W^T;  yb_i = ub + rb W
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.y, k, W, ldw, X, ldx, ws.nr, d, (int)n, (int)d, (int)k, st, 0));
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.gb, k, W, ldw, nullptr, 0, ws.rb, d, (int)n, (int)d, (int)k, st, 1));
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.rb, d, ws.Wt, d, ws.ub, k, ws.yb, k, (int)n, (int)k, (int)d, st, 1));
+    if (gw) {
+      // Wb += r_i^T gb + rb^T y_i = -(nr^T gb) + rb^T y_i
+      LASSO_HIP_TRY(launch_gram_tn(ws.nr, d, (int)d, ws.gb, k, (int)k, (int)n, ws.T1, k, 0, ws.scratch, splits, st));
+      LASSO_HIP_TRY(launch_gram_tn(ws.rb, d, (int)d, ws.y, k, (int)k, (int)n, ws.T2, k, 0, ws.scratch, splits, st));
+      LASSO_HIP_TRY(launch_bw_axpy(gw, ws.T2, 1.0f, ws.T1, -1.0f, d * k, st));
+    }
+    if (gx) LASSO_HIP_TRY(launch_bw_axpy(gx, ws.rb, -1.0f, nullptr, 0.0f, n * d, st));
+    std::swap(zb_next, zb_cur);       // zb_cur (adjoint of z_i so far) becomes the next "zb_{i+1}"
+  }
+  if (gz0) {
+    // z0b = zb_0 + yb_0  (y_0 = z_0)
+    LASSO_HIP_TRY(hipMemcpyAsync(gz0, zb_next, (size_t)nk * 4, hipMemcpyDeviceToDevice, st));
+    LASSO_HIP_TRY(launch_bw_axpy(gz0, ws.yb, 1.0f, nullptr, 0.0f, nk, st));
+  }
+  return LASSO_OK;
+}
+
 }  // extern "C"

@@ -127,6 +127,11 @@ hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStre
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+hipError_t launch_bw_prox(float* zb_next, float* zb_cur, const float* yb, const float* z_next, float* ub, float* gb,
+                          int64_t total, float c, float lr, hipStream_t stream);
+hipError_t launch_bw_point(const float* z, const float* z_prev, float* y, int64_t total, float c, hipStream_t stream);
+hipError_t launch_bw_axpy(float* a, const float* b, float s1, const float* c, float s2, int64_t total,
+                          hipStream_t stream);
 hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream);
 hipError_t launch_conv_pack_w(const float* w, float* wt, int K, int ckk, hipStream_t stream);
 hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,

@@ -89,6 +89,11 @@ def _declare(lib):
     lib.lasso_conv_lip_workspace_bytes.argtypes = [i64, i64, i32, i32]
     lib.lasso_conv_lip_bound.restype = i32
     lib.lasso_conv_lip_bound.argtypes = [vp, i64, i64, i32, i32, i32, i32, C.POINTER(dbl), vp, sz, vp]
+    lib.lasso_fista_backward_workspace_bytes.restype = sz
+    lib.lasso_fista_backward_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.lasso_fista_backward.restype = i32
+    lib.lasso_fista_backward.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, dbl, i32, i32,
+                                         vp, vp, vp, vp, sz, vp]
     lib.lasso_cd_solve.restype = i32
     lib.lasso_cd_solve.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32,
                                    dbl, pi32, pi32, vp, sz, vp]

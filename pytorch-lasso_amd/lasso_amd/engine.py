@@ -45,9 +45,11 @@ class HipEngine:
         from .linear.lipschitz import lipschitz_constant
         return lipschitz_constant(W)
 
-    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False):
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False,
+                  z_out=None):
         """`iters` iterations from (z_in, y_in); returns (z, y, delta[iters] or None).
-        Building block of the distributed exact-stop E-step (lasso_fista_run)."""
+        Building block of the distributed exact-stop E-step and of the traced forward pass
+        of the autograd path (lasso_fista_run).  `z_out`: optional [n,k] destination."""
         n, d = X.shape
         k = W.shape[1]
         L = self.lib
@@ -57,7 +59,7 @@ class HipEngine:
             if not prepared:
                 nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32,
                                                 nat.ptr(ws), ws.numel(), self._stream()))
-            z = torch.empty((n, k), dtype=torch.float32, device=self.device)
+            z = z_out if z_out is not None else torch.empty((n, k), dtype=torch.float32, device=self.device)
             y = torch.empty((n, k), dtype=torch.float32, device=self.device)
             delta = torch.empty(iters, dtype=torch.float32, device=self.device) if want_delta else None
             nat.check(L.lasso_fista_run(
@@ -67,6 +69,24 @@ class HipEngine:
                 float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), nat.ptr(delta),
                 nat.ptr(ws), ws.numel(), self._stream()))
         return z, y, delta
+
+    def fista_backward(self, X, W, trace, grad_z, lr, fast, need_x, need_w, need_z0):
+        """Reverse pass through the unrolled fixed-step solve (lasso_fista_backward);
+        trace [T+1,n,k] holds z_0..z_T.  Returns (gx, gw, gz0), None where not needed."""
+        n, d = X.shape
+        k = W.shape[1]
+        T = trace.shape[0] - 1
+        L = self.lib
+        with torch.cuda.device(self.device):
+            ws = self._ws(L.lasso_fista_backward_workspace_bytes(n, d, k), "bw")
+            gx = torch.empty((n, d), dtype=torch.float32, device=self.device) if need_x else None
+            gw = torch.empty((d, k), dtype=torch.float32, device=self.device) if need_w else None
+            gz0 = torch.empty((n, k), dtype=torch.float32, device=self.device) if need_z0 else None
+            nat.check(L.lasso_fista_backward(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0), nat.ptr(trace),
+                                             nat.ptr(grad_z), n, d, k, nat.LASSO_F32, float(lr), int(bool(fast)),
+                                             int(T), nat.ptr(gx), nat.ptr(gw), nat.ptr(gz0), nat.ptr(ws),
+                                             ws.numel(), self._stream()))
+        return gx, gw, gz0
 
     # -- objective ---------------------------------------------------------------
     def objective_sums(self, X, Z, W, alpha):

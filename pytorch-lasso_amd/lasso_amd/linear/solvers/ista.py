@@ -37,6 +37,44 @@ def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
     return z, dict(iterations=done, last_delta=last)
 
 
+class _UnrolledIsta(torch.autograd.Function):
+    """Differentiable fixed-step solve: the reference's loop is plain
+    torch code, so torch.autograd differentiates through its unrolled iterations
+    (ista.py:79-102).  Forward: the HIP kernel one iteration per launch, keeping the
+    iterates z_0..z_T; backward: lasso_fista_backward (csrc/autograd.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, z0, weight, alpha, fast, lr, maxiter, tol):
+        from ...engine import HipEngine
+        dev = x.device
+        eng = HipEngine(dev)
+        n, k = z0.shape
+        xg, wg = x.detach().contiguous(), weight.detach().contiguous()
+        trace = torch.empty((maxiter + 1, n, k), dtype=torch.float32, device=dev)
+        trace[0].copy_(z0.detach())
+        budget = torch.tensor(float(n * k) * tol, dtype=torch.float32).item()
+        y, done = None, 0
+        for it in range(maxiter):
+            _, y, delta = eng.fista_run(xg, wg, trace[it], y, alpha, lr, fast, it, 1, tol > 0,
+                                        prepared=it > 0, z_out=trace[it + 1])
+            done = it + 1
+            if tol > 0 and delta[0].item() <= budget:                    # ista.py:93-95
+                break
+        ctx.save_for_backward(xg, wg, trace[:done + 1])
+        ctx.lr, ctx.fast = lr, fast
+        return trace[done].clone()
+
+    @staticmethod
+    def backward(ctx, grad_z):
+        from ...engine import HipEngine
+        xg, wg, trace = ctx.saved_tensors
+        eng = HipEngine(xg.device)
+        gx, gw, gz0 = eng.fista_backward(xg, wg, trace.contiguous(), grad_z.contiguous().float(), ctx.lr,
+                                         ctx.fast, ctx.needs_input_grad[0], ctx.needs_input_grad[2],
+                                         ctx.needs_input_grad[1])
+        return gx, gz0, gw, None, None, None, None, None
+
+
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
          return_info=False):
@@ -91,6 +129,17 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         from ..lipschitz import lipschitz_constant
         lr = 1.0 / lipschitz_constant(wg)                          # ista.py:59-63
     lr = float(lr)
+
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad):
+        # differentiable path (the reference's loop is autograd-traceable, README "autograd")
+        if backtrack:
+            raise NotImplementedError("lasso_amd: autograd through the backtracking line search is not implemented")
+        if not (x.is_cuda and weight.is_cuda and z0.is_cuda):
+            raise NotImplementedError("lasso_amd: the differentiable path needs x, weight, z0 on the HIP device")
+        if d > 256 or k > 1024:
+            raise NotImplementedError("lasso_amd: the differentiable path is limited to d <= 256, k <= 1024")
+        z = _UnrolledIsta.apply(x, z0, weight, float(alpha), bool(fast), lr, int(maxiter), float(tol))
+        return (z, dict(iterations=None, last_delta=None)) if return_info else z
 
     if verbose and not backtrack:
         z, info = _ista_verbose(xg, zg, wg, alpha, fast, lr, maxiter, tol, dev)
