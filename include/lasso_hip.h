@@ -251,6 +251,22 @@ int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int6
                          void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- patch front end: image -> patches -> centre -> dict_learning ->
+ * reconstruct.  The reference's notebook that did this (examples/dict_learning_omniglot.ipynb)
+ * is absent from its checkout, so there is no reference code to mirror: the layout is that of
+ * torch.nn.functional.unfold -- images [N][C][H][W]; patch row m = (n, u, v) with
+ * u < (H-ph)/sh+1, v < (W-pw)/sw+1; column (c, a, b).
+ *   lasso_patches_extract     : patches [M][C*ph*pw] (ld); center != 0 subtracts each patch's
+ *                               mean (stored in means_dev [M] when non-NULL).
+ *   lasso_patches_reconstruct : overlap-AVERAGE of (patch + its mean) back into images.
+ */
+int lasso_patches_extract(const void* img_dev, void* patches_dev, int64_t ld, float* means_dev,
+                          int64_t N, int64_t C, int64_t H, int64_t W, int ph, int pw, int sh, int sw,
+                          int center, void* stream);
+int lasso_patches_reconstruct(const void* patches_dev, int64_t ld, const float* means_dev, void* img_out_dev,
+                              int64_t N, int64_t C, int64_t H, int64_t W, int ph, int pw, int sh, int sw,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,64 @@ __global__ void conv_lip_sum_kernel(const float* __restrict__ maxes, int O, int 
   }
 }
 
+
+// ---- patch front end (image -> patches -> centre -> dict_learning ->
+// reconstruct; the reference's Omniglot notebook that did this is not in the checkout, so
+// the layout follows torch.nn.functional.unfold: row = (n, u, v), column = (c, a, b)) -------
+// One wave per patch row: copy the patch, optionally subtract its mean (kept in means[]).
+__global__ __launch_bounds__(256) void patches_extract_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                              int64_t ld, float* __restrict__ means,
+                                                              const ConvGeom g, int center) {
+  const int lane = threadIdx.x & 63;
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  const int d = g.C * g.kh * g.kw;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
+    const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
+    float sum = 0.0f;
+    for (int t = lane; t < d; t += 64) {
+      const int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);
+      const float val = img[(((int64_t)n * g.C + c) * g.H + u * g.sh + a) * g.W + v * g.sw + b];
+      out[m * ld + t] = val;
+      sum += val;
+    }
+    if (center) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mean = sum / (float)d;
+      for (int t = lane; t < d; t += 64) out[m * ld + t] -= mean;
+      if (means && lane == 0) means[m] = mean;
+    }
+  }
+}
+
+// img[n][c][i][j] = average over the patches covering the pixel of (patch value + its mean);
+// pixels no patch covers are 0
+__global__ __launch_bounds__(256) void patches_reconstruct_kernel(const float* __restrict__ pat, int64_t ld,
+                                                                  const float* __restrict__ means,
+                                                                  float* __restrict__ img, const ConvGeom g) {
+  const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e % g.W), i = (int)((e / g.W) % g.H);
+    const int c = (int)((e / ((int64_t)g.W * g.H)) % g.C);
+    const int n = (int)(e / ((int64_t)g.W * g.H * g.C));
+    float acc = 0.0f;
+    int cnt = 0;
+    for (int a = 0; a < g.kh; ++a) {
+      const int ii = i - a;
+      if (ii < 0 || ii % g.sh != 0 || ii / g.sh >= g.Hz) continue;
+      for (int b = 0; b < g.kw; ++b) {
+        const int jj = j - b;
+        if (jj < 0 || jj % g.sw != 0 || jj / g.sw >= g.Wz) continue;
+        const int64_t m = ((int64_t)n * g.Hz + ii / g.sh) * g.Wz + jj / g.sw;
+        acc += pat[m * ld + ((int64_t)c * g.kh + a) * g.kw + b] + (means ? means[m] : 0.0f);
+        ++cnt;
+      }
+    }
+    img[e] = cnt ? acc / (float)cnt : 0.0f;
+  }
+}
+
 inline int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 8192); }
 
 }  // namespace
@@ -185,6 +243,23 @@ hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, flo
   if (e != hipSuccess) return e;
   (void)scratch; (void)cus;
   return launch_gram_tn(rct, M, (int)M, Wt, g.K, g.K, ckk, G, g.K, 0, nullptr, 1, stream);
+}
+
+hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,
+                                  int center, hipStream_t stream) {
+  const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
+  if (M == 0) return hipSuccess;
+  hipLaunchKernelGGL(patches_extract_kernel, dim3((unsigned)std::min<int64_t>((M + 3) / 4, 8192)), dim3(256), 0,
+                     stream, img, out, ld, means, g, center);
+  return hipGetLastError();
+}
+
+hipError_t launch_patches_reconstruct(const float* pat, int64_t ld, const float* means, float* img,
+                                      const ConvGeom& g, hipStream_t stream) {
+  const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(patches_reconstruct_kernel, dim3(grid_for(total)), dim3(256), 0, stream, pat, ld, means, img, g);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_lip(const float* taps, int O, int I, int64_t so, int64_t si, int ks, int padding,

@@ -1220,4 +1220,37 @@ int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int6
   return LASSO_OK;
 }
 
+// ---- patch front end (conv.hip) --------------------------------------------------------
+namespace {
+int patch_geom(ConvGeom& g, int64_t N, int64_t C, int64_t H, int64_t W, int ph, int pw, int sh, int sw) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || sh <= 0 || sw <= 0 || ph > H || pw > W)
+    return fail(LASSO_ERR_BAD_ARG, "bad patch geometry");
+  g = make_geom(N, C, H, W, 1, (H - ph) / sh + 1, (W - pw) / sw + 1, ph, pw, sh, sw, 0, 0);
+  if ((int64_t)g.N * g.Hz * g.Wz > INT32_MAX / 2) return fail(LASSO_ERR_UNSUPPORTED, "too many patches");
+  return LASSO_OK;
+}
+}  // namespace
+
+int lasso_patches_extract(const void* img_dev, void* patches_dev, int64_t ld, float* means_dev, int64_t N,
+                          int64_t C, int64_t H, int64_t W, int ph, int pw, int sh, int sw, int center,
+                          void* stream) {
+  ConvGeom g;
+  if (int s = patch_geom(g, N, C, H, W, ph, pw, sh, sw)) return s;
+  if ((N > 0 && (!img_dev || !patches_dev)) || ld < (int64_t)C * ph * pw) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  LASSO_HIP_TRY(launch_patches_extract((const float*)img_dev, (float*)patches_dev, ld, means_dev, g, center,
+                                       static_cast<hipStream_t>(stream)));
+  return LASSO_OK;
+}
+
+int lasso_patches_reconstruct(const void* patches_dev, int64_t ld, const float* means_dev, void* img_out_dev,
+                              int64_t N, int64_t C, int64_t H, int64_t W, int ph, int pw, int sh, int sw,
+                              void* stream) {
+  ConvGeom g;
+  if (int s = patch_geom(g, N, C, H, W, ph, pw, sh, sw)) return s;
+  if ((N > 0 && (!img_out_dev || !patches_dev)) || ld < (int64_t)C * ph * pw) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  LASSO_HIP_TRY(launch_patches_reconstruct((const float*)patches_dev, ld, means_dev, (float*)img_out_dev, g,
+                                           static_cast<hipStream_t>(stream)));
+  return LASSO_OK;
+}
+
 }  // extern "C"

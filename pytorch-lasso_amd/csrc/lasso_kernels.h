@@ -138,6 +138,10 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x
                                 const ConvGeom& g, hipStream_t stream);
 hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, float* G, float* scratch,
                                 const ConvGeom& g, int cus, hipStream_t stream);
+hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,
+                                  int center, hipStream_t stream);
+hipError_t launch_patches_reconstruct(const float* pat, int64_t ld, const float* means, float* img,
+                                      const ConvGeom& g, hipStream_t stream);
 hipError_t launch_conv_lip(const float* taps, int O, int I, int64_t so, int64_t si, int ks, int padding,
                            const float* freq, int sample, int take_sqrt, float* maxes, double* out,
                            hipStream_t stream);

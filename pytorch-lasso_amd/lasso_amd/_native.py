@@ -94,6 +94,10 @@ def _declare(lib):
     lib.lasso_fista_backward.restype = i32
     lib.lasso_fista_backward.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, dbl, i32, i32,
                                          vp, vp, vp, vp, sz, vp]
+    lib.lasso_patches_extract.restype = i32
+    lib.lasso_patches_extract.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp]
+    lib.lasso_patches_reconstruct.restype = i32
+    lib.lasso_patches_reconstruct.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.lasso_cd_solve.restype = i32
     lib.lasso_cd_solve.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32,
                                    dbl, pi32, pi32, vp, sz, vp]
