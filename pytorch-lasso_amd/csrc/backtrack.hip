@@ -282,8 +282,13 @@ hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, 
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
+  return launch_bt_decide(p, alpha, lr, trial_index, force, stream);
+}
+
+hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,
+                            hipStream_t stream) {
   hipLaunchKernelGGL(bt_decide_kernel, dim3(1), dim3(256), 0, stream, p.partials, p.ntiles,
-                     (float)alpha, (float)(0.5 / lr), lr_f, trial_index, force, p.flags, p.fvals);
+                     (float)alpha, (float)(0.5 / lr), (float)lr, trial_index, force, p.flags, p.fvals);
   return hipGetLastError();
 }
 

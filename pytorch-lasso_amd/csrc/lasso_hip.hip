@@ -251,10 +251,11 @@ constexpr int kBtMaxTrials = 1000;   // ista.py:17 (maxiter=1000)
 struct BtWorkspace {
   float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
   float* G; float* C; float* Y;
+  float* Zf;       // bf16 tensors: fp32 working copy of z
   size_t bytes;
 };
 
-BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp) {
+BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false) {
   BtWorkspace w;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -274,35 +275,49 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp) {
   w.G = take((size_t)n * k * 4);
   w.C = take((size_t)n * k * 4);
   w.Y = take((size_t)n * k * 4);
+  w.Zf = half ? take((size_t)n * k * 4) : nullptr;      // (wp / wtp hold the two bf16 packs then)
   w.bytes = off;
   return w;
 }
 
-int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* z0,
-                       int64_t ldz0, float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, int kp,
-                       double alpha, double lr0, int fast, int maxiter, double tol, double eta,
+int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_t ldw, const void* z0_any,
+                       int64_t ldz0, void* zout_any, int64_t ldz_any, int64_t n, int64_t d, int64_t k, int kp,
+                       int dtype, double alpha, double lr0, int fast, int maxiter, double tol, double eta,
                        int32_t* iters_out, float* last_delta_out, void* workspace, size_t ws_bytes,
                        hipStream_t st) {
-  BtWorkspace ws = carve_bt(workspace, n, k, kp);
+  const bool half = dtype == LASSO_BF16;      // bf16 tensors: bt_bf16.hip kernels, 64-row tiles
+  BtWorkspace ws = carve_bt(workspace, n, k, kp, half);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
-  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  const int tile_rows = half ? 64 : kTileM;
+  const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
   const int grid = std::min(ntiles, cus);
-  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, st, w, ldw, (int)d,
-                     (int)k, kp, ws.wp, ws.wtp);
-  LASSO_HIP_TRY(hipGetLastError());
-  // working state: z lives in zout, y in the workspace (y0 = z0, ista.py:76-78)
-  if (z0) {
-    if (z0 != zout)
-      LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  const float* x = (const float*)x_any;
+  float* zout = half ? ws.Zf : (float*)zout_any;
+  const int64_t ldz = half ? k : ldz_any;
+  if (half) {
+    LASSO_HIP_TRY(launch_pack_w_bf16(w_any, ldw, (int)d, (int)k, kp, 1, ws.wp, ws.wtp, st));
+    if (z0_any) LASSO_HIP_TRY(launch_cvt_bf16(z0_any, ldz0, zout, k, (int)n, (int)k, 1, st));
+    else LASSO_HIP_TRY(hipMemsetAsync(zout, 0, (size_t)n * k * 4, st));
   } else {
-    LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+    const float* z0 = (const float*)z0_any;
+    hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, kFistaD / 32), dim3(32, 8), 0, st, (const float*)w_any, ldw,
+                       (int)d, (int)k, kp, ws.wp, ws.wtp);
+    LASSO_HIP_TRY(hipGetLastError());
+    // working state: z lives in zout, y in the workspace (y0 = z0, ista.py:76-78)
+    if (z0) {
+      if (z0 != zout)
+        LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+    } else {
+      LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+    }
   }
   LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
 
   BtParams p;
   p.X = x; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
+  p.Xh = x_any; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
   p.G = ws.G; p.C = ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
   const float budget = (float)((double)n * (double)k * tol);
@@ -317,7 +332,8 @@ int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw,
     p.P = fast ? ws.Y : zout;
     p.ldp = fast ? k : ldz;
     LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
-    LASSO_HIP_TRY(launch_bt_grad(p, kp, grid, st));
+    if (half) LASSO_HIP_TRY(launch_bt16_grad(p, kp, grid, st));
+    else LASSO_HIP_TRY(launch_bt_grad(p, kp, grid, st));
     double lr = lr0;
     int t = 0;
     bool accepted = false;
@@ -325,13 +341,16 @@ int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw,
       const bool give_up = t >= kBtMaxTrials;
       const int batch = give_up ? 1 : std::min(kBtBatch, kBtMaxTrials - t);
       for (int b = 0; b < batch; ++b) {
-        if (give_up) {   // ista.py:48-52: warn and revert to the initial step size
-          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr0, t, 1, st));
-          warned = true;
+        const double lr_t = give_up ? lr0 : lr;      // ista.py:48-52: warn and revert to the initial step size
+        const int idx = give_up ? t : t + b, force = give_up ? 1 : 0;
+        if (half) {
+          LASSO_HIP_TRY(launch_bt16_trial(p, kp, grid, (float)lr_t, (float)(alpha * lr_t), force, st));
+          LASSO_HIP_TRY(launch_bt_decide(p, alpha, lr_t, idx, force, st));
         } else {
-          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr, t + b, 0, st));
-          lr = lr / eta;                                                               // :47
+          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr_t, idx, force, st));
         }
+        if (give_up) warned = true;
+        else lr = lr / eta;                                                            // :47
       }
       t += batch;
       LASSO_HIP_TRY(launch_bt_finish(zout, ldz, ws.Y, ws.C, (int)n, (int)k, coef, ws.flags, ws.dpart,
@@ -347,6 +366,7 @@ int solve_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw,
     t_mom = t_next;
     if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95
   }
+  if (half) LASSO_HIP_TRY(launch_cvt_bf16(zout, k, zout_any, ldz_any, (int)n, (int)k, 0, st));
   if (iters_out) *iters_out = it;
   if (last_delta_out) *last_delta_out = last;
   return warned ? fail(LASSO_WARN_LINESEARCH, "backtracking line search failed; reverted to lr0") : LASSO_OK;
@@ -550,7 +570,7 @@ size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, i
   if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
-  if (backtrack) return carve_bt(nullptr, n, k, kp).bytes;
+  if (backtrack) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16).bytes;
   const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
 }
@@ -605,7 +625,10 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
-  if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
+  // LASSO_BF16 tensors (x, W, z0, z_out all bf16) are native on the line-search path
+  // (BASELINE config 3); everything else takes fp32 tensors
+  const bool half_bt = dtype == LASSO_BF16 && backtrack && fused_shape(d, k) && maxiter > 0 && n > 0;
+  if (int s = check_common(n, d, k, half_bt ? LASSO_F32 : dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
   if (!fused_shape(d, k) && backtrack)
@@ -641,8 +664,9 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                          workspace_bytes, st);
   const int kp = pad_k(k);
   if (backtrack)
-    return solve_backtracking(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, kp,
-                              alpha, lr, fast, maxiter, stop_rule ? tol : 0.0, eta_backtrack,
+    return solve_backtracking(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp,
+                              half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,
+                              stop_rule ? tol : 0.0, eta_backtrack,
                               iters_out, last_delta_out, workspace_dev, workspace_bytes, st);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)

@@ -72,6 +72,8 @@ struct BtParams {
   float* partials;                       // [5][ntiles]
   int* flags; float* fvals;
   int n, d, k, ntiles;
+  // bf16 variant (bt_bf16.hip): x in bf16, fragment-major bf16 copies of W, 64-row tiles
+  const void* Xh; const void* Wq1; const void* Wq2;
 };
 
 // greedy coordinate descent (cd.hip): per-row state padded to kp = 256*NC columns
@@ -107,6 +109,15 @@ hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W,
 hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
                            int trial_index, int force, hipStream_t stream);
+hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,
+                            hipStream_t stream);
+hipError_t launch_bt16_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
+hipError_t launch_bt16_trial(const BtParams& p, int kpad, int grid, float lr, float lam, int force,
+                             hipStream_t stream);
+hipError_t launch_pack_w_bf16(const void* W, int64_t ldw, int d, int k, int kp, int w_is_bf16, void* q1, void* q2,
+                              hipStream_t stream);
+hipError_t launch_cvt_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int n, int k, int to_f32,
+                           hipStream_t stream);
 hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
                             float coef, const int* flags, float* dpart, int grid, hipStream_t stream);
 

@@ -6,11 +6,13 @@ import torch
 
 from ... import _native as nat
 
-_DT = {torch.float32: nat.LASSO_F32}
-# bf16 tensors are accepted at the API (BASELINE config 3): the engine computes in fp32
-# (exact up-conversion of x, W, z0; one rounding of the result back to bf16), which is at
-# least as accurate as the reference's all-bf16 arithmetic -- parity is judged on the
-# objective (rtol 2e-3).  A native bf16-MFMA kernel is future work.
+_DT = {torch.float32: nat.LASSO_F32, torch.bfloat16: nat.LASSO_BF16}
+# bf16 tensors (BASELINE config 3).  With the backtracking line search -- the configuration
+# BASELINE names -- bf16 x, W, z0 go to the native bf16-MFMA kernels (csrc/bt_bf16.hip:
+# bf16 operands, fp32 accumulation and state).  Everything else computes in fp32 on exact
+# up-conversions of x, W, z0 with one rounding of the result back to the tensor dtype.  Both
+# are at least as accurate as the reference's all-bf16 arithmetic; parity is judged on the
+# objective (rtol 2e-3).
 _UPCAST = (torch.bfloat16, torch.float16)
 
 
@@ -105,6 +107,11 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
             raise TypeError("lasso_amd: lr='auto' is not supported for %s inputs" % x.dtype)
         if maxiter == 0:
             return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
+        native = (x.dtype == torch.bfloat16 and backtrack and d <= 256 and k <= 1024 and n > 0
+                  and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)))
+        if native:
+            return _solve_native(x, z0, weight, alpha, fast, float(lr), maxiter, tol, backtrack, eta_backtrack,
+                                 verbose, return_info)
         out = ista(x.float(), z0.float(), weight.float(), alpha, fast, lr, maxiter, tol, backtrack,
                    eta_backtrack, verbose, return_info)
         if return_info:
@@ -146,6 +153,23 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         z = z if z.device == out_device else z.to(out_device)
         return (z, info) if return_info else z
 
+    return _solve_native(xg, zg, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
+                         return_info, out_device=out_device)
+
+
+def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
+                  return_info, out_device=None):
+    """One call of lasso_fista_solve on tensors of one dtype (float32, or bfloat16 with the
+    line search)."""
+    n, d = x.shape
+    k = weight.shape[1]
+    if out_device is None:
+        out_device = z0.device
+    dev = x.device if x.is_cuda else (weight.device if weight.is_cuda else
+                                      (z0.device if z0.is_cuda else torch.device('cuda', torch.cuda.current_device())))
+    xg = _to_device(x.detach(), dev).contiguous()
+    wg = _to_device(weight.detach(), dev).contiguous()
+    zg = _to_device(z0.detach(), dev).contiguous()
     L = nat.lib()
     z = torch.empty((n, k), dtype=x.dtype, device=dev)
     with torch.cuda.device(dev):
