@@ -16,7 +16,9 @@
  *     (iteration count, stop decision) is produced -- stated per function;
  *   - return value: lasso_status (0 = ok).  No exceptions cross the boundary;
  *     lasso_hip_last_error() gives the detail string for the calling thread;
- *   - dtype: LASSO_F32 only in this revision (LASSO_BF16 is reserved);
+ *   - dtype: LASSO_F32; LASSO_BF16 (x, W, z0, z_out all bf16, leading dimensions in bf16
+ *     elements) is accepted by lasso_fista_solve with backtrack != 0 on the fused shapes
+ *     (bf16-MFMA kernels, fp32 accumulation and state) and LASSO_ERR_UNSUPPORTED elsewhere;
  *   - shapes: d <= 256 and k <= 1024 run the fused kernels; beyond that lasso_fista_solve
  *     (fixed step), lasso_objective and lasso_gram_accumulate take any d, k (unfused
  *     MFMA GEMM paths), lasso_dict_sweep d <= 1024 and k <= 4096, lasso_cd_* k <= 4096;

@@ -168,9 +168,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
 
 // One block.  partials layout: [0][t] rss0, [1][t] rss1, [2][t] l1, [3][t] dz.g0, [4][t] dz^2.
 // flags: [0] accepted, [1] trials evaluated so far this iteration, [2] index of accepted trial.
-// fvals: [0] F, [1] Q of the last evaluated trial (diagnostics), [2] accepted lr
+// fvals: [0] F, [1] Q of the last evaluated trial (diagnostics), [2] accepted lr, [3] its alpha*lr
 __global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict__ partials, int ntiles,
-                                                        float alpha, float half_over_lr, float lr,
+                                                        float alpha, float half_over_lr, float lr, float lam,
                                                         int trial_index, int force,
                                                         int* __restrict__ flags, float* __restrict__ fvals) {
   if (!force && flags[0] != 0) return;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict_
     const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(half_over_lr, dz2)), al1);  // :32-35
     fvals[0] = F; fvals[1] = Q;
     flags[1] = trial_index + 1;
-    if (force || F <= Q) { flags[0] = 1; flags[2] = trial_index; fvals[2] = lr; }  // :45
+    if (force || F <= Q) { flags[0] = 1; flags[2] = trial_index; fvals[2] = lr; fvals[3] = lam; }  // :45
   }
 }
 
@@ -219,6 +219,36 @@ __global__ __launch_bounds__(256) void bt_finish_kernel(float* __restrict__ Z, i
       acc += __builtin_fabsf(__fsub_rn(zo, zn));                                   // ista.py:93
       Y[idx] = __fadd_rn(zn, __fmul_rn(coef, __fsub_rn(zn, zo)));                  // :99-100
       Z[r * ldz + cc] = zn;                                                        // :102
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dpart[blockIdx.x] = sh[0];
+}
+
+// Same as bt_finish_kernel, but the accepted candidate is recomputed from the point and its
+// gradient with the accepted step (fvals[2], fvals[3]) instead of being read back -- the
+// bf16 trial kernels do not write their candidates to HBM.
+__global__ __launch_bounds__(256) void bt_finish_recompute_kernel(float* __restrict__ Z, float* __restrict__ Y,
+                                                                  const float* __restrict__ P,
+                                                                  const float* __restrict__ G, int64_t total,
+                                                                  float coef, const int* __restrict__ flags,
+                                                                  const float* __restrict__ fvals,
+                                                                  float* __restrict__ dpart) {
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  if (flags[0] != 0) {
+    const float lr = fvals[2], lam = fvals[3];
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+      const float zo = Z[idx];
+      const float zn = soft_threshold(__fsub_rn(P[idx], __fmul_rn(lr, G[idx])), lam);   // ista.py:40
+      acc += __builtin_fabsf(__fsub_rn(zo, zn));                                          // :93
+      Y[idx] = __fadd_rn(zn, __fmul_rn(coef, __fsub_rn(zn, zo)));                         // :99-100 (P may alias Y)
+      Z[idx] = zn;                                                                        // :102
     }
   }
   sh[threadIdx.x] = acc;
@@ -288,7 +318,16 @@ hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, 
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,
                             hipStream_t stream) {
   hipLaunchKernelGGL(bt_decide_kernel, dim3(1), dim3(256), 0, stream, p.partials, p.ntiles,
-                     (float)alpha, (float)(0.5 / lr), (float)lr, trial_index, force, p.flags, p.fvals);
+                     (float)alpha, (float)(0.5 / lr), (float)lr, (float)(alpha * lr), trial_index, force, p.flags,
+                     p.fvals);
+  return hipGetLastError();
+}
+
+hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
+                                      const int* flags, const float* fvals, float* dpart, int grid,
+                                      hipStream_t stream) {
+  hipLaunchKernelGGL(bt_finish_recompute_kernel, dim3(grid), dim3(256), 0, stream, Z, Y, P, G, total, coef, flags,
+                     fvals, dpart);
   return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@
 //     wave is one contiguous, fully coalesced 1 KiB global load straight into VGPRs
 //     (prefetched two steps ahead) -- no LDS bandwidth is spent on W at all.
 // With the GEMMs ~10x shorter the kernels are HBM-bound: grad reads p and writes g
-// (8*n*k bytes), a trial reads p, g and writes the candidate (12*n*k bytes).
+// (8*n*k bytes), a trial reads p and g (8*n*k bytes; the candidate never goes to HBM).
 #include "tile_device.hpp"
 
 namespace lasso {
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(kThreads, 1) void bt16_grad_kernel(const BtParams p
 }
 
 // ---------------------------------------------------------------------------
-// trial: z+ = S(p - lr g0) -> C (fp32 candidate), r1 = z+ W^T - x,
+// trial: z+ = S(p - lr g0) (kept in LDS only: the finish kernel recomputes the accepted one),
+// r1 = z+ W^T - x,
 // partials {[1] sum r1^2, [2] sum|z+|, [3] sum dz*g0, [4] sum dz^2}                 (ista.py:26-42)
 // ---------------------------------------------------------------------------
 template <int K>
@@ -233,17 +234,6 @@ __global__ __launch_bounds__(kThreads, 1) void bt16_trial_kernel(const BtParams 
         l1 += __builtin_fabsf(zn[e]);
         dzg = __fadd_rn(dzg, __fmul_rn(dz, gv[e]));
         dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
-      }
-      if (row0 + r < p.n && 8 * ch < p.k) {
-        float* cp = p.C + (int64_t)(row0 + r) * p.k + 8 * ch;
-        if (gvec && 8 * ch + 8 <= p.k) {
-          *(f32x4*)cp = (f32x4){zn[0], zn[1], zn[2], zn[3]};
-          *(f32x4*)(cp + 4) = (f32x4){zn[4], zn[5], zn[6], zn[7]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (8 * ch + e < p.k) cp[e] = zn[e];
-        }
       }
       *(lds_bf16x8*)(zt + tile16_off<K * 2>(r, ch)) = to_bf16x8(zn);
     }

@@ -324,7 +324,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   bool warned = false;
   double t_mom = 1.0;   // ista.py:78 (python int 1; same arithmetic in double)
   struct { int flags[4]; float delta; } host;
-  int it = 0;
+  int it = 0, prev_trials = kBtBatch - 1;
   float last = NAN;
   for (; it < maxiter; ++it) {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;             // :98
@@ -339,7 +339,10 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     bool accepted = false;
     while (!accepted) {
       const bool give_up = t >= kBtMaxTrials;
-      const int batch = give_up ? 1 : std::min(kBtBatch, kBtMaxTrials - t);
+      // the first batch of an iteration is sized from the previous iteration's trial count
+      // (trials enqueued after the accepted one only cost their launch, but that adds up)
+      const int want = t == 0 ? std::min(kBtBatch, std::max(2, prev_trials + 1)) : kBtBatch / 2;
+      const int batch = give_up ? 1 : std::min(want, kBtMaxTrials - t);
       for (int b = 0; b < batch; ++b) {
         const double lr_t = give_up ? lr0 : lr;      // ista.py:48-52: warn and revert to the initial step size
         const int idx = give_up ? t : t + b, force = give_up ? 1 : 0;
@@ -353,8 +356,12 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
         else lr = lr / eta;                                                            // :47
       }
       t += batch;
-      LASSO_HIP_TRY(launch_bt_finish(zout, ldz, ws.Y, ws.C, (int)n, (int)k, coef, ws.flags, ws.dpart,
-                                     kBtFinishGrid, st));
+      if (half)   // P is Y (fast) or Z itself: element-wise in place is safe either way
+        LASSO_HIP_TRY(launch_bt_finish_recompute(zout, ws.Y, p.P, ws.G, n * k, coef, ws.flags, ws.fvals, ws.dpart,
+                                                 kBtFinishGrid, st));
+      else
+        LASSO_HIP_TRY(launch_bt_finish(zout, ldz, ws.Y, ws.C, (int)n, (int)k, coef, ws.flags, ws.dpart,
+                                       kBtFinishGrid, st));
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kBtFinishGrid, ws.delta);
       LASSO_HIP_TRY(hipGetLastError());
       LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -362,6 +369,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       LASSO_HIP_TRY(hipStreamSynchronize(st));
       accepted = host.flags[0] != 0;
     }
+    prev_trials = host.flags[2] + 1;
     last = host.delta;
     t_mom = t_next;
     if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95

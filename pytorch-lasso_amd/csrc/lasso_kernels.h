@@ -118,6 +118,9 @@ hipError_t launch_pack_w_bf16(const void* W, int64_t ldw, int d, int k, int kp, 
                               hipStream_t stream);
 hipError_t launch_cvt_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int n, int k, int to_f32,
                            hipStream_t stream);
+hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
+                                      const int* flags, const float* fvals, float* dpart, int grid,
+                                      hipStream_t stream);
 hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
                             float coef, const int* flags, float* dpart, int grid, hipStream_t stream);
 

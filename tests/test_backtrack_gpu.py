@@ -105,3 +105,31 @@ def test_c3_bf16_leg(golden):
     assert abs(obj - float(g["bf16_fixed_obj_fp32eval"])) <= 2e-3 * obj
     with pytest.raises(TypeError):
         sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5)
+
+
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (100, 48, 200), (130, 128, 512), (1, 3, 2),
+                                   (257, 200, 1000)])
+@pytest.mark.parametrize("fast", [True, False])
+def test_native_bf16_line_search_kernels(n, d, k, fast):
+    """bf16 tensors + backtrack run the bf16-MFMA kernels (csrc/bt_bf16.hip: 64-row tiles,
+    bf16 operands, fp32 accumulation and state).  Against the fp32 kernels fed the same
+    (exactly up-converted) bf16 data the objective agrees to 1e-3 -- inside the 2e-3 the
+    reference's own all-bf16 arithmetic is allowed -- and a warm start works."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    g = torch.Generator().manual_seed(n + k)
+    W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).bfloat16()
+    X = torch.randn(n, d, generator=g).bfloat16()
+    z0 = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    for start in (torch.zeros_like(z0), z0):
+        zb = ista(X.cuda(), start.cuda(), W.cuda(), 0.3, fast=fast, lr=1.0, maxiter=6, tol=0.0, backtrack=True)
+        assert zb.dtype == torch.bfloat16 and zb.shape == (n, k)
+        zf = ista(X.float().cuda(), start.float().cuda(), W.float().cuda(), 0.3, fast=fast, lr=1.0, maxiter=6,
+                  tol=0.0, backtrack=True)
+        ob = orc.lasso_objective(X.float(), zb.float().cpu(), W.float(), 0.3).item()
+        of = orc.lasso_objective(X.float(), zf.cpu(), W.float(), 0.3).item()
+        assert abs(ob - of) <= 1e-3 * abs(of), (ob, of)
+    # the stop rule is honoured on this path too
+    zt, info = ista(X.cuda(), torch.zeros_like(z0).cuda(), W.cuda(), 0.3, fast=fast, lr=1.0, maxiter=300, tol=1e-3,
+                    backtrack=True, return_info=True)
+    assert 1 <= info["iterations"] <= 300
