@@ -255,12 +255,27 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
   __shared__ int s_idx[kSweepMaxK];
   __shared__ int s_count;
   __shared__ float sh[256];
+  // ordered list of the degenerate atoms: every thread scans a contiguous slice of the flags,
+  // an exclusive scan over the 256 slice counts gives each slice its place in the list
+  // (the usual case -- no degenerate atom at all -- costs one pass instead of k dependent loads)
+  __shared__ int s_cnt[256];
+  const int per = (p.k + 255) / 256;
+  const int lo = min((int)threadIdx.x * per, p.k), hi = min(lo + per, p.k);
+  int mine = 0;
+  for (int j = lo; j < hi; ++j) mine += p.degenerate[j] != 0;
+  s_cnt[threadIdx.x] = mine;
+  __syncthreads();
   if (threadIdx.x == 0) {
     int c = 0;
-    for (int j = 0; j < p.k; ++j)
-      if (p.degenerate[j]) { s_idx[c] = j; ++c; }
+    for (int t = 0; t < 256; ++t) { const int v = s_cnt[t]; s_cnt[t] = c; c += v; }
     s_count = c;
     p.ndeg_in_out[0] = c;
+  }
+  __syncthreads();
+  if (mine) {
+    int at = s_cnt[threadIdx.x];
+    for (int j = lo; j < hi; ++j)
+      if (p.degenerate[j]) s_idx[at++] = j;
   }
   __syncthreads();
   const int cnt = s_count;
