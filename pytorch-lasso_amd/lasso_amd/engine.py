@@ -46,15 +46,19 @@ class HipEngine:
         return lipschitz_constant(W)
 
     def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False,
-                  z_out=None):
+                  z_out=None, cap=0):
         """`iters` iterations from (z_in, y_in); returns (z, y, delta[iters] or None).
         Building block of the distributed exact-stop E-step and of the traced forward pass
-        of the autograd path (lasso_fista_run).  `z_out`: optional [n,k] destination."""
+        of the autograd path (lasso_fista_run).  `z_out`: optional [n,k] destination.
+        `prepared=True` skips re-packing W: only valid while the workspace buffer is the one
+        the previous call used, so such callers pass `cap` (the largest it0+iters they will
+        reach) to size it once."""
         n, d = X.shape
         k = W.shape[1]
         L = self.lib
         with torch.cuda.device(self.device):
-            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, it0 + iters, 0.0, nat.STOP_NONE, 0)
+            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, max(it0 + iters, int(cap)), 0.0,
+                                                   nat.STOP_NONE, 0)
             ws = self._ws(nbytes, "fista")
             if not prepared:
                 nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32,

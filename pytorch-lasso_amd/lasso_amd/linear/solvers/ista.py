@@ -58,7 +58,7 @@ class _UnrolledIsta(torch.autograd.Function):
         y, done = None, 0
         for it in range(maxiter):
             _, y, delta = eng.fista_run(xg, wg, trace[it], y, alpha, lr, fast, it, 1, tol > 0,
-                                        prepared=it > 0, z_out=trace[it + 1])
+                                        prepared=it > 0, z_out=trace[it + 1], cap=maxiter)
             done = it + 1
             if tol > 0 and delta[0].item() <= budget:                    # ista.py:93-95
                 break
