@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
             dzg = __fadd_rn(dzg, __fmul_rn(dz, g[e]));
             dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
           }
-        store_row4(p.C, p.k, row0 + r, p.n, p.k, cc, zn, gvec);
+        if (p.C) store_row4(p.C, p.k, row0 + r, p.n, p.k, cc, zn, gvec);   // nullptr: the finish kernel recomputes it
       }
       *(lds_f32x4*)(zt + tile_chunk_off<K>(r, cc)) = zn;
     });

@@ -318,7 +318,10 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   BtParams p;
   p.X = x; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
   p.Xh = x_any; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
-  p.G = ws.G; p.C = ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
+  // candidates stay on chip and the finish kernel recomputes the accepted one whenever the
+  // state is a flat [n][k] array (always for bf16 tensors; fp32: unless z_out is strided)
+  const bool recompute = half || ldz == k;
+  p.G = ws.G; p.C = recompute ? nullptr : ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
   const float budget = (float)((double)n * (double)k * tol);
   bool warned = false;
@@ -356,7 +359,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
         else lr = lr / eta;                                                            // :47
       }
       t += batch;
-      if (half)   // P is Y (fast) or Z itself: element-wise in place is safe either way
+      if (recompute)   // P is Y (fast) or Z itself: element-wise in place is safe either way
         LASSO_HIP_TRY(launch_bt_finish_recompute(zout, ws.Y, p.P, ws.G, n * k, coef, ws.flags, ws.fvals, ws.dpart,
                                                  kBtFinishGrid, st));
       else
