@@ -36,5 +36,9 @@ def run(dtype, reps=10):
 
 
 if __name__ == "__main__":
-    print(json.dumps({"workload": "config 3: backtracking FISTA n=16384 d=256 k=1024, 10 outer iterations",
-                      "fp32": run(torch.float32), "bf16_api": run(torch.bfloat16)}))
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 10
+    res = {"workload": "config 3: backtracking FISTA n=16384 d=256 k=1024, 10 outer iterations"}
+    if "--bf16-only" not in sys.argv:
+        res["fp32"] = run(torch.float32, reps)
+    res["bf16_api"] = run(torch.bfloat16, reps)
+    print(json.dumps(res))
