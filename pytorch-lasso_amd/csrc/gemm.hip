@@ -146,7 +146,7 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
                    ((uintptr_t)B & 15) == 0;
   // 128 x 128 blocks once they give every CU a workgroup, 64 x 64 below that
   const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
-  const bool big = big_blocks >= 192;
+  const bool big = big_blocks >= 192 && m > 64 && nn > 64;    // a thin operand would waste most of a 128-wide block
   if (big)
     return vec ? launch_tile<128, 128, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
                : launch_tile<128, 128, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream);
