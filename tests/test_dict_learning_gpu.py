@@ -239,3 +239,18 @@ def test_sharded_driver_world1_equals_single_gpu(golden):
         if created:
             dist.destroy_process_group()
     assert torch.equal(losses, lref) and torch.equal(D, Dref)
+
+
+def test_dict_learning_with_coordinate_descent_e_step():
+    """`algorithm='cd'` inside the EM loop (dict_learning forwards solver kwargs to
+    sparse_encode, dict_learning.py:38): HIP coordinate descent + HIP M-step vs the oracle."""
+    from lasso_amd.linear import dict_learning
+    orc = _orc()
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(200, 16, generator=g)
+    torch.manual_seed(1)
+    Dref, lref = orc.dict_learning(X, 32, alpha=0.3, steps=3, progbar=False, algorithm='cd', maxiter=30)
+    torch.manual_seed(1)
+    D, losses = dict_learning(X, 32, alpha=0.3, steps=3, progbar=False, algorithm='cd', maxiter=30)
+    assert (losses.cpu() - lref).abs().max().item() <= 1e-4 * lref.abs().max().item()
+    assert (D.cpu() - Dref).abs().max().item() <= 2e-3
