@@ -260,6 +260,11 @@ __global__ __launch_bounds__(256) void bt_finish_recompute_kernel(float* __restr
   if (threadIdx.x == 0) dpart[blockIdx.x] = sh[0];
 }
 
+// LDS of the grad kernel: p tile + r tile + the per-wave DMA rings + partial sums
+static size_t bt_grad_lds_bytes(int K) {
+  return (size_t)kTileM * K * 4 + (size_t)kTileM * kFistaD * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
+}
+
 template <int K>
 static hipError_t set_lds(const void* fn, size_t lds) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -267,7 +272,7 @@ static hipError_t set_lds(const void* fn, size_t lds) {
 
 template <int K>
 static hipError_t launch_grad_k(const BtParams& p, int grid, hipStream_t stream) {
-  const size_t lds = fista_tile_lds_bytes(K);
+  const size_t lds = bt_grad_lds_bytes(K);
   static bool done = false;
   if (!done) {
     hipError_t e = set_lds<K>(reinterpret_cast<const void*>(&bt_grad_kernel<K>), lds);

@@ -152,23 +152,9 @@ int device_cus() {
   return cached;
 }
 
-// Kernel variant (developer A/B switch): LASSO_FISTA_VARIANT = w8 | w16 | w8p (default:
-// w8p, the software-pipelined 8-wave kernel).
-int fista_variant() {
-  static int v = 0;
-  if (!v) {
-    const char* e = getenv("LASSO_FISTA_VARIANT");
-    if (e && !strcmp(e, "w8")) v = 8;
-    else if (e && !strcmp(e, "w16")) v = 16;
-    else v = 1;
-  }
-  return v;
-}
-
 bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
 
 int pad_d(int64_t d, int kp) {
-  if (fista_variant() != 1) return kFistaD;          // legacy variants: 16 x 256 tiles only
   if (d <= 64 && kp <= 256) return 64;
   if (d <= 128 && kp <= 512) return 128;
   return kFistaD;
@@ -215,11 +201,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
-  switch (fista_variant()) {
-    case 8: LASSO_HIP_TRY(launch_fista_tile(p, kp, grid, stream)); break;
-    case 16: LASSO_HIP_TRY(launch_fista_tile16(p, kp, grid, stream)); break;
-    default: LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream)); break;
-  }
+  LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream));
   if (delta && iters > 0) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
                        ntiles, delta);
@@ -700,7 +682,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     const int tile_rows = 4096 / pad_d(d, kp);
     const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
     const int cus = device_cus();
-    if (fista_variant() == 1 && ntiles <= cus && !getenv("LASSO_STOP_CHUNKED")) {
+    if (ntiles <= cus && !getenv("LASSO_STOP_CHUNKED")) {
       LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * ntiles * 8, st));
       LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
       if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,

@@ -93,9 +93,6 @@ struct ConvGeom {
   int N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw;
 };
 
-size_t fista_tile_lds_bytes(int kpad);
-hipError_t launch_fista_tile(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
-hipError_t launch_fista_tile16(const FistaTileParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,

@@ -189,51 +189,6 @@ struct TileCtx {
   }
 };
 
-// GEMM-1:  acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T   (cb = 0,1).
-// Pre:  ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave.
-// Post: ring slots 0/1 have `tail0` / `tail1` (+ tail_voff) in flight.
-template <int K>
-__device__ __forceinline__ void gemm1_stream(const TileCtx<K>& c, lds_char* at, f32x4 (&acc)[2],
-                                             const float* tail0, const float* tail1,
-                                             const unsigned (&tail_voff)[4]) {
-  constexpr int S1 = K / 32;
-  auto step = [&](int s2, auto par_c, const float* pf_src, const unsigned (&pf_voff)[4]) {
-    constexpr int par = decltype(par_c)::value;
-    lds_char* const slot = c.ring + par * kStepBytes;
-    LASSO_WAIT_VMCNT(4);  // this step's 4 DMA pieces have landed
-    f32x4 b[2][2], a[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-        b[cb][ss] = *(const lds_f32x4*)(slot + cb * 2048 + c.boff[ss]);
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss)
-      a[ss] = *(const lds_f32x4*)(at + c.n * (K * 4) + s2 * 256 + c.aoff[par][ss]);
-    LASSO_WAIT_LGKM0();   // slot is free once its fragments are in registers
-    dma_step(pf_src, pf_voff, slot);
-    LASSO_PRIO_HI();
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[0][ss][j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][j], b[1][ss][j], acc[1], 0, 0, 0);
-      }
-    LASSO_PRIO_LO();
-  };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-#pragma unroll 1
-  for (int s2 = 0; s2 < S1 / 2 - 1; ++s2) {
-    step(s2, P0{}, c.w1 + 64 * s2 + 64, c.voff1);
-    step(s2, P1{}, c.w1 + 64 * s2 + 96, c.voff1);
-  }
-  step(S1 / 2 - 1, P0{}, tail0, tail_voff);
-  step(S1 / 2 - 1, P1{}, tail1, tail_voff);
-}
-
-
 // GEMM-2, pass PS:  g2[cb] = r_tile[16][256] * Wtp[wid*K/8 + 32*PS + 16*cb .. +16][256]^T.
 // `rf` are the r fragments (A layout) of the whole tile; the ring is refilled two steps
 // ahead from the W^T stream and, past its end, with steps 0/1 of the next GEMM-1.
@@ -381,7 +336,9 @@ __device__ __forceinline__ void no_stage() {}
 
 }  // namespace sp
 
-// Pipelined GEMM-1 with the same contract as gemm1_stream():
+// Pipelined GEMM-1:  acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T (cb = 0,1).
+// Pre: ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave; post: they have
+// `tail0` / `tail1` (+ tail_voff) in flight.
 //   acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T
 // Pre:  ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave.
 // Post: ring slots 0/1 have `tail0` / `tail1` (+ tail_voff) in flight.
