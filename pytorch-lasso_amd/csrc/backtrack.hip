@@ -266,19 +266,9 @@ static size_t bt_grad_lds_bytes(int K) {
 }
 
 template <int K>
-static hipError_t set_lds(const void* fn, size_t lds) {
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
-template <int K>
 static hipError_t launch_grad_k(const BtParams& p, int grid, hipStream_t stream) {
   const size_t lds = bt_grad_lds_bytes(K);
-  static bool done = false;
-  if (!done) {
-    hipError_t e = set_lds<K>(reinterpret_cast<const void*>(&bt_grad_kernel<K>), lds);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_grad_kernel<K>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(bt_grad_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
 }
@@ -287,12 +277,7 @@ template <int K>
 static hipError_t launch_trial_k(const BtParams& p, float lr, float lam, int force, int grid,
                                  hipStream_t stream) {
   const size_t lds = (size_t)kFistaWaves * kRingBytesPerWave + (size_t)kTileM * K * 4 + 256;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = set_lds<K>(reinterpret_cast<const void*>(&bt_trial_kernel<K>), lds);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_trial_kernel<K>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(bt_trial_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p, lr, lam, force);
   return hipGetLastError();
 }

@@ -295,13 +295,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const void* __restrict__ 
 template <int K>
 hipError_t grad_k(const BtParams& p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)kRows * K * 2 + 256;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bt16_grad_kernel<K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt16_grad_kernel<K>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(bt16_grad_kernel<K>, dim3(grid), dim3(kThreads), lds, stream, p);
   return hipGetLastError();
 }
@@ -309,13 +303,7 @@ hipError_t grad_k(const BtParams& p, int grid, hipStream_t stream) {
 template <int K>
 hipError_t trial_k(const BtParams& p, float lr, float lam, int force, int grid, hipStream_t stream) {
   const size_t lds = (size_t)kRows * K * 2 + 256;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bt16_trial_kernel<K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt16_trial_kernel<K>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(bt16_trial_kernel<K>, dim3(grid), dim3(kThreads), lds, stream, p, lr, lam, force);
   return hipGetLastError();
 }

@@ -364,13 +364,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
 template <int K, int M, bool STOP>
 static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)M * K * 4 + (size_t)M * (4096 / M) * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP>), lds);
+      e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
 }

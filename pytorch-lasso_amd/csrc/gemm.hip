@@ -123,13 +123,10 @@ hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk, int add,
                        hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, VEC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (lds > 48 * 1024)
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, VEC>), lds);
+        e != hipSuccess)
+      return e;
   const dim3 grid((nn + BN - 1) / BN, (m + BM - 1) / BM);
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0, ldc0, C,
                      ldc, m, nn, kk, add);

@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "../../include/lasso_hip.h"
@@ -142,14 +145,10 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 }
 
 int device_cus() {
-  static int cached = -1;
-  if (cached > 0) return cached;
-  int dev = 0;
+  int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  cached = prop.multiProcessorCount;
-  return cached;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return cus;
 }
 
 bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
@@ -528,6 +527,21 @@ ConvGeom make_geom(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_
 }
 
 }  // namespace
+}  // namespace lasso
+
+namespace lasso {
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kernel, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.insert({kernel, dev});
+  return e;
+}
 }  // namespace lasso
 
 using namespace lasso;

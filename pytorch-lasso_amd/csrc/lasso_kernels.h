@@ -93,6 +93,10 @@ struct ConvGeom {
   int N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw;
 };
 
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per
+// (kernel, device); thread-safe, cheap on the repeat path.  Defined in lasso_hip.hip.
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,

@@ -417,15 +417,10 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
 template <int NW>
 static hipError_t sweep_blocks(const SweepParams& p, hipStream_t stream) {
   const size_t lds = (size_t)kSweepBlock * 256 * NW * 4;
-  static bool attr_set = false;
-  if (!attr_set && lds > 32 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_block_kernel<true, NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_block_kernel<false, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 32 * 1024) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<true, NW>), lds);
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<false, NW>), lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   for (int j0 = 0; j0 < p.k; j0 += kSweepBlock) {
     if (j0 + kSweepBlock <= p.k)

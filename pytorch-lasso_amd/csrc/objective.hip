@@ -92,13 +92,7 @@ __global__ __launch_bounds__(256) void objective_finalize_kernel(const float* __
 template <int K>
 static hipError_t launch_obj_k(const ObjectiveParams& p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)kFistaWaves * kRingBytesPerWave + (size_t)kTileM * K * 4 + 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&objective_tile_kernel<K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&objective_tile_kernel<K>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(objective_tile_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
 }
