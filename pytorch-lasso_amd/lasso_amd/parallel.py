@@ -92,7 +92,9 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     active stop rule: exact GLOBAL rule through chunked speculation + one all-reduce of
     the chunk's delta vector (see module docstring)."""
     world, _ = _world(group)
-    if world == 1:
+    if world == 1 or kw.get('algorithm', 'ista') == 'cd':
+        # coordinate descent stops every row on its own (coordinate_descent.py:45-48): a row
+        # shard needs no collective and reproduces the full batch exactly
         return engine.encode(X, W, alpha, z0, **kw)
     fast = kw.pop('fast', True)
     lr = kw.pop('lr', 'auto')
@@ -102,7 +104,7 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     kw.pop('eta_backtrack', None)
     kw.pop('verbose', None)
     if kw.get('algorithm', 'ista') != 'ista':
-        raise NotImplementedError("sharded E-step supports algorithm='ista' only")
+        raise NotImplementedError("sharded E-step supports algorithm='ista' and 'cd' only")
     kw.pop('algorithm', None)
     if kw:
         raise TypeError("ista() got unexpected keyword arguments %s" % sorted(kw))
