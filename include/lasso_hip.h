@@ -17,8 +17,9 @@
  *   - return value: lasso_status (0 = ok).  No exceptions cross the boundary;
  *     lasso_hip_last_error() gives the detail string for the calling thread;
  *   - dtype: LASSO_F32; LASSO_BF16 (x, W, z0, z_out all bf16, leading dimensions in bf16
- *     elements) is accepted by lasso_fista_solve with backtrack != 0 on the fused shapes
- *     (bf16-MFMA kernels, fp32 accumulation and state) and LASSO_ERR_UNSUPPORTED elsewhere;
+ *     elements) is accepted by lasso_fista_solve on the fused shapes (bf16-MFMA kernels,
+ *     fp32 accumulation and state; fixed step or line search) and LASSO_ERR_UNSUPPORTED
+ *     elsewhere;
  *   - shapes: d <= 256 and k <= 1024 run the fused kernels; beyond that lasso_fista_solve
  *     (fixed step), lasso_objective and lasso_gram_accumulate take any d, k (unfused
  *     MFMA GEMM paths), lasso_dict_sweep d <= 1024 and k <= 4096, lasso_cd_* k <= 4096;

@@ -366,6 +366,58 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
 
 
 // ---------------------------------------------------------------------------
+// Fixed-step solve on bf16 tensors: the bf16-MFMA gradient kernel of the line search
+// (bt_bf16.hip: g = (y W^T - x) W, bf16 operands, fp32 accumulation) + the fp32
+// prox/momentum pass, state in fp32 -- no up-converted copies of x and W, and at large n
+// faster than the fp32 fused kernel fed such copies.  The stop rule is evaluated on the host
+// once per iteration like the reference does (ista.py:93).
+// ---------------------------------------------------------------------------
+int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t ldw, const void* z0_any,
+                     int64_t ldz0, void* zout_any, int64_t ldz_any, int64_t n, int64_t d, int64_t k, int kp,
+                     double alpha, double lr, int fast, int maxiter, double tol, int32_t* iters_out,
+                     float* last_delta_out, void* workspace, size_t ws_bytes, hipStream_t st) {
+  BtWorkspace ws = carve_bt(workspace, n, k, kp, true);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  const int cus = device_cus();
+  if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
+  const int ntiles = (int)((n + 63) / 64);
+  float* Z = ws.Zf;
+  LASSO_HIP_TRY(launch_pack_w_bf16(w_any, ldw, (int)d, (int)k, kp, 1, ws.wp, ws.wtp, st));
+  if (z0_any) LASSO_HIP_TRY(launch_cvt_bf16(z0_any, ldz0, Z, k, (int)n, (int)k, 1, st));
+  else LASSO_HIP_TRY(hipMemsetAsync(Z, 0, (size_t)n * k * 4, st));
+  LASSO_HIP_TRY(hipMemcpyAsync(ws.Y, Z, (size_t)n * k * 4, hipMemcpyDeviceToDevice, st));
+  BtParams p;
+  p.X = nullptr; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
+  p.Xh = x_any; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
+  p.G = ws.G; p.C = nullptr; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
+  p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
+  const float budget = (float)((double)n * (double)k * tol);
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  double t_mom = 1.0;
+  float last = NAN;
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
+    p.P = ws.Y; p.ldp = k;                    // ISTA: coef = 0 keeps y == z
+    LASSO_HIP_TRY(launch_bt16_grad(p, kp, std::min(ntiles, cus), st));
+    LASSO_HIP_TRY(launch_generic_prox(Z, k, ws.Y, ws.G, (int)n, (int)k, lr_f, lam, coef, ws.dpart, kBtFinishGrid, st));
+    t_mom = t_next;
+    if (tol > 0.0) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kBtFinishGrid, ws.delta);
+      LASSO_HIP_TRY(hipGetLastError());
+      LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      if (last <= budget) { ++it; break; }
+    }
+  }
+  LASSO_HIP_TRY(launch_cvt_bf16(Z, k, zout_any, ldz_any, (int)n, (int)k, 0, st));
+  if (iters_out) *iters_out = it;
+  if (last_delta_out) *last_delta_out = last;
+  return LASSO_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Unfused path for shapes beyond the fused kernel (d > 256 or k > 1024): two MFMA GEMM
 // launches + one elementwise launch per iteration, state in HBM.  Same arithmetic
 // (ista.py:72-73,90,93,98-102); the stop rule is evaluated on the host every iteration
@@ -577,7 +629,7 @@ size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, i
   if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
-  if (backtrack) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16).bytes;
+  if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16).bytes;
   const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
 }
@@ -632,10 +684,10 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
-  // LASSO_BF16 tensors (x, W, z0, z_out all bf16) are native on the line-search path
-  // (BASELINE config 3); everything else takes fp32 tensors
-  const bool half_bt = dtype == LASSO_BF16 && backtrack && fused_shape(d, k) && maxiter > 0 && n > 0;
-  if (int s = check_common(n, d, k, half_bt ? LASSO_F32 : dtype, /*allow_large=*/true)) return s;
+  // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
+  const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
+  const bool half_bt = half_any && backtrack;
+  if (int s = check_common(n, d, k, half_any ? LASSO_F32 : dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
   if (!fused_shape(d, k) && backtrack)
@@ -670,6 +722,10 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                          maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
                          workspace_bytes, st);
   const int kp = pad_k(k);
+  if (half_any && !backtrack)
+    return solve_fixed_bf16(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr, fast,
+                            maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
+                            workspace_bytes, st);
   if (backtrack)
     return solve_backtracking(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp,
                               half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,

@@ -7,12 +7,12 @@ import torch
 from ... import _native as nat
 
 _DT = {torch.float32: nat.LASSO_F32, torch.bfloat16: nat.LASSO_BF16}
-# bf16 tensors (BASELINE config 3).  With the backtracking line search -- the configuration
-# BASELINE names -- bf16 x, W, z0 go to the native bf16-MFMA kernels (csrc/bt_bf16.hip:
-# bf16 operands, fp32 accumulation and state).  Everything else computes in fp32 on exact
-# up-conversions of x, W, z0 with one rounding of the result back to the tensor dtype.  Both
-# are at least as accurate as the reference's all-bf16 arithmetic; parity is judged on the
-# objective (rtol 2e-3).
+# bf16 tensors (BASELINE config 3).  On the fused shapes bf16 x, W, z0 go to the native
+# bf16-MFMA kernels (csrc/bt_bf16.hip: bf16 operands, fp32 accumulation and state), with or
+# without the backtracking line search.  Everything else (fp16, larger shapes, verbose,
+# autograd) computes in fp32 on exact up-conversions of x, W, z0 with one rounding of the
+# result back to the tensor dtype.  Both are at least as accurate as the reference's all-bf16
+# arithmetic; parity is judged on the objective (rtol 2e-3).
 _UPCAST = (torch.bfloat16, torch.float16)
 
 
@@ -107,7 +107,7 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
             raise TypeError("lasso_amd: lr='auto' is not supported for %s inputs" % x.dtype)
         if maxiter == 0:
             return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
-        native = (x.dtype == torch.bfloat16 and backtrack and d <= 256 and k <= 1024 and n > 0
+        native = (x.dtype == torch.bfloat16 and d <= 256 and k <= 1024 and n > 0 and not (verbose and not backtrack)
                   and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)))
         if native:
             return _solve_native(x, z0, weight, alpha, fast, float(lr), maxiter, tol, backtrack, eta_backtrack,

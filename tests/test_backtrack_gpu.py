@@ -133,3 +133,31 @@ def test_native_bf16_line_search_kernels(n, d, k, fast):
     zt, info = ista(X.cuda(), torch.zeros_like(z0).cuda(), W.cuda(), 0.3, fast=fast, lr=1.0, maxiter=300, tol=1e-3,
                     backtrack=True, return_info=True)
     assert 1 <= info["iterations"] <= 300
+
+
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (130, 128, 512), (257, 200, 1000)])
+def test_native_bf16_fixed_step(n, d, k):
+    """bf16 tensors without the line search: bf16-MFMA gradient kernel + fp32 prox/momentum
+    (lasso_hip.hip solve_fixed_bf16).  Same bar as above against the fp32 fused kernel fed
+    the up-converted data; stop rule and warm start included."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    g = torch.Generator().manual_seed(n + d)
+    W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).bfloat16()
+    X = torch.randn(n, d, generator=g).bfloat16()
+    z0 = (torch.randn(n, k, generator=g) * 0.05).bfloat16()
+    lr = 1.0 / orc.lipschitz_constant(W.float(), "exact")
+    for fast in (True, False):
+        for start in (torch.zeros_like(z0), z0):
+            zb = ista(X.cuda(), start.cuda(), W.cuda(), 0.3, fast=fast, lr=lr, maxiter=12, tol=0.0)
+            assert zb.dtype == torch.bfloat16 and zb.shape == (n, k)
+            zf = ista(X.float().cuda(), start.float().cuda(), W.float().cuda(), 0.3, fast=fast, lr=lr, maxiter=12,
+                      tol=0.0)
+            ob = orc.lasso_objective(X.float(), zb.float().cpu(), W.float(), 0.3).item()
+            of = orc.lasso_objective(X.float(), zf.cpu(), W.float(), 0.3).item()
+            assert abs(ob - of) <= 1e-3 * abs(of), (fast, ob, of)
+    zt, info = ista(X.cuda(), torch.zeros_like(z0).cuda(), W.cuda(), 0.3, lr=lr, maxiter=500, tol=1e-3,
+                    return_info=True)
+    zr, rinfo = ista(X.float().cuda(), torch.zeros_like(z0).float().cuda(), W.float().cuda(), 0.3, lr=lr,
+                     maxiter=500, tol=1e-3, return_info=True)
+    assert abs(info["iterations"] - rinfo["iterations"]) <= max(2, rinfo["iterations"] // 20)

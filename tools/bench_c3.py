@@ -41,4 +41,19 @@ if __name__ == "__main__":
     if "--bf16-only" not in sys.argv:
         res["fp32"] = run(torch.float32, reps)
     res["bf16_api"] = run(torch.bfloat16, reps)
+    if "--fixed" in sys.argv:      # same data, fixed step 1/L, 10 iterations: fp32 fused kernel vs bf16 path
+        from recipes import LAMBDA_MAX_C2
+        X, W = recipe_xw(16384, 256, 1024)
+        for name, dt in (("fixed_fp32", torch.float32), ("fixed_bf16", torch.bfloat16)):
+            Xg, Wg = X.cuda().to(dt), W.cuda().to(dt)
+            z0 = torch.zeros(16384, 1024, device="cuda", dtype=dt)
+            f = lambda: ista(Xg, z0, Wg, 0.5, lr=1.0 / LAMBDA_MAX_C2, maxiter=10, tol=0.0)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.3:
+                f()
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            res[name + "_ms_per_10_iterations"] = (time.perf_counter() - t) / reps * 1e3
     print(json.dumps(res))
