@@ -10,11 +10,11 @@
 // rest of the library already has, against ONE weight matrix Wt [C*kh*kw][K]:
 //   COLSt [CKK][M] = Wt Ym^T                    (gemm_nt_kernel: every code pixel's patch)
 //   R     [N][C][H][W] = overlap-add(COLSt) - x (conv_residual_kernel, gather form: no atomics)
-//   RCt   [CKK][M]     = patches of R            (conv_patches_kernel, im2col)
-//   G     [M][K]       = RCt^T Wt                (gram_tn_kernel, contraction over CKK)
+//   RC    [M][CKK]     = patches of R            (conv_patches_kernel, im2col, pixel-major)
+//   G     [M][K]       = RC W^T                  (gemm_nt_kernel, contraction over CKK)
 //   prox / momentum / sum|z - z+|                (generic_prox_kernel on the matrices)
-// COLSt and RCt are stored tap-major so that neighbouring threads (neighbouring pixels)
-// touch neighbouring addresses in the two data-movement kernels.  Stride and padding live
+// COLSt is stored tap-major so that the overlap-add gather of neighbouring pixels touches
+// neighbouring addresses; RC is pixel-major (rows = contraction-contiguous GEMM operand).  Stride and padding live
 // only in the index arithmetic of those two kernels.
 // Rooflines: the GEMMs are MFMA-bound (2*2*M*CKK*K flop per iteration); the two
 // data-movement kernels are HBM-bound (each reads or writes the M*CKK patch matrix once).
@@ -72,21 +72,36 @@ __global__ __launch_bounds__(256) void conv_residual_kernel(const float* __restr
   }
 }
 
-// RCt[(c,a,b)][(n,u,v)] = R[n][c][u*sh - ph + a][v*sw - pw + b]   (0 outside the image)
-__global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restrict__ r, float* __restrict__ rct,
-                                                           const ConvGeom g) {
+// RC[(n,u,v)][(c,a,b)] = R[n][c][u*sh - ph + a][v*sw - pw + b]   (0 outside the image), row
+// stride ldr (the tap count rounded up to a multiple of 4 so that the GEMM can stage it with
+// 16-byte loads; the padding columns are zero)
+__global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restrict__ r, float* __restrict__ rc,
+                                                           int ldr, const ConvGeom g) {
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
-  const int64_t total = (int64_t)g.C * g.kh * g.kw * M;
+  const int ckk = g.C * g.kh * g.kw;
+  const int64_t total = M * ldr;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t m = e % M;
-    const int t = (int)(e / M);
-    const int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);
-    const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
-    const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
-    const int i = u * g.sh - g.ph + a, j = v * g.sw - g.pw + b;
+    const int64_t m = e / ldr;
+    const int t = (int)(e % ldr);
     float val = 0.0f;
-    if (i >= 0 && i < g.H && j >= 0 && j < g.W) val = r[(((int64_t)n * g.C + c) * g.H + i) * g.W + j];
-    rct[e] = val;
+    if (t < ckk) {
+      const int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);
+      const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
+      const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
+      const int i = u * g.sh - g.ph + a, j = v * g.sw - g.pw + b;
+      if (i >= 0 && i < g.H && j >= 0 && j < g.W) val = r[(((int64_t)n * g.C + c) * g.H + i) * g.W + j];
+    }
+    rc[e] = val;
+  }
+}
+
+// Wp[k][t] = w[k][t] with the row stride padded like RC (zeros in the padding)
+__global__ __launch_bounds__(256) void conv_pad_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                         int ckk, int ldr) {
+  const int total = K * ldr;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int k = e / ldr, t = e % ldr;
+    wp[e] = t < ckk ? w[(int64_t)k * ckk + t] : 0.0f;
   }
 }
 
@@ -216,8 +231,9 @@ hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int 
   return hipGetLastError();
 }
 
-hipError_t launch_conv_pack_w(const float* w, float* wt, int K, int ckk, hipStream_t stream) {
+hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int ckk, int ldr, hipStream_t stream) {
   hipLaunchKernelGGL(conv_pack_w_kernel, dim3(grid_for((int64_t)K * ckk)), dim3(256), 0, stream, w, wt, K, ckk);
+  hipLaunchKernelGGL(conv_pad_w_kernel, dim3(grid_for((int64_t)K * ldr)), dim3(256), 0, stream, w, wp, K, ckk, ldr);
   return hipGetLastError();
 }
 
@@ -233,16 +249,15 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x
   return hipGetLastError();
 }
 
-// G [M][K] = conv2d(R, W) in row layout: patches, then the contraction over the taps
-hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, float* G, float* scratch,
-                                const ConvGeom& g, int cus, hipStream_t stream) {
-  const int ckk = g.C * g.kh * g.kw;
+// G [M][K] = conv2d(R, W) in row layout: pixel-major patches, then G = RC Wp^T on the general
+// MFMA GEMM (contraction over the taps)
+hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int ldr, float* G, const ConvGeom& g,
+                                hipStream_t stream) {
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
-  hipLaunchKernelGGL(conv_patches_kernel, dim3(grid_for((int64_t)ckk * M)), dim3(256), 0, stream, r, rct, g);
+  hipLaunchKernelGGL(conv_patches_kernel, dim3(grid_for(M * ldr)), dim3(256), 0, stream, r, rc, ldr, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  (void)scratch; (void)cus;
-  return launch_gram_tn(rct, M, (int)M, Wt, g.K, g.K, ckk, G, g.K, 0, nullptr, 1, stream);
+  return launch_gemm_nt_sub(rc, ldr, Wp, ldr, nullptr, 0, G, g.K, (int)M, g.K, ldr, stream, /*add=*/1);
 }
 
 hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,

@@ -141,14 +141,24 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
   if (m <= 0 || nn <= 0) return hipSuccess;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
-  // 128 x 128 blocks once they give every CU a workgroup, 64 x 64 below that
+  // Block shape: 128-wide sides once the problem still gives every CU a workgroup, except
+  // where a side is so short that 64-wide blocks waste less padding (m or nn just above a
+  // multiple of 128, or below 64).
+  auto pad = [](int v, int b) { return (v + b - 1) / b * b; };
   const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
-  const bool big = big_blocks >= 192 && m > 64 && nn > 64;    // a thin operand would waste most of a 128-wide block
-  if (big)
-    return vec ? launch_tile<128, 128, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
-               : launch_tile<128, 128, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream);
-  return vec ? launch_tile<64, 64, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
-             : launch_tile<64, 64, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream);
+  const bool roomy = big_blocks >= 192;
+  const int bm = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
+  const int bn = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+#define LASSO_GEMM_CASE(BM_, BN_)                                                                              \
+  if (bm == BM_ && bn == BN_)                                                                                   \
+    return vec ? launch_tile<BM_, BN_, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)         \
+               : launch_tile<BM_, BN_, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
+  LASSO_GEMM_CASE(128, 128);
+  LASSO_GEMM_CASE(128, 64);
+  LASSO_GEMM_CASE(64, 128);
+  LASSO_GEMM_CASE(64, 64);
+#undef LASSO_GEMM_CASE
+  return hipErrorInvalidValue;
 }
 
 }  // namespace lasso

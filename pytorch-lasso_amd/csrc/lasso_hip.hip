@@ -530,7 +530,7 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
 // ---------------------------------------------------------------------------
 // convolutional ISTA (conv.hip)
 // ---------------------------------------------------------------------------
-struct ConvWorkspace { float* Wt; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums; size_t bytes; };
+struct ConvWorkspace { float* Wt; float* Wp; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums; size_t bytes; };
 
 ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
   ConvWorkspace w;
@@ -542,11 +542,13 @@ ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
     return r;
   };
   const size_t ckk = (size_t)g.C * g.kh * g.kw, M = (size_t)g.N * g.Hz * g.Wz;
+  const size_t ldr = (ckk + 3) / 4 * 4;       // row stride of the pixel-major patch matrix
   w.Wt = (float*)take(ckk * g.K * 4);
+  w.Wp = (float*)take(ldr * g.K * 4);
   w.Zm = (float*)take(M * g.K * 4);
   w.Ym = (float*)take(M * g.K * 4);
   w.G = (float*)take(M * g.K * 4);
-  w.PT = (float*)take(ckk * M * 4);
+  w.PT = (float*)take(ldr * M * 4);
   w.R = (float*)take((size_t)g.N * g.C * g.H * g.W * 4);
   w.dpart = (float*)take((size_t)kGenGrid * 2 * 4);
   w.delta = (float*)take(256);
@@ -1116,8 +1118,8 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   if (N == 0) return LASSO_OK;
   const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
   const int64_t M = (int64_t)g.N * P;
-  const int cus = device_cus();
-  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, g.K, ckk, st));
+  const int ldr = (ckk + 3) / 4 * 4;
+  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, ws.Wp, g.K, ckk, ldr, st));
   if (z0_dev) LASSO_HIP_TRY(launch_conv_relayout((const float*)z0_dev, ws.Zm, g.N, g.K, P, 1, st));
   else LASSO_HIP_TRY(hipMemsetAsync(ws.Zm, 0, (size_t)M * g.K * 4, st));
   LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Zm, (size_t)M * g.K * 4, hipMemcpyDeviceToDevice, st));
@@ -1130,7 +1132,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
     LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));   // :19
-    LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wt, ws.PT, ws.G, nullptr, g, cus, st));           // :20
+    LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wp, ws.PT, ldr, ws.G, g, st));                    // :20
     LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,
                                       kGenGrid, st));                                             // :29,:42,:44
     t_mom = t_next;
@@ -1162,7 +1164,7 @@ int lasso_conv_objective(const void* x_dev, const void* w_dev, const void* z_dev
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
   const int64_t M = (int64_t)g.N * P;
-  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, g.K, ckk, st));
+  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, ws.Wp, g.K, ckk, (ckk + 3) / 4 * 4, st));
   LASSO_HIP_TRY(launch_conv_relayout((const float*)z_dev, ws.Zm, g.N, g.K, P, 1, st));
   LASSO_HIP_TRY(launch_conv_residual(ws.Zm, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));
   LASSO_HIP_TRY(launch_objective_reduce(ws.R, (int64_t)g.N * g.C * g.H * g.W, ws.Zm, g.K, (int)M, g.K, ws.dpart,

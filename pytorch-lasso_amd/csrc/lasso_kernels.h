@@ -148,11 +148,11 @@ hipError_t launch_bw_point(const float* z, const float* z_prev, float* y, int64_
 hipError_t launch_bw_axpy(float* a, const float* b, float s1, const float* c, float s2, int64_t total,
                           hipStream_t stream);
 hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream);
-hipError_t launch_conv_pack_w(const float* w, float* wt, int K, int ckk, hipStream_t stream);
+hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int ckk, int ldr, hipStream_t stream);
 hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
                                 const ConvGeom& g, hipStream_t stream);
-hipError_t launch_conv_gradient(const float* r, const float* Wt, float* rct, float* G, float* scratch,
-                                const ConvGeom& g, int cus, hipStream_t stream);
+hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int ldr, float* G, const ConvGeom& g,
+                                hipStream_t stream);
 hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,
                                   int center, hipStream_t stream);
 hipError_t launch_patches_reconstruct(const float* pat, int64_t ld, const float* means, float* img,
