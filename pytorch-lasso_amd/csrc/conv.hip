@@ -27,18 +27,26 @@
 namespace lasso {
 namespace {
 
-// Zm[(n,u,v)][k] <- z[n][k][u][v]   (to_rows != 0)   or the inverse
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Zm[(n,u,v)][k] <- z[n][k][u][v]   (to_rows != 0)   or the inverse: per image a K x P
+// matrix transpose through a 32 x 33 LDS tile (both sides coalesced); blockIdx.z = image.
 __global__ __launch_bounds__(256) void conv_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                            int N, int K, int P /* Hz*Wz */, int to_rows) {
-  const int64_t total = (int64_t)N * K * P;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    // i enumerates the NCHW tensor: ((n*K + k)*P + pix)
-    const int pix = (int)(i % P);
-    const int k = (int)((i / P) % K);
-    const int64_t n = i / ((int64_t)P * K);
-    const int64_t j = (n * P + pix) * K + k;
-    if (to_rows) dst[j] = src[i];
-    else dst[i] = src[j];
+                                                            int K, int P, int to_rows) {
+  __shared__ float t[32][33];
+  const int64_t img = (int64_t)blockIdx.z * K * P;
+  // source matrix of this image: rows x cols, destination: cols x rows
+  const int rows = to_rows ? K : P, cols = to_rows ? P : K;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < rows && c < cols) ? src[img + (int64_t)r * cols + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;        // destination row = c, column = r
+    if (c < cols && r < rows) dst[img + (int64_t)c * rows + r] = t[tx][i];
   }
 }
 
@@ -54,18 +62,29 @@ __global__ __launch_bounds__(256) void conv_residual_kernel(const float* __restr
     const int c = (int)((e / ((int64_t)g.W * g.H)) % g.C);
     const int n = (int)(e / ((int64_t)g.W * g.H * g.C));
     float acc = 0.0f;
-    for (int a = 0; a < g.kh; ++a) {
-      const int ii = i + g.ph - a;
-      if (ii < 0 || ii % g.sh != 0) continue;
-      const int u = ii / g.sh;
-      if (u >= g.Hz) continue;
-      for (int b = 0; b < g.kw; ++b) {
-        const int jj = j + g.pw - b;
-        if (jj < 0 || jj % g.sw != 0) continue;
-        const int v = jj / g.sw;
-        if (v >= g.Wz) continue;
-        const int64_t t = ((int64_t)c * g.kh + a) * g.kw + b;
-        acc += colst[t * M + ((int64_t)n * g.Hz + u) * g.Wz + v];
+    if (g.sh == 1 && g.sw == 1) {               // the usual case: no divisions in the tap loops
+      const int a_lo = max(0, i + g.ph - (g.Hz - 1)), a_hi = min(g.kh - 1, i + g.ph);
+      const int b_lo = max(0, j + g.pw - (g.Wz - 1)), b_hi = min(g.kw - 1, j + g.pw);
+      for (int a = a_lo; a <= a_hi; ++a) {
+        const int u = i + g.ph - a;
+        const float* row = colst + ((int64_t)n * g.Hz + u) * g.Wz + (j + g.pw);
+        const int64_t tb = ((int64_t)c * g.kh + a) * g.kw;
+        for (int b = b_lo; b <= b_hi; ++b) acc += row[(tb + b) * M - b];
+      }
+    } else {
+      for (int a = 0; a < g.kh; ++a) {
+        const int ii = i + g.ph - a;
+        if (ii < 0 || ii % g.sh != 0) continue;
+        const int u = ii / g.sh;
+        if (u >= g.Hz) continue;
+        for (int b = 0; b < g.kw; ++b) {
+          const int jj = j + g.pw - b;
+          if (jj < 0 || jj % g.sw != 0) continue;
+          const int v = jj / g.sw;
+          if (v >= g.Wz) continue;
+          const int64_t t = ((int64_t)c * g.kh + a) * g.kw + b;
+          acc += colst[t * M + ((int64_t)n * g.Hz + u) * g.Wz + v];
+        }
       }
     }
     r[e] = acc - (x ? x[e] : 0.0f);
@@ -79,19 +98,25 @@ __global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restri
                                                            int ldr, const ConvGeom g) {
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
   const int ckk = g.C * g.kh * g.kw;
-  const int64_t total = M * ldr;
+  const int q4 = ldr / 4;                        // float4 groups per patch row
+  const int64_t total = M * q4;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t m = e / ldr;
-    const int t = (int)(e % ldr);
-    float val = 0.0f;
-    if (t < ckk) {
-      const int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);
-      const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
-      const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
-      const int i = u * g.sh - g.ph + a, j = v * g.sw - g.pw + b;
-      if (i >= 0 && i < g.H && j >= 0 && j < g.W) val = r[(((int64_t)n * g.C + c) * g.H + i) * g.W + j];
+    const int64_t m = e / q4;
+    int t = (int)(e - m * q4) * 4;
+    const int v = (int)(m % g.Wz), u = (int)((m / g.Wz) % g.Hz);
+    const int n = (int)(m / ((int64_t)g.Wz * g.Hz));
+    int b = t % g.kw, a = (t / g.kw) % g.kh, c = t / (g.kw * g.kh);     // decoded once, then stepped
+    const int i0 = u * g.sh - g.ph, j0 = v * g.sw - g.pw;
+    f32x4 out;
+#pragma unroll
+    for (int s = 0; s < 4; ++s, ++t) {
+      float val = 0.0f;
+      const int i = i0 + a, j = j0 + b;
+      if (t < ckk && i >= 0 && i < g.H && j >= 0 && j < g.W) val = r[(((int64_t)n * g.C + c) * g.H + i) * g.W + j];
+      out[s] = val;
+      if (++b == g.kw) { b = 0; if (++a == g.kh) { a = 0; ++c; } }
     }
-    rc[e] = val;
+    *(f32x4*)(rc + m * ldr + (e - m * q4) * 4) = out;
   }
 }
 
@@ -225,9 +250,13 @@ inline int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255)
 }  // namespace
 
 hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream) {
-  const int64_t total = (int64_t)N * K * P;
-  if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(conv_relayout_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, N, K, P, to_rows);
+  if ((int64_t)N * K * P == 0) return hipSuccess;
+  const int rows = to_rows ? K : P, cols = to_rows ? P : K;
+  for (int n0 = 0; n0 < N; n0 += 65535) {        // gridDim.z limit
+    const int nb = std::min(N - n0, 65535);
+    hipLaunchKernelGGL(conv_relayout_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, nb), dim3(256), 0, stream,
+                       src + (int64_t)n0 * K * P, dst + (int64_t)n0 * K * P, K, P, to_rows);
+  }
   return hipGetLastError();
 }
 
@@ -254,7 +283,7 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x
 hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int ldr, float* G, const ConvGeom& g,
                                 hipStream_t stream) {
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
-  hipLaunchKernelGGL(conv_patches_kernel, dim3(grid_for(M * ldr)), dim3(256), 0, stream, r, rc, ldr, g);
+  hipLaunchKernelGGL(conv_patches_kernel, dim3(grid_for(M * (ldr / 4))), dim3(256), 0, stream, r, rc, ldr, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_gemm_nt_sub(rc, ldr, Wp, ldr, nullptr, 0, G, g.K, (int)M, g.K, ldr, stream, /*add=*/1);
