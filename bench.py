@@ -181,10 +181,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X, W, lr)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        # cheap sanity: objective of the result equals the reference's known answer
+        # cheap sanity: objective of the result (HIP lasso_loss) next to the reference's known answer
         if args.iters == 100:
-            from oracle import lasso_oracle as orc
-            obj = orc.lasso_objective(X, z.cpu(), W, ALPHA).item()
+            from lasso_amd.linear import lasso_loss
+            obj = lasso_loss(Xg, z, Wg, ALPHA).item()
             out["objective_after_100"] = obj
             out["objective_reference"] = 63.609337
     if dist is not None:
