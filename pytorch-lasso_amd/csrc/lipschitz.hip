@@ -21,72 +21,92 @@ namespace {
 
 constexpr int kLipTile = 32;   // output tile per workgroup (256 threads, 2x2 per thread)
 
-// sum of the diagonal of an m x m matrix, fixed order, computed redundantly per block
-__device__ double block_trace(const double* __restrict__ A, int m, int ld, double* sh) {
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < m; i += blockDim.x) acc += A[(size_t)i * ld + i];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-    __syncthreads();
-  }
-  const double t = sh[0];
-  __syncthreads();
-  return t;
-}
-
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// C[mp x mp] = (s A)(s A)^T on v_mfma_f64_16x16x4_f64, A given as elem(i,t) = A[i*si + t*st]
-// (TIn = float for the Gram of W, double for the squarings), rows >= m and t >= len read 0.
-// One workgroup = 4 waves = one 32x32 tile (a 16x16 block per wave); the t-range is staged
-// through LDS in chunks of 32.  SCALE: s = 1/tr(A) (A square, ld = si), else s = 1.
+constexpr int kLipSpan = 256;      // contraction elements whose loads one workgroup keeps in flight together
+constexpr int kLipMaxSplits = 16;  // partial products along the contraction (blockIdx.z)
+
+// C_z[mp x mp] = (s A)(s A)^T restricted to the contraction range of split z, on
+// v_mfma_f64_16x16x4_f64; A given as elem(i,t) = A[i*si + t*st] (TIn = float for the Gram of W,
+// double for the squarings), rows >= m and t >= len read 0.
+// One workgroup = 4 waves = one 32x32 tile (a 16x16 block per wave).  These products are
+// tiny and latency-bound, so ALL global loads of a 256-element span of the contraction are
+// issued up front (8 chunks of 32 into registers) and then staged through LDS chunk by
+// chunk: one exposed memory latency per span instead of one per chunk.
+// SCALE: s = 1/tr(A) (A square, ld = si), else s = 1.  Split z writes its partial product to
+// C + z*mp*mp; fold_partials_kernel sums the splits in a fixed order.
 // MFMA f64 layouts: A/B one double per lane (row l&15, k = l>>4); C/D col = l&15,
 // row = (l>>4) + 4*reg.
 template <typename TIn, bool SCALE>
 __global__ __launch_bounds__(256) void syrk_f64_kernel(const TIn* __restrict__ A, int64_t si, int64_t st,
-                                                       int m, int len, int mp, double* __restrict__ C) {
+                                                       int m, int len, int mp, int spans_per_split,
+                                                       double* __restrict__ C) {
   constexpr int RS = 33;                            // padded row stride (doubles)
   __shared__ double sa[32][RS], sb[32][RS];
   __shared__ double sh[256];
+  auto elem = [&](int64_t off) -> double { return (double)A[off]; };
   double inv = 1.0;
-  if constexpr (SCALE) inv = 1.0 / block_trace(reinterpret_cast<const double*>(A), m, (int)si, sh);
+  if constexpr (SCALE) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) acc += elem((int64_t)i * si + i);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    inv = 1.0 / sh[0];
+    __syncthreads();
+  }
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
   const int l15 = lane & 15, q = lane >> 4;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  // register-prefetched staging: the global loads of chunk t+1 fly under the MFMAs of chunk t
-  double ra[4], rb[4];
-  auto fetch = [&](int t0) {
+  const int span0 = blockIdx.z * spans_per_split;
+  for (int sp = span0; sp < span0 + spans_per_split; ++sp) {
+    const int tbase = sp * kLipSpan;
+    if (tbase >= len) break;
+    double ra[8][4], rb[8][4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int e = tid + 256 * h;
-      const int r = e >> 5, cc = e & 31;            // consecutive threads -> consecutive t
-      const int t = t0 + cc;
-      ra[h] = (i0 + r < m && t < len) ? (double)A[(int64_t)(i0 + r) * si + (int64_t)t * st] : 0.0;
-      rb[h] = (j0 + r < m && t < len) ? (double)A[(int64_t)(j0 + r) * si + (int64_t)t * st] : 0.0;
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int e = tid + 256 * h;
+        const int r = e >> 5, t = tbase + 32 * c + (e & 31);     // consecutive threads -> consecutive t
+        ra[c][h] = (i0 + r < m && t < len) ? elem((int64_t)(i0 + r) * si + (int64_t)t * st) : 0.0;
+        rb[c][h] = (j0 + r < m && t < len) ? elem((int64_t)(j0 + r) * si + (int64_t)t * st) : 0.0;
+      }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (tbase + 32 * c >= len) break;
+      __syncthreads();                               // previous chunk's fragment reads are done
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int e = tid + 256 * h;
+        sa[e >> 5][e & 31] = ra[c][h] * inv;
+        sb[e >> 5][e & 31] = rb[c][h] * inv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[iw + l15][4 * ks + q], sb[jw + l15][4 * ks + q], acc, 0, 0, 0);
     }
-  };
-  fetch(0);
-  for (int t0 = 0; t0 < len; t0 += 32) {
-    __syncthreads();                               // previous chunk's fragment reads are done
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int e = tid + 256 * h;
-      sa[e >> 5][e & 31] = ra[h] * inv;
-      sb[e >> 5][e & 31] = rb[h] * inv;
-    }
-    __syncthreads();
-    if (t0 + 32 < len) fetch(t0 + 32);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[iw + l15][4 * ks + q], sb[jw + l15][4 * ks + q], acc, 0, 0, 0);
   }
+  double* const Cz = C + (int64_t)blockIdx.z * mp * mp;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg)
-    C[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
+    Cz[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
+}
+
+// C[e] = sum_z part[z][e]  (fixed order)
+__global__ __launch_bounds__(256) void fold_partials_kernel(const double* __restrict__ part, int splits, int64_t mm,
+                                                            double* __restrict__ C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= mm) return;
+  double v = part[e];
+  for (int s = 1; s < splits; ++s) v += part[e + s * mm];
+  C[e] = v;
 }
 
 // out[0] = <G, P>_F / tr(P)   (single block, fixed summation order)
@@ -94,7 +114,16 @@ __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __re
                                                               const double* __restrict__ P, int mp,
                                                               double* __restrict__ out) {
   __shared__ double sh[1024];
-  const double tr = block_trace(P, mp, mp, sh);
+  double tr = 0.0;
+  for (int i = threadIdx.x; i < mp; i += 1024) tr += P[(size_t)i * mp + i];
+  sh[threadIdx.x] = tr;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  tr = sh[0];
+  __syncthreads();
   double acc = 0.0;
   const size_t total = (size_t)mp * mp;
   for (size_t e = threadIdx.x; e < total; e += 1024) acc = fma(G[e], P[e], acc);
@@ -109,10 +138,19 @@ __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __re
 
 }  // namespace
 
+// splits of a product with contraction length len: one 256-element span per workgroup up to
+// kLipMaxSplits, several spans per workgroup beyond that
+static void lip_splits(int len, int* splits, int* spans_per_split) {
+  const int spans = (len + kLipSpan - 1) / kLipSpan;
+  *spans_per_split = (spans + kLipMaxSplits - 1) / kLipMaxSplits;
+  *splits = (spans + *spans_per_split - 1) / *spans_per_split;
+}
+
 size_t lipschitz_workspace_bytes(int64_t d, int64_t k) {
   const int64_t m = d < k ? d : k;
   const int64_t mp = (m + kLipTile - 1) / kLipTile * kLipTile;
-  return (size_t)(3 * mp * mp + 32) * sizeof(double);
+  // out[32] + G + two ping-pong P + the split partials of the product in flight
+  return (size_t)((3 + kLipMaxSplits) * mp * mp + 32) * sizeof(double);
 }
 
 // Enqueue the whole computation; the result lands in ((double*)workspace)[0].
@@ -121,16 +159,23 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   const bool rows = d <= k;                 // G = W W^T (rows) or W^T W (columns)
   const int m = (int)(rows ? d : k), len = (int)(rows ? k : d);
   const int mp = (m + kLipTile - 1) / kLipTile * kLipTile;
+  const int64_t mm = (int64_t)mp * mp;
   double* out = static_cast<double*>(workspace);
   double* G = out + 32;
-  double* P[2] = {G + (size_t)mp * mp, G + 2 * (size_t)mp * mp};
-  const dim3 grid(mp / kLipTile, mp / kLipTile);
-  hipLaunchKernelGGL((syrk_f64_kernel<float, false>), grid, dim3(256), 0, stream, W,
-                     rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, G);
+  double* P[2] = {G + mm, G + 2 * mm};
+  double* part = G + 3 * mm;
+  int gs, gspans, ps, pspans;
+  lip_splits(len, &gs, &gspans);
+  lip_splits(mp, &ps, &pspans);
+  const dim3 fold_grid((unsigned)((mm + 255) / 256));
+  hipLaunchKernelGGL((syrk_f64_kernel<float, false>), dim3(mp / kLipTile, mp / kLipTile, gs), dim3(256), 0, stream,
+                     W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
+  if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G);
   const double* src = G;
   for (int p = 0; p < squarings; ++p) {
-    hipLaunchKernelGGL((syrk_f64_kernel<double, true>), grid, dim3(256), 0, stream, src, (int64_t)mp,
-                       (int64_t)1, mp, mp, mp, P[p & 1]);
+    hipLaunchKernelGGL((syrk_f64_kernel<double, true>), dim3(mp / kLipTile, mp / kLipTile, ps), dim3(256), 0,
+                       stream, src, (int64_t)mp, (int64_t)1, mp, mp, mp, pspans, ps > 1 ? part : P[p & 1]);
+    if (ps > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, ps, mm, P[p & 1]);
     src = P[p & 1];
   }
   hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, src, mp, out);
