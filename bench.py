@@ -1,18 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- FISTA iterations/sec on BASELINE config 2 (n=4096 d=256 k=1024 fp32,
-fixed step 1/L, tol=0) through the C ABI, one process per GPU.
+"""bench.py -- BASELINE's metric on MI355X: FISTA iterations/sec (+ time-to-tol) on
+n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU.
 
-A "step" is one sparse_encode solve of --iters FISTA iterations (default 100, the
-count BASELINE.md's config-2 timing uses) over a 4096 x 256 batch against a
-1024-atom dictionary, inputs resident in HBM.  Multi-GPU is weak scaling: every
-rank owns its own 4096-row shard (rows are independent lasso problems; no
-data-path collective), value = iterations/s summed over ranks.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em] [--scaling strong|weak]
+
+--workload fista (default): a "step" is one sparse_encode solve of --iters FISTA iterations
+  (default 100, the count BASELINE.md's config-2 timing uses), inputs resident in HBM, tol=0.
+  N = 1: the 4096-row batch of BASELINE config 2 on one GPU.
+  N > 1, --scaling strong (default; this IS BASELINE's "n=4096 at 1/2/4/8 GPU"): the SAME
+    4096 rows sharded over the ranks (4096/N rows per GPU; rows are independent lasso
+    problems, no data-path collective).  value = iterations/s of the whole 4096-row batch
+    (every rank runs the same iteration count on its shard; time = max over ranks).
+    The weak-scaling figure (4096 rows PER GPU) is measured in the same run and reported
+    beside it under "weak_scaling".
+  N > 1, --scaling weak: the weak figure is `value`.
+--workload em: BASELINE config 4, the dict_learning EM loop (FISTA E-step with the defaults
+  lr='auto', maxiter=10, tol=1e-5 + constrained least-squares M-step) on n=65536 rows sharded
+  over the ranks, with the RCCL all-reduce of [Z^T Z | Z^T X | objective sums] per step;
+  a "step" is one EM step; value = EM steps/s; the all-reduce time is reported separately.
+
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script spawns its N
+ranks itself through `python -m torch.distributed.run` on 127.0.0.1; under a launcher whose
+WORLD_SIZE differs from --gpus, or with fewer visible GPUs than ranks, it exits non-zero.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,14 +38,15 @@ for _p in (ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "te
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-
 N_ROWS, D, K, ALPHA = 4096, 256, 1024, 0.5
+N_EM = 65536
 LAMBDA_MAX = 8.877719052098003          # fp64 lambda_max(W^T W) of the recipe dictionary
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+OBJ_REF_100, OBJ_RTOL = 63.609337, 2e-6  # mean objective after 100 iterations
 
 
 def recipe(n_total):
+    import torch
     g = torch.Generator().manual_seed(0)
     W = torch.nn.functional.normalize(torch.randn(D, K, generator=g), dim=0)
     X = torch.randn(n_total, D, generator=g)
@@ -37,21 +55,23 @@ def recipe(n_total):
 
 def hbm_traffic_from_profiles():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, profiles/*/hbm_traffic.json);
-    PMC counters cannot be collected live inside the timed run."""
-    best = None
+    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, profiles/*/hbm_traffic.json):
+    PMC counters cannot be collected inside the timed run, so this figure is the latest
+    profile's, and the JSON says which."""
+    best, src = None, None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, name, "hbm_traffic.json")
         if os.path.exists(f):
             with open(f) as fh:
-                best = json.load(fh).get("hbm_bytes_per_launch")
-    return best
+                best, src = json.load(fh).get("hbm_bytes_per_launch"), "profiles/%s/hbm_traffic.json" % name
+    return best, src
 
 
 def cpu_baseline(X, W, lr, budget_s=12.0):
     """Time the CPU oracle (restatement of the reference, same ATen ops) on the host
     cores of this box on a bounded sample of the same workload."""
+    import torch
     from oracle import lasso_oracle as orc
     z0 = X.new_zeros(X.shape[0], K)
     # pick the thread count that is fastest on this host (ATen's elementwise passes stop
@@ -87,109 +107,315 @@ def cpu_baseline(X, W, lr, budget_s=12.0):
                       "os.cpu_count()=%s, %s" % (iters, X.shape[0], D, K, os.cpu_count(), model)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--iters", type=int, default=100, help="FISTA iterations per step (solve)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-time-to-tol", action="store_true")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------
+# launcher
+# --------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: run the N ranks through torch.distributed.run on
+    127.0.0.1 (the same command line the driver uses) and relay rank 0's JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def world_from_env(args):
+    """(rank, local_rank, world); exits non-zero when the launcher and --gpus disagree."""
+    if "WORLD_SIZE" not in os.environ:
+        return 0, 0, 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    return rank, local_rank, world
 
+
+class Ranks:
+    """barrier + max-over-ranks timing, on RCCL ('nccl') or -- launcher self-test -- gloo."""
+
+    def __init__(self, rank, world, device, backend):
+        self.rank, self.world, self.device, self.dist = rank, world, device, None
+        if world > 1:
+            import torch.distributed as dist
+            kw = {"device_id": device} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            self.dist = dist
+
+    def sync(self):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+    def max(self, seconds):
+        import torch
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ranks, step, steps, warmup, events=True):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both
+    sides; returns (max-over-ranks seconds, sorted per-step device ms on this rank)."""
+    import torch
+    for _ in range(warmup):
+        step()
+    ranks.sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(steps)] if events else []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if events:
+            ev[i][0].record()
+        step()
+        if events:
+            ev[i][1].record()
+    ranks.sync()
+    elapsed = ranks.max(time.perf_counter() - t0)
+    return elapsed, sorted(s.elapsed_time(e) for s, e in ev)
+
+
+# --------------------------------------------------------------------------------------
+# workloads
+# --------------------------------------------------------------------------------------
+def run_fista(args, ranks):
+    import torch
     from lasso_amd.linear.solvers import ista
-
-    X_all, W = recipe(N_ROWS * world)
-    X = X_all[rank * N_ROWS:(rank + 1) * N_ROWS]
-    Xg, Wg = X.to(dev), W.to(dev)
-    z0 = torch.zeros(N_ROWS, K, device=dev)
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
     lr = 1.0 / LAMBDA_MAX
 
-    def solve():
-        return ista(Xg, z0, Wg, ALPHA, fast=True, lr=lr, maxiter=args.iters, tol=0.0)
+    def shard_solver(n_total, rows):
+        X_all, W = recipe(n_total)
+        X = X_all[rank * rows:(rank + 1) * rows]
+        Xg, Wg = X.to(dev), W.to(dev)
+        z0 = torch.zeros(rows, K, device=dev)
+        return X, W, Xg, Wg, z0, (lambda: ista(Xg, z0, Wg, ALPHA, fast=True, lr=lr, maxiter=args.iters, tol=0.0))
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def kernel_name(rows):
+        from lasso_amd import _native as nat
+        return nat.lib().lasso_fista_kernel_name(rows, D, K, nat.LASSO_F32, 0).decode()
 
-    for _ in range(args.warmup):
-        solve()
-    sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        z = solve()
-        e.record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    avg_launch_ms = sum(kern_ms) / len(kern_ms)
-
+    results = {}
+    modes = ["strong"] if world == 1 else ["strong", "weak"]
+    for mode in modes:
+        rows = N_ROWS // world if mode == "strong" else N_ROWS
+        if mode == "strong" and N_ROWS % world:
+            raise SystemExit("bench.py: %d rows do not split over %d ranks" % (N_ROWS, world))
+        X, W, Xg, Wg, z0, solve = shard_solver(rows * world, rows)
+        elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
+        results[mode] = dict(rows=rows, elapsed=elapsed, kern_ms=kern_ms, X=X, W=W, Xg=Xg, Wg=Wg, z0=z0,
+                             z=solve())
+    main_mode = args.scaling if world > 1 else "strong"
+    r = results[main_mode]
     out = None
     if rank == 0:
-        flop_per_launch = 4.0 * N_ROWS * D * K * args.iters
+        def line(mode):
+            q = results[mode]
+            batches = world if mode == "weak" else 1
+            return batches * args.steps * args.iters / q["elapsed"]
+        avg_launch_ms = sum(r["kern_ms"]) / len(r["kern_ms"])
+        flop_per_launch = 4.0 * r["rows"] * D * K * args.iters          # this rank's launch
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
-        total_iters = world * args.steps * args.iters
+        traffic, traffic_src = hbm_traffic_from_profiles()
         out = {
-            "metric": "fista_iterations_per_sec (n=4096 d=256 k=1024 fp32 per GPU, fixed L, tol=0)",
-            "value": total_iters / elapsed,
+            "metric": "fista_iterations_per_sec (n=4096 d=256 k=1024 fp32, fixed L, tol=0)",
+            "value": line(main_mode),
             "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * r["elapsed"] / args.steps,
+            "higher_is_better": True, "scaling": main_mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: FISTA n=4096 d=256 k=1024 fp32, fixed L, "
                                    "no backtrack; step = one solve of %d iterations" % args.iters,
-                       "iters_per_step": args.iters, "rows_per_gpu": N_ROWS,
+                       "iters_per_step": args.iters, "rows_per_gpu": r["rows"],
+                       "rows_total": r["rows"] * world,
                        "parallelism": "row-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": hbm_traffic_from_profiles(),
-                         "kernel": "lasso::sp::fista_tile_sp_kernel<1024, false>",
-                         "flop_per_launch": flop_per_launch,
-                         "avg_launch_ms": avg_launch_ms, "median_launch_ms": kern_ms[len(kern_ms) // 2]},
+                         "traffic": traffic if world == 1 else None,
+                         "traffic_source": (traffic_src + " (rocprofv3 PMC pass of this command; "
+                                            "not collected in this run)") if traffic_src and world == 1 else None,
+                         "kernel": kernel_name(r["rows"]),
+                         "flop_per_launch": flop_per_launch, "per": "GPU (rank 0)",
+                         "avg_launch_ms": avg_launch_ms,
+                         "median_launch_ms": r["kern_ms"][len(r["kern_ms"]) // 2]},
         }
+        if world > 1:
+            other = "weak" if main_mode == "strong" else "strong"
+            q = results[other]
+            out[other + "_scaling"] = {"value": line(other), "unit": "iterations/s", "rows_per_gpu": q["rows"],
+                                       "rows_total": q["rows"] * world,
+                                       "ms_per_step": 1e3 * q["elapsed"] / args.steps}
         if not args.no_time_to_tol:
+            # time-to-tol of THIS rank's shard with the reference's global rule on the shard
+            Xg, Wg, z0 = r["Xg"], r["Wg"], r["z0"]
             ista(Xg, z0, Wg, ALPHA, lr=lr, maxiter=2000, tol=1e-5)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             _, info = ista(Xg, z0, Wg, ALPHA, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
             torch.cuda.synchronize()
             out["time_to_tol"] = {"ms": 1e3 * (time.perf_counter() - t1),
-                                  "iterations": info["iterations"], "tol": 1e-5,
-                                  "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), exact global"}
+                                  "iterations": info["iterations"], "tol": 1e-5, "rows": r["rows"],
+                                  "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), exact global over the "
+                                          "rows of rank 0"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X, W, lr)
+            out["cpu_baseline"] = cpu_baseline(r["X"], r["W"], lr)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        # cheap sanity: objective of the result (HIP lasso_loss) next to the reference's known answer
-        if args.iters == 100:
-            from lasso_amd.linear import lasso_loss
-            obj = lasso_loss(Xg, z, Wg, ALPHA).item()
+    # objective of the timed result (HIP lasso_loss) against the reference's known answer; the
+    # whole 4096-row batch when it is sharded (strong): sums all-reduced
+    if args.iters == 100:
+        from lasso_amd.engine import HipEngine
+        q = results["strong"]
+        _, sums = HipEngine(dev).objective_sums(q["Xg"], q["z"], q["Wg"], ALPHA)
+        if ranks.dist is not None:
+            ranks.dist.all_reduce(sums)
+        obj = ((0.5 * sums[0] + ALPHA * sums[1]) / N_ROWS).item()
+        if rank == 0:
             out["objective_after_100"] = obj
-            out["objective_reference"] = 63.609337
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["objective_reference"] = OBJ_REF_100
+            if abs(obj - OBJ_REF_100) > OBJ_RTOL * OBJ_REF_100:
+                print(json.dumps(out))
+                raise SystemExit("bench.py: objective after 100 iterations %.6f differs from the reference's "
+                                 "%.6f by more than rtol %g -- the timed kernel is wrong" % (obj, OBJ_REF_100, OBJ_RTOL))
+    return out
+
+
+def run_em(args, ranks):
+    """BASELINE config 4: one EM step = E-step (FISTA, reference defaults) + objective + Gram +
+    all-reduce + atom sweep on n=65536 rows sharded over the ranks."""
+    import torch
+    from lasso_amd.engine import HipEngine
+    from lasso_amd import parallel
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from recipes import recipe_c4_init
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    if N_EM % world:
+        raise SystemExit("bench.py: %d rows do not split over %d ranks" % (N_EM, world))
+    rows = N_EM // world
+    X_all, _ = recipe(N_EM)
+    Xg = X_all[rank * rows:(rank + 1) * rows].to(dev)
+    eng = HipEngine(dev)
+    state = {"D": recipe_c4_init().to(dev)}
+    comm_ms = []
+    real_all_reduce = parallel._all_reduce
+
+    def timed_all_reduce(t, group):        # the collective of the M-step, timed on the device
+        if ranks.dist is None or t.numel() < 1024:
+            return real_all_reduce(t, group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_all_reduce(t, group)
+        e1.record()
+        comm_ms.append((e0, e1))
+        return t
+    parallel._all_reduce = timed_all_reduce
+
+    def em(steps):
+        state["D"], state["loss"] = parallel.em_loop(eng, Xg, state["D"], ALPHA, constrained=True, steps=steps,
+                                                     solver_kwargs=dict(algorithm="ista"))
+    if args.warmup:
+        em(args.warmup)
+    ranks.sync()
+    del comm_ms[:]
+    t0 = time.perf_counter()
+    em(args.steps)                     # exactly K EM steps between the two barriers
+    ranks.sync()
+    elapsed = ranks.max(time.perf_counter() - t0)
+    out = None
+    if rank == 0:
+        ar = sorted(a.elapsed_time(b) for a, b in comm_ms[-args.steps:]) if comm_ms else []
+        # E-step flops dominate: 10 iterations x 4 n d k per rank, + Gram 2nk^2 + 2nkd + objective 2ndk
+        flop = (10 * 4.0 + 2.0 + 2.0) * rows * D * K + 2.0 * rows * K * K
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "dict_learning_em_steps_per_sec (n=65536 d=256 k=1024 fp32, constrained, defaults)",
+            "value": args.steps / elapsed, "unit": "EM steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: dict_learning EM step, n=65536 d=256 k=1024, FISTA E-step "
+                                   "(lr='auto', maxiter=10, tol=1e-5) + constrained M-step",
+                       "rows_per_gpu": rows, "rows_total": N_EM,
+                       "parallelism": "row-sharded x%d, one all-reduce of [A|B|sums] per step" % world},
+            "all_reduce_ms": {"median": ar[len(ar) // 2] if ar else 0.0, "max": ar[-1] if ar else 0.0,
+                              "bytes": 4 * (K * K + K * D + 2), "note": "device time of the one RCCL all-reduce per "
+                              "EM step (0 at N=1: no collective)"},
+            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel": "whole EM step (E-step kernel dominates)",
+                         "flop_per_launch": flop, "per": "GPU (rank 0)"},
+            "objective_last_step": float(state["loss"][-1]),
+        }
+    return out
+
+
+def run_launcher_selftest(args, ranks):
+    """No compute: the launcher / barrier / max-over-ranks protocol only (CPU, gloo)."""
+    def step():
+        time.sleep(0.002 * (ranks.rank + 1))
+    elapsed, _ = timed_steps(ranks, step, args.steps, args.warmup, events=False)
+    if ranks.rank != 0:
+        return None
+    return {"metric": "launcher_selftest", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": ranks.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+            "config": {"workload": "launcher self-test (no kernel)"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=100, help="FISTA iterations per step (solve)")
+    ap.add_argument("--workload", choices=["fista", "em", "launcher-selftest"], default="fista")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="which figure is `value` at N > 1 (both are measured and reported)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-tol", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    selftest = args.workload == "launcher-selftest"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not selftest:
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible -- one process per GPU, "
+                                 "ranks cannot share a device" % (args.gpus, have))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank, local_rank, world = world_from_env(args)
+    import torch
+    if selftest:
+        ranks = Ranks(rank, world, torch.device("cpu"), "gloo")
+        out = run_launcher_selftest(args, ranks)
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        ranks = Ranks(rank, world, torch.device("cuda", local_rank), "nccl")
+        out = run_em(args, ranks) if args.workload == "em" else run_fista(args, ranks)
+    ranks.close()
     if rank == 0:
         print(json.dumps(out))
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LASSO_HIP_ABI_VERSION 1
+#define LASSO_HIP_ABI_VERSION 2
 
 typedef enum {
   LASSO_OK = 0,
@@ -52,7 +52,12 @@ typedef enum { LASSO_F32 = 0, LASSO_BF16 = 1 } lasso_dtype;
 /* How the global stopping rule of ista.py:93 is evaluated. */
 typedef enum {
   LASSO_STOP_GLOBAL = 0,  /* exact reference rule: sum over the whole batch <= n*k*tol */
-  LASSO_STOP_NONE = 1     /* run exactly maxiter iterations (same as tol = 0)          */
+  LASSO_STOP_NONE = 1,    /* run exactly maxiter iterations (same as tol = 0)          */
+  LASSO_STOP_GLOBAL_CHUNKED = 2  /* the same exact rule, but always evaluated by the
+                             chunked speculate-and-replay path (no in-kernel handshake
+                             between workgroups): for callers that share the GPU with
+                             other streams / processes; LASSO_STOP_GLOBAL falls back to
+                             it by itself when its workgroups are not all resident      */
 } lasso_stop_mode;
 
 int lasso_hip_abi_version(void);
@@ -73,6 +78,13 @@ int lasso_hip_device_cus(int* cus_out);
  *   evaluate the global stop rule exactly (speculate-and-replay).
  *   iters_out / last_delta_out (HOST pointers, nullable): iterations executed and
  *   the last evaluated sum|z - z_next| (only when the stop rule is active).
+ *   trials_out / accepted_lr_out (HOST arrays of `maxiter` entries, nullable; written
+ *   for the executed iterations when backtrack != 0): the number of line-search trials
+ *   evaluated up to and including the accepted one, and the step size the iteration
+ *   used -- the quantities ista.py:43-47 prints with verbose=True.
+ *   objective_out (HOST float, nullable): mean objective (0.5*||x - z W^T||^2 +
+ *   alpha*||z||_1)/n of the returned code, evaluated in fp32 (dict_learning.py:10-13,
+ *   ista.py:66-69); synchronises `stream`.
  *   x, W, z0 are never written; z_out may alias z0.
  *   backtrack != 0: Beck-Teboulle backtracking line search (ista.py:17-54) from lr
  *   every outer iteration (the accepted step is discarded, ista.py:87), eta_backtrack
@@ -83,6 +95,9 @@ int lasso_hip_device_cus(int* cus_out);
  */
 size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
                                    int maxiter, double tol, int stop_mode, int backtrack);
+/* Name of the device kernel lasso_fista_solve dispatches this problem to on the current
+ * device (the name rocprofv3 --kernel-trace reports; for benchmark / profile bookkeeping). */
+const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, int backtrack);
 
 int lasso_fista_solve(const void* x_dev, int64_t ldx,
                       const void* w_dev, int64_t ldw,
@@ -93,18 +108,23 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx,
                       double tol, int stop_mode,
                       int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out,
+                      int32_t* trials_out, float* accepted_lr_out, float* objective_out,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- building blocks for multi-GPU / custom drivers ---------------------------------
  * lasso_fista_prepare packs W into the padded layouts the kernels stream
- * (W [256][Kp] and W^T [Kp][256]) at the start of `workspace_dev`.
- * lasso_fista_run executes `iters` iterations numbered it0 .. it0+iters-1 of the
+ * (W [256][Kp] and W^T [Kp][256]) at the start of `workspace_dev` and builds the
+ * momentum table of iterations 0 .. maxiter-1 (ista.py:98-99) behind them; the
+ * workspace is sized by lasso_fista_workspace_bytes(n, d, k, dtype, maxiter, 0,
+ * LASSO_STOP_NONE, 0) with n = the largest batch it will be used with.
+ * lasso_fista_run executes `iters` iterations numbered it0 .. it0+iters-1 (< maxiter, the
+ * value given to prepare) of the
  * momentum schedule from state (z_in, y_in) to (z_out, y_out) and writes
  * delta_dev[i] = sum over THIS shard of |z - z_next| for each executed iteration
  * (device array of `iters` floats, nullable).  No host synchronisation.
  * y_in_dev == NULL means y = z_in (start of a solve); y_out_dev may be NULL.
  */
-int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype,
+int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype, int maxiter,
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
 int lasso_fista_run(const void* x_dev, int64_t ldx,
@@ -113,7 +133,7 @@ int lasso_fista_run(const void* x_dev, int64_t ldx,
                     void* z_out_dev, int64_t ldz_out,
                     void* y_out_dev, int64_t ldy_out,
                     int64_t n, int64_t d, int64_t k, int dtype,
-                    double alpha, double lr, int fast, int it0, int iters,
+                    double alpha, double lr, int fast, int it0, int iters, int maxiter,
                     float* delta_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
@@ -153,6 +173,12 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
  *   N(0,1) vector keyed by (seed, atom).  degenerate_dev [k] (int32, device) is set to
  *   1 for those atoms; ndeg_out (HOST, nullable) receives their count and, when
  *   non-NULL, makes the call synchronise `stream`.
+ * lasso_dict_fill_degenerate: deferred form of that replacement for drivers that want to
+ *   draw directions only when an atom actually degenerated (the sweep never READS a
+ *   replacement -- the degenerate atom leaves the model): call lasso_dict_sweep with
+ *   pool_dev == NULL, and if ndeg > 0 draw ndeg directions [ndeg][d] and pass them here;
+ *   the i-th flagged atom (atom order) becomes pool row i, clamped at 0 if `positive`,
+ *   normalised (:93-96).
  * lasso_zero_columns: Z[:, j] = 0 where degenerate_dev[j] != 0 (:98).
  */
 size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k);
@@ -166,6 +192,9 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
                      const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
                      int32_t* degenerate_dev, int32_t* ndeg_out,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
+int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
+                               const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
+                               int64_t pool_ld, int positive, void* stream);
 int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
                        const int32_t* degenerate_dev, void* stream);
 

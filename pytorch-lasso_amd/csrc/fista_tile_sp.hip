@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
 
-    bool stopped = false;
+    bool stopped = false, aborted = false;
     for (int it = 0; it < p.iters; ++it) {
       const float coef = p.coef[it];
       float dsum = 0.0f;
@@ -186,13 +186,22 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
               part += __uint_as_float((unsigned)gr[e]);
             }
           ok = __all(ok);
-          if (!ok) __builtin_amdgcn_s_sleep(8);
-        } while (!ok && ++spins < (1 << 22));
+          if (!ok) {
+            __builtin_amdgcn_s_sleep(8);
+            // another workgroup gave up (it is not co-resident with the rest): leave at once
+            if ((spins & 63) == 63 &&
+                __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+              break;
+          }
+        } while (!ok && ++spins < kStopSpinLimit);
         const float total = wave_sum(part);
         if (lane == 0) {
-          red[NW] = (ok && total <= p.stop_budget) ? 1.0f : 0.0f;        // ista.py:93
+          // red[NW]: 0 = go on, 1 = iteration it-1 met the rule (ista.py:93), 2 = handshake
+          // timed out -- some workgroup of the grid is not resident; EVERY workgroup aborts
+          // and the host repeats the solve on the chunked path (lasso_hip.hip)
+          red[NW] = !ok ? 2.0f : (total <= p.stop_budget ? 1.0f : 0.0f);
           red[NW + 1] = total;
-          if (!ok && blockIdx.x == 0) p.stop_out[2] = 1;
+          if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       // r tile -> LDS, everyone reads all of it
@@ -205,7 +214,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       __builtin_amdgcn_s_barrier();
       LASSO_DESYNC();
       if (STOP && check && red[NW] != 0.0f) {      // iteration it-1 met the stop rule: z (registers) is its z_next
-        if (blockIdx.x == 0 && tid == 0) {
+        aborted = red[NW] == 2.0f;
+        if (blockIdx.x == 0 && tid == 0 && !aborted) {
           p.stop_out[0] = it;
           p.stop_out[1] = __float_as_int(red[NW + 1]);
         }
@@ -324,14 +334,15 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         }
         ok = __all(ok);
         if (!ok) __builtin_amdgcn_s_sleep(8);
-      } while (!ok && ++spins < (1 << 22));
+      } while (!ok && ++spins < kStopSpinLimit);
       const float total = wave_sum(part);
       if (lane == 0) {
         p.stop_out[0] = p.iters;
         p.stop_out[1] = __float_as_int(total);
-        if (!ok) p.stop_out[2] = 1;
+        if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    if (STOP && aborted) break;     // z_out untouched: the host re-runs the solve
 
     {
       int no = n, qo = q;
@@ -372,11 +383,37 @@ static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stre
 }
 
 template <int K, int M>
+static hipError_t occupancy_k(int* blocks_per_cu) {
+  const size_t lds = (size_t)M * K * 4 + (size_t)M * (4096 / M) * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
+  const void* fn = reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, true>);
+  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kFistaThreads, lds);
+}
+
+template <int K, int M>
 static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
   return p.stop_on ? launch_ks<K, M, true>(p, grid, stream) : launch_ks<K, M, false>(p, grid, stream);
 }
 
 }  // namespace sp
+
+hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu) {
+  if (dpad == 256) {
+    switch (kpad) {
+      case 256: return sp::occupancy_k<256, 16>(blocks_per_cu);
+      case 512: return sp::occupancy_k<512, 16>(blocks_per_cu);
+      case 1024: return sp::occupancy_k<1024, 16>(blocks_per_cu);
+    }
+  } else if (dpad == 128) {
+    switch (kpad) {
+      case 256: return sp::occupancy_k<256, 32>(blocks_per_cu);
+      case 512: return sp::occupancy_k<512, 32>(blocks_per_cu);
+    }
+  } else if (dpad == 64) {
+    if (kpad == 256) return sp::occupancy_k<256, 64>(blocks_per_cu);
+  }
+  return hipErrorInvalidValue;
+}
 
 // rows per tile for a padded feature count (256 -> 16, 128 -> 32, 64 -> 64)
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream) {

@@ -153,6 +153,13 @@ int device_cus() {
 
 bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
 
+// workgroups of the fused kernel that can be resident at once (occupancy query x CUs)
+int fista_resident_workgroups(int kp, int dpad) {
+  int per_cu = 0;
+  if (fista_tile_sp_occupancy(kp, dpad, &per_cu) != hipSuccess) return 0;
+  return per_cu * device_cus();
+}
+
 int pad_d(int64_t d, int kp) {
   if (d <= 64 && kp <= 256) return 64;
   if (d <= 128 && kp <= 512) return 128;
@@ -264,8 +271,8 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
 int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_t ldw, const void* z0_any,
                        int64_t ldz0, void* zout_any, int64_t ldz_any, int64_t n, int64_t d, int64_t k, int kp,
                        int dtype, double alpha, double lr0, int fast, int maxiter, double tol, double eta,
-                       int32_t* iters_out, float* last_delta_out, void* workspace, size_t ws_bytes,
-                       hipStream_t st) {
+                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
+                       void* workspace, size_t ws_bytes, hipStream_t st) {
   const bool half = dtype == LASSO_BF16;      // bf16 tensors: bt_bf16.hip kernels, 64-row tiles
   BtWorkspace ws = carve_bt(workspace, n, k, kp, half);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
@@ -307,7 +314,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   const float budget = (float)((double)n * (double)k * tol);
   bool warned = false;
   double t_mom = 1.0;   // ista.py:78 (python int 1; same arithmetic in double)
-  struct { int flags[4]; float delta; } host;
+  struct { int flags[4]; float fvals[4]; float delta; } host;
   int it = 0, prev_trials = kBtBatch - 1;
   float last = NAN;
   for (; it < maxiter; ++it) {
@@ -350,10 +357,14 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       LASSO_HIP_TRY(hipGetLastError());
       LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipMemcpyAsync(&host.delta, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+      if (accepted_lr_out)
+        LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
       accepted = host.flags[0] != 0;
     }
     prev_trials = host.flags[2] + 1;
+    if (trials_out) trials_out[it] = host.flags[2] + 1;            // trials evaluated up to the accepted one
+    if (accepted_lr_out) accepted_lr_out[it] = host.fvals[2];      // the step the iteration used (ista.py:40,52)
     last = host.delta;
     t_mom = t_next;
     if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95
@@ -624,40 +635,67 @@ int lasso_hip_device_cus(int* cus_out) {
   return c > 0 ? LASSO_OK : fail(LASSO_ERR_HIP, "no HIP device visible");
 }
 
-size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
-                                   double tol, int stop_mode, int backtrack) {
-  (void)dtype;
-  if (n < 0 || d <= 0 || k <= 0) return 0;
+// bytes of the solver's own workspace (the objective_out region follows it)
+static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                                     int stop_mode, int backtrack) {
   if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
   if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16).bytes;
-  const bool with_state = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL && maxiter > 0;
+  const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
 }
 
-int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype,
+// region behind the solver's workspace that objective_out needs: the lasso_objective workspace,
+// a device float, and -- bf16 tensors -- fp32 copies of x, W and z
+static size_t objective_region_bytes(int64_t n, int64_t d, int64_t k, int dtype) {
+  size_t b = align_up(lasso_objective_workspace_bytes(n, d, k)) + 256;
+  if (dtype == LASSO_BF16)
+    b += align_up((size_t)n * d * 4) + align_up((size_t)d * k * 4) + align_up((size_t)n * k * 4);
+  return b;
+}
+
+const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, int backtrack) {
+  if (n <= 0 || d <= 0 || k <= 0) return "";
+  if (!fused_shape(d, k)) return "lasso::gemm_nt_kernel x2 + lasso::generic_prox_kernel (unfused)";
+  if (backtrack) return dtype == LASSO_BF16 ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt_grad_kernel / bt_trial_kernel";
+  if (dtype == LASSO_BF16) return "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
+  const int kp = pad_k(k), dpad = pad_d(d, kp);
+  switch (dpad) {
+    case 256: return kp == 1024 ? "lasso::sp::fista_tile_sp_kernel<1024, 16, false>"
+                   : kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 16, false>"
+                               : "lasso::sp::fista_tile_sp_kernel<256, 16, false>";
+    case 128: return kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 32, false>"
+                               : "lasso::sp::fista_tile_sp_kernel<256, 32, false>";
+    default: return "lasso::sp::fista_tile_sp_kernel<256, 64, false>";
+  }
+}
+
+size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
+                                   double tol, int stop_mode, int backtrack) {
+  if (n < 0 || d <= 0 || k <= 0) return 0;
+  const size_t solver = solver_workspace_bytes(n, d, k, dtype, maxiter, tol, stop_mode, backtrack);
+  if (solver == 0) return 0;
+  return align_up(solver) + objective_region_bytes(n, d, k, dtype);
+}
+
+int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype, int maxiter,
                         void* workspace_dev, size_t workspace_bytes, void* stream) {
-  // coefficient-table capacity is whatever fits: derive it from the workspace size the
-  // caller obtained from lasso_fista_workspace_bytes(n=.., maxiter=..): we cannot know
-  // maxiter here, so prepare() only packs W; lasso_fista_run() (re)builds the table.
+  // packs W and builds the momentum table for iterations 0 .. maxiter-1 (the workspace must
+  // come from lasso_fista_workspace_bytes with the same maxiter)
   if (int s = check_common(0, d, k, dtype)) return s;
   if (!w_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
-  if (ldw < k) return fail(LASSO_ERR_BAD_ARG, "ldw < k");
+  if (ldw < k || maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "ldw < k or maxiter < 0");
   const int kp = pad_k(k);
-  Workspace ws = carve(workspace_dev, 0, k, kp, 0, false);
+  Workspace ws = carve(workspace_dev, 0, k, kp, maxiter, false);
   if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
-  const int dpad = pad_d(d, kp);
-  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0,
-                     (hipStream_t)stream, (const float*)w_dev, ldw, (int)d, (int)k, kp, ws.wp, ws.wtp, dpad);
-  LASSO_HIP_TRY(hipGetLastError());
-  return LASSO_OK;
+  return prepare_impl(ws, kp, (const float*)w_dev, ldw, d, k, maxiter, (hipStream_t)stream);
 }
 
 int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_t ldz_in,
                     const void* y_in_dev, int64_t ldy_in, void* z_out_dev, int64_t ldz_out,
                     void* y_out_dev, int64_t ldy_out, int64_t n, int64_t d, int64_t k, int dtype,
-                    double alpha, double lr, int fast, int it0, int iters, float* delta_dev,
+                    double alpha, double lr, int fast, int it0, int iters, int maxiter, float* delta_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (int s = check_common(n, d, k, dtype)) return s;
   if (!x_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
@@ -668,23 +706,22 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
       (y_out_dev && ldy_out < k))
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   const int kp = pad_k(k);
-  const int cap = it0 + iters;
-  Workspace ws = carve(workspace_dev, n, k, kp, cap, false);
+  if (it0 + iters > maxiter) return fail(LASSO_ERR_BAD_ARG, "it0 + iters = %d > maxiter = %d", it0 + iters, maxiter);
+  // same carve as lasso_fista_prepare(maxiter): the momentum table it built is read here
+  Workspace ws = carve(workspace_dev, n, k, kp, maxiter, false);
   if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, st, ws.coef, ws.zeros,
-                     std::max(cap, 1));
-  LASSO_HIP_TRY(hipGetLastError());
   return run_impl(ws, kp, (const float*)x_dev, ldx, (const float*)z_in_dev, ldz_in,
                   (const float*)y_in_dev, ldy_in, (float*)z_out_dev, ldz_out, (float*)y_out_dev,
                   ldy_out, n, d, k, alpha, lr, fast, it0, iters, delta_dev, st);
 }
 
-int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
                       const void* z0_dev, int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n,
                       int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
-                      int32_t* iters_out, float* last_delta_out, void* workspace_dev,
+                      int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
+                      float* accepted_lr_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
@@ -717,7 +754,9 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return LASSO_OK;
   }
 
-  const bool stop_rule = tol > 0.0 && stop_mode == LASSO_STOP_GLOBAL;
+  if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
+    return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
+  const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
   if (!fused_shape(d, k))
     return solve_generic(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
@@ -732,7 +771,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return solve_backtracking(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp,
                               half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,
                               stop_rule ? tol : 0.0, eta_backtrack,
-                              iters_out, last_delta_out, workspace_dev, workspace_bytes, st);
+                              iters_out, last_delta_out, trials_out, accepted_lr_out, workspace_dev,
+                              workspace_bytes, st);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
     return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
@@ -750,35 +790,40 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // ---- exact global stop rule, in-kernel: when every tile has its own resident workgroup
   // the persistent kernel evaluates the rule itself (one-iteration lag) and a
   // single launch runs to the stopping iteration -- one host sync, at the end. ------------
-  {
+  const float* cur_z = z0;  int64_t cur_ldz = ldz0;
+  const float* cur_y = nullptr; int64_t cur_ldy = 0;
+  if (z0 && z0 == zout) {     // aliasing: keep the initial state intact for a replay / a second attempt
+    LASSO_HIP_TRY(hipMemcpy2DAsync(ws.state[2], k * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+    cur_z = ws.state[2]; cur_ldz = k;
+  }
+  if (stop_mode == LASSO_STOP_GLOBAL) {
     const int tile_rows = 4096 / pad_d(d, kp);
     const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
-    const int cus = device_cus();
-    if (ntiles <= cus && !getenv("LASSO_STOP_CHUNKED")) {
+    // The handshake needs every workgroup of the grid resident at once: one workgroup per CU
+    // (LDS-bound), so the grid must not exceed what the occupancy query admits.  CUs held by
+    // OTHER work (a second stream, another process) are invisible to that query: then the
+    // handshake times out, the kernel aborts as a whole without touching z_out, and the solve
+    // is repeated on the chunked path below.
+    if (ntiles <= fista_resident_workgroups(kp, pad_d(d, kp))) {
       LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * ntiles * 8, st));
       LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
-      if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
+      if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                            alpha, lr, fast, 0, maxiter, nullptr, st, budget))
         return s;
       int hout[4] = {0, 0, 0, 0};
       LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
-      if (hout[2]) return fail(LASSO_ERR_HIP, "in-kernel stop rule: granule handshake timed out");
-      float lastf;
-      memcpy(&lastf, &hout[1], sizeof(float));
-      if (iters_out) *iters_out = hout[0];
-      if (last_delta_out) *last_delta_out = lastf;
-      return LASSO_OK;
+      if (!hout[2]) {
+        float lastf;
+        memcpy(&lastf, &hout[1], sizeof(float));
+        if (iters_out) *iters_out = hout[0];
+        if (last_delta_out) *last_delta_out = lastf;
+        return LASSO_OK;
+      }
     }
   }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
   // replay the chunk up to the stopping iteration if one fired ----------
-  const float* cur_z = z0;  int64_t cur_ldz = ldz0;
-  const float* cur_y = nullptr; int64_t cur_ldy = 0;
-  if (z0 && z0 == zout) {     // aliasing: keep the initial state intact for a replay
-    LASSO_HIP_TRY(hipMemcpy2DAsync(ws.state[2], k * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
-    cur_z = ws.state[2]; cur_ldz = k;
-  }
   int done = 0, flip = 0;
   std::vector<float> hdelta(kChunkMax);
   float last = NAN;
@@ -841,6 +886,52 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   if (iters_out) *iters_out = done;
   if (last_delta_out) *last_delta_out = last;
   return LASSO_OK;
+}
+
+int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                      const void* z0_dev, int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n,
+                      int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
+                      int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
+                      int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
+                      float* accepted_lr_out, float* objective_out, void* workspace_dev,
+                      size_t workspace_bytes, void* stream) {
+  if (objective_out) *objective_out = NAN;
+  const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
+                                fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
+                                last_delta_out, trials_out, accepted_lr_out, workspace_dev, workspace_bytes,
+                                stream);
+  if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
+  // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
+  // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
+  char saved[sizeof(g_err)];
+  memcpy(saved, g_err, sizeof(saved));          // keep the line-search warning text
+  const size_t solver = align_up(solver_workspace_bytes(n, d, k, dtype, maxiter, tol, stop_mode, backtrack));
+  if (!workspace_dev || workspace_bytes < solver + objective_region_bytes(n, d, k, dtype))
+    return fail(LASSO_ERR_WORKSPACE, "objective_out: workspace %zu < %zu bytes", workspace_bytes,
+                solver + objective_region_bytes(n, d, k, dtype));
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace_dev + solver;
+  float* loss_dev = (float*)base;
+  char* obj_ws = base + 256;
+  const size_t obj_bytes = align_up(lasso_objective_workspace_bytes(n, d, k));
+  const void* xo = x_dev; const void* wo = w_dev; const void* zo = z_out_dev;
+  int64_t ldxo = ldx, ldwo = ldw, ldzo = ldz;
+  if (dtype == LASSO_BF16) {
+    float* xf = (float*)(obj_ws + obj_bytes);
+    float* wf = (float*)((char*)xf + align_up((size_t)n * d * 4));
+    float* zf = (float*)((char*)wf + align_up((size_t)d * k * 4));
+    LASSO_HIP_TRY(launch_cvt_bf16(x_dev, ldx, xf, d, (int)n, (int)d, 1, st));
+    LASSO_HIP_TRY(launch_cvt_bf16(w_dev, ldw, wf, k, (int)d, (int)k, 1, st));
+    LASSO_HIP_TRY(launch_cvt_bf16(z_out_dev, ldz, zf, k, (int)n, (int)k, 1, st));
+    xo = xf; wo = wf; zo = zf; ldxo = d; ldwo = k; ldzo = k;
+  }
+  if (int s2 = lasso_objective(xo, ldxo, wo, ldwo, zo, ldzo, n, d, k, LASSO_F32, alpha, loss_dev, nullptr, obj_ws,
+                               obj_bytes, stream))
+    return s2;
+  LASSO_HIP_TRY(hipMemcpyAsync(objective_out, loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+  LASSO_HIP_TRY(hipStreamSynchronize(st));
+  memcpy(g_err, saved, sizeof(saved));
+  return status;
 }
 
 // ---------------------------------------------------------------------------
@@ -994,6 +1085,17 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
   }
+  return LASSO_OK;
+}
+
+int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
+                               const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
+                               int64_t pool_ld, int positive, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!d_dev || !degenerate_dev || !pool_dev || d <= 0 || k <= 0 || ldd < k || pool_rows <= 0 || pool_ld < d)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  LASSO_HIP_TRY(launch_fill_degenerate((float*)d_dev, ldd, (int)d, (int)k, degenerate_dev, pool_dev, (int)pool_rows,
+                                       pool_ld, positive, (hipStream_t)stream));
   return LASSO_OK;
 }
 

@@ -29,11 +29,16 @@ struct FistaTileParams {
   float lr, lam;                         // step size, alpha*lr
   // in-kernel exact global stop rule (fista_tile_sp.hip; needs gridDim.x == ntiles):
   unsigned long long* stop_gran;         // [kStopRing][ntiles] {tag = it+1, |dz| partial} granules, zeroed per solve
-  int* stop_out;                         // [0] iterations executed, [1] last delta (float bits), [2] error
+  int* stop_out;                         // [0] iterations executed, [1] last delta (float bits), [2] abort flag
   float stop_budget;                     // n*k*tol (ista.py:64)
   int stop_on;
 };
 constexpr int kStopRing = 64;
+// Bound of every in-kernel handshake spin (one poll = a few L2 round trips + s_sleep, roughly
+// a microsecond): ~0.1 s, far beyond any skew between co-resident workgroups.  Hitting it
+// means part of the grid is not resident (CUs held by another stream / process); the kernels
+// then abort as a whole and the host repeats the solve on a path without handshakes.
+constexpr int kStopSpinLimit = 1 << 17;
 
 // lasso_loss tile kernel (objective.hip)
 struct ObjectiveParams {
@@ -98,6 +103,8 @@ struct ConvGeom {
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
+// workgroups of the stop-rule instantiation the occupancy query admits per CU
+hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);
@@ -142,6 +149,8 @@ hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStre
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+hipError_t launch_fill_degenerate(float* D, int64_t ldd, int d, int k, const int* degenerate, const float* pool,
+                                  int pool_rows, int64_t pool_ld, int positive, hipStream_t stream);
 hipError_t launch_bw_prox(float* zb_next, float* zb_cur, const float* yb, const float* z_next, float* ub, float* gb,
                           int64_t total, float c, float lr, hipStream_t stream);
 hipError_t launch_bw_point(const float* z, const float* z_prev, float* y, int64_t total, float c, hipStream_t stream);

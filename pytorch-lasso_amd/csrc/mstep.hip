@@ -304,6 +304,42 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
   }
 }
 
+// Deferred form of the replacement (multi-GPU driver): the sweep never reads a replacement
+// direction (a degenerate atom leaves the model), so the host can draw exactly as many
+// directions as atoms degenerated AFTER the sweep and write them here: the i-th flagged atom
+// (atom order) takes pool row i, clamped if `positive`, normalised (dict_learning.py:93-96).
+__global__ __launch_bounds__(256) void fill_degenerate_kernel(float* __restrict__ D, int64_t ldd, int d, int k,
+                                                              const int* __restrict__ degenerate,
+                                                              const float* __restrict__ pool, int pool_rows,
+                                                              int64_t pool_ld, int positive) {
+  __shared__ float sh[256];
+  int i = 0;
+  for (int j = 0; j < k; ++j) {
+    if (!degenerate[j]) continue;                       // uniform over the block
+    const float* row = pool + (int64_t)min(i, pool_rows - 1) * pool_ld;
+    float part = 0.0f;
+    for (int dd = threadIdx.x; dd < d; dd += 256) {
+      float g = row[dd];
+      if (positive) g = fmaxf(g, 0.0f);
+      part = fmaf(g, g, part);
+    }
+    sh[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float inv = 1.0f / sqrtf(sh[0]);
+    __syncthreads();
+    for (int dd = threadIdx.x; dd < d; dd += 256) {
+      float g = row[dd];
+      if (positive) g = fmaxf(g, 0.0f);
+      D[(int64_t)dd * ldd + j] = g * inv;
+    }
+    ++i;
+  }
+}
+
 // U[j'][:] -= sum_a A[j'][j0+a] * dD[a][:]   for j' >= j0 + JB; one row per workgroup
 // iteration, blockIdx.y = panel of 256 features
 __global__ __launch_bounds__(256) void trailing_update_kernel(const SweepParams p, int j0) {
@@ -446,6 +482,13 @@ hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_degenerate(float* D, int64_t ldd, int d, int k, const int* degenerate, const float* pool,
+                                  int pool_rows, int64_t pool_ld, int positive, hipStream_t stream) {
+  hipLaunchKernelGGL(fill_degenerate_kernel, dim3(1), dim3(256), 0, stream, D, ldd, d, k, degenerate, pool,
+                     pool_rows, pool_ld, positive);
   return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@ by ``__graft_entry__.build()`` / ``make -C pytorch-lasso_amd/csrc``.
 """
 import ctypes as C
 import os
+import threading
 import warnings
 
 import torch
@@ -13,7 +14,8 @@ import torch
 LASSO_OK, LASSO_ERR_BAD_ARG, LASSO_ERR_UNSUPPORTED = 0, 1, 2
 LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_F32, LASSO_BF16 = 0, 1
-STOP_GLOBAL, STOP_NONE = 0, 1
+STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -23,9 +25,18 @@ class NativeError(RuntimeError):
     """The HIP extension is missing, or a native call failed."""
 
 
+_LIB_PATH = os.path.join(_HERE, "liblasso_hip.so")
+
+
 def lib_path():
-    # LASSO_HIP_LIB: developer override used for A/B builds of the kernels (tools/)
-    return os.environ.get("LASSO_HIP_LIB") or os.path.join(_HERE, "liblasso_hip.so")
+    return _LIB_PATH
+
+
+def use_library(path):
+    """Bind a different build of the library (A/B builds of the kernels under tools/); must be
+    called before the first native call."""
+    global _LIB_PATH, _LIB
+    _LIB_PATH, _LIB = path, None
 
 
 def _declare(lib):
@@ -37,17 +48,20 @@ def _declare(lib):
     lib.lasso_hip_device_cus.argtypes = [C.POINTER(i32)]
     lib.lasso_fista_workspace_bytes.restype = sz
     lib.lasso_fista_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, dbl, i32, i32]
+    lib.lasso_fista_kernel_name.restype = C.c_char_p
+    lib.lasso_fista_kernel_name.argtypes = [i64, i64, i64, i32, i32]
     lib.lasso_fista_solve.restype = i32
     lib.lasso_fista_solve.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
         dbl, dbl, i32, i32, dbl, i32, i32, dbl, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+        C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float),
         vp, sz, vp]
     lib.lasso_fista_prepare.restype = i32
-    lib.lasso_fista_prepare.argtypes = [vp, i64, i64, i64, i32, vp, sz, vp]
+    lib.lasso_fista_prepare.argtypes = [vp, i64, i64, i64, i32, i32, vp, sz, vp]
     lib.lasso_fista_run.restype = i32
     lib.lasso_fista_run.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
-        dbl, dbl, i32, i32, i32, vp, vp, sz, vp]
+        dbl, dbl, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.lasso_lipschitz_workspace_bytes.restype = sz
     lib.lasso_lipschitz_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_lipschitz.restype = i32
@@ -66,6 +80,8 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_dict_fill_degenerate.restype = i32
+    lib.lasso_dict_fill_degenerate.argtypes = [vp, i64, i64, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.lasso_zero_columns.restype = i32
     lib.lasso_zero_columns.argtypes = [vp, i64, i64, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
@@ -117,7 +133,7 @@ def lib():
         except OSError as e:  # pragma: no cover
             raise NativeError("lasso_amd: cannot load %s: %s" % (path, e))
         _declare(handle)
-        if handle.lasso_hip_abi_version() != 1:
+        if handle.lasso_hip_abi_version() != ABI_VERSION:
             raise NativeError("lasso_amd: ABI version mismatch")
         _LIB = handle
     return _LIB
@@ -154,13 +170,25 @@ def ptr(t):
 
 
 _WS = {}
+_WS_LOCK = threading.Lock()
 
 
 def workspace(device, nbytes, tag='fista'):
-    """A cached device scratch buffer (caller-owned memory of the C ABI)."""
-    key = (device.type, device.index, tag)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-        _WS[key] = buf
+    """A cached device scratch buffer (caller-owned memory of the C ABI).  One buffer per
+    (device, HIP stream, host thread, purpose): calls enqueued on one stream are ordered, so
+    they may share scratch; different streams or threads never do (the C library itself is
+    re-entrant -- all state lives in the workspace the caller passes)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream,
+           threading.get_ident(), tag)
+    with _WS_LOCK:
+        buf = _WS.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+            _WS[key] = buf
     return buf
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (e.g. after a one-off large problem)."""
+    with _WS_LOCK:
+        _WS.clear()

@@ -45,24 +45,39 @@ class HipEngine:
         from .linear.lipschitz import lipschitz_constant
         return lipschitz_constant(W)
 
-    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False,
-                  z_out=None, cap=0):
+    def fista_workspace(self, n, d, k, cap):
+        """A caller-held workspace for a SEQUENCE of fista_run calls against one dictionary
+        (iterations it0 .. < cap): W is packed into it by the first call that uses it, later
+        calls skip the packing.  Held by the caller, never shared through the scratch cache."""
+        with torch.cuda.device(self.device):
+            nbytes = self.lib.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, int(cap), 0.0,
+                                                          nat.STOP_NONE, 0)
+            return {"buf": torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device),
+                    "packed": False, "shape": (n, d, k), "cap": int(cap)}
+
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, ws=None, z_out=None):
         """`iters` iterations from (z_in, y_in); returns (z, y, delta[iters] or None).
         Building block of the distributed exact-stop E-step and of the traced forward pass
         of the autograd path (lasso_fista_run).  `z_out`: optional [n,k] destination.
-        `prepared=True` skips re-packing W: only valid while the workspace buffer is the one
-        the previous call used, so such callers pass `cap` (the largest it0+iters they will
-        reach) to size it once."""
+        `ws`: a workspace from fista_workspace() (W is packed once per workspace); None = a
+        scratch buffer of this stream, W packed by this call."""
         n, d = X.shape
         k = W.shape[1]
         L = self.lib
         with torch.cuda.device(self.device):
-            nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, max(it0 + iters, int(cap)), 0.0,
-                                                   nat.STOP_NONE, 0)
-            ws = self._ws(nbytes, "fista")
-            if not prepared:
-                nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32,
-                                                nat.ptr(ws), ws.numel(), self._stream()))
+            if ws is None:
+                cap = it0 + iters
+                nbytes = L.lasso_fista_workspace_bytes(n, d, k, nat.LASSO_F32, cap, 0.0, nat.STOP_NONE, 0)
+                buf, packed = self._ws(nbytes, "fista"), False
+            else:
+                if ws["shape"] != (n, d, k) or it0 + iters > ws["cap"]:
+                    raise ValueError("fista_run: workspace was sized for %s, cap %d" % (ws["shape"], ws["cap"]))
+                buf, packed, cap = ws["buf"], ws["packed"], ws["cap"]
+            if not packed:
+                nat.check(L.lasso_fista_prepare(nat.ptr(W), W.stride(0), d, k, nat.LASSO_F32, int(cap),
+                                                nat.ptr(buf), buf.numel(), self._stream()))
+                if ws is not None:
+                    ws["packed"] = True
             z = z_out if z_out is not None else torch.empty((n, k), dtype=torch.float32, device=self.device)
             y = torch.empty((n, k), dtype=torch.float32, device=self.device)
             delta = torch.empty(iters, dtype=torch.float32, device=self.device) if want_delta else None
@@ -70,8 +85,8 @@ class HipEngine:
                 nat.ptr(X), X.stride(0), nat.ptr(z_in), z_in.stride(0) if z_in is not None else 0,
                 nat.ptr(y_in), y_in.stride(0) if y_in is not None else 0,
                 nat.ptr(z), z.stride(0), nat.ptr(y), y.stride(0), n, d, k, nat.LASSO_F32,
-                float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), nat.ptr(delta),
-                nat.ptr(ws), ws.numel(), self._stream()))
+                float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), int(cap), nat.ptr(delta),
+                nat.ptr(buf), buf.numel(), self._stream()))
         return z, y, delta
 
     def fista_backward(self, X, W, trace, grad_z, lr, fast, need_x, need_w, need_z0):
@@ -140,6 +155,15 @@ class HipEngine:
                 pool_dev.stride(0) if pool_dev is not None else 0, int(seed) & (2 ** 64 - 1),
                 nat.ptr(mask), C.byref(ndeg), nat.ptr(ws), ws.numel(), self._stream()))
         return mask, ndeg.value
+
+    def fill_degenerate(self, D, mask, pool, positive):
+        """The i-th flagged atom of D becomes pool row i, normalised (dict_learning.py:93-96)."""
+        d, k = D.shape
+        pool = pool.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_dict_fill_degenerate(
+                nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, nat.ptr(mask), nat.ptr(pool), pool.shape[0],
+                pool.stride(0), int(bool(positive)), self._stream()))
 
     def zero_columns(self, Z, mask):
         n, k = Z.shape

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 from .. import _native as nat
 from ..engine import HipEngine
-from ..parallel import em_loop, constrained_mstep, DegeneratePool
+from ..parallel import em_loop, constrained_mstep
 from .sparse_encode import sparse_encode
 
 
@@ -45,7 +45,7 @@ def update_dict(dictionary, X, Z, random_seed=None, positive=False, eps=1e-10):
     d, k = Dg.shape
     buf = torch.empty(k * k + k * d, dtype=torch.float32, device=eng.device)
     A, B = eng.gram(Zg, Xg, buf)
-    mask = constrained_mstep(eng, A, B, Dg, DegeneratePool(d), eps=eps, positive=positive)
+    mask = constrained_mstep(eng, A, B, Dg, eps=eps, positive=positive)
     if mask is not None:
         eng.zero_columns(Zg, mask)
     if Dg.data_ptr() != dictionary.data_ptr():

@@ -29,10 +29,11 @@ def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
     n, k = z0.shape
     budget = torch.tensor(float(n * k) * tol, dtype=torch.float32).item()
     z, y, done, last = z0, None, 0, float('nan')
+    ws = eng.fista_workspace(n, x.shape[1], k, maxiter)
     for it in range(maxiter):
         loss, _ = eng.objective_sums(x, z, weight, alpha)
         print('loss: %0.4f' % loss.item())
-        z, y, delta = eng.fista_run(x, weight, z, y, alpha, lr, fast, it, 1, True, prepared=False)
+        z, y, delta = eng.fista_run(x, weight, z, y, alpha, lr, fast, it, 1, True, ws=ws)
         done, last = it + 1, delta[0].item()
         if last <= budget:
             break
@@ -52,17 +53,31 @@ class _UnrolledIsta(torch.autograd.Function):
         eng = HipEngine(dev)
         n, k = z0.shape
         xg, wg = x.detach().contiguous(), weight.detach().contiguous()
-        trace = torch.empty((maxiter + 1, n, k), dtype=torch.float32, device=dev)
-        trace[0].copy_(z0.detach())
+        # the iterates z_0 .. z_T are kept for the reverse pass; the trace grows in blocks so an
+        # early stop by the tol rule never pays for maxiter iterates
+        block = 32
+        chunks = [torch.empty((min(block, maxiter) + 1, n, k), dtype=torch.float32, device=dev)]
+        chunks[0][0].copy_(z0.detach())
         budget = torch.tensor(float(n * k) * tol, dtype=torch.float32).item()
+        ws = eng.fista_workspace(n, xg.shape[1], k, maxiter)
         y, done = None, 0
+        cur, pos = chunks[0], 0          # z_done lives in cur[pos]
         for it in range(maxiter):
-            _, y, delta = eng.fista_run(xg, wg, trace[it], y, alpha, lr, fast, it, 1, tol > 0,
-                                        prepared=it > 0, z_out=trace[it + 1], cap=maxiter)
+            if pos + 1 == cur.shape[0]:
+                nxt = torch.empty((min(block, maxiter - it), n, k), dtype=torch.float32, device=dev)
+                chunks.append(nxt)
+                src, cur, pos = cur[pos], nxt, -1
+            else:
+                src = cur[pos]
+            _, y, delta = eng.fista_run(xg, wg, src, y, alpha, lr, fast, it, 1, tol > 0, ws=ws,
+                                        z_out=cur[pos + 1])
+            pos += 1
             done = it + 1
             if tol > 0 and delta[0].item() <= budget:                    # ista.py:93-95
                 break
-        ctx.save_for_backward(xg, wg, trace[:done + 1])
+        trace = chunks[0][:pos + 1] if len(chunks) == 1 else \
+            torch.cat([c if i + 1 < len(chunks) else c[:pos + 1] for i, c in enumerate(chunks)])
+        ctx.save_for_backward(xg, wg, trace)
         ctx.lr, ctx.fast = lr, fast
         return trace[done].clone()
 
@@ -79,13 +94,16 @@ class _UnrolledIsta(torch.autograd.Function):
 
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
-         return_info=False):
+         return_info=False, stop_mode='global'):
     """Solve min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 on the GPU.
 
     x [n,d], z0 [n,k], weight [d,k]; returns a NEW tensor z [n,k] with the
     dtype/device of z0 (``maxiter=0`` returns ``z0`` itself, ista.py:76,104).
     Inputs are never modified.  ``return_info`` (extension) additionally
-    returns ``dict(iterations=..., last_delta=...)``.
+    returns ``dict(iterations=..., last_delta=...)`` (plus ``trials`` / ``accepted_lr`` per
+    outer iteration with the line search; ``return_info='objective'`` adds the mean objective
+    of the result).  ``stop_mode`` (extension): 'global' = the reference's rule (default),
+    'chunked' = the same rule without the in-kernel handshake, 'none' = run maxiter iterations.
     Tensors that live on the CPU are staged through the current HIP device
     (the arithmetic still runs in the HIP kernels; there is no CPU fallback).
     """
@@ -111,9 +129,9 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
                   and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)))
         if native:
             return _solve_native(x, z0, weight, alpha, fast, float(lr), maxiter, tol, backtrack, eta_backtrack,
-                                 verbose, return_info)
+                                 verbose, return_info, stop_mode=stop_mode)
         out = ista(x.float(), z0.float(), weight.float(), alpha, fast, lr, maxiter, tol, backtrack,
-                   eta_backtrack, verbose, return_info)
+                   eta_backtrack, verbose, return_info, stop_mode)
         if return_info:
             return out[0].to(x.dtype), out[1]
         return out.to(x.dtype)
@@ -154,11 +172,14 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         return (z, info) if return_info else z
 
     return _solve_native(xg, zg, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                         return_info, out_device=out_device)
+                         return_info, out_device=out_device, stop_mode=stop_mode)
+
+
+_STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                  return_info, out_device=None):
+                  return_info, out_device=None, stop_mode='global'):
     """One call of lasso_fista_solve on tensors of one dtype (float32, or bfloat16 with the
     line search)."""
     n, d = x.shape
@@ -178,11 +199,15 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         ws = nat.workspace(dev, nbytes)
         iters = C.c_int32(0)
         last = C.c_float(float('nan'))
+        want_trace = bool(backtrack) and bool(return_info)
+        trials = (C.c_int32 * max(int(maxiter), 1))() if want_trace else None
+        acc_lr = (C.c_float * max(int(maxiter), 1))() if want_trace else None
+        obj = C.c_float(float('nan')) if return_info == 'objective' else None
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
-            int(maxiter), float(tol), nat.STOP_GLOBAL, int(bool(backtrack)), float(eta_backtrack),
-            C.byref(iters), C.byref(last),
+            int(maxiter), float(tol), _STOP[stop_mode], int(bool(backtrack)), float(eta_backtrack),
+            C.byref(iters), C.byref(last), trials, acc_lr, C.byref(obj) if obj is not None else None,
             nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         nat.check(st)
     if z.device != out_device:
@@ -190,5 +215,11 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
     if verbose:
         print('iterations: %d' % iters.value)
     if return_info:
-        return z, dict(iterations=iters.value, last_delta=last.value)
+        info = dict(iterations=iters.value, last_delta=last.value)
+        if want_trace:      # what ista.py:43-47 prints per trial with verbose=True, condensed
+            info['trials'] = list(trials[:iters.value])
+            info['accepted_lr'] = list(acc_lr[:iters.value])
+        if obj is not None:
+            info['objective'] = obj.value
+        return z, info
     return z

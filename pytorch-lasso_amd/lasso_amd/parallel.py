@@ -6,9 +6,10 @@ replicated.  Per EM step:
   * E-step: local FISTA on the shard.  With the reference's global stop rule active
     (tol > 0) the per-iteration |z - z_next| sums of a chunk are all-reduced ONCE per
     chunk and every rank replays to the same stopping iteration (exact global rule);
-  * objective: {sum r^2, sum |z|} all-reduced (2 doubles);
-  * M-step: ONE all-reduce of the fp32 buffer [A = Z^T Z | B = Z^T X], then every rank
-    runs the identical deterministic atom sweep (no broadcast of D).
+  * objective + M-step: ONE all-reduce of the fp32 buffer
+    [A = Z^T Z | B = Z^T X | sum r^2, sum |z|], then every rank runs the identical
+    deterministic atom sweep (no broadcast of D; replacement directions for degenerate
+    atoms are broadcast only in the steps where an atom actually degenerated).
 The reference has no distributed code; this is the only parallelism strategy the build
 adds (BASELINE.json north_star).
 """
@@ -28,63 +29,64 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _host_staged(t, group):
+    """gloo moves host memory: device tensors are staged through the host explicitly (the
+    production backend is 'nccl' = RCCL, which reduces device buffers over xGMI in place)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _all_reduce(t, group):
     world, _ = _world(group)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
-class DegeneratePool:
-    """Replacement directions for degenerate atoms, drawn the way the reference does
+def _broadcast(t, group):
+    src = dist.get_global_rank(group, 0) if group else 0
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def draw_directions(d, count):
+    """`count` replacement directions for degenerate atoms, drawn the way the reference does
     (``dictionary[:, k].normal_()`` on a CPU tensor, dict_learning.py:93): same generator,
-    same non-contiguous-view code path, and only the directions actually consumed
-    advance the generator."""
-
-    def __init__(self, d, rows=8):
-        self.d, self.rows = d, rows
-
-    def draw(self, rows=None):
-        rows = rows or self.rows
-        state = torch.get_rng_state()
-        buf = torch.empty(self.d, 2)
-        col = buf[:, 0]
-        out = torch.empty(rows, self.d)
-        for i in range(rows):
-            col.normal_()
-            out[i] = col
-        return state, out
-
-    def commit(self, state, used):
-        torch.set_rng_state(state)
-        if used:
-            buf = torch.empty(self.d, 2)
-            col = buf[:, 0]
-            for _ in range(used):
-                col.normal_()
+    same non-contiguous-view code path, one draw per degenerate atom in atom order."""
+    buf = torch.empty(d, 2)
+    col = buf[:, 0]
+    out = torch.empty(count, d)
+    for i in range(count):
+        col.normal_()
+        out[i] = col
+    return out
 
 
-def constrained_mstep(engine, A, B, D, pool, eps=1e-10, positive=False, group=None):
+def constrained_mstep(engine, A, B, D, eps=1e-10, positive=False, group=None):
     """Atom sweep on the (already all-reduced) Gram matrices; D updated in place.
-    Returns the degenerate mask (device int32[k]) or None when no atom degenerated."""
+    Returns the degenerate mask (device int32[k]) or None when no atom degenerated.
+    The sweep never reads a replacement direction (a degenerate atom leaves the model,
+    dict_learning.py:92-98), so directions are drawn -- on rank 0, then broadcast -- only
+    in the steps where an atom actually degenerated, and exactly as many as needed: the
+    common step costs no RNG call, no broadcast and no copy of D."""
     world, rank = _world(group)
-    rows = pool.rows
-    while True:
-        state, cand = pool.draw(rows)
-        if world > 1:   # every rank must use rank 0's directions
-            cand_dev = cand.to(D.device) if D.is_cuda else cand
-            dist.broadcast(cand_dev, src=dist.get_global_rank(group, 0) if group else 0, group=group)
-            cand = cand_dev
-        D_backup = D.clone() if rows < D.shape[1] else None
-        mask, ndeg = engine.sweep(A, B, D, cand, eps, positive)
-        if ndeg <= rows:
-            pool.commit(state, ndeg)
-            return mask if ndeg > 0 else None
-        # more degenerate atoms than candidates: redo with a larger pool
-        torch.set_rng_state(state)
-        if D_backup is not None:
-            D.copy_(D_backup)
-        rows = min(D.shape[1], max(2 * rows, ndeg))
+    mask, ndeg = engine.sweep(A, B, D, None, eps, positive)
+    if ndeg == 0:
+        return None
+    cand = draw_directions(D.shape[0], ndeg).to(D.device)      # every rank advances its generator alike
+    if world > 1:   # every rank must use rank 0's directions
+        _broadcast(cand, group)
+    engine.fill_degenerate(D, mask, cand, positive)
+    return mask
 
 
 def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
@@ -151,8 +153,9 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     _all_reduce(n_glob, group)
     n_total = n_glob.item()
     losses = torch.zeros(steps, device=X.device)
-    buf = torch.empty(k * k + k * d, dtype=torch.float32, device=X.device)
-    pool = DegeneratePool(d)
+    # ONE message per EM step: [A = Z^T Z | B = Z^T X | sum r^2, sum |z|]
+    buf = torch.empty(k * k + k * d + 2, dtype=torch.float32, device=X.device)
+    tail = buf[k * k + k * d:]
     Z0 = None
     bar = None
     if progbar and rank == 0:
@@ -161,17 +164,17 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     for i in range(steps):
         Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, **solver_kwargs)   # :38
         loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
-        if world > 1:
-            _all_reduce(sums, group)
-            losses[i] = ((0.5 * sums[0] + alpha * sums[1]) / n_total).to(torch.float32)
-        else:
-            losses[i] = loss_local
         if persist:
             Z0 = Z                                                                        # :40-41
         A, B = engine.gram(Z, X, buf)
-        _all_reduce(buf, group)
+        if world > 1:
+            tail.copy_(sums)                 # the two objective sums ride in the Gram message
+            _all_reduce(buf, group)
+            losses[i] = (0.5 * tail[0] + alpha * tail[1]) / n_total
+        else:
+            losses[i] = loss_local
         if constrained:
-            mask = constrained_mstep(engine, A, B, weight, pool, group=group)             # :44-45
+            mask = constrained_mstep(engine, A, B, weight, group=group)                   # :44-45
             if mask is not None:
                 engine.zero_columns(Z, mask)                                              # :98
         else:
@@ -204,7 +207,7 @@ def dict_learning_sharded(X_shard, n_components, alpha=1.0, constrained=True, pe
     Xd = engine.to_device(X_shard)
     weight = engine.to_device(weight).clone()
     if world > 1:
-        dist.broadcast(weight, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+        _broadcast(weight, group)
     return em_loop(engine, Xd, weight, alpha, constrained=constrained, persist=persist,
                    lambd=lambd, steps=steps, progbar=progbar, solver_kwargs=solver_kwargs,
                    group=group)

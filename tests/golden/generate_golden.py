@@ -12,7 +12,7 @@ The reference does not import as-is under scipy 1.15 (iterative_ridge.py:5
 imports a private scipy symbol); the 3-line shim below aliases that symbol
 BEFORE importing -- no reference file is edited or copied.
 
-Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g4 g5 small inits cd conv]
+Usage:  python tests/golden/generate_golden.py [g1 g2 g3 g3trace g4 g5 small inits cd conv]
 """
 import os
 import sys
@@ -169,6 +169,39 @@ def g3():
                   lr=1.0 / LAMBDA_MAX_C2, maxiter=10, tol=0.0)
     out["bf16_fixed_obj_fp32eval"] = ref_loss(Xb.float(), zb.float(), Wb.float(), 0.5).item()
     save("g3_c3_backtrack", **out)
+
+
+def g3trace():
+    """Line-search trace of the C3 recipe: trials per outer iteration and the
+    accepted step, recorded by wrapping the reference's own `backtracking` at run time (ista()
+    discards the returned step, ista.py:87), plus the per-iteration objective ista() prints
+    with verbose=True (ista.py:80-81)."""
+    import math
+    X, W = recipe_xw(16384, 256, 1024)
+    out = {}
+    orig = ref_ista_mod.backtracking
+
+    def run(tag, x, w, fast, iters):
+        log = []
+
+        def wrapped(z, x_, weight, alpha, lr0, eta=1.5, maxiter=1000, verbose=False):
+            z_next, lr = orig(z, x_, weight, alpha, lr0, eta, maxiter, verbose)
+            log.append((lr, int(round(math.log(lr0 / lr) / math.log(eta))) + 1))
+            return z_next, lr
+        ref_ista_mod.backtracking = wrapped
+        try:
+            ref_ista(x, x.new_zeros(x.shape[0], w.shape[1]), w, 0.5, fast=fast, lr=1.0, maxiter=iters,
+                     tol=0.0, backtrack=True)
+        finally:
+            ref_ista_mod.backtracking = orig
+        out[tag + "_lr"] = np.array([a for a, _ in log], dtype=np.float64)
+        out[tag + "_trials"] = np.array([b for _, b in log], dtype=np.int32)
+        print(tag, out[tag + "_trials"].tolist(), out[tag + "_lr"].tolist())
+
+    run("fp32_fista", X, W, True, 10)
+    run("fp32_ista", X, W, False, 5)
+    run("bf16_fista", X.bfloat16(), W.bfloat16(), True, 10)
+    save("g3_c3_trace", **out)
 
 
 def g4():

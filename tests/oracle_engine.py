@@ -21,7 +21,7 @@ class OracleEngine:
     def lipschitz(self, W):
         return orc.lipschitz_constant(W, "exact")
 
-    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, prepared=False):
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, ws=None, z_out=None):
         coefs = orc.momentum_schedule(it0 + iters) if fast else [0.0] * (it0 + iters)
         z = z_in if z_in is not None else X.new_zeros(X.shape[0], W.shape[1])
         y = y_in if y_in is not None else z
@@ -50,13 +50,20 @@ class OracleEngine:
     def sweep(self, A, B, D, pool, eps, positive, seed=0):
         used = [0]
 
-        def fresh(j):
-            v = pool[min(used[0], pool.shape[0] - 1)]
+        def fresh(j):       # pool None: a placeholder direction, overwritten by fill_degenerate
+            v = pool[min(used[0], pool.shape[0] - 1)] if pool is not None else torch.ones(D.shape[0])
             used[0] += 1
             return v
         _, deg = orc.update_dict_gram(D, A.clone(), B.clone(), positive=positive, eps=eps,
                                       fresh_atom=fresh)
         return deg.to(torch.int32), int(deg.sum())
+
+    def fill_degenerate(self, D, mask, pool, positive):
+        for i, j in enumerate(torch.nonzero(mask).flatten().tolist()):
+            v = pool[i].clone()
+            if positive:
+                v.clamp_(0, None)
+            D[:, j] = v / v.norm()
 
     def zero_columns(self, Z, mask):
         Z[:, mask.bool()] = 0

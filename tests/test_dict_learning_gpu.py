@@ -254,3 +254,39 @@ def test_dict_learning_with_coordinate_descent_e_step():
     D, losses = dict_learning(X, 32, alpha=0.3, steps=3, progbar=False, algorithm='cd', maxiter=30)
     assert (losses.cpu() - lref).abs().max().item() <= 1e-4 * lref.abs().max().item()
     assert (D.cpu() - Dref).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("shape", ["c1", "wide", "c2rows"])
+def test_dict_evaluate(golden, shape):
+    """dict_evaluate (dict_learning.py:16-20): X moves to the dictionary's device, is encoded
+    with the forwarded solver kwargs and scored by lasso_loss.  C1 (README) data against the
+    reference's own number, a d > 256 shape (unfused kernels) and config-2 rows vs the oracle."""
+    from lasso_amd.linear import dict_evaluate
+    orc = _orc()
+    if shape == "c1":
+        g = golden("g1_readme")
+        X, D = T(g["data"]), T(g["D_fix"])
+        # the reference's sparse_encode(data, D_fix, alpha=0.2) then lasso_loss, stored as loss_z_auto
+        # only for D_auto; use the oracle (pinned bitwise to the reference) for D_fix
+        kw = dict(lr=0.05, maxiter=40, tol=0.0)
+        alpha = 0.2
+    elif shape == "wide":
+        gen = torch.Generator().manual_seed(4)
+        X = torch.randn(150, 300, generator=gen)
+        D = torch.nn.functional.normalize(torch.randn(300, 1100, generator=gen), dim=0)
+        kw = dict(lr=0.02, maxiter=15, tol=0.0)
+        alpha = 0.3
+    else:
+        X, D = recipe_xw(512)
+        kw = dict(lr=1.0 / LAMBDA_MAX_C2, maxiter=25, tol=0.0)
+        alpha = 0.5
+    ref = orc.dict_evaluate(X, D, alpha, **kw).item()
+    got = dict_evaluate(X, D.cuda(), alpha, **kw)          # X on the host: moved like the reference does
+    assert got.dim() == 0 and got.is_cuda
+    assert abs(got.item() - ref) <= 2e-6 * abs(ref), (shape, got.item(), ref)
+    got2 = dict_evaluate(X.cuda(), D.cuda(), alpha, algorithm='ista', **kw)
+    assert got2.item() == got.item()
+    if shape == "c1":      # defaults (lr='auto', maxiter=10, tol=1e-5) against the reference's stored number
+        g = golden("g1_readme")
+        val = dict_evaluate(T(g["data"]).cuda(), T(g["D_auto"]).cuda(), 0.2, algorithm='ista')
+        assert abs(val.item() - float(g["loss_z_auto"])) <= 1e-4

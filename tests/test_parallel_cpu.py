@@ -41,7 +41,7 @@ def test_degenerate_atoms_follow_reference_rng():
     """An atom nobody uses is re-drawn from torch's generator exactly like
     dict_learning.py:92-98 (same values, same generator advance), and its codes
     are zeroed."""
-    from lasso_amd.parallel import constrained_mstep, DegeneratePool
+    from lasso_amd.parallel import constrained_mstep
     X, D0 = _problem(n=64, d=10, k=12)
     Z = orc.sparse_encode(X, D0, 0.2, lr=0.1, maxiter=20)
     Z[:, 3] = 0
@@ -55,7 +55,7 @@ def test_degenerate_atoms_follow_reference_rng():
     buf = torch.empty(12 * 12 + 12 * 10)
     A, B = eng.gram(Z, X, buf)
     torch.manual_seed(5)
-    mask = constrained_mstep(eng, A, B, D, DegeneratePool(10, rows=1))   # forces a pool regrow
+    mask = constrained_mstep(eng, A, B, D)
     after = torch.rand(1)
     assert mask is not None and mask.tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0]
     assert torch.equal(after, after_ref)

@@ -99,13 +99,9 @@ def test_in_kernel_stop_rule_stress():
         tol = [1e-3, 3e-4, 1e-4][i % 3]
         x = Xg[:n].contiguous()
         z0 = torch.zeros(n, 1024, device="cuda")
-        os.environ.pop("LASSO_STOP_CHUNKED", None)
         z_in, info_in = ista(x, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True)
-        os.environ["LASSO_STOP_CHUNKED"] = "1"
-        try:
-            z_ch, info_ch = ista(x, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True)
-        finally:
-            os.environ.pop("LASSO_STOP_CHUNKED", None)
+        z_ch, info_ch = ista(x, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True,
+                             stop_mode='chunked')
         # the two paths sum the per-tile partials in different (fixed) orders, so a sum that
         # lands within an ulp of the budget may stop one iteration apart
         assert abs(info_in["iterations"] - info_ch["iterations"]) <= 1, (n, fast, tol, info_in, info_ch)
@@ -116,3 +112,32 @@ def test_in_kernel_stop_rule_stress():
         z_b, info_b = ista(Xg, torch.zeros(4096, 1024, device="cuda"), Wg, 0.5, lr=lr, maxiter=500,
                            tol=1e-3, return_info=True)
     assert info_b["iterations"] > 0
+
+
+def test_stop_rule_survives_a_busy_gpu():
+    """The in-kernel stop rule needs every workgroup of the solve resident at once.  With a second
+    stream saturating the GPU that may not hold: the handshake then times out, the kernel aborts as
+    a whole, and lasso_fista_solve repeats the solve on the chunked path -- same iteration count,
+    same code, no error."""
+    from lasso_amd.linear.solvers import ista
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(4096, 1024, device="cuda")
+    lr = 1.0 / LAMBDA_MAX_C2
+    z_ref, info_ref = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
+    assert info_ref["iterations"] == 263
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    b = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 4 * trial):            # ~10 ms each: the GPU stays busy for a while
+                a = torch.mm(a, b) * 1e-2
+        z, info = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
+        assert info["iterations"] == 263, (trial, info)
+        assert torch.equal(z, z_ref), trial
+        torch.cuda.synchronize()
+    # the chunked mode on its own (what the fall-back runs)
+    z, info = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=2000, tol=1e-5, return_info=True, stop_mode='chunked')
+    assert info["iterations"] == 263 and torch.equal(z, z_ref)

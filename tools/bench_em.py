@@ -9,7 +9,7 @@ import torch
 from recipes import recipe_xw, recipe_c4_init, LAMBDA_MAX_C4
 from lasso_amd.engine import HipEngine
 from lasso_amd.linear import sparse_encode, dict_learning
-from lasso_amd.parallel import DegeneratePool, constrained_mstep
+from lasso_amd.parallel import constrained_mstep
 
 def timeit(fn, reps=10):
     fn(); torch.cuda.synchronize()
@@ -34,7 +34,7 @@ for n in (8192, 65536):
     out["gram_ms"] = timeit(lambda: eng.gram(Z, X, buf))
     A, B = eng.gram(Z, X, buf)
     D = D0.clone()
-    out["sweep_ms"] = timeit(lambda: constrained_mstep(eng, A, B, D, DegeneratePool(256)))
+    out["sweep_ms"] = timeit(lambda: constrained_mstep(eng, A, B, D))
     out["ridge_ms"] = timeit(lambda: eng.ridge(A, B, 1e-2 * n))
     t = time.perf_counter()
     dict_learning(X, 1024, alpha=0.5, steps=10, algorithm='ista', progbar=False, device='cuda', init_weight=D0)
