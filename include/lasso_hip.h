@@ -60,6 +60,18 @@ typedef enum {
                              it by itself when its workgroups are not all resident      */
 } lasso_stop_mode;
 
+/* Kernel-selection hint for the fused shapes: OR it into `stop_mode` of lasso_fista_solve, pass
+ * it as `kernel_hint` to lasso_fista_run.  AUTO picks by batch size: the tile kernel (one
+ * workgroup per 16-row tile, no traffic between workgroups) fills the chip from n ~ 16 x #CUs
+ * rows; below that the split-k kernel shares each tile among Kpad/128 workgroups.  Both give
+ * bitwise the same code for a row.  SPLITK is a request, not a guarantee (in-place calls,
+ * d <= 128 tall tiles and lock-step stop-rule launches with more tiles than groups keep the
+ * tile kernel). */
+#define LASSO_KERNEL_AUTO 0
+#define LASSO_KERNEL_TILE 0x100
+#define LASSO_KERNEL_SPLITK 0x200
+#define LASSO_KERNEL_MASK 0xF00
+
 int lasso_hip_abi_version(void);
 const char* lasso_hip_status_string(int status);
 const char* lasso_hip_last_error(void);
@@ -134,7 +146,7 @@ int lasso_fista_run(const void* x_dev, int64_t ldx,
                     void* y_out_dev, int64_t ldy_out,
                     int64_t n, int64_t d, int64_t k, int dtype,
                     double alpha, double lr, int fast, int it0, int iters, int maxiter,
-                    float* delta_dev,
+                    int kernel_hint, float* delta_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- Lipschitz constant: replaces _lipschitz_constant, ista.py:8-14 -----------------

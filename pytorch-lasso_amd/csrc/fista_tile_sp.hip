@@ -1,5 +1,5 @@
-// Software-pipelined 8-wave variant of the fused persistent FISTA kernel.
-// Algorithm, LDS layouts, W streaming and MFMA operand convention: see fista_tile.hip.
+// The fused persistent FISTA kernel: one 8-wave workgroup per 16-row tile, software-pipelined.
+// Algorithm, LDS layouts, W streaming and MFMA operand convention: DESIGN.md section 3.1.
 //
 // Why: all waves of a workgroup run the same instruction stream in near lockstep (the
 // two barriers per iteration re-align them), so any stretch in which a wave is NOT
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   lds_char* const yt = rings + NW * kRingBytesPerWave;
   lds_char* const rt = yt + YT_BYTES;
   lds_f32* const red = (lds_f32*)(rt + RT_BYTES);
+
+  // stand-by launch behind a split-k launch: nothing to do unless that kernel gave up
+  if (p.run_if != nullptr && __hip_atomic_load(p.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
 
   TileCtx<K, D> c;
   c.init(p.Wp, p.Wtp, rings);
@@ -149,6 +152,12 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       const bool check = STOP && p.stop_on && it > 0;
       const unsigned long long* const grow =
           p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * p.ntiles : nullptr;
+      // The contraction over the atoms is summed in SLICES of 128 atoms (two trips): the MFMA
+      // chain restarts from 0 at every slice boundary and the slice totals are added left to
+      // right, r = ((p_0 + p_1) + p_2) + ... with p_0's chain starting from -x.  This is the
+      // order in which the split-k kernel (fista_splitk.hip, one slice per workgroup) can
+      // form the same r -- a row's code is bitwise independent of the kernel that computed it.
+      f32x4 run[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
       for (int s2 = 0; s2 < S1 / 2 - 2; ++s2) {
         if (STOP && check && wid == 0 && s2 == S1 / 8) {
@@ -158,6 +167,15 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
               gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
+        if (s2 & 1) {                                  // end of slice s2 / 2
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              run[cb][rg] = (s2 == 1) ? acc[cb][rg] : __fadd_rn(run[cb][rg], acc[cb][rg]);
+              acc[cb][rg] = 0.0f;
+            }
+        }
       }
       // steps S1-4, S1-3: refills are W step S1-1 and W^T step 0
       trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, c.w2, c.voff2, F{});
@@ -165,6 +183,10 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
       trip(S1 / 2 - 1, c.w2 + (size_t)(32 * (1 / T2)) * D + 32 * (1 % T2), c.voff2,
            c.w2 + (size_t)(32 * (2 / T2)) * D + 32 * (2 % T2), c.voff2, T{});
       // now X.b = B fragments of GEMM-2 step 0; slot1 <- W^T step 1, slot0 <- W^T step 2
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[cb][rg] = __fadd_rn(run[cb][rg], acc[cb][rg]);   // + the last slice
 
       if (STOP && check && wid == 0) {
         // every granule must carry tag == it (iteration it-1 published as it-1+1); re-poll the
@@ -310,7 +332,11 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         float tsum = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += red[w];
-        if (p.partials) p.partials[(int64_t)it * p.ntiles + tile] = tsum;
+        if (p.partials) {
+          float* const dst = p.partials + (int64_t)it * p.part_stride + (int64_t)tile * p.part_mul;
+          dst[0] = tsum;
+          for (int m = 1; m < p.part_mul; ++m) dst[m] = 0.0f;
+        }
         if (STOP && p.stop_on)   // one 8-byte write-through store {tag = it+1, value}: the data is the flag
           __hip_atomic_store(p.stop_gran + (size_t)(it & (kStopRing - 1)) * p.ntiles + tile,
                              ((unsigned long long)(unsigned)(it + 1) << 32) | __float_as_uint(tsum),

@@ -54,15 +54,19 @@ int pad_d(int64_t d, int kp);
 // ---------------------------------------------------------------------------
 constexpr int kChunkMax = 64;     // iterations per launch when deltas are recorded
 
+constexpr int kSplitMaxParts = 256;   // groups x members of the split-k kernel never exceed the CU count
+
 struct Workspace {
   float* wp;        // [256][Kp]
   float* wtp;       // [Kp][256]
   float* coef;      // [coef_cap]  FISTA momentum coefficients
   float* zeros;     // [coef_cap]  ISTA "coefficients"
-  float* partials;  // [kChunkMax][ntiles]
+  float* partials;  // [kChunkMax][ntiles * members]
   float* delta;     // [kChunkMax]
-  unsigned long long* gran;  // [kStopRing][ntiles] in-kernel stop-rule granules
+  unsigned long long* gran;  // [kStopRing][max(ntiles, 256)] in-kernel stop-rule granules
   int* stop_out;    // [4]
+  float* xch;       // split-k kernel: [2][256][16 KiB] partial-residual exchange
+  unsigned* xflags; // split-k kernel: [256][waves] epoch tags
   float* state[4];  // zA, yA, zB, yB  [n][k]   (stop rule only)
   size_t bytes;
 };
@@ -81,10 +85,14 @@ Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool wit
   w.wtp = take((size_t)kp * kFistaD * 4);
   w.coef = take((size_t)std::max(coef_cap, 1) * 4);
   w.zeros = take((size_t)std::max(coef_cap, 1) * 4);
-  w.partials = take((size_t)kChunkMax * ntiles * 4);
+  const int members = kp / 128;                       // split-k: members per group
+  w.partials = take((size_t)kChunkMax * ntiles * members * 4);
   w.delta = take((size_t)kChunkMax * 4);
-  w.gran = reinterpret_cast<unsigned long long*>(take((size_t)kStopRing * std::max<int64_t>(ntiles, 1) * 8));
+  w.gran = reinterpret_cast<unsigned long long*>(
+      take((size_t)kStopRing * std::max<int64_t>(ntiles, kSplitMaxParts) * 8));
   w.stop_out = reinterpret_cast<int*>(take(256));
+  w.xch = take(fista_splitk_exchange_bytes(kp, kSplitMaxParts / members));
+  w.xflags = reinterpret_cast<unsigned*>(take((size_t)kSplitMaxParts * kFistaWaves * 4));
   for (int i = 0; i < 4; ++i) w.state[i] = with_state ? take((size_t)n * k * 4) : nullptr;
   w.bytes = off;
   return w;
@@ -179,10 +187,42 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
   return LASSO_OK;
 }
 
+// Which fused kernel runs a batch: the split-k kernel (a 16-row tile shared by Kp/128
+// workgroups, fista_splitk.hip) when the one-workgroup-per-tile kernel would leave most of the
+// chip idle.  `lockstep`: the in-kernel stop rule needs every tile to own a resident group.
+// kSplitRel: measured time of one split-k iteration relative to one iteration of the tile
+// kernel (both at one tile per workgroup group; tools/bench_matrix.py).
+constexpr double kSplitRel = 0.20;
+struct KernelPlan { bool split; int groups; };
+
+int splitk_max_groups(int kp) {
+  int per_cu = 0;
+  if (fista_splitk_occupancy(kp, &per_cu) != hipSuccess) return 0;
+  const int resident = std::min(per_cu * device_cus(), kSplitMaxParts);
+  const int members = fista_splitk_members(kp);
+  return resident / (8 * members) * 8;                // whole rows of 8 groups (one per XCD)
+}
+
+KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint) {
+  KernelPlan plan = {false, 0};
+  if (dpad != kFistaD || hint == LASSO_KERNEL_TILE) return plan;
+  const int gmax = splitk_max_groups(kp);
+  if (gmax <= 0) return plan;
+  const int cus = device_cus();
+  const int rounds = (ntiles + gmax - 1) / gmax, tile_rounds = (ntiles + cus - 1) / cus;
+  if (lockstep && rounds > 1) return plan;
+  if (hint != LASSO_KERNEL_SPLITK && !(rounds * kSplitRel < (double)tile_rounds)) return plan;
+  plan.split = true;
+  plan.groups = std::min(ntiles, gmax);
+  return plan;
+}
+
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
              int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
-             int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f) {
+             int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f,
+             int hint = LASSO_KERNEL_AUTO, bool* used_split = nullptr) {
+  if (used_split) *used_split = false;
   if (n == 0) return LASSO_OK;
   const int dpad = pad_d(d, kp);
   const int tile_rows = 4096 / dpad;
@@ -204,15 +244,53 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.stop_budget = stop_budget;
   p.stop_gran = ws.gran;
   p.stop_out = ws.stop_out;
+  p.xch = nullptr; p.xflags = nullptr; p.groups = 0;
+  p.run_if = nullptr; p.part_stride = ntiles; p.part_mul = 1;
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
-  const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
-  LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream));
+  // in-place launches keep the tile kernel: a split-k launch that gives up is redone from its
+  // inputs, which must still be there
+  const bool in_place = (z_in && z_in == z_out) || (y_in && y_in == y_out) || (y_in && y_in == z_out) ||
+                        (z_in && y_out && z_in == y_out);
+  const KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, in_place ? LASSO_KERNEL_TILE : hint);
+  int nparts = ntiles;
+  if (plan.split) {
+    // cross-workgroup hand-offs: epoch tags and the abort flag start from zero in every launch
+    p.xch = ws.xch; p.xflags = ws.xflags; p.groups = plan.groups;
+    LASSO_HIP_TRY(hipMemsetAsync(ws.xflags, 0, (size_t)kSplitMaxParts * kFistaWaves * 4, stream));
+    if (!p.stop_on) LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, stream));   // (the stop-rule caller zeroed it)
+    LASSO_HIP_TRY(launch_fista_splitk(p, kp, stream));
+    nparts = ntiles * fista_splitk_members(kp);
+    if (used_split) *used_split = true;
+    if (!p.stop_on) {
+      // No host synchronisation on this path, so the stand-by is enqueued right behind: the tile
+      // kernel, which returns at once unless the split-k kernel raised its abort flag (a peer
+      // workgroup was not resident) -- then it redoes the launch from the untouched inputs.
+      // (With the stop rule on, the caller reads the flag at its synchronisation instead.)
+      FistaTileParams f = p;
+      f.run_if = ws.stop_out + 2;
+      f.part_stride = nparts; f.part_mul = fista_splitk_members(kp);
+      LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(ntiles, cus), stream));
+    }
+  } else {
+    const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
+    LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream));
+  }
   if (delta && iters > 0) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
-                       ntiles, delta);
+                       nparts, delta);
     LASSO_HIP_TRY(hipGetLastError());
   }
+  return LASSO_OK;
+}
+
+// true if the split-k kernel of the launch(es) enqueued so far gave up (a peer workgroup was
+// not resident); synchronises the stream.  The caller then repeats the work with LASSO_KERNEL_TILE.
+int splitk_aborted(const Workspace& ws, hipStream_t stream, bool* aborted) {
+  int hout[4] = {0, 0, 0, 0};
+  LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, stream));
+  LASSO_HIP_TRY(hipStreamSynchronize(stream));
+  *aborted = hout[2] != 0;
   return LASSO_OK;
 }
 
@@ -661,6 +739,10 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
   if (backtrack) return dtype == LASSO_BF16 ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt_grad_kernel / bt_trial_kernel";
   if (dtype == LASSO_BF16) return "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
   const int kp = pad_k(k), dpad = pad_d(d, kp);
+  if (plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO).split)
+    return kp == 1024 ? "lasso::splitk::fista_splitk_kernel<1024, false>"
+         : kp == 512 ? "lasso::splitk::fista_splitk_kernel<512, false>"
+                     : "lasso::splitk::fista_splitk_kernel<256, false>";
   switch (dpad) {
     case 256: return kp == 1024 ? "lasso::sp::fista_tile_sp_kernel<1024, 16, false>"
                    : kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 16, false>"
@@ -695,8 +777,8 @@ int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, in
 int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_t ldz_in,
                     const void* y_in_dev, int64_t ldy_in, void* z_out_dev, int64_t ldz_out,
                     void* y_out_dev, int64_t ldy_out, int64_t n, int64_t d, int64_t k, int dtype,
-                    double alpha, double lr, int fast, int it0, int iters, int maxiter, float* delta_dev,
-                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+                    double alpha, double lr, int fast, int it0, int iters, int maxiter, int kernel_hint,
+                    float* delta_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (int s = check_common(n, d, k, dtype)) return s;
   if (!x_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (it0 < 0 || iters < 0) return fail(LASSO_ERR_BAD_ARG, "negative iteration range");
@@ -707,13 +789,15 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   const int kp = pad_k(k);
   if (it0 + iters > maxiter) return fail(LASSO_ERR_BAD_ARG, "it0 + iters = %d > maxiter = %d", it0 + iters, maxiter);
+  if (kernel_hint != LASSO_KERNEL_AUTO && kernel_hint != LASSO_KERNEL_TILE && kernel_hint != LASSO_KERNEL_SPLITK)
+    return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", kernel_hint);
   // same carve as lasso_fista_prepare(maxiter): the momentum table it built is read here
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, false);
   if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   hipStream_t st = (hipStream_t)stream;
   return run_impl(ws, kp, (const float*)x_dev, ldx, (const float*)z_in_dev, ldz_in,
                   (const float*)y_in_dev, ldy_in, (float*)z_out_dev, ldz_out, (float*)y_out_dev,
-                  ldy_out, n, d, k, alpha, lr, fast, it0, iters, delta_dev, st);
+                  ldy_out, n, d, k, alpha, lr, fast, it0, iters, delta_dev, st, -1.0f, kernel_hint);
 }
 
 static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
@@ -754,8 +838,12 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return LASSO_OK;
   }
 
+  int hint = stop_mode & LASSO_KERNEL_MASK;            // kernel-selection hint rides in stop_mode
+  stop_mode &= ~LASSO_KERNEL_MASK;
   if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
     return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
+  if (hint != LASSO_KERNEL_AUTO && hint != LASSO_KERNEL_TILE && hint != LASSO_KERNEL_SPLITK)
+    return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
   if (!fused_shape(d, k))
@@ -780,7 +868,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
 
   if (!stop_rule) {
     if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
-                         alpha, lr, fast, 0, maxiter, nullptr, st))
+                         alpha, lr, fast, 0, maxiter, nullptr, st, -1.0f, hint))
       return s;
     if (iters_out) *iters_out = maxiter;
     return LASSO_OK;
@@ -805,10 +893,10 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     // handshake times out, the kernel aborts as a whole without touching z_out, and the solve
     // is repeated on the chunked path below.
     if (ntiles <= fista_resident_workgroups(kp, pad_d(d, kp))) {
-      LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * ntiles * 8, st));
+      LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * std::max(ntiles, kSplitMaxParts) * 8, st));
       LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
       if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
-                           alpha, lr, fast, 0, maxiter, nullptr, st, budget))
+                           alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint))
         return s;
       int hout[4] = {0, 0, 0, 0};
       LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, st));
@@ -820,6 +908,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
         if (last_delta_out) *last_delta_out = lastf;
         return LASSO_OK;
       }
+      hint = LASSO_KERNEL_TILE;      // some workgroup was not resident: no cross-workgroup traffic from here on
     }
   }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
@@ -836,7 +925,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     float* ny = ws.state[2 * flip + 1];
     // the aliasing copy above used state[2]; first chunk writes state[0]/[1] (flip = 0)
     if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, nz, nldz, ny, k, n, d, k,
-                         alpha, lr, fast, done, c, ws.delta, st))
+                         alpha, lr, fast, done, c, ws.delta, st, -1.0f, hint))
       return s;
     LASSO_HIP_TRY(hipMemcpyAsync(hdelta.data(), ws.delta, c * sizeof(float), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -848,7 +937,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     if (hit >= 0) {
       if (hit + 1 < c) {   // replay the chunk from its (intact) input state
         if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, zout, ldz, nullptr, 0,
-                             n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st))
+                             n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st, -1.0f, hint))
           return s;
       } else if (!final_chunk) {
         LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, nz, nldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));

@@ -32,6 +32,14 @@ struct FistaTileParams {
   int* stop_out;                         // [0] iterations executed, [1] last delta (float bits), [2] abort flag
   float stop_budget;                     // n*k*tol (ista.py:64)
   int stop_on;
+  // split-k kernel (fista_splitk.hip): partial-residual exchange between the members of a group
+  float* xch;                            // [2][groups][C][16 KiB] payload, parity = epoch & 1
+  unsigned* xflags;                      // [groups][C][waves] epoch tags, zeroed per launch
+  int groups;                            // groups of C = Kpad/128 workgroups; group g owns tiles g, g+groups, ...
+  // tile kernel as the stand-by of a split-k launch: runs only if *run_if != 0 (the split-k
+  // kernel's abort flag), and writes its per-tile partial sums in the split-k layout
+  const int* run_if;                     // nullable
+  int part_stride, part_mul;             // partials[it * part_stride + tile * part_mul] (+ zeros up to part_mul)
 };
 constexpr int kStopRing = 64;
 // Bound of every in-kernel handshake spin (one poll = a few L2 round trips + s_sleep, roughly
@@ -105,6 +113,12 @@ hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
 // workgroups of the stop-rule instantiation the occupancy query admits per CU
 hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu);
+// small-batch variant: a 16-row tile shared by Kpad/128 workgroups (fista_splitk.hip); needs
+// p.xch / p.xflags / p.groups / p.stop_out, flags and stop_out zeroed on the stream before the launch
+hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, hipStream_t stream);
+hipError_t fista_splitk_occupancy(int kpad, int* blocks_per_cu);
+int fista_splitk_members(int kpad);
+size_t fista_splitk_exchange_bytes(int kpad, int groups);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);

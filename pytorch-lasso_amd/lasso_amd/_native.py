@@ -16,6 +16,7 @@ LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
 ABI_VERSION = 2
+KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -61,7 +62,7 @@ def _declare(lib):
     lib.lasso_fista_run.restype = i32
     lib.lasso_fista_run.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
-        dbl, dbl, i32, i32, i32, i32, vp, vp, sz, vp]
+        dbl, dbl, i32, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.lasso_lipschitz_workspace_bytes.restype = sz
     lib.lasso_lipschitz_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_lipschitz.restype = i32

@@ -55,7 +55,8 @@ class HipEngine:
             return {"buf": torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device),
                     "packed": False, "shape": (n, d, k), "cap": int(cap)}
 
-    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, ws=None, z_out=None):
+    def fista_run(self, X, W, z_in, y_in, alpha, lr, fast, it0, iters, want_delta, ws=None, z_out=None,
+                  kernel=nat.KERNEL_AUTO):
         """`iters` iterations from (z_in, y_in); returns (z, y, delta[iters] or None).
         Building block of the distributed exact-stop E-step and of the traced forward pass
         of the autograd path (lasso_fista_run).  `z_out`: optional [n,k] destination.
@@ -85,7 +86,8 @@ class HipEngine:
                 nat.ptr(X), X.stride(0), nat.ptr(z_in), z_in.stride(0) if z_in is not None else 0,
                 nat.ptr(y_in), y_in.stride(0) if y_in is not None else 0,
                 nat.ptr(z), z.stride(0), nat.ptr(y), y.stride(0), n, d, k, nat.LASSO_F32,
-                float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), int(cap), nat.ptr(delta),
+                float(alpha), float(lr), int(bool(fast)), int(it0), int(iters), int(cap), int(kernel),
+                nat.ptr(delta),
                 nat.ptr(buf), buf.numel(), self._stream()))
         return z, y, delta
 

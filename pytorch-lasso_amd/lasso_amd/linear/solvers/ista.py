@@ -94,7 +94,7 @@ class _UnrolledIsta(torch.autograd.Function):
 
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
-         return_info=False, stop_mode='global'):
+         return_info=False, stop_mode='global', kernel='auto'):
     """Solve min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 on the GPU.
 
     x [n,d], z0 [n,k], weight [d,k]; returns a NEW tensor z [n,k] with the
@@ -104,6 +104,8 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     outer iteration with the line search; ``return_info='objective'`` adds the mean objective
     of the result).  ``stop_mode`` (extension): 'global' = the reference's rule (default),
     'chunked' = the same rule without the in-kernel handshake, 'none' = run maxiter iterations.
+    ``kernel`` (extension): 'auto' | 'tile' | 'splitk' -- which fused kernel runs the batch
+    (include/lasso_hip.h, LASSO_KERNEL_*); the code is bitwise the same either way.
     Tensors that live on the CPU are staged through the current HIP device
     (the arithmetic still runs in the HIP kernels; there is no CPU fallback).
     """
@@ -129,9 +131,9 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
                   and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)))
         if native:
             return _solve_native(x, z0, weight, alpha, fast, float(lr), maxiter, tol, backtrack, eta_backtrack,
-                                 verbose, return_info, stop_mode=stop_mode)
+                                 verbose, return_info, stop_mode=stop_mode, kernel=kernel)
         out = ista(x.float(), z0.float(), weight.float(), alpha, fast, lr, maxiter, tol, backtrack,
-                   eta_backtrack, verbose, return_info, stop_mode)
+                   eta_backtrack, verbose, return_info, stop_mode, kernel)
         if return_info:
             return out[0].to(x.dtype), out[1]
         return out.to(x.dtype)
@@ -172,14 +174,15 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         return (z, info) if return_info else z
 
     return _solve_native(xg, zg, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                         return_info, out_device=out_device, stop_mode=stop_mode)
+                         return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel)
 
 
 _STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
+_KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNEL_SPLITK}
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                  return_info, out_device=None, stop_mode='global'):
+                  return_info, out_device=None, stop_mode='global', kernel='auto'):
     """One call of lasso_fista_solve on tensors of one dtype (float32, or bfloat16 with the
     line search)."""
     n, d = x.shape
@@ -206,7 +209,7 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
-            int(maxiter), float(tol), _STOP[stop_mode], int(bool(backtrack)), float(eta_backtrack),
+            int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel], int(bool(backtrack)), float(eta_backtrack),
             C.byref(iters), C.byref(last), trials, acc_lr, C.byref(obj) if obj is not None else None,
             nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         nat.check(st)
