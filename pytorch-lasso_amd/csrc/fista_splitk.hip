@@ -34,6 +34,7 @@ namespace splitk {
 
 constexpr int kSlice = 128;           // atoms per member
 constexpr int kPartBytes = kTileM * kFistaD * 4;   // one partial residual tile: 16 KiB
+constexpr int kSplitMaxParts = kSplitkMaxParts;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
   lds_char* const yt = (lds_char*)smem;
   lds_char* const rt = yt + YT_BYTES;
   lds_char* const xt = rt + RT_BYTES;                   // -x in the GEMM-1 accumulator layout, [wave][cb][lane] x 16 B
-  lds_f32* const red = (lds_f32*)(xt + RT_BYTES);       // [NW] delta sums, [NW] verdict, [NW+1] total, [NW+2] abort
+  lds_f32* const red = (lds_f32*)(xt + RT_BYTES);       // [NW] delta sums, [NW] verdict, [NW+1] total, [NW+2] abort, [NW+3] one-XCD
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -107,6 +108,54 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
   unsigned* const my_flag = p.xflags + (size_t)(grp * C + mem) * NW + wid;
   const unsigned* const peer_flag = p.xflags + (size_t)(grp * C) * NW + wid;   // + peer * NW
   const int col0 = kSlice * mem + 16 * wid;             // first atom of this wave's z / y block
+
+  // ---- are all members of this group on ONE XCD? ------------------------------------------
+  // The hand-off below is correct on any placement (write-through stores, L1-bypassing loads).
+  // When the C members share an XCD -- the dispatcher is observed to put block b on XCD b % 8,
+  // and the block -> (group, member) map above follows that -- they also share its L2, which is
+  // the coherence point of an XCD: plain stores (acknowledged by L2 at vmcnt(0), L1 is
+  // write-through) are then visible to the peers' L1-bypassing loads without crossing the
+  // fabric, and the lines stay in that L2 for the next iteration.  That is decided at run time
+  // from the hardware's XCC id, exchanged once per launch with the placement-independent form:
+  // a different placement only selects the slower path.
+  bool local;
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* const xid =
+        reinterpret_cast<unsigned long long*>(p.xflags + (size_t)kSplitMaxParts * NW) + (size_t)grp * C;
+    if (wid == 0) {
+      if (lane == 0)
+        __hip_atomic_store(xid + mem, (1ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      bool ok, same;
+      do {
+        unsigned long long v = (1ull << 32) | xcc;
+        if (lane < C) v = __hip_atomic_load(xid + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = __all((unsigned)(v >> 32) == 1u);
+        same = __all((unsigned)v == xcc);
+        if (!ok) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((spins & 63) == 63 &&
+              __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            break;
+        }
+      } while (!ok && ++spins < kStopSpinLimit);
+      if (lane == 0) {
+        red[NW + 3] = (ok && same) ? 1.0f : 0.0f;
+        red[NW + 2] = ok ? 0.0f : 1.0f;
+        if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    local = red[NW + 3] != 0.0f;
+    if (red[NW + 2] != 0.0f) return;                    // a peer never showed up: the host re-runs the solve
+    __builtin_amdgcn_s_barrier();                        // red[] is rewritten per tile below
+  }
+  const __amdgpu_buffer_rsrc_t frsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.xflags, 0, kSplitMaxParts * NW * 4, 0x00020000);
+  const unsigned my_flag_off = (unsigned)(((grp * C + mem) * NW + wid) * 4);
 
   unsigned epoch = 0;
   bool aborted = false;
@@ -170,11 +219,19 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
         }
       }
       // publish: two write-through 16-byte stores per lane, drained, then the wave's flag
+      if (local) {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-        __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, my_part + par_off + cb * 1024, 0, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int cb = 0; cb < 2; ++cb)
+          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, my_part + par_off + cb * 1024, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // in the XCD's L2
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off, 0, 0);
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, my_part + par_off + cb * 1024, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through
+        if (lane == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
 
       // in-kernel stop rule: fetch the previous iteration's |dz| granules now, look at them
       // after the partials have arrived (same protocol as fista_tile_sp.hip)

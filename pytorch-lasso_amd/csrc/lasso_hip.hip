@@ -54,7 +54,7 @@ int pad_d(int64_t d, int kp);
 // ---------------------------------------------------------------------------
 constexpr int kChunkMax = 64;     // iterations per launch when deltas are recorded
 
-constexpr int kSplitMaxParts = 256;   // groups x members of the split-k kernel never exceed the CU count
+constexpr int kSplitMaxParts = kSplitkMaxParts;
 
 struct Workspace {
   float* wp;        // [256][Kp]
@@ -92,7 +92,7 @@ Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool wit
       take((size_t)kStopRing * std::max<int64_t>(ntiles, kSplitMaxParts) * 8));
   w.stop_out = reinterpret_cast<int*>(take(256));
   w.xch = take(fista_splitk_exchange_bytes(kp, kSplitMaxParts / members));
-  w.xflags = reinterpret_cast<unsigned*>(take((size_t)kSplitMaxParts * kFistaWaves * 4));
+  w.xflags = reinterpret_cast<unsigned*>(take(kSplitkFlagBytes));
   for (int i = 0; i < 4; ++i) w.state[i] = with_state ? take((size_t)n * k * 4) : nullptr;
   w.bytes = off;
   return w;
@@ -190,9 +190,10 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 // Which fused kernel runs a batch: the split-k kernel (a 16-row tile shared by Kp/128
 // workgroups, fista_splitk.hip) when the one-workgroup-per-tile kernel would leave most of the
 // chip idle.  `lockstep`: the in-kernel stop rule needs every tile to own a resident group.
-// kSplitRel: measured time of one split-k iteration relative to one iteration of the tile
-// kernel (both at one tile per workgroup group; tools/bench_matrix.py).
-constexpr double kSplitRel = 0.20;
+// split_rel: measured time of one split-k round (one tile per group, every group busy)
+// relative to one round of the tile kernel (one tile per workgroup), per padded dictionary
+// size; MI355X, tools/bench_small.py: K=1024 5.8 / 31.7 us, K=512 5.3 / 16.1 us, K=256 5.1 / 8.3 us.
+double split_rel(int kp) { return kp >= 1024 ? 0.18 : kp >= 512 ? 0.33 : 0.62; }
 struct KernelPlan { bool split; int groups; };
 
 int splitk_max_groups(int kp) {
@@ -211,7 +212,7 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint) {
   const int cus = device_cus();
   const int rounds = (ntiles + gmax - 1) / gmax, tile_rounds = (ntiles + cus - 1) / cus;
   if (lockstep && rounds > 1) return plan;
-  if (hint != LASSO_KERNEL_SPLITK && !(rounds * kSplitRel < (double)tile_rounds)) return plan;
+  if (hint != LASSO_KERNEL_SPLITK && !(rounds * split_rel(kp) < (double)tile_rounds)) return plan;
   plan.split = true;
   plan.groups = std::min(ntiles, gmax);
   return plan;
@@ -257,7 +258,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   if (plan.split) {
     // cross-workgroup hand-offs: epoch tags and the abort flag start from zero in every launch
     p.xch = ws.xch; p.xflags = ws.xflags; p.groups = plan.groups;
-    LASSO_HIP_TRY(hipMemsetAsync(ws.xflags, 0, (size_t)kSplitMaxParts * kFistaWaves * 4, stream));
+    LASSO_HIP_TRY(hipMemsetAsync(ws.xflags, 0, kSplitkFlagBytes, stream));
     if (!p.stop_on) LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, stream));   // (the stop-rule caller zeroed it)
     LASSO_HIP_TRY(launch_fista_splitk(p, kp, stream));
     nparts = ntiles * fista_splitk_members(kp);

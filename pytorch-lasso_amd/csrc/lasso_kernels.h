@@ -42,6 +42,9 @@ struct FistaTileParams {
   int part_stride, part_mul;             // partials[it * part_stride + tile * part_mul] (+ zeros up to part_mul)
 };
 constexpr int kStopRing = 64;
+constexpr int kSplitkMaxParts = 256;   // split-k kernel: groups x members never exceed the CU count
+// split-k hand-off words (zeroed before every launch): [parts][waves] epoch flags, then [parts] 8-byte XCC-id granules
+constexpr size_t kSplitkFlagBytes = (size_t)kSplitkMaxParts * kFistaWaves * 4 + (size_t)kSplitkMaxParts * 8;
 // Bound of every in-kernel handshake spin (one poll = a few L2 round trips + s_sleep, roughly
 // a microsecond): ~0.1 s, far beyond any skew between co-resident workgroups.  Hitting it
 // means part of the grid is not resident (CUs held by another stream / process); the kernels
