@@ -70,7 +70,9 @@ typedef enum {
 #define LASSO_KERNEL_AUTO 0
 #define LASSO_KERNEL_TILE 0x100
 #define LASSO_KERNEL_SPLITK 0x200
-#define LASSO_KERNEL_MASK 0xF00
+/* tuning knob: split-k with exactly T = 1, 2 or 4 tiles per workgroup group (default: by cost model) */
+#define LASSO_KERNEL_SPLITK_TILES(T) (0x200 | ((T) == 1 ? 0x1000 : (T) == 2 ? 0x2000 : 0x3000))
+#define LASSO_KERNEL_MASK 0x3F00
 
 int lasso_hip_abi_version(void);
 const char* lasso_hip_status_string(int status);

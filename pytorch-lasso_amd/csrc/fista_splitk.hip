@@ -1,4 +1,4 @@
-// Small-batch variant of the fused persistent FISTA kernel: ONE 16-row tile is owned by a
+// Small-batch variant of the fused persistent FISTA kernel: a 16-row tile is owned by a
 // GROUP of C = K/128 workgroups (C = 8 at K = 1024), each on its own CU, so that a batch of
 // n rows keeps n/16 * C compute units busy instead of n/16 (BASELINE's n = 4096 on 8 GPUs is
 // 512 rows = 32 tiles per GPU: 32 CUs with the one-workgroup-per-tile kernel, 256 here).
@@ -9,23 +9,26 @@
 //     of W[:, 16 atoms of the wave] for GEMM-2 -- together the 256 x 128 slice twice, 256 KiB
 //     of the CU's 512 KiB register file); nothing is streamed from L2 inside the loop;
 //   * GEMM-1 contracts over the member's own atoms only: p_j = y[:, slice] W[:, slice]^T, a
-//     16 x 256 PARTIAL residual.  The members exchange their partials through L2/fabric
-//     (write-through 16-byte stores + one flag per producing wave; consumers poll the flags
-//     and read with L1-bypassing loads -- the placement-independent R1 hand-off of the CDNA
-//     programming guide, no fence) and every member forms the same r = p_0 + p_1 + ... in the
-//     same fixed order (p_0's MFMA chain starts from -x);
+//     16 x 256 PARTIAL residual.  The members exchange their partials through L2 (16-byte
+//     stores + one flag per producing wave; consumers poll the flags and read with
+//     L1-bypassing loads) and every member forms the same r = p_0 + p_1 + ... in the same
+//     fixed order (p_0's MFMA chain starts from -x);
 //   * GEMM-2 + prox + momentum act on the member's own atoms: g[:, slice] = r W[:, slice],
 //     so z, y of the slice never leave the CU (z in registers, y in an 8 KiB LDS tile).
+// A group works on T tiles at once (T = 1, 2, 4): per iteration GEMM-1 of all T tiles, then
+// per tile {wait for the peers' partials, sum, GEMM-2, prox}.  The hand-off latency of tile t
+// (~2 us) is hidden behind the GEMMs of the other tiles; with T = 1 it is exposed.
+//
 // Arithmetic is IDENTICAL to fista_tile_sp.hip, operation by operation: that kernel sums
 // GEMM-1 in the same 128-atom slices in the same order, GEMM-2's chain and the epilogue are
 // the same instruction sequence -- a row's code does not depend on which kernel (or how many
-// GPUs) computed it (tests/test_properties_gpu.py, bitwise).
+// GPUs) computed it (tests/test_splitk_gpu.py, bitwise).
 //
 // Hand-off safety: tags are a per-launch epoch counter (never 0; flags zeroed by the host
 // before every launch); payload buffers alternate by epoch parity -- a wave can publish epoch
 // e+1 only after it consumed epoch e, which needs every peer's epoch-e publish, which each
 // peer issues after ITS epoch e-1 loads returned.  Every spin is bounded: on a timeout (a peer
-// is not resident) the whole grid aborts without touching z_out and the host re-runs the solve
+// is not resident) the whole grid aborts without touching z_out and the host re-runs the work
 // on the one-workgroup-per-tile kernel.
 #include "tile_device.hpp"
 
@@ -51,28 +54,35 @@ __device__ __forceinline__ u32x4 as_u32x4(f32x4 v) {
   return r;
 }
 
-// STOP: compile the in-kernel global stop rule in (needs one group per tile, all resident).
-template <int K, bool STOP>
+constexpr size_t lds_bytes(int T) {
+  return (size_t)T * (kTileM * kSlice * 4) + (size_t)T * (kTileM * kFistaD * 4) + 2 * (size_t)(kTileM * kFistaD * 4) + 128;
+}
+
+// STOP: compile the in-kernel global stop rule in (needs every tile in a resident group slot).
+template <int K, int T, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const FistaTileParams p) {
   constexpr int C = K / kSlice;
   constexpr int D = kFistaD;
   constexpr int NW = kFistaWaves;
-  constexpr int YT_BYTES = kTileM * kSlice * 4;     // 8 KiB
+  constexpr int YT_BYTES = kTileM * kSlice * 4;     // 8 KiB per tile slot
   constexpr int RT_BYTES = kTileM * D * 4;          // 16 KiB
-  static_assert(C >= 2 && C <= 8 && K % kSlice == 0, "geometry");
+  // partial loads in flight per wave: all C peers at T = 1 (latency), half of them when other
+  // tiles cover the latency anyway (registers)
+  constexpr int PB = (T == 1 || C <= 4) ? C : C / 2;
+  static_assert(C >= 2 && C <= 8 && K % kSlice == 0 && (T == 1 || T == 2 || T == 4), "geometry");
 
   // block -> (group, member): the C members of a group sit on blocks that are congruent
-  // mod 8, i.e. -- as dispatch is observed to go -- on ONE XCD (speed only, never correctness)
+  // mod 8, i.e. -- as dispatch is observed to go -- on ONE XCD
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int mem = idx % C;                              // member = atom slice
   const int grp = (idx / C) * 8 + xcd;
   if (grp >= p.groups) return;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const yt = (lds_char*)smem;
-  lds_char* const rt = yt + YT_BYTES;
-  lds_char* const xt = rt + RT_BYTES;                   // -x in the GEMM-1 accumulator layout, [wave][cb][lane] x 16 B
-  lds_f32* const red = (lds_f32*)(xt + RT_BYTES);       // [NW] delta sums, [NW] verdict, [NW+1] total, [NW+2] abort, [NW+3] one-XCD
+  lds_char* const yt = (lds_char*)smem;                 // [T] y slices
+  lds_char* const xt = yt + T * YT_BYTES;               // [T] -x in the GEMM-1 accumulator layout, [wave][cb][lane] x 16 B
+  lds_char* const rt = xt + T * RT_BYTES;               // [2] residual tiles (ping-pong over the tiles of an iteration)
+  lds_f32* const red = (lds_f32*)(rt + 2 * RT_BYTES);   // [NW] delta sums, [NW] verdict, [NW+1] total, [NW+2] abort, [NW+3] one-XCD
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,18 +109,19 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       b2[t][ss] = *reinterpret_cast<const f32x4*>(p.Wtp + (size_t)(kSlice * mem + 16 * wid + n) * D + 32 * t +
                                                    16 * ss + 4 * q);
 
-  // exchange buffers: payload [parity][group][member][wave][cb][lane] x 16 B, flags [group][member][wave]
+  // exchange buffers: payload [parity][group][slot][member][wave][cb][lane] x 16 B,
+  // flags [group][member][wave][slot]
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 2 * p.groups * C * kPartBytes, 0x00020000);
-  const unsigned my_part = (unsigned)((grp * C + mem) * kPartBytes + wid * 2048 + lane * 16);
-  const unsigned peer_part0 = (unsigned)(grp * C * kPartBytes + wid * 2048 + lane * 16);
-  const unsigned parity_stride = (unsigned)(p.groups * C * kPartBytes);
-  unsigned* const my_flag = p.xflags + (size_t)(grp * C + mem) * NW + wid;
-  const unsigned* const peer_flag = p.xflags + (size_t)(grp * C) * NW + wid;   // + peer * NW
+      __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 2 * p.groups * T * C * kPartBytes, 0x00020000);
+  const unsigned my_part = (unsigned)((grp * T * C + mem) * kPartBytes + wid * 2048 + lane * 16);   // + slot * C * kPartBytes
+  const unsigned peer_part0 = (unsigned)(grp * T * C * kPartBytes + wid * 2048 + lane * 16);
+  const unsigned parity_stride = (unsigned)(p.groups * T * C * kPartBytes);
+  unsigned* const my_flag = p.xflags + ((size_t)(grp * C + mem) * NW + wid) * T;                     // + slot
+  const unsigned* const peer_flag = p.xflags + ((size_t)(grp * C) * NW + wid) * T;                   // + peer * NW * T + slot
   const int col0 = kSlice * mem + 16 * wid;             // first atom of this wave's z / y block
 
   // ---- are all members of this group on ONE XCD? ------------------------------------------
-  // The hand-off below is correct on any placement (write-through stores, L1-bypassing loads).
+  // The hand-off is correct on any placement (write-through stores, L1-bypassing loads).
   // When the C members share an XCD -- the dispatcher is observed to put block b on XCD b % 8,
   // and the block -> (group, member) map above follows that -- they also share its L2, which is
   // the coherence point of an XCD: plain stores (acknowledged by L2 at vmcnt(0), L1 is
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* const xid =
-        reinterpret_cast<unsigned long long*>(p.xflags + (size_t)kSplitMaxParts * NW) + (size_t)grp * C;
+        reinterpret_cast<unsigned long long*>(p.xflags + (size_t)kSplitMaxParts * NW * 4) + (size_t)grp * C;
     if (wid == 0) {
       if (lane == 0)
         __hip_atomic_store(xid + mem, (1ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,43 +161,50 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
     local = red[NW + 3] != 0.0f;
-    if (red[NW + 2] != 0.0f) return;                    // a peer never showed up: the host re-runs the solve
-    __builtin_amdgcn_s_barrier();                        // red[] is rewritten per tile below
+    if (red[NW + 2] != 0.0f) return;                    // a peer never showed up: the host re-runs the work
+    __builtin_amdgcn_s_barrier();                        // red[] is rewritten below
   }
   const __amdgpu_buffer_rsrc_t frsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.xflags, 0, kSplitMaxParts * NW * 4, 0x00020000);
-  const unsigned my_flag_off = (unsigned)(((grp * C + mem) * NW + wid) * 4);
+      __builtin_amdgcn_make_buffer_rsrc(p.xflags, 0, kSplitMaxParts * NW * 4 * 4, 0x00020000);
+  const unsigned my_flag_off = (unsigned)((((grp * C + mem) * NW + wid) * T) * 4);
 
   unsigned epoch = 0;
   bool aborted = false;
-  for (int tile = grp; tile < p.ntiles; tile += p.groups) {
-    const int row0 = tile * kTileM;
-    // ---- state of the tile: z (registers), y (LDS slice), -x (member 0's GEMM-1 start) ----
-    f32x4 zreg, yreg;
-    {
+  const int nparts = p.groups * C;                      // one |dz| granule / partial per workgroup and iteration
+  // group g owns tiles g + groups * (T * round + slot)
+  for (int round = 0; grp + p.groups * T * round < p.ntiles; ++round) {
+    int nt = 0;                                         // active slots of this round (uniform)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (grp + p.groups * (T * round + t) < p.ntiles) nt = t + 1;
+    // ---- state of the tiles: z (registers), y (LDS slices), -x (member 0's GEMM-1 start) ---
+    f32x4 zreg[T];
+    static_for<T>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int r = 4 * q + rg, cc = col0 + n;
-        const bool in = (row0 + r) < p.n && cc < p.k;
-        zreg[rg] = (p.z_in && in) ? p.z_in[(int64_t)(row0 + r) * p.ldz_in + cc] : 0.0f;
-        yreg[rg] = (ysrc && in) ? ysrc[(int64_t)(row0 + r) * ldy + cc] : 0.0f;
-        *(lds_f32*)(yt + tile_off<kSlice>(r, 16 * wid + n)) = yreg[rg];
+        const bool in = t < nt && (row0 + r) < p.n && cc < p.k;
+        zreg[t][rg] = (p.z_in && in) ? p.z_in[(int64_t)(row0 + r) * p.ldz_in + cc] : 0.0f;
+        const float yv = (ysrc && in) ? ysrc[(int64_t)(row0 + r) * ldy + cc] : 0.0f;
+        *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n)) = yv;
       }
-    }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      f32x4 xn;
+      for (int cb = 0; cb < 2; ++cb) {
+        f32x4 xn;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
-        float v = 0.0f;
-        if (mem == 0 && (row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
-        xn[rg] = -v;                                     // members > 0 start their chain at 0
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+          float v = 0.0f;
+          if (mem == 0 && t < nt && (row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+          xn[rg] = -v;                                   // members > 0 start their chain at 0
+        }
+        *(lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16) = xn;
       }
-      *(lds_f32x4*)(xt + wid * 2048 + cb * 1024 + lane * 16) = xn;
-    }
+    });
     if (tid == 0) red[NW + 2] = 0.0f;
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
@@ -197,202 +215,216 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       ++epoch;
       const unsigned par_off = (epoch & 1u) * parity_stride;
 
-      // ======================= GEMM-1: p_mem = y[:, slice] W[:, slice]^T (- x) ==============
-      f32x4 acc[2];
+      // ============ GEMM-1 of every tile: p_mem = y[:, slice] W[:, slice]^T (- x), published ====
+      static_for<T>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if (t < nt) {
+          f32x4 acc[2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc[cb] = *(const lds_f32x4*)(xt + wid * 2048 + cb * 1024 + lane * 16);
-      {
-        const lds_char* const yrow = yt + n * (kSlice * 4);
+          for (int cb = 0; cb < 2; ++cb)
+            acc[cb] = *(const lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16);
+          const lds_char* const yrow = yt + t * YT_BYTES + n * (kSlice * 4);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          f32x4 a[2];
+          for (int s = 0; s < 4; ++s) {
+            f32x4 a[2];
 #pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-            a[ss] = *(const lds_f32x4*)(yrow + (s >> 1) * 256 + (((8 * (s & 1) + 4 * ss + q) ^ n) << 4));
+            for (int ss = 0; ss < 2; ++ss)
+              a[ss] = *(const lds_f32x4*)(yrow + (s >> 1) * 256 + (((8 * (s & 1) + 4 * ss + q) ^ n) << 4));
 #pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
+            for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+              for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-              for (int cb = 0; cb < 2; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b1[s][ss][cb][jj], acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb)
+                  acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b1[s][ss][cb][jj], acc[cb], 0, 0, 0);
+          }
+          // publish: two 16-byte stores per lane, drained, then the wave's flag for this slot
+          const unsigned dst = my_part + par_off + t * (C * kPartBytes);
+          if (local) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // in the XCD's L2
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off + t * 4, 0, 0);
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through
+            if (lane == 0) __hip_atomic_store(my_flag + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-      }
-      // publish: two write-through 16-byte stores per lane, drained, then the wave's flag
-      if (local) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, my_part + par_off + cb * 1024, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // in the XCD's L2
-        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off, 0, 0);
-      } else {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, my_part + par_off + cb * 1024, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through
-        if (lane == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      });
 
-      // in-kernel stop rule: fetch the previous iteration's |dz| granules now, look at them
-      // after the partials have arrived (same protocol as fista_tile_sp.hip)
+      // in-kernel stop rule: fetch the previous iteration's |dz| granules (one per workgroup)
+      // now, look at them once the first tile's partials have arrived
       unsigned long long gr[4] = {0ull, 0ull, 0ull, 0ull};
       const bool check = STOP && p.stop_on && it > 0;
-      const int ngran = p.ntiles * C;
       const unsigned long long* const grow =
-          p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * ngran : nullptr;
+          p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * nparts : nullptr;
       if (STOP && check && wid == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (lane + 64 * e < ngran)
+          if (lane + 64 * e < nparts)
             gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 
-      // wait for the same wave of every peer, then read their partials (L1-bypassing loads)
-      {
-        int spins = 0;
-        bool ok;
-        do {
-          unsigned v = epoch;
-          if (lane < C && lane != mem)
-            v = __hip_atomic_load(peer_flag + lane * NW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = __all(v == epoch);
-          if (!ok) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((spins & 63) == 63 &&
-                __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-              break;
-          }
-        } while (!ok && ++spins < kStopSpinLimit * 8);
-        if (!ok && lane == 0) {       // a peer is not resident: the whole grid gives up
-          __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          red[NW + 2] = 1.0f;
-        }
-      }
-      if (STOP && check && wid == 0) {
-        const unsigned want = (unsigned)it;
-        float partsum = 0.0f;
-        int spins = 0;
-        bool ok;
-        do {
-          ok = true;
-          partsum = 0.0f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (lane + 64 * e < ngran) {
-              if ((unsigned)(gr[e] >> 32) != want) {
-                gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && ((unsigned)(gr[e] >> 32) == want);
-              }
-              partsum += __uint_as_float((unsigned)gr[e]);
-            }
-          ok = __all(ok);
-          if (!ok) {
-            __builtin_amdgcn_s_sleep(8);
-            if ((spins & 63) == 63 &&
-                __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-              break;
-          }
-        } while (!ok && ++spins < kStopSpinLimit);
-        const float total = wave_sum(partsum);
-        if (lane == 0) {
-          red[NW] = !ok ? 2.0f : (total <= p.stop_budget ? 1.0f : 0.0f);      // ista.py:93
-          red[NW + 1] = total;
-          if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      f32x4 part[C][2];
-#pragma unroll
-      for (int pe = 0; pe < C; ++pe)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          part[pe][cb] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(
-              xrsrc, peer_part0 + par_off + pe * kPartBytes + cb * 1024, 0, 16));
-      // r = p_0 + p_1 + ... + p_{C-1}, left to right (the own partial is read back like the
-      // others: it was written through, and the accumulator registers are free meanwhile)
-      f32x4 rsum[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        rsum[cb] = part[0][cb];
-#pragma unroll
-        for (int pe = 1; pe < C; ++pe)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) rsum[cb][rg] = __fadd_rn(rsum[cb][rg], part[pe][cb][rg]);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          *(lds_f32*)(rt + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = rsum[cb][rg];
-
-      LASSO_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();                      // r tile complete (and the verdicts)
-      if (red[NW + 2] != 0.0f || (STOP && check && red[NW] == 2.0f)) { aborted = true; break; }
-      if (STOP && check && red[NW] == 1.0f) {          // iteration it-1 met the rule: z is its z_next
-        if (blockIdx.x == 0 && tid == 0) {
-          p.stop_out[0] = it;
-          p.stop_out[1] = __float_as_int(red[NW + 1]);
-        }
-        stopped = true;
-        break;
-      }
-
-      // ================= GEMM-2 on the wave's 16 atoms + prox / momentum =====================
-      f32x4 g2 = {0.f, 0.f, 0.f, 0.f};
-      {
-        const lds_char* const rrow = rt + n * (D * 4);
-#pragma unroll
-        for (int t = 0; t < D / 32; ++t) {
-          f32x4 a[2];
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-            a[ss] = *(const lds_f32x4*)(rrow + (t >> 1) * 256 + (((8 * (t & 1) + 4 * ss + q) ^ n) << 4));
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-              g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b2[t][ss][jj], g2, 0, 0, 0);
-        }
-      }
       float dsum = 0.0f;
+      bool leave = false;
+      // ============ per tile: gather the partials, r, GEMM-2 on the wave's 16 atoms, prox ========
+      static_for<T>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if (t < nt && !leave) {
+          // wait for the same wave of every peer (L1-bypassing polls), then read their partials
+          {
+            int spins = 0;
+            bool ok;
+            do {
+              unsigned v = epoch;
+              if (lane < C && lane != mem)
+                v = __hip_atomic_load(peer_flag + (size_t)lane * NW * T + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = __all(v == epoch);
+              if (!ok) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 63) == 63 &&
+                    __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                  break;
+              }
+            } while (!ok && ++spins < kStopSpinLimit * 4);
+            if (!ok && lane == 0) {       // a peer is not resident: the whole grid gives up
+              __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              red[NW + 2] = 1.0f;
+            }
+          }
+          if (t == 0 && STOP && check && wid == 0) {
+            const unsigned want = (unsigned)it;
+            float partsum = 0.0f;
+            int spins = 0;
+            bool ok;
+            do {
+              ok = true;
+              partsum = 0.0f;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const float zo = zreg[rg];
-        const float stp = __fmul_rn(p.lr, g2[rg]);                         // lr * grad
-        const float zn = soft_threshold(__fsub_rn(yreg[rg], stp), p.lam);
-        dsum += __builtin_fabsf(__fsub_rn(zo, zn));                         // |z - z_next|
-        const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));               // c (z_next - z)
-        yreg[rg] = __fadd_rn(zn, mom);
-        zreg[rg] = zn;
-        *(lds_f32*)(yt + tile_off<kSlice>(4 * q + rg, 16 * wid + n)) = yreg[rg];
-      }
+              for (int e = 0; e < 4; ++e)
+                if (lane + 64 * e < nparts) {
+                  if ((unsigned)(gr[e] >> 32) != want) {
+                    gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && ((unsigned)(gr[e] >> 32) == want);
+                  }
+                  partsum += __uint_as_float((unsigned)gr[e]);
+                }
+              ok = __all(ok);
+              if (!ok) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((spins & 63) == 63 &&
+                    __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                  break;
+              }
+            } while (!ok && ++spins < kStopSpinLimit);
+            const float total = wave_sum(partsum);
+            if (lane == 0) {
+              red[NW] = !ok ? 2.0f : (total <= p.stop_budget ? 1.0f : 0.0f);      // ista.py:93
+              red[NW + 1] = total;
+              if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          // r = p_0 + p_1 + ... + p_{C-1}, left to right (the own partial is read back like the
+          // others: it sits in L2, and the accumulator registers are free meanwhile)
+          const unsigned src = peer_part0 + par_off + t * (C * kPartBytes);
+          f32x4 rsum[2];
+          static_for<C / PB>([&](auto h_c) {
+            constexpr int h = decltype(h_c)::value;
+            f32x4 part[PB][2];
+#pragma unroll
+            for (int pe = 0; pe < PB; ++pe)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb)
+                part[pe][cb] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(
+                    xrsrc, src + (h * PB + pe) * kPartBytes + cb * 1024, 0, 16));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              if constexpr (h == 0) rsum[cb] = part[0][cb];
+#pragma unroll
+              for (int pe = (h == 0 ? 1 : 0); pe < PB; ++pe)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) rsum[cb][rg] = __fadd_rn(rsum[cb][rg], part[pe][cb][rg]);
+            }
+          });
+          lds_char* const rbuf = rt + (t & 1) * RT_BYTES;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              *(lds_f32*)(rbuf + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = rsum[cb][rg];
+          LASSO_WAIT_LGKM0();
+          __builtin_amdgcn_s_barrier();                  // r tile complete (and, at t = 0, the verdicts)
+          if (red[NW + 2] != 0.0f || (t == 0 && STOP && check && red[NW] == 2.0f)) {
+            aborted = true;
+            leave = true;
+          } else if (t == 0 && STOP && check && red[NW] == 1.0f) {   // iteration it-1 met the rule: z is its z_next
+            if (blockIdx.x == 0 && tid == 0) {
+              p.stop_out[0] = it;
+              p.stop_out[1] = __float_as_int(red[NW + 1]);
+            }
+            stopped = true;
+            leave = true;
+          } else {
+            f32x4 g2 = {0.f, 0.f, 0.f, 0.f};
+            const lds_char* const rrow = rbuf + n * (D * 4);
+#pragma unroll
+            for (int tt = 0; tt < D / 32; ++tt) {
+              f32x4 a[2];
+#pragma unroll
+              for (int ss = 0; ss < 2; ++ss)
+                a[ss] = *(const lds_f32x4*)(rrow + (tt >> 1) * 256 + (((8 * (tt & 1) + 4 * ss + q) ^ n) << 4));
+#pragma unroll
+              for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                  g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b2[tt][ss][jj], g2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              lds_f32* const yp = (lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n));
+              const float zo = zreg[t][rg];
+              const float stp = __fmul_rn(p.lr, g2[rg]);                         // lr * grad
+              const float zn = soft_threshold(__fsub_rn(*yp, stp), p.lam);
+              dsum += __builtin_fabsf(__fsub_rn(zo, zn));                         // |z - z_next|
+              const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));               // c (z_next - z)
+              *yp = __fadd_rn(zn, mom);
+              zreg[t][rg] = zn;
+            }
+          }
+        }
+      });
+      if (leave) break;
       dsum = wave_sum(dsum);
       if (lane == 0) red[wid] = dsum;
       LASSO_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();                      // y slice complete; red[] complete
+      __builtin_amdgcn_s_barrier();                      // y slices complete; red[] complete
       if ((p.partials || (STOP && p.stop_on)) && tid == 0) {
         float tsum = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += red[w];
-        if (p.partials) p.partials[(int64_t)it * ngran + tile * C + mem] = tsum;
+        if (p.partials) p.partials[((int64_t)it * p.part_stride) + (int64_t)round * nparts + grp * C + mem] = tsum;
         if (STOP && p.stop_on)
-          __hip_atomic_store(p.stop_gran + (size_t)(it & (kStopRing - 1)) * ngran + tile * C + mem,
+          __hip_atomic_store(p.stop_gran + (size_t)(it & (kStopRing - 1)) * nparts + grp * C + mem,
                              ((unsigned long long)(unsigned)(it + 1) << 32) | __float_as_uint(tsum),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (aborted) break;                                  // z_out untouched: the host re-runs the solve
+    if (aborted) break;                                  // z_out untouched: the host re-runs the work
     if (STOP && p.stop_on && !stopped && blockIdx.x == 0 && wid == 0 && p.iters > 0) {
       // ran to maxiter: report the last iteration's global delta (does not change z)
       const unsigned want = (unsigned)p.iters;
-      const int ngran = p.ntiles * C;
-      const unsigned long long* const lrow = p.stop_gran + (size_t)((p.iters - 1) & (kStopRing - 1)) * ngran;
+      const unsigned long long* const lrow = p.stop_gran + (size_t)((p.iters - 1) & (kStopRing - 1)) * nparts;
       float partsum = 0.0f;
       int spins = 0;
       bool ok;
       do {
         ok = true;
         partsum = 0.0f;
-        for (int e = lane; e < ngran; e += 64) {
+        for (int e = lane; e < nparts; e += 64) {
           const unsigned long long gv = __hip_atomic_load(lrow + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = ok && ((unsigned)(gv >> 32) == want);
           partsum += __uint_as_float((unsigned)gv);
@@ -408,40 +440,64 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       }
     }
 
+    static_for<T>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int r = 4 * q + rg, cc = col0 + n;
-      if ((row0 + r) < p.n && cc < p.k) {
-        p.z_out[(int64_t)(row0 + r) * p.ldz_out + cc] = zreg[rg];
-        if (p.y_out) p.y_out[(int64_t)(row0 + r) * p.ldy_out + cc] = yreg[rg];
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = col0 + n;
+        if (t < nt && (row0 + r) < p.n && cc < p.k) {
+          p.z_out[(int64_t)(row0 + r) * p.ldz_out + cc] = zreg[t][rg];
+          if (p.y_out)
+            p.y_out[(int64_t)(row0 + r) * p.ldy_out + cc] =
+                *(const lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n));
+        }
       }
-    }
-    __builtin_amdgcn_s_barrier();                        // yt / red reuse by the next tile
+    });
+    __builtin_amdgcn_s_barrier();                        // yt / red reuse by the next round
   }
 }
 
-template <int K, bool STOP>
-static hipError_t launch_ks(const FistaTileParams& p, hipStream_t stream) {
+template <int K, int T, bool STOP>
+static hipError_t launch_kts(const FistaTileParams& p, hipStream_t stream) {
   constexpr int C = K / kSlice;
-  const size_t lds = (size_t)kTileM * kSlice * 4 + 2 * (size_t)kTileM * kFistaD * 4 + 64;
+  const size_t lds = lds_bytes(T);
+  const void* fn = reinterpret_cast<const void*>(&fista_splitk_kernel<K, T, STOP>);
+  if (lds > 64 * 1024)
+    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
   const int grid = (p.groups + 7) / 8 * 8 * C;
-  hipLaunchKernelGGL((fista_splitk_kernel<K, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  hipLaunchKernelGGL((fista_splitk_kernel<K, T, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
   return hipGetLastError();
+}
+
+template <int K, int T>
+static hipError_t launch_kt(const FistaTileParams& p, hipStream_t stream) {
+  return p.stop_on ? launch_kts<K, T, true>(p, stream) : launch_kts<K, T, false>(p, stream);
+}
+
+template <int K>
+static hipError_t launch_k(const FistaTileParams& p, int tiles, hipStream_t stream) {
+  switch (tiles) {
+    case 1: return launch_kt<K, 1>(p, stream);
+    case 2: return launch_kt<K, 2>(p, stream);
+    case 4: return launch_kt<K, 4>(p, stream);
+  }
+  return hipErrorInvalidValue;
 }
 
 template <int K>
 static hipError_t occupancy_k(int* blocks_per_cu) {
-  const size_t lds = (size_t)kTileM * kSlice * 4 + 2 * (size_t)kTileM * kFistaD * 4 + 64;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      blocks_per_cu, reinterpret_cast<const void*>(&fista_splitk_kernel<K, true>), kFistaThreads, lds);
+  const void* fn = reinterpret_cast<const void*>(&fista_splitk_kernel<K, 1, true>);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kFistaThreads, lds_bytes(1));
 }
 
 }  // namespace splitk
 
 int fista_splitk_members(int kpad) { return kpad / splitk::kSlice; }
 
-size_t fista_splitk_exchange_bytes(int kpad, int groups) {
-  return (size_t)2 * groups * (kpad / splitk::kSlice) * splitk::kPartBytes;
+// payload bytes for `groups` groups working on `tiles` tiles at once
+size_t fista_splitk_exchange_bytes(int kpad, int groups, int tiles) {
+  return (size_t)2 * groups * tiles * (kpad / splitk::kSlice) * splitk::kPartBytes;
 }
 
 hipError_t fista_splitk_occupancy(int kpad, int* blocks_per_cu) {
@@ -453,11 +509,12 @@ hipError_t fista_splitk_occupancy(int kpad, int* blocks_per_cu) {
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, hipStream_t stream) {
+// `tiles` (1, 2 or 4): tiles a group works on at once
+hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, int tiles, hipStream_t stream) {
   switch (kpad) {
-    case 256: return p.stop_on ? splitk::launch_ks<256, true>(p, stream) : splitk::launch_ks<256, false>(p, stream);
-    case 512: return p.stop_on ? splitk::launch_ks<512, true>(p, stream) : splitk::launch_ks<512, false>(p, stream);
-    case 1024: return p.stop_on ? splitk::launch_ks<1024, true>(p, stream) : splitk::launch_ks<1024, false>(p, stream);
+    case 256: return splitk::launch_k<256>(p, tiles, stream);
+    case 512: return splitk::launch_k<512>(p, tiles, stream);
+    case 1024: return splitk::launch_k<1024>(p, tiles, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -332,11 +332,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
         float tsum = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += red[w];
-        if (p.partials) {
-          float* const dst = p.partials + (int64_t)it * p.part_stride + (int64_t)tile * p.part_mul;
-          dst[0] = tsum;
-          for (int m = 1; m < p.part_mul; ++m) dst[m] = 0.0f;
-        }
+        if (p.partials) p.partials[(int64_t)it * p.part_stride + tile] = tsum;
         if (STOP && p.stop_on)   // one 8-byte write-through store {tag = it+1, value}: the data is the flag
           __hip_atomic_store(p.stop_gran + (size_t)(it & (kStopRing - 1)) * p.ntiles + tile,
                              ((unsigned long long)(unsigned)(it + 1) << 32) | __float_as_uint(tsum),

@@ -86,12 +86,19 @@ Workspace carve(void* base, int64_t n, int64_t k, int kp, int coef_cap, bool wit
   w.coef = take((size_t)std::max(coef_cap, 1) * 4);
   w.zeros = take((size_t)std::max(coef_cap, 1) * 4);
   const int members = kp / 128;                       // split-k: members per group
-  w.partials = take((size_t)kChunkMax * ntiles * members * 4);
+  // [kChunkMax][ntiles] of the tile kernel, then the split-k kernel's rows: one partial per
+  // workgroup and round, rounds * groups * members <= (ntiles + 256) * members
+  w.partials = take((size_t)kChunkMax * ntiles * 4 + (size_t)kChunkMax * (ntiles + kSplitMaxParts) * members * 4);
   w.delta = take((size_t)kChunkMax * 4);
   w.gran = reinterpret_cast<unsigned long long*>(
       take((size_t)kStopRing * std::max<int64_t>(ntiles, kSplitMaxParts) * 8));
   w.stop_out = reinterpret_cast<int*>(take(256));
-  w.xch = take(fista_splitk_exchange_bytes(kp, kSplitMaxParts / members));
+  // exchange payload of the split-k kernel: up to 256 workgroups x T tiles at once, T by batch size
+  {
+    const int64_t slots = (ntiles * members + kSplitMaxParts - 1) / kSplitMaxParts;   // tiles per group if all 256 CUs take part
+    const int tmax = slots <= 1 ? 1 : slots <= 2 ? 2 : kSplitkMaxTiles;
+    w.xch = take(fista_splitk_exchange_bytes(kp, kSplitMaxParts / members, tmax));
+  }
   w.xflags = reinterpret_cast<unsigned*>(take(kSplitkFlagBytes));
   for (int i = 0; i < 4; ++i) w.state[i] = with_state ? take((size_t)n * k * 4) : nullptr;
   w.bytes = off;
@@ -136,10 +143,13 @@ __global__ void momentum_table_kernel(float* __restrict__ coef, float* __restric
   }
 }
 
-// delta[i] = sum_t partials[i][t], fixed summation order (deterministic).
+// delta[i] = sum_t partials[i][t], fixed summation order (deterministic).  `alt` (nullable):
+// the rows of the stand-by launch, taken instead when *alt_if != 0 (the split-k kernel gave up).
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles,
-                                       float* __restrict__ delta) {
+                                       float* __restrict__ delta, const float* __restrict__ alt = nullptr,
+                                       int alt_count = 0, const int* __restrict__ alt_if = nullptr) {
   __shared__ float sh[256];
+  if (alt && *alt_if != 0) { partials = alt; ntiles = alt_count; }
   const float* row = partials + (size_t)blockIdx.x * ntiles;
   float acc = 0.0f;
   for (int t = threadIdx.x; t < ntiles; t += 256) acc += row[t];
@@ -190,11 +200,16 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 // Which fused kernel runs a batch: the split-k kernel (a 16-row tile shared by Kp/128
 // workgroups, fista_splitk.hip) when the one-workgroup-per-tile kernel would leave most of the
 // chip idle.  `lockstep`: the in-kernel stop rule needs every tile to own a resident group.
-// split_rel: measured time of one split-k round (one tile per group, every group busy)
-// relative to one round of the tile kernel (one tile per workgroup), per padded dictionary
-// size; MI355X, tools/bench_small.py: K=1024 5.8 / 31.7 us, K=512 5.3 / 16.1 us, K=256 5.1 / 8.3 us.
-double split_rel(int kp) { return kp >= 1024 ? 0.18 : kp >= 512 ? 0.33 : 0.62; }
-struct KernelPlan { bool split; int groups; };
+// Cost model of the two kernels in microseconds per iteration and round on MI355X
+// (tools/bench_small.py): the tile kernel runs ceil(ntiles / #CUs) rounds of tile_us; the
+// split-k kernel with T tiles per group runs ceil(ntiles / (groups * T)) rounds of split_us[T].
+struct KernelCost { double tile_us, split_us[3]; };   // split_us: T = 1, 2, 4
+KernelCost kernel_cost(int kp) {
+  if (kp >= 1024) return {31.7, {5.9, 10.6, 20.7}};
+  if (kp >= 512) return {16.1, {5.45, 9.9, 19.4}};
+  return {8.35, {5.2, 9.6, 18.9}};
+}
+struct KernelPlan { bool split; int groups, tiles; };
 
 int splitk_max_groups(int kp) {
   int per_cu = 0;
@@ -204,17 +219,26 @@ int splitk_max_groups(int kp) {
   return resident / (8 * members) * 8;                // whole rows of 8 groups (one per XCD)
 }
 
-KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint) {
-  KernelPlan plan = {false, 0};
-  if (dpad != kFistaD || hint == LASSO_KERNEL_TILE) return plan;
+KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bits) {
+  KernelPlan plan = {false, 0, 1};
+  const int hint = hint_bits & 0xF00;
+  if (dpad != kFistaD || hint == LASSO_KERNEL_TILE || ntiles <= 0) return plan;
   const int gmax = splitk_max_groups(kp);
   if (gmax <= 0) return plan;
   const int cus = device_cus();
-  const int rounds = (ntiles + gmax - 1) / gmax, tile_rounds = (ntiles + cus - 1) / cus;
-  if (lockstep && rounds > 1) return plan;
-  if (hint != LASSO_KERNEL_SPLITK && !(rounds * split_rel(kp) < (double)tile_rounds)) return plan;
-  plan.split = true;
-  plan.groups = std::min(ntiles, gmax);
+  const KernelCost cost = kernel_cost(kp);
+  // (5 % in favour of the tile kernel: it has no cross-workgroup dependencies)
+  double best = hint == LASSO_KERNEL_SPLITK ? 1e30 : 0.95 * cost.tile_us * ((ntiles + cus - 1) / cus);
+  const int forced = (hint_bits >> 12) & 3;           // LASSO_KERNEL_SPLITK_TILES(T): 1, 2, 3 -> T = 1, 2, 4
+  for (int ti = 0; ti < 3; ++ti) {
+    if (forced && ti != forced - 1) continue;
+    const int T = 1 << ti;
+    const int groups = std::min(gmax, (ntiles + T - 1) / T);
+    const int rounds = (ntiles + groups * T - 1) / (groups * T);
+    if (lockstep && rounds > 1) continue;             // the in-kernel stop rule needs every tile in a resident slot
+    const double us = cost.split_us[ti] * rounds;
+    if (us < best) { best = us; plan.split = true; plan.groups = groups; plan.tiles = T; }
+  }
   return plan;
 }
 
@@ -246,7 +270,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.stop_gran = ws.gran;
   p.stop_out = ws.stop_out;
   p.xch = nullptr; p.xflags = nullptr; p.groups = 0;
-  p.run_if = nullptr; p.part_stride = ntiles; p.part_mul = 1;
+  p.run_if = nullptr; p.part_stride = ntiles;
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   // in-place launches keep the tile kernel: a split-k launch that gives up is redone from its
@@ -255,13 +279,18 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
                         (z_in && y_out && z_in == y_out);
   const KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, in_place ? LASSO_KERNEL_TILE : hint);
   int nparts = ntiles;
+  float* const split_rows = ws.partials + (size_t)kChunkMax * ntiles;    // behind the tile kernel's rows
   if (plan.split) {
     // cross-workgroup hand-offs: epoch tags and the abort flag start from zero in every launch
     p.xch = ws.xch; p.xflags = ws.xflags; p.groups = plan.groups;
+    const int members = fista_splitk_members(kp);
+    const int rounds = (ntiles + plan.groups * plan.tiles - 1) / (plan.groups * plan.tiles);
+    nparts = rounds * plan.groups * members;          // one partial per workgroup and round
+    p.part_stride = nparts;
+    if (p.partials) p.partials = split_rows;
     LASSO_HIP_TRY(hipMemsetAsync(ws.xflags, 0, kSplitkFlagBytes, stream));
     if (!p.stop_on) LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, stream));   // (the stop-rule caller zeroed it)
-    LASSO_HIP_TRY(launch_fista_splitk(p, kp, stream));
-    nparts = ntiles * fista_splitk_members(kp);
+    LASSO_HIP_TRY(launch_fista_splitk(p, kp, plan.tiles, stream));
     if (used_split) *used_split = true;
     if (!p.stop_on) {
       // No host synchronisation on this path, so the stand-by is enqueued right behind: the tile
@@ -270,7 +299,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
       // (With the stop rule on, the caller reads the flag at its synchronisation instead.)
       FistaTileParams f = p;
       f.run_if = ws.stop_out + 2;
-      f.part_stride = nparts; f.part_mul = fista_splitk_members(kp);
+      f.part_stride = ntiles;
+      if (f.partials) f.partials = ws.partials;
       LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(ntiles, cus), stream));
     }
   } else {
@@ -278,8 +308,12 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream));
   }
   if (delta && iters > 0) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials,
-                       nparts, delta);
+    if (plan.split)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, split_rows, nparts, delta,
+                         ws.partials, ntiles, ws.stop_out + 2);
+    else
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials, ntiles, delta,
+                         nullptr, 0, nullptr);
     LASSO_HIP_TRY(hipGetLastError());
   }
   return LASSO_OK;
@@ -740,10 +774,12 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
   if (backtrack) return dtype == LASSO_BF16 ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt_grad_kernel / bt_trial_kernel";
   if (dtype == LASSO_BF16) return "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
   const int kp = pad_k(k), dpad = pad_d(d, kp);
-  if (plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO).split)
-    return kp == 1024 ? "lasso::splitk::fista_splitk_kernel<1024, false>"
-         : kp == 512 ? "lasso::splitk::fista_splitk_kernel<512, false>"
-                     : "lasso::splitk::fista_splitk_kernel<256, false>";
+  const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
+  if (plan.split) {
+    static thread_local char name[96];
+    snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
+    return name;
+  }
   switch (dpad) {
     case 256: return kp == 1024 ? "lasso::sp::fista_tile_sp_kernel<1024, 16, false>"
                    : kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 16, false>"
@@ -790,7 +826,8 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   const int kp = pad_k(k);
   if (it0 + iters > maxiter) return fail(LASSO_ERR_BAD_ARG, "it0 + iters = %d > maxiter = %d", it0 + iters, maxiter);
-  if (kernel_hint != LASSO_KERNEL_AUTO && kernel_hint != LASSO_KERNEL_TILE && kernel_hint != LASSO_KERNEL_SPLITK)
+  if ((kernel_hint & ~LASSO_KERNEL_MASK) || ((kernel_hint & 0xF00) != LASSO_KERNEL_AUTO &&
+      (kernel_hint & 0xF00) != LASSO_KERNEL_TILE && (kernel_hint & 0xF00) != LASSO_KERNEL_SPLITK))
     return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", kernel_hint);
   // same carve as lasso_fista_prepare(maxiter): the momentum table it built is read here
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, false);
@@ -843,7 +880,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   stop_mode &= ~LASSO_KERNEL_MASK;
   if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
     return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
-  if (hint != LASSO_KERNEL_AUTO && hint != LASSO_KERNEL_TILE && hint != LASSO_KERNEL_SPLITK)
+  if ((hint & 0xF00) != LASSO_KERNEL_AUTO && (hint & 0xF00) != LASSO_KERNEL_TILE && (hint & 0xF00) != LASSO_KERNEL_SPLITK)
     return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");

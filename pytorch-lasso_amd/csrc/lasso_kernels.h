@@ -33,18 +33,20 @@ struct FistaTileParams {
   float stop_budget;                     // n*k*tol (ista.py:64)
   int stop_on;
   // split-k kernel (fista_splitk.hip): partial-residual exchange between the members of a group
-  float* xch;                            // [2][groups][C][16 KiB] payload, parity = epoch & 1
-  unsigned* xflags;                      // [groups][C][waves] epoch tags, zeroed per launch
-  int groups;                            // groups of C = Kpad/128 workgroups; group g owns tiles g, g+groups, ...
+  float* xch;                            // [2][groups][T][C][16 KiB] payload, parity = epoch & 1
+  unsigned* xflags;                      // [groups][C][waves][T] epoch tags (+ XCC-id granules), zeroed per launch
+  int groups;                            // groups of C = Kpad/128 workgroups; group g owns tiles g + groups * (T * round + slot)
   // tile kernel as the stand-by of a split-k launch: runs only if *run_if != 0 (the split-k
-  // kernel's abort flag), and writes its per-tile partial sums in the split-k layout
+  // kernel's abort flag)
   const int* run_if;                     // nullable
-  int part_stride, part_mul;             // partials[it * part_stride + tile * part_mul] (+ zeros up to part_mul)
+  int part_stride;                       // partials[it * part_stride + part]
 };
 constexpr int kStopRing = 64;
 constexpr int kSplitkMaxParts = 256;   // split-k kernel: groups x members never exceed the CU count
-// split-k hand-off words (zeroed before every launch): [parts][waves] epoch flags, then [parts] 8-byte XCC-id granules
-constexpr size_t kSplitkFlagBytes = (size_t)kSplitkMaxParts * kFistaWaves * 4 + (size_t)kSplitkMaxParts * 8;
+// split-k hand-off words (zeroed before every launch): [parts][waves][tile slots] epoch flags, then [parts] 8-byte XCC-id granules
+constexpr int kSplitkMaxTiles = 4;     // tiles a group works on at once
+constexpr size_t kSplitkFlagBytes =
+    (size_t)kSplitkMaxParts * kFistaWaves * kSplitkMaxTiles * 4 + (size_t)kSplitkMaxParts * 8;
 // Bound of every in-kernel handshake spin (one poll = a few L2 round trips + s_sleep, roughly
 // a microsecond): ~0.1 s, far beyond any skew between co-resident workgroups.  Hitting it
 // means part of the grid is not resident (CUs held by another stream / process); the kernels
@@ -118,10 +120,10 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
 hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu);
 // small-batch variant: a 16-row tile shared by Kpad/128 workgroups (fista_splitk.hip); needs
 // p.xch / p.xflags / p.groups / p.stop_out, flags and stop_out zeroed on the stream before the launch
-hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, hipStream_t stream);
+hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, int tiles, hipStream_t stream);
 hipError_t fista_splitk_occupancy(int kpad, int* blocks_per_cu);
 int fista_splitk_members(int kpad);
-size_t fista_splitk_exchange_bytes(int kpad, int groups);
+size_t fista_splitk_exchange_bytes(int kpad, int groups, int tiles);
 
 hipError_t launch_objective(const ObjectiveParams& p, int kpad, int grid, double alpha,
                             double n_total, double* sums, float* loss_out, hipStream_t stream);

@@ -20,7 +20,7 @@ def _case(n, d, k, seed=1):
 
 @pytest.mark.parametrize("n,d,k", [(16, 256, 1024), (37, 256, 1024), (512, 256, 1024), (1000, 256, 1024),
                                    (2048, 256, 1024), (3000, 200, 1000), (130, 256, 512), (777, 150, 600),
-                                   (90, 200, 256), (1, 129, 130)])
+                                   (90, 200, 256), (1, 129, 130), (4096, 256, 512), (2100, 200, 256)])
 @pytest.mark.parametrize("fast", [True, False])
 def test_split_kernel_is_bitwise_the_tile_kernel(n, d, k, fast):
     from lasso_amd.linear.solvers import ista
@@ -33,8 +33,9 @@ def test_split_kernel_is_bitwise_the_tile_kernel(n, d, k, fast):
     for z0 in (torch.zeros(n, k, device="cuda"), warm):
         for iters in (1, 2, 9, 40):
             zt = ista(Xg, z0, Wg, 0.3, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel='tile')
-            zs = ista(Xg, z0, Wg, 0.3, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel='splitk')
-            assert torch.equal(zt, zs), (iters, (zt - zs).abs().max().item())
+            for kern in ('splitk', 'splitk1', 'splitk2', 'splitk4'):   # cost-model choice, then T = 1, 2, 4 tiles per group
+                zs = ista(Xg, z0, Wg, 0.3, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel=kern)
+                assert torch.equal(zt, zs), (kern, iters, (zt - zs).abs().max().item())
     ref = orc.fista(X, X.new_zeros(n, k), W, 0.3, fast=fast, lr=lr, maxiter=40, tol=0.0)
     assert (zs.cpu() - orc.fista(X, warm.cpu(), W, 0.3, fast=fast, lr=lr, maxiter=40, tol=0.0)).abs().max() <= 5e-5
     zc = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, fast=fast, lr=lr, maxiter=40, tol=0.0, kernel='splitk')
@@ -65,7 +66,7 @@ def test_split_kernel_state_handover_in_chunks():
     assert torch.equal(d2, deltas[0])
 
 
-@pytest.mark.parametrize("n", [512, 100, 16])
+@pytest.mark.parametrize("n", [512, 100, 16, 1024, 2048, 1500])
 def test_split_kernel_in_kernel_stop_rule(n):
     """n <= 512 rows (the per-GPU shard of BASELINE's n=4096 on 8 GPUs): the stop rule is evaluated
     inside the split-k kernel; iteration count = the oracle's, code = the tile kernel's."""
@@ -94,5 +95,6 @@ def test_auto_dispatch_names():
     from lasso_amd import _native as nat
     L = nat.lib()
     assert b"splitk" in L.lasso_fista_kernel_name(512, 256, 1024, nat.LASSO_F32, 0)
+    assert b"fista_splitk_kernel<1024, 2" in L.lasso_fista_kernel_name(1024, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(4096, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(512, 64, 256, nat.LASSO_F32, 0)     # tall tiles: no split

@@ -26,7 +26,7 @@ for d, k in ((256, 1024), (256, 512), (200, 256)):
         Xg, Wg = X.cuda(), W.cuda()
         z0 = torch.zeros(n, k, device="cuda")
         row = {"n": n, "d": d, "k": k}
-        for kern in ("tile", "splitk", "auto"):
+        for kern in ("tile", "splitk1", "splitk2", "splitk4", "auto"):
             ms = timed(lambda: ista(Xg, z0, Wg, 0.5, lr=0.05, maxiter=100, tol=0.0, kernel=kern))
             row[kern + "_us_per_iter"] = ms * 10.0
             row[kern + "_iters_per_s"] = 100 / ms * 1e3
