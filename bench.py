@@ -211,12 +211,13 @@ def run_fista(args, ranks):
         from lasso_amd import _native as nat
         return nat.lib().lasso_fista_kernel_name(rows, D, K, nat.LASSO_F32, 0).decode()
 
+    n_rows = args.rows
     results = {}
     modes = ["strong"] if world == 1 else ["strong", "weak"]
     for mode in modes:
-        rows = N_ROWS // world if mode == "strong" else N_ROWS
-        if mode == "strong" and N_ROWS % world:
-            raise SystemExit("bench.py: %d rows do not split over %d ranks" % (N_ROWS, world))
+        rows = n_rows // world if mode == "strong" else n_rows
+        if mode == "strong" and n_rows % world:
+            raise SystemExit("bench.py: %d rows do not split over %d ranks" % (n_rows, world))
         X, W, Xg, Wg, z0, solve = shard_solver(rows * world, rows)
         elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
         results[mode] = dict(rows=rows, elapsed=elapsed, kern_ms=kern_ms, X=X, W=W, Xg=Xg, Wg=Wg, z0=z0,
@@ -234,15 +235,16 @@ def run_fista(args, ranks):
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
         traffic, traffic_src = hbm_traffic_from_profiles()
         out = {
-            "metric": "fista_iterations_per_sec (n=4096 d=256 k=1024 fp32, fixed L, tol=0)",
+            "metric": "fista_iterations_per_sec (n=%d d=256 k=1024 fp32, fixed L, tol=0)" % n_rows,
             "value": line(main_mode),
             "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * r["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": main_mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: FISTA n=4096 d=256 k=1024 fp32, fixed L, "
-                                   "no backtrack; step = one solve of %d iterations" % args.iters,
+            "config": {"workload": ("BASELINE config 2: FISTA n=%d d=256 k=1024 fp32, fixed L, no backtrack; "
+                                    "step = one solve of %d iterations" % (n_rows, args.iters)) +
+                                   ("" if n_rows == N_ROWS else " (NOT the 4096-row headline batch)"),
                        "iters_per_step": args.iters, "rows_per_gpu": r["rows"],
                        "rows_total": r["rows"] * world,
                        "parallelism": "row-sharded x%d, no data-path collective" % world},
@@ -262,6 +264,20 @@ def run_fista(args, ranks):
             out[other + "_scaling"] = {"value": line(other), "unit": "iterations/s", "rows_per_gpu": q["rows"],
                                        "rows_total": q["rows"] * world,
                                        "ms_per_step": 1e3 * q["elapsed"] / args.steps}
+        if world == 1 and not args.no_shards and n_rows == N_ROWS:
+            # what ONE rank of an N-GPU strong-scaling run of this batch does (4096/N rows, no
+            # data-path collective): timed here on this GPU -- the per-rank ceiling of the N-GPU value
+            shards = {}
+            for nshard in (2, 4, 8):
+                rows_s = N_ROWS // nshard
+                Xs, Ws = recipe(N_ROWS)
+                Xsg, Wsg = Xs[:rows_s].to(dev), Ws.to(dev)
+                z0s = torch.zeros(rows_s, K, device=dev)
+                el, kms = timed_steps(ranks, lambda: ista(Xsg, z0s, Wsg, ALPHA, fast=True, lr=lr, maxiter=args.iters,
+                                                          tol=0.0), args.steps, args.warmup)
+                shards[str(nshard)] = {"rows": rows_s, "iterations_per_s": args.steps * args.iters / el,
+                                       "ms_per_step": 1e3 * el / args.steps, "kernel": kernel_name(rows_s)}
+            out["strong_scaling_shards_on_one_gpu"] = shards
         if not args.no_time_to_tol:
             # time-to-tol of THIS rank's shard with the reference's global rule on the shard
             Xg, Wg, z0 = r["Xg"], r["Wg"], r["z0"]
@@ -280,7 +296,7 @@ def run_fista(args, ranks):
             out["cpu_baseline"] = None
     # objective of the timed result (HIP lasso_loss) against the reference's known answer; the
     # whole 4096-row batch when it is sharded (strong): sums all-reduced
-    if args.iters == 100:
+    if args.iters == 100 and n_rows == N_ROWS:
         from lasso_amd.engine import HipEngine
         q = results["strong"]
         _, sums = HipEngine(dev).objective_sums(q["Xg"], q["z"], q["Wg"], ALPHA)
@@ -388,6 +404,10 @@ def main():
     ap.add_argument("--workload", choices=["fista", "em", "launcher-selftest"], default="fista")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="which figure is `value` at N > 1 (both are measured and reported)")
+    ap.add_argument("--rows", type=int, default=N_ROWS,
+                    help="fista workload: total rows of the batch (default 4096 = BASELINE config 2; e.g. 512 = "
+                         "the shard one rank of an 8-GPU strong-scaling run works on)")
+    ap.add_argument("--no-shards", action="store_true", help="skip the per-shard timings of the N=1 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
     args = ap.parse_args()

@@ -456,6 +456,15 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
     });
     __builtin_amdgcn_s_barrier();                        // yt / red reuse by the next round
   }
+  // rounds in which this group had no tile left: its slots of the per-iteration sums are zero
+  if (p.partials && !aborted && tid < p.iters) {
+    const int total_rounds = p.part_stride / nparts;
+    int mine = 0;
+    while (grp + p.groups * T * mine < p.ntiles) ++mine;
+    for (int r = mine; r < total_rounds; ++r)
+      for (int it = tid; it < p.iters; it += kFistaThreads)
+        p.partials[(int64_t)it * p.part_stride + (int64_t)r * nparts + grp * C + mem] = 0.0f;
+  }
 }
 
 template <int K, int T, bool STOP>

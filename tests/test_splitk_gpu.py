@@ -98,3 +98,24 @@ def test_auto_dispatch_names():
     assert b"fista_splitk_kernel<1024, 2" in L.lasso_fista_kernel_name(1024, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(4096, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(512, 64, 256, nat.LASSO_F32, 0)     # tall tiles: no split
+
+
+@pytest.mark.parametrize("n", [1425, 600, 2500, 3300])
+def test_chunked_stop_rule_through_multi_round_split_launches(n):
+    """The chunked evaluation of the stop rule records per-iteration sums from whatever plan the
+    cost model picks -- including split-k launches of several rounds whose last round leaves
+    some groups without a tile: same iteration count as the oracle and the in-kernel rule."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    X, W = recipe_xw(n)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(n, 1024, device="cuda")
+    lr = 1.0 / LAMBDA_MAX_C2
+    for fast, tol in ((False, 1e-3), (True, 3e-4)):
+        tr = orc.FistaTrace()
+        orc.fista(X, X.new_zeros(n, 1024), W, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, trace=tr)
+        for kern in ('auto', 'splitk1', 'splitk2', 'splitk4', 'tile'):
+            z, info = ista(Xg, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=500, tol=tol, return_info=True,
+                           stop_mode='chunked', kernel=kern)
+            assert info["iterations"] == tr.iterations, (kern, info, tr.iterations)
+            assert abs(info["last_delta"] - tr.delta[-1]) <= 2e-6 * tr.delta[-1]
