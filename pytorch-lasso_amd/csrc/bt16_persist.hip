@@ -1,0 +1,569 @@
+// Persistent single-launch ISTA/FISTA solve on bf16 tensors, with or without the backtracking
+// line search (BASELINE config 3: n=16384, d=256, k=1024, bf16; reference
+// lasso/linear/solvers/ista.py:17-54,57-104 run on bf16 tensors).
+//
+// One workgroup (8 waves) owns one 64-row tile for the WHOLE solve; all tiles are resident at
+// once (n <= 64 x #CUs -- config 3 is exactly 256 tiles on 256 CUs).  On chip, per tile:
+//   * the point p (= y for FISTA, z for ISTA) as a 64 x K bf16 LDS tile in GEMM A-operand layout
+//     (128 KiB at K = 1024) -- it IS the A operand of the gradient's GEMM-1 and is read 16 bytes
+//     per thread by every trial; updated in place at the end of an outer iteration;
+//   * x (bf16) in registers; a 32 KiB LDS region that is the residual tile of GEMM-2 during the
+//     gradient and a double-buffered 64-atom staging tile for candidates during the trials.
+//   * the gradient g of the current outer iteration: bf16, 64 VGPRs per thread (its row, 8 atoms
+//     of each of the K/64 passes below); GEMM-2 leaves g in MFMA layout, so it takes one trip
+//     through memory per outer iteration to get there (written 8 bytes, read back 16 bytes per
+//     thread).
+// The iterate z lives in memory as bf16 -- the precision the reference's own bf16 tensors hold
+// it in: read and written once per outer iteration (in place in the caller's z_out), 16-byte,
+// row-contiguous accesses.  The multi-launch path of bt_bf16.hip moved p, g AND z
+// through HBM in fp32 on every gradient, trial and finish (11 GB per config-3 solve) with a
+// launch per phase and a host round trip per outer iteration; here: ~1.3 GB, one launch, none.
+//
+// A trial never materialises its candidate z+ = S(p - lr g): the K atoms are walked in passes
+// of 64; per pass every thread forms 8 candidate values (one row, 8 atoms) from p (LDS) and g
+// (registers), accumulates the three element sums of ista.py:30-35 and stores the
+// bf16 candidate into the staging tile, and GEMM-1 consumes that tile (2 MFMA steps) while the
+// next pass is being formed -- one barrier per pass.
+//
+// GEMM-1  r = A W^T - x     : A fragments from LDS, W fragments fragment-major from L2 (Wq1).
+// GEMM-2  g^T = W^T r^T     : the TRANSPOSED product (MFMA A operand = W fragment, B operand =
+//     residual fragment), so that a lane ends up with 4 CONSECUTIVE atoms of one row and stores
+//     8 bytes of bf16 g.  (Wq2's fragment-major pack is the same bytes in either role.)
+//
+// Global decisions without leaving the kernel (ista.py:26-35,45 sum over the WHOLE batch):
+// every workgroup publishes its partial sums of a trial as two tagged 16-byte granules
+// (write-through), every workgroup sweeps all granules of that trial and reduces them in the
+// same fixed order -- identical verdict everywhere, no host round trip, no extra launch.
+// The sweep of trial t is taken AFTER trial t+1 has been computed speculatively (step/eta), so
+// the granules' flight time hides behind a GEMM; an accepted trial t discards t+1's work.
+// The stop rule (ista.py:93) uses the same exchange with one granule per workgroup.
+// Every spin is bounded; on a timeout the grid aborts (out[2]) and the host falls back to the
+// multi-launch kernels.
+#include "bf16_device.hpp"
+
+namespace lasso {
+namespace {
+
+using namespace bf16dev;
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+constexpr int kRing = 8;             // granule ring (epochs in flight never span more than 4)
+constexpr int kMaxTrials = 1000;     // ista.py:17 (maxiter=1000)
+constexpr int kPass = 64;            // atoms per trial pass
+constexpr int kStageBytes = kRows * kPass * 2;       // 8 KiB
+constexpr int kScratchBytes = kRows * kFistaD * 2;   // 32 KiB: residual tile | 2 staging tiles + reductions
+
+__device__ __forceinline__ u32x2 pack4(const float (&v)[4]) {
+  bf16x4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (__bf16)v[e];
+  return __builtin_bit_cast(u32x2, b);
+}
+__device__ __forceinline__ void unpack4(u32x2 u, float (&v)[4]) {
+  const bf16x4 b = __builtin_bit_cast(bf16x4, u);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (float)b[e];
+}
+__device__ __forceinline__ void unpack8(u32x4 u, float (&v)[8]) {
+  const bf16x8 b = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)b[e];
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  bf16x8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[e];
+  return __builtin_bit_cast(u32x4, b);
+}
+__device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }
+// Unpack a register-resident entry HERE: the volatile no-op keeps the compiler from hoisting the
+// bf16 -> fp32 conversions of the (loop-invariant) g out of the trial loop, which would hold it
+// a second time in fp32 -- 128 more VGPRs than there are.
+__device__ __forceinline__ void unpack8_here(u32x4 u, float (&v)[8]) {
+  asm volatile("" : "+v"(u));
+  unpack8(u, v);
+}
+
+// wave-wide sum in double, fixed (butterfly) order, same value in every lane
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+
+// byte offset of 16-byte chunk c8 (0..7) of row `row` in a staging tile (128 B per row)
+__device__ __forceinline__ int stage_off(int row, int c8) { return row * (kPass * 2) + ((c8 ^ (row & 7)) << 4); }
+
+template <int K>
+__global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16PersistParams p) {
+  constexpr int NAB = K / 128;                 // 16-atom blocks per wave (GEMM-2)
+  constexpr int NP = K / kPass;                // trial passes
+  constexpr int S2 = kFistaD / 32;             // contraction steps of GEMM-2
+  constexpr int PT_BYTES = kRows * K * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const pt = (lds_char*)smem;        // the point p, [64][K] bf16, A-operand layout
+  lds_char* const st = pt + PT_BYTES;          // 32 KiB scratch (see above)
+  lds_f32* const red = (lds_f32*)(st + 2 * kStageBytes);   // valid while `st` is not the residual tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cl = lane & 15, q = lane >> 4;
+  const int erow = tid >> 3, ec8 = tid & 7;    // element-wise role: one row, 8 consecutive atoms per pass
+  const int tile = blockIdx.x, row0 = tile * kRows;
+  const __bf16* const Xg = (const __bf16*)p.X;
+  const bf16x8* const wq1 = (const bf16x8*)p.Wq1 + (int64_t)wid * (K / 32) * 2 * 64;
+  const bf16x8* const wq2 = (const bf16x8*)p.Wq2 + (int64_t)wid * S2 * NAB * 64;
+  __bf16* const Zg = (__bf16*)p.Z;
+  __bf16* const Gg = (__bf16*)p.G;             // [ntiles * 64][K] bf16, row stride K
+  const __bf16* const Z0g = (const __bf16*)p.Z0;
+  const bool zvec = (p.ldz & 7) == 0 && (((uintptr_t)p.Z) & 15) == 0 && (p.k & 7) == 0;
+  const bool z0vec = Z0g && (p.ldz0 & 7) == 0 && (((uintptr_t)p.Z0) & 15) == 0 && (p.k & 7) == 0;
+  const bool erow_ok = (row0 + erow) < p.n;
+  const __amdgpu_buffer_rsrc_t grsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.gran, 0, kRing * p.ntiles * 32, 0x00020000);
+  // The unrolled trial passes address W fragments, the p tile and the staging tiles as
+  // (one lane-dependent register) + (compile-time offset): a buffer descriptor for the wave's
+  // Wq1 pack, and even/odd-pass lane constants for the swizzled LDS tiles -- otherwise the
+  // compiler materialises ~100 loop-invariant addresses and spills them.
+  const __amdgpu_buffer_rsrc_t w1rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(wq1), 0, (K / 32) * 2 * 64 * 16, 0x00020000);
+  const unsigned lane16 = lane * 16;
+  auto wfrag1 = [&](int frag) {                 // fragment index (step * 2 + col block) of this wave's pack
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, lane16, frag * 1024, 0));
+  };
+  // p tile chunk of (erow, pass j): erow * 2K + 256 (j >> 1) + ((((j & 1) << 3 | ec8) ^ (erow & 15)) << 4)
+  const int ptE = erow * (2 * K) + ((ec8 ^ (erow & 15)) << 4), ptO = erow * (2 * K) + (((8 | ec8) ^ (erow & 15)) << 4);
+  auto pt_off = [&](int j) { return ((j & 1) ? ptO : ptE) + 256 * (j >> 1); };
+  // staging: this thread's chunk, and the A fragments (row 16 rb + cl, chunk 4 u + q)
+  const int stW = stage_off(erow, ec8);
+  const int stA0 = stage_off(cl, q), stA1 = stage_off(cl, 4 + q);   // + 2048 rb  (row & 7 == cl & 7 for every rb)
+
+  // 8 consecutive z values (bf16) of this thread's row, pass j
+  auto load_z8 = [&](const __bf16* base, int64_t ld, bool vec, int j, float (&v)[8]) {
+    const int a0 = kPass * j + 8 * ec8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (!base || !erow_ok || a0 >= p.k) return;
+    const __bf16* src = base + (int64_t)(row0 + erow) * ld + a0;
+    if (vec) {
+      unpack8(*reinterpret_cast<const u32x4*>(src), v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (a0 + e < p.k) v[e] = (float)src[e];
+    }
+  };
+  auto store_z8 = [&](int j, const float (&v)[8]) {
+    const int a0 = kPass * j + 8 * ec8;
+    if (!erow_ok || a0 >= p.k) return;
+    __bf16* dst = Zg + (int64_t)(row0 + erow) * p.ldz + a0;
+    if (zvec) {
+      *reinterpret_cast<u32x4*>(dst) = pack8(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (a0 + e < p.k) dst[e] = (__bf16)v[e];
+    }
+  };
+  // g rows are padded to whole tiles in the workspace, so every thread's row exists
+  const __bf16* const grow = Gg + (int64_t)(row0 + erow) * K + 8 * ec8;   // + kPass * j
+  auto load_g8 = [&](int j) { return *reinterpret_cast<const u32x4*>(grow + kPass * j); };
+
+  // ---- x in GEMM-1's accumulator layout (4 rows per packed entry), resident ------------------
+  u32x2 Xr[4][2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float v[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = row0 + 16 * rb + 4 * q + rg, cc = 32 * wid + 16 * cb + cl;
+        v[rg] = (r < p.n && cc < p.d) ? (float)Xg[(int64_t)r * p.ldx + cc] : 0.0f;
+      }
+      Xr[rb][cb] = pack4(v);
+    }
+  // ---- y_0 = z_0 (ista.py:76-78) -> the p tile -------------------------------------------------
+#pragma unroll 1
+  for (int j = 0; j < NP; ++j) {
+    float v[8];
+    load_z8(Z0g, p.ldz0, z0vec, j, v);
+    *(lds_u32x4*)(pt + tile16_off<K * 2>(erow, 8 * j + ec8)) = pack8(v);
+  }
+  __syncthreads();
+
+  // residual of an accumulator set: acc <- acc - x, returns this lane's sum r^2
+  auto residual = [&](f32x4 (&acc)[4][2]) {
+    float rss = 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        float xv[4];
+        u32x2 xr = Xr[rb][cb];
+        asm volatile("" : "+v"(xr));             // unpack here, not hoisted out of the solve (see unpack8_here)
+        unpack4(xr, xv);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float res = acc[rb][cb][rg] - xv[rg];
+          acc[rb][cb][rg] = res;
+          rss = fmaf(res, res, rss);
+        }
+      }
+    return rss;
+  };
+  auto abort_now = [&]() { __hip_atomic_store(p.out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+  u32x4 Greg[NP];                              // g of this thread's row, 8 atoms per pass (bf16)
+  unsigned epoch = 0;                          // trials published so far (tags are epoch numbers, never 0)
+  int iterations = 0;
+  float last_delta = __builtin_nanf("");
+  bool warned = false, aborted = false;
+
+  for (int it = 0; it < p.maxiter && !aborted; ++it) {
+    const float coef = p.fast ? p.coef[it] : 0.0f;
+    // ================================ gradient at p (ista.py:22-24 / 72-73) =================
+    float rss0;
+    {
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gemm1_bf16<K>(pt, wq1, lane, acc);
+      rss0 = residual(acc);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * rb + 4 * q + rg, cc = 32 * wid + 16 * cb + cl;
+            *(lds_bf16*)(st + tile16_off<kFistaD * 2>(r, cc >> 3) + 2 * (cc & 7)) = (__bf16)acc[rb][cb][rg];
+          }
+    }
+    __syncthreads();                            // residual tile complete
+    // g^T = W^T r^T for the wave's K/8 atoms, two atom blocks at a time, stored as bf16
+    static_for<(NAB + 1) / 2>([&](auto h_c) {
+      constexpr int h = decltype(h_c)::value;
+      constexpr int NB = (2 * h + 1 < NAB) ? 2 : 1;
+      f32x4 gt[NB][4];
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) gt[a][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[2][NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) wf[0][a] = wq2[(0 * NAB + 2 * h + a) * 64 + lane];
+#pragma unroll 1
+      for (int j = 0; j < S2 / 2; ++j) {
+        static_for<2>([&](auto u_c) {
+          constexpr int u = decltype(u_c)::value;
+          const int s = 2 * j + u;
+          const int sp = min(s + 1, S2 - 1);
+#pragma unroll
+          for (int a = 0; a < NB; ++a) wf[(u + 1) & 1][a] = wq2[(sp * NAB + 2 * h + a) * 64 + lane];
+          bf16x8 rf[4];
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            rf[rb] = *(const lds_bf16x8*)(st + tile16_off<kFistaD * 2>(16 * rb + cl, 4 * s + q));
+#pragma unroll
+          for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              gt[a][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][a], rf[rb], gt[a][rb], 0, 0, 0);
+        });
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          // lane: atoms (K/8) w + 16 (2h + a) + 4q .. +3 of row 16 rb + cl (padded atoms are exact zeros)
+          const float v[4] = {gt[a][rb][0], gt[a][rb][1], gt[a][rb][2], gt[a][rb][3]};
+          *reinterpret_cast<u32x2*>(Gg + (int64_t)(row0 + 16 * rb + cl) * K + (K / 8) * wid + 16 * (2 * h + a) + 4 * q) =
+              pack4(v);
+        }
+    });
+    __syncthreads();                            // g is in memory (this CU reads it back); the residual tile is dead
+    // this thread's share of g (its row, 8 atoms of every pass) stays in registers for all the
+    // trials and the accept step of this outer iteration: 4 VGPRs per pass
+#pragma unroll
+    for (int j = 0; j < NP; ++j) Greg[j] = load_g8(j);
+    {                                           // sum r0^2 of the tile -> red[48] (kept until the next gradient)
+      const float r0w = wave_sum(rss0);
+      if (lane == 0) red[40 + wid] = r0w;
+      __syncthreads();
+      if (tid == 0) {
+        float a = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) a += red[40 + w];
+        red[48] = a;
+      }
+    }
+
+    // trial with step (lr, lam): candidate passes -> staging -> GEMM-1, sums published as epoch e
+    auto run_trial = [&](float lr, float lam, unsigned e) {
+      float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 b[2][2][2];                        // [pass parity][step][col block] W fragments, one pass ahead
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) b[0][u][cb] = wfrag1(u * 2 + cb);
+      static_for<NP>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        constexpr int par = j & 1;
+        // ---- candidate values of pass j: z+ = S(p - lr g), rounded like the reference's bf16 tensor
+        float pv[8], gv[8], zn[8];
+        unpack8(*(const lds_u32x4*)(pt + pt_off(j)), pv);
+        unpack8_here(Greg[j], gv);
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr, gv[e8])), lam));   // ista.py:40
+          const float dz = __fsub_rn(zn[e8], pv[e8]);                                             // :31
+          l1 += __builtin_fabsf(zn[e8]);
+          dzg = __fadd_rn(dzg, __fmul_rn(dz, gv[e8]));
+          dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+        }
+        lds_char* const sb = st + par * kStageBytes;
+        *(lds_u32x4*)(sb + stW) = pack8(zn);
+        // W fragments of the next pass
+        if constexpr (j + 1 < NP) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) b[par ^ 1][u][cb] = wfrag1((2 * (j + 1) + u) * 2 + cb);
+        }
+        __syncthreads();                        // staging tile `par` complete (and tile par^1 free again)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x8 a[4];
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) a[rb] = *(const lds_bf16x8*)(sb + (u ? stA1 : stA0) + 2048 * rb);
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[par][u][cb], acc[rb][cb], 0, 0, 0);
+        }
+      });
+      float rss1 = residual(acc);
+      rss1 = wave_sum(rss1); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
+      if (lane == 0) { red[4 * wid] = rss1; red[4 * wid + 1] = l1; red[4 * wid + 2] = dzg; red[4 * wid + 3] = dz2; }
+      __syncthreads();                          // red[] complete; both staging tiles are free
+      if (tid == 0) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) s[jj] += red[4 * w + jj];
+        const unsigned off = (unsigned)(((e % kRing) * p.ntiles + tile) * 32);
+        const u32x4 g0 = {e, __float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2])};
+        const u32x4 g1 = {e, __float_as_uint(s[3]), __float_as_uint(red[48]), 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(g0, grsrc, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(g1, grsrc, off + 16, 0, 16);
+      }
+    };
+    // decision of the trial published as epoch e with 0.5 / step (every workgroup: same data,
+    // same order, same verdict): 0 = rejected, 1 = accepted, 2 = handshake timed out
+    auto decide = [&](unsigned e, float half_over_lr, float& f_out) {
+      if (wid == 0) {
+        double s[5] = {0., 0., 0., 0., 0.};
+        const unsigned base = (unsigned)((e % kRing) * p.ntiles * 32);
+        bool ok = true;
+        for (int wg = lane; wg < p.ntiles; wg += 64) {
+          u32x4 a, b;
+          int spins = 0;
+          for (;;) {
+            a = __builtin_amdgcn_raw_buffer_load_b128(grsrc, base + wg * 32, 0, 16);
+            b = __builtin_amdgcn_raw_buffer_load_b128(grsrc, base + wg * 32 + 16, 0, 16);
+            if (a[0] == e && b[0] == e) break;
+            if (++spins >= kStopSpinLimit ||
+                ((spins & 63) == 63 &&
+                 __hip_atomic_load(p.out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              ok = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          s[0] += __uint_as_float(a[1]); s[1] += __uint_as_float(a[2]); s[2] += __uint_as_float(a[3]);
+          s[3] += __uint_as_float(b[1]); s[4] += __uint_as_float(b[2]);
+        }
+        ok = __all(ok);
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) s[jj] = wave_sum_f64(s[jj]);
+        if (lane == 0) {
+          const float rss1 = (float)s[0], l1 = (float)s[1], dzg = (float)s[2], dz2 = (float)s[3], rss0t = (float)s[4];
+          const float f0 = __fmul_rn(0.5f, rss0t);                                     // ista.py:23
+          const float al1 = __fmul_rn((float)p.alpha, l1);
+          const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                      // :28
+          const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(half_over_lr, dz2)), al1);   // :32-35
+          red[32] = !ok ? 2.0f : (F <= Q ? 1.0f : 0.0f);                              // :45
+          red[34] = F;
+          if (!ok) abort_now();
+        }
+      }
+      __syncthreads();
+      const float v = red[32];
+      f_out = red[34];
+      __syncthreads();                          // red[32] may be rewritten by the next decision
+      return v;
+    };
+
+    // ================================ step size (ista.py:86-90) =============================
+    float lr_acc = (float)p.lr0, lam_acc = (float)(p.alpha * p.lr0), f_acc = __builtin_nanf("");
+    int t_acc = 0;
+    if (p.backtrack) {
+      // step s computes trial s (step / eta^s, in double like the reference's python floats, :47)
+      // and then decides trial s-1: the sweep of a trial's granules is taken one GEMM later
+      double lr_d = p.lr0;
+      float lr_prev = 0.f, lam_prev = 0.f, hol_prev = 0.f;
+      for (int s = 0;; ++s) {
+        const float lr_s = (float)lr_d, lam_s = (float)(p.alpha * lr_d), hol_s = (float)(0.5 / lr_d);
+        if (s < kMaxTrials) run_trial(lr_s, lam_s, ++epoch);      // for s >= 1 speculative: wasted only if s-1 is accepted
+        if (s >= 1) {
+          float fv;
+          const float verdict = decide(epoch - (s < kMaxTrials ? 1u : 0u), hol_prev, fv);
+          if (verdict == 2.0f) { aborted = true; break; }
+          if (verdict == 1.0f) { lr_acc = lr_prev; lam_acc = lam_prev; t_acc = s - 1; f_acc = fv; break; }
+          if (s >= kMaxTrials) { warned = true; t_acc = kMaxTrials - 1; break; }   // :48-52: revert to lr0
+        }
+        lr_prev = lr_s; lam_prev = lam_s; hol_prev = hol_s;
+        lr_d = lr_d / p.eta;
+      }
+      if (aborted) break;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      if (p.trials) p.trials[it] = t_acc + 1;
+      if (p.lrs) p.lrs[it] = lr_acc;
+      if (p.fvals) p.fvals[it] = f_acc;
+    }
+
+    // ================================ accept: z+, |z - z+|, momentum (ista.py:93-102) ========
+    float dsum = 0.0f;
+    static_for<NP>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      float pv[8], gv[8], zo[8], zn[8], yn[8];
+      lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
+      unpack8(*pp, pv);
+      unpack8_here(Greg[j], gv);
+      if (it == 0) load_z8(Z0g, p.ldz0, z0vec, j, zo);
+      else load_z8(Zg, p.ldz, zvec, j, zo);
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
+        dsum += __builtin_fabsf(__fsub_rn(zo[e8], zn[e8]));                         // :93
+        yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo[e8])));     // :99-100
+      }
+      store_z8(j, zn);                                                               // :102
+      *pp = pack8(yn);                                                               // next point, in place
+      if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);                 // at most 4 passes of z loads in flight
+    });
+    iterations = it + 1;
+    __syncthreads();                            // the p tile is complete for the next gradient
+    if (p.budget >= 0.0f) {
+      // global stop rule: one 8-byte granule per workgroup, swept by wave 0 of every workgroup
+      dsum = wave_sum(dsum);
+      if (lane == 0) red[wid] = dsum;
+      __syncthreads();
+      if (tid == 0) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tsum += red[w];
+        __hip_atomic_store(p.dgran + (size_t)(it % kRing) * p.ntiles + tile,
+                           ((unsigned long long)(unsigned)(it + 1) << 32) | __float_as_uint(tsum),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (wid == 0) {
+        const unsigned want = (unsigned)(it + 1);
+        const unsigned long long* const row = p.dgran + (size_t)(it % kRing) * p.ntiles;
+        double part = 0.0;
+        bool ok = true;
+        for (int wg = lane; wg < p.ntiles; wg += 64) {
+          unsigned long long gv;
+          int spins = 0;
+          for (;;) {
+            gv = __hip_atomic_load(row + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(gv >> 32) == want) break;
+            if (++spins >= kStopSpinLimit ||
+                ((spins & 63) == 63 &&
+                 __hip_atomic_load(p.out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              ok = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          part += __uint_as_float((unsigned)gv);
+        }
+        ok = __all(ok);
+        const float total = (float)wave_sum_f64(part);
+        if (lane == 0) {
+          red[32] = !ok ? 2.0f : (total <= p.budget ? 1.0f : 0.0f);
+          red[34] = total;
+          if (!ok) abort_now();
+        }
+      }
+      __syncthreads();
+      const float v = red[32];
+      last_delta = red[34];
+      __syncthreads();
+      if (v == 2.0f) { aborted = true; break; }
+      if (v == 1.0f) break;                     // :93-95
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0 && !aborted) {
+    p.out[0] = iterations;
+    p.out[1] = __float_as_int(last_delta);
+    p.out[3] = warned ? 1 : 0;
+  }
+}
+
+template <int K>
+hipError_t persist_k(const Bt16PersistParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)kRows * K * 2 + kScratchBytes;
+  const void* fn = reinterpret_cast<const void*>(&bt16_persist_kernel<K>);
+  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(bt16_persist_kernel<K>, dim3(p.ntiles), dim3(kThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+template <int K>
+hipError_t persist_occ(int* per_cu) {
+  const size_t lds = (size_t)kRows * K * 2 + kScratchBytes;
+  const void* fn = reinterpret_cast<const void*>(&bt16_persist_kernel<K>);
+  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, fn, kThreads, lds);
+}
+
+}  // namespace
+
+size_t bt16_persist_granule_bytes(int ntiles) {
+  return (size_t)kRing * ntiles * 32 + (size_t)kRing * ntiles * 8;
+}
+
+hipError_t bt16_persist_occupancy(int kpad, int* per_cu) {
+  switch (kpad) {
+    case 256: return persist_occ<256>(per_cu);
+    case 512: return persist_occ<512>(per_cu);
+    case 1024: return persist_occ<1024>(per_cu);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_bt16_persist(const Bt16PersistParams& p, int kpad, hipStream_t stream) {
+  switch (kpad) {
+    case 256: return persist_k<256>(p, stream);
+    case 512: return persist_k<512>(p, stream);
+    case 1024: return persist_k<1024>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace lasso

@@ -353,10 +353,17 @@ struct BtWorkspace {
   float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
   float* G; float* C; float* Y;
   float* Zf;       // bf16 tensors: fp32 working copy of z
+  // persistent bf16 solve (bt16_persist.hip)
+  void* pG;        // [ntiles64 * 64][kp] bf16 gradient
+  void* pZ0;       // [n][k] bf16 copy of z0 when it aliases z_out (a fall-back needs it intact)
+  float* pcoef;    // [maxiter] momentum coefficients (+ [maxiter] zeros)
+  void* pgran;     // trial granules + |dz| granules
+  int* pout;       // [4]
+  int* ptrials; float* plrs; float* pfvals;   // [maxiter] each
   size_t bytes;
 };
 
-BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false) {
+BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false, int maxiter = 0) {
   BtWorkspace w;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -377,8 +384,83 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
   w.C = take((size_t)n * k * 4);
   w.Y = take((size_t)n * k * 4);
   w.Zf = half ? take((size_t)n * k * 4) : nullptr;      // (wp / wtp hold the two bf16 packs then)
+  w.pG = w.pZ0 = w.pgran = nullptr; w.pcoef = nullptr; w.pout = nullptr; w.ptrials = nullptr; w.plrs = w.pfvals = nullptr;
+  if (half) {
+    const int64_t nt64 = (n + 63) / 64;
+    const int cap = std::max(maxiter, 1);
+    w.pG = take((size_t)nt64 * 64 * kp * 2);
+    w.pZ0 = take((size_t)n * k * 2);
+    w.pcoef = take((size_t)cap * 4 * 2);
+    w.pgran = take(bt16_persist_granule_bytes((int)std::max<int64_t>(nt64, 1)));
+    w.pout = reinterpret_cast<int*>(take(256));
+    w.ptrials = reinterpret_cast<int*>(take((size_t)cap * 4));
+    w.plrs = take((size_t)cap * 4);
+    w.pfvals = take((size_t)cap * 4);
+  }
   w.bytes = off;
   return w;
+}
+
+// Persistent single-launch solve on bf16 tensors (bt16_persist.hip), fixed step or line search.
+// Returns LASSO_OK / LASSO_WARN_LINESEARCH when it ran; `*ran` false when it does not apply (more
+// tiles than resident workgroups) or the kernel gave up (a workgroup was not resident): the caller
+// then takes the multi-launch path.
+int solve_bf16_persistent(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* z0_dev,
+                          int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int kp,
+                          double alpha, double lr, int fast, int maxiter, double tol, int backtrack, double eta,
+                          int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
+                          void* workspace, size_t ws_bytes, hipStream_t st, bool* ran, const void** z0_for_fallback) {
+  *ran = false;
+  *z0_for_fallback = z0_dev;
+  BtWorkspace ws = carve_bt(workspace, n, k, kp, true, maxiter);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  const int ntiles = (int)((n + 63) / 64);
+  int per_cu = 0;
+  if (bt16_persist_occupancy(kp, &per_cu) != hipSuccess) return LASSO_OK;
+  if (ntiles > per_cu * device_cus()) return LASSO_OK;            // not all tiles resident: multi-launch path
+  LASSO_HIP_TRY(launch_pack_w_bf16(w_dev, ldw, (int)d, (int)k, kp, 1, ws.wp, ws.wtp, st));
+  hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, st, ws.pcoef, ws.pcoef + std::max(maxiter, 1),
+                     std::max(maxiter, 1));
+  LASSO_HIP_TRY(hipGetLastError());
+  const void* z0 = z0_dev;
+  if (z0_dev && z0_dev == z_out_dev) {      // in place: keep the start for a fall-back run
+    LASSO_HIP_TRY(hipMemcpy2DAsync(ws.pZ0, k * 2, z0_dev, ldz0 * 2, k * 2, n, hipMemcpyDeviceToDevice, st));
+    *z0_for_fallback = ws.pZ0;
+  }
+  LASSO_HIP_TRY(hipMemsetAsync(ws.pgran, 0, bt16_persist_granule_bytes(ntiles), st));
+  LASSO_HIP_TRY(hipMemsetAsync(ws.pout, 0, 16, st));
+  Bt16PersistParams p;
+  p.X = x_dev; p.ldx = ldx; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
+  p.Z0 = z0; p.ldz0 = ldz0; p.Z = z_out_dev; p.ldz = ldz; p.G = ws.pG;
+  p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
+  p.maxiter = maxiter; p.fast = fast; p.backtrack = backtrack;
+  p.alpha = alpha; p.lr0 = lr; p.eta = eta;
+  p.budget = tol > 0.0 ? (float)((double)n * (double)k * tol) : -1.0f;
+  p.coef = ws.pcoef;
+  p.gran = ws.pgran;
+  p.dgran = reinterpret_cast<unsigned long long*>((char*)ws.pgran + (size_t)8 * ntiles * 32);
+  p.out = ws.pout;
+  p.trials = ws.ptrials; p.lrs = ws.plrs; p.fvals = ws.pfvals;
+  LASSO_HIP_TRY(launch_bt16_persist(p, kp, st));
+  int hout[4] = {0, 0, 0, 0};
+  LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.pout, 16, hipMemcpyDeviceToHost, st));
+  LASSO_HIP_TRY(hipStreamSynchronize(st));
+  if (hout[2]) {                              // some workgroup was not resident: nothing usable was produced
+    if (z0_dev && z0_dev == z_out_dev) {
+      // z_out was updated in place by the iterations that did complete: restore the start
+      LASSO_HIP_TRY(hipMemcpy2DAsync(z_out_dev, ldz * 2, ws.pZ0, k * 2, k * 2, n, hipMemcpyDeviceToDevice, st));
+    }
+    return LASSO_OK;
+  }
+  *ran = true;
+  const int its = hout[0];
+  if (iters_out) *iters_out = its;
+  if (last_delta_out) memcpy(last_delta_out, &hout[1], sizeof(float));
+  if (backtrack && its > 0 && (trials_out || accepted_lr_out)) {
+    if (trials_out) LASSO_HIP_TRY(hipMemcpy(trials_out, ws.ptrials, (size_t)its * 4, hipMemcpyDeviceToHost));
+    if (accepted_lr_out) LASSO_HIP_TRY(hipMemcpy(accepted_lr_out, ws.plrs, (size_t)its * 4, hipMemcpyDeviceToHost));
+  }
+  return hout[3] ? fail(LASSO_WARN_LINESEARCH, "backtracking line search failed; reverted to lr0") : LASSO_OK;
 }
 
 int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_t ldw, const void* z0_any,
@@ -754,7 +836,7 @@ static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
   if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
-  if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16).bytes;
+  if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16, maxiter).bytes;
   const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
   return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
 }
@@ -771,8 +853,15 @@ static size_t objective_region_bytes(int64_t n, int64_t d, int64_t k, int dtype)
 const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, int backtrack) {
   if (n <= 0 || d <= 0 || k <= 0) return "";
   if (!fused_shape(d, k)) return "lasso::gemm_nt_kernel x2 + lasso::generic_prox_kernel (unfused)";
-  if (backtrack) return dtype == LASSO_BF16 ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt_grad_kernel / bt_trial_kernel";
-  if (dtype == LASSO_BF16) return "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
+  if (dtype == LASSO_BF16) {
+    int per_cu = 0;
+    const int kpb = pad_k(k);
+    if (bt16_persist_occupancy(kpb, &per_cu) == hipSuccess && (n + 63) / 64 <= (int64_t)per_cu * device_cus())
+      return kpb == 1024 ? "lasso::bt16_persist_kernel<1024>" : kpb == 512 ? "lasso::bt16_persist_kernel<512>"
+                                                                            : "lasso::bt16_persist_kernel<256>";
+    return backtrack ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
+  }
+  if (backtrack) return "lasso::bt_grad_kernel / bt_trial_kernel";
   const int kp = pad_k(k), dpad = pad_d(d, kp);
   const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
   if (plan.split) {
@@ -889,6 +978,19 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                          maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
                          workspace_bytes, st);
   const int kp = pad_k(k);
+  if (half_any && (hint & 0xF00) != LASSO_KERNEL_TILE) {
+    // bf16 tensors: the persistent single-launch kernel when every 64-row tile has its own
+    // resident workgroup (LASSO_KERNEL_TILE asks for the multi-launch kernels instead)
+    bool ran = false;
+    const void* z0_fb = z0_dev;
+    const int s = solve_bf16_persistent(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr,
+                                        fast, maxiter, stop_rule ? tol : 0.0, backtrack, eta_backtrack, iters_out,
+                                        last_delta_out, trials_out, accepted_lr_out, workspace_dev, workspace_bytes,
+                                        st, &ran, &z0_fb);
+    if (ran || (s != LASSO_OK && s != LASSO_WARN_LINESEARCH)) return s;
+    z0_dev = z0_fb;
+    if (z0_fb != z0) ldz0 = k;
+  }
   if (half_any && !backtrack)
     return solve_fixed_bf16(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr, fast,
                             maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,

@@ -94,6 +94,27 @@ struct BtParams {
   const void* Xh; const void* Wq1; const void* Wq2;
 };
 
+// persistent bf16 solve (bt16_persist.hip): one launch per solve, one 64-row tile per workgroup
+struct Bt16PersistParams {
+  const void* X; int64_t ldx;            // bf16 [n][d]
+  const void* Wq1; const void* Wq2;      // fragment-major bf16 packs of W (launch_pack_w_bf16)
+  const void* Z0; int64_t ldz0;          // bf16 [n][k] initial code, nullable -> zeros
+  void* Z; int64_t ldz;                  // bf16 [n][k]: the iterate z, updated in place; the result
+  void* G;                               // bf16 [ntiles * 64][Kpad] workspace: the gradient at the current point
+  int n, d, k, ntiles;
+  int maxiter, fast, backtrack;
+  double alpha, lr0, eta;
+  float budget;                          // n*k*tol (ista.py:64), < 0: no stop rule
+  const float* coef;                     // [maxiter] momentum coefficients (device)
+  void* gran;                            // [ring][ntiles][2] 16-byte trial granules, zeroed per launch
+  unsigned long long* dgran;             // [ring][ntiles] |dz| granules, zeroed per launch
+  int* out;                              // [0] iterations, [1] last delta (float bits), [2] abort, [3] line search failed
+  int* trials; float* lrs; float* fvals; // [maxiter] device trace of the line search (nullable)
+};
+size_t bt16_persist_granule_bytes(int ntiles);
+hipError_t bt16_persist_occupancy(int kpad, int* per_cu);
+hipError_t launch_bt16_persist(const Bt16PersistParams& p, int kpad, hipStream_t stream);
+
 // greedy coordinate descent (cd.hip): per-row state padded to kp = 256*NC columns
 struct CdParams {
   float* B;                // [n][kp] correlation vectors b
