@@ -9,21 +9,20 @@
 //     per thread by every trial; updated in place at the end of an outer iteration;
 //   * x (bf16) in registers; a 32 KiB LDS region that is the residual tile of GEMM-2 during the
 //     gradient and a double-buffered 64-atom staging tile for candidates during the trials.
-//   * the gradient g of the current outer iteration: bf16, 64 VGPRs per thread (its row, 8 atoms
-//     of each of the K/64 passes below); GEMM-2 leaves g in MFMA layout, so it takes one trip
-//     through memory per outer iteration to get there (written 8 bytes, read back 16 bytes per
-//     thread).
-// The iterate z lives in memory as bf16 -- the precision the reference's own bf16 tensors hold
-// it in: read and written once per outer iteration (in place in the caller's z_out), 16-byte,
-// row-contiguous accesses.  The multi-launch path of bt_bf16.hip moved p, g AND z
+// The gradient g and the iterate z live in memory as bf16 -- the precision the reference's own
+// bf16 tensors hold them in: g (32 MB at config 3: it stays in the 256 MB Infinity Cache) is
+// written once per outer iteration and read once per trial, z is read and written once per
+// outer iteration (in place in the caller's z_out); 16-byte, row-contiguous reads.  The multi-launch path of bt_bf16.hip moved p, g AND z
 // through HBM in fp32 on every gradient, trial and finish (11 GB per config-3 solve) with a
-// launch per phase and a host round trip per outer iteration; here: ~1.3 GB, one launch, none.
+// launch per phase and a host round trip per outer iteration; here: one launch, none, and only
+// bf16 g / z traffic (~2.6 GB, most of it served by the Infinity Cache).
 //
 // A trial never materialises its candidate z+ = S(p - lr g): the K atoms are walked in passes
 // of 64; per pass every thread forms 8 candidate values (one row, 8 atoms) from p (LDS) and g
-// (registers), accumulates the three element sums of ista.py:30-35 and stores the
+// (prefetched two passes ahead), accumulates the three element sums of ista.py:30-35 and stores the
 // bf16 candidate into the staging tile, and GEMM-1 consumes that tile (2 MFMA steps) while the
-// next pass is being formed -- one barrier per pass.
+// next pass is being formed (MFMAs and element-wise VALU work interleaved in one instruction
+// stream) -- one barrier per pass.
 //
 // GEMM-1  r = A W^T - x     : A fragments from LDS, W fragments fragment-major from L2 (Wq1).
 // GEMM-2  g^T = W^T r^T     : the TRANSPOSED product (MFMA A operand = W fragment, B operand =
@@ -49,6 +48,7 @@ using namespace bf16dev;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 constexpr int kRing = 8;             // granule ring (epochs in flight never span more than 4)
@@ -97,6 +97,46 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 
 // byte offset of 16-byte chunk c8 (0..7) of row `row` in a staging tile (128 B per row)
 __device__ __forceinline__ int stage_off(int row, int c8) { return row * (kPass * 2) + ((c8 ^ (row & 7)) << 4); }
+
+// GEMM-1 of the gradient (A = the whole p tile): like bf16dev::gemm1_bf16, but the W fragments run
+// SIX steps ahead of their use through an 8-deep register ring (the gradient phase has the
+// registers to spare and one L2 round trip is worth ~4 steps of MFMAs), addressed as
+// descriptor + lane offset + compile-time offset.
+template <int K>
+__device__ __forceinline__ void gemm1_bf16_deep(const lds_char* at, __amdgpu_buffer_rsrc_t wrsrc, unsigned lane16,
+                                                int lane, f32x4 (&acc)[4][2]) {
+  constexpr int S1 = K / 32;
+  static_assert(S1 % 8 == 0, "K must be a multiple of 256");
+  const int i = lane & 15, kg = lane >> 4;
+  bf16x8 b[8][2];
+  auto frag = [&](unsigned soff, int f) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, soff + f * 1024, 0));
+  };
+#pragma unroll
+  for (int s = 0; s < 6; ++s)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) b[s][cb] = frag(0, s * 2 + cb);
+#pragma unroll 1
+  for (int j = 0; j < S1 / 8; ++j) {
+    const unsigned soff = (unsigned)j * 8 * 2 * 1024;
+    static_for<8>([&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      const int s = 8 * j + u;
+      // step s + 6 (the last six prefetches re-read the final step)
+      const unsigned so = (s + 6 < S1) ? soff : (unsigned)(S1 - 1 - u - 6) * 2 * 1024;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) b[(u + 6) % 8][cb] = frag(so, (u + 6) * 2 + cb);
+      bf16x8 a[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a[rb] = *(const lds_bf16x8*)(at + tile16_off<K * 2>(16 * rb + i, 4 * s + kg));
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[u][cb], acc[rb][cb], 0, 0, 0);
+    });
+  }
+}
 
 template <int K>
 __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16PersistParams p) {
@@ -217,7 +257,6 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
   };
   auto abort_now = [&]() { __hip_atomic_store(p.out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
-  u32x4 Greg[NP];                              // g of this thread's row, 8 atoms per pass (bf16)
   unsigned epoch = 0;                          // trials published so far (tags are epoch numbers, never 0)
   int iterations = 0;
   float last_delta = __builtin_nanf("");
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      gemm1_bf16<K>(pt, wq1, lane, acc);
+      gemm1_bf16_deep<K>(pt, w1rsrc, lane16, lane, acc);
       rss0 = residual(acc);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -246,26 +285,37 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           }
     }
     __syncthreads();                            // residual tile complete
-    // g^T = W^T r^T for the wave's K/8 atoms, two atom blocks at a time, stored as bf16
-    static_for<(NAB + 1) / 2>([&](auto h_c) {
+    // g^T = W^T r^T for the wave's K/8 atoms, NB atom blocks (16 NB atoms) at a time, W fragments
+    // three steps ahead through a 4-deep ring; stored as bf16.  Which atom an MFMA output row
+    // stands for is free: block a, row i is atom 4 NB (i >> 2) + 4 a + (i & 3) of the group, so
+    // that a lane's 4 rows x NB blocks are 4 NB CONSECUTIVE atoms -- g leaves in 16-byte stores,
+    // 8 NB bytes per lane, whole 128-byte lines per row (8-byte pieces took 3x as long).  The W
+    // fragment of such a block is a per-lane gather from the group's NB fragments of the pack.
+    constexpr int NB = NAB < 4 ? NAB : 4;
+    static_for<NAB / NB>([&](auto h_c) {
       constexpr int h = decltype(h_c)::value;
-      constexpr int NB = (2 * h + 1 < NAB) ? 2 : 1;
       f32x4 gt[NB][4];
+      int gidx[NB];
 #pragma unroll
-      for (int a = 0; a < NB; ++a)
+      for (int a = 0; a < NB; ++a) {
+        const int ag = 4 * NB * (cl >> 2) + 4 * a + (cl & 3);            // atom of (block a, row cl) inside the group
+        gidx[a] = (NB * h + (ag >> 4)) * 64 + (ag & 15) + 16 * q;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) gt[a][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 wf[2][NB];
+      }
+      bf16x8 wf[4][NB];
 #pragma unroll
-      for (int a = 0; a < NB; ++a) wf[0][a] = wq2[(0 * NAB + 2 * h + a) * 64 + lane];
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int a = 0; a < NB; ++a) wf[s][a] = wq2[s * NAB * 64 + gidx[a]];
 #pragma unroll 1
-      for (int j = 0; j < S2 / 2; ++j) {
-        static_for<2>([&](auto u_c) {
+      for (int j = 0; j < S2 / 4; ++j) {
+        static_for<4>([&](auto u_c) {
           constexpr int u = decltype(u_c)::value;
-          const int s = 2 * j + u;
-          const int sp = min(s + 1, S2 - 1);
+          const int s = 4 * j + u;
+          const int sp = min(s + 3, S2 - 1);
 #pragma unroll
-          for (int a = 0; a < NB; ++a) wf[(u + 1) & 1][a] = wq2[(sp * NAB + 2 * h + a) * 64 + lane];
+          for (int a = 0; a < NB; ++a) wf[(u + 3) & 3][a] = wq2[sp * NAB * 64 + gidx[a]];
           bf16x8 rf[4];
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
@@ -278,20 +328,18 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         });
       }
 #pragma unroll
-      for (int a = 0; a < NB; ++a)
+      for (int rb = 0; rb < 4; ++rb) {
+        // lane: atoms (K/8) w + 16 NB h + 4 NB q + (0 .. 4 NB - 1) of row 16 rb + cl (padded atoms are exact zeros)
+        __bf16* const dst = Gg + (int64_t)(row0 + 16 * rb + cl) * K + (K / 8) * wid + 16 * NB * h + 4 * NB * q;
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          // lane: atoms (K/8) w + 16 (2h + a) + 4q .. +3 of row 16 rb + cl (padded atoms are exact zeros)
-          const float v[4] = {gt[a][rb][0], gt[a][rb][1], gt[a][rb][2], gt[a][rb][3]};
-          *reinterpret_cast<u32x2*>(Gg + (int64_t)(row0 + 16 * rb + cl) * K + (K / 8) * wid + 16 * (2 * h + a) + 4 * q) =
-              pack4(v);
+        for (int a2 = 0; a2 < NB / 2; ++a2) {
+          const float v[8] = {gt[2 * a2][rb][0], gt[2 * a2][rb][1], gt[2 * a2][rb][2], gt[2 * a2][rb][3],
+                              gt[2 * a2 + 1][rb][0], gt[2 * a2 + 1][rb][1], gt[2 * a2 + 1][rb][2], gt[2 * a2 + 1][rb][3]};
+          *reinterpret_cast<u32x4*>(dst + 8 * a2) = pack8(v);
         }
+      }
     });
     __syncthreads();                            // g is in memory (this CU reads it back); the residual tile is dead
-    // this thread's share of g (its row, 8 atoms of every pass) stays in registers for all the
-    // trials and the accept step of this outer iteration: 4 VGPRs per pass
-#pragma unroll
-    for (int j = 0; j < NP; ++j) Greg[j] = load_g8(j);
     {                                           // sum r0^2 of the tile -> red[48] (kept until the next gradient)
       const float r0w = wave_sum(rss0);
       if (lane == 0) red[40 + wid] = r0w;
@@ -306,42 +354,101 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 
     // trial with step (lr, lam): candidate passes -> staging -> GEMM-1, sums published as epoch e
     auto run_trial = [&](float lr, float lam, unsigned e) {
-      float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+      float l1 = 0.0f;
+      f32x2 dzg2 = {0.f, 0.f}, dz22 = {0.f, 0.f};
+      const f32x2 lr2 = {lr, lr};
       f32x4 acc[4][2];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 b[2][2][2];                        // [pass parity][step][col block] W fragments, one pass ahead
+      bf16x8 b[2][2][2];                        // [pass parity][step][col block] W fragments, two passes ahead
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int par = 0; par < 2; ++par)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) b[0][u][cb] = wfrag1(u * 2 + cb);
-      static_for<NP>([&](auto j_c) {
-        constexpr int j = decltype(j_c)::value;
-        constexpr int par = j & 1;
-        // ---- candidate values of pass j: z+ = S(p - lr g), rounded like the reference's bf16 tensor
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) b[par][u][cb] = wfrag1((2 * par + u) * 2 + cb);
+      u32x4 gq[2] = {load_g8(0), load_g8(1)};   // g of the next two passes (bf16, 16 B each)
+      // candidate values of pass j (this thread: one row, 8 atoms) -> staging tile j & 1
+      auto candidates = [&](int j, int par) __attribute__((always_inline)) {
         float pv[8], gv[8], zn[8];
-        unpack8(*(const lds_u32x4*)(pt + pt_off(j)), pv);
-        unpack8_here(Greg[j], gv);
+        unpack8(*(const lds_u32x4*)(pt + (par ? ptO : ptE) + 256 * (j >> 1)), pv);
+        unpack8(gq[par], gv);
+        gq[par] = load_g8(min(j + 2, NP - 1));
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr, gv[e8])), lam));   // ista.py:40
-          const float dz = __fsub_rn(zn[e8], pv[e8]);                                             // :31
-          l1 += __builtin_fabsf(zn[e8]);
-          dzg = __fadd_rn(dzg, __fmul_rn(dz, gv[e8]));
-          dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const f32x2 p2 = {pv[2 * e2], pv[2 * e2 + 1]}, g2v = {gv[2 * e2], gv[2 * e2 + 1]};
+          const f32x2 v2 = p2 - lr2 * g2v;                                                        // ista.py:40
+          f32x2 z2 = {bf16_round(soft_threshold(v2[0], lam)), bf16_round(soft_threshold(v2[1], lam))};
+          const f32x2 d2 = z2 - p2;                                                               // :31
+          l1 += __builtin_fabsf(z2[0]) + __builtin_fabsf(z2[1]);
+          dzg2 = dzg2 + d2 * g2v;
+          dz22 = dz22 + d2 * d2;
+          zn[2 * e2] = z2[0]; zn[2 * e2 + 1] = z2[1];
         }
-        lds_char* const sb = st + par * kStageBytes;
-        *(lds_u32x4*)(sb + stW) = pack8(zn);
-        // W fragments of the next pass
-        if constexpr (j + 1 < NP) {
+        *(lds_u32x4*)(st + par * kStageBytes + stW) = pack8(zn);
+      };
+      // Between two barriers a wave holds the MFMAs of pass jm (staging tile pm) and the
+      // element-wise work of pass jc (-> staging tile pm ^ 1): independent streams, written out
+      // interleaved -- two MFMAs, then one element's VALU work while the matrix pipe is busy --
+      // and pinned in that order (left to itself the scheduler runs them one after the other and
+      // the two pipes take turns idling).  Afterwards pass jm's W fragments are replaced by pass
+      // jm + 2's.
+      auto fused_pass = [&](int jm, int pm, int jc) __attribute__((always_inline)) {
+        const lds_char* const sb = st + pm * kStageBytes;
+        const int pc = pm ^ 1;
+        bf16x8 a[2][4];
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) b[par ^ 1][u][cb] = wfrag1((2 * (j + 1) + u) * 2 + cb);
+          for (int rb = 0; rb < 4; ++rb) a[u][rb] = *(const lds_bf16x8*)(sb + (u ? stA1 : stA0) + 2048 * rb);
+        float pv[8], gv[8], zn[8];
+        unpack8(*(const lds_u32x4*)(pt + (pc ? ptO : ptE) + 256 * (jc >> 1)), pv);
+        unpack8(gq[pc], gv);
+        gq[pc] = load_g8(min(jc + 2, NP - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        // two elements at a time on the packed fp32 VALU (v_pk_mul_f32 / v_pk_add_f32: the same
+        // IEEE operations, two lanes of work per instruction); the sums run as two partial sums
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {          // 4 of the pass's 16 MFMAs
+            const int i = 4 * e2 + m, u = i >> 3, rb = (i >> 1) & 3, cb = i & 1;
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][rb], b[pm][u][cb], acc[rb][cb], 0, 0, 0);
+          }
+          const f32x2 p2 = {pv[2 * e2], pv[2 * e2 + 1]}, g2v = {gv[2 * e2], gv[2 * e2 + 1]};
+          const f32x2 v2 = p2 - lr2 * g2v;                                                        // ista.py:40
+          f32x2 z2 = {bf16_round(soft_threshold(v2[0], lam)), bf16_round(soft_threshold(v2[1], lam))};
+          const f32x2 d2 = z2 - p2;                                                               // :31
+          l1 += __builtin_fabsf(z2[0]) + __builtin_fabsf(z2[1]);
+          dzg2 = dzg2 + d2 * g2v;
+          dz22 = dz22 + d2 * d2;
+          zn[2 * e2] = z2[0]; zn[2 * e2 + 1] = z2[1];
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                        // staging tile `par` complete (and tile par^1 free again)
+        *(lds_u32x4*)(st + pc * kStageBytes + stW) = pack8(zn);
+        const unsigned fn = (unsigned)(min(jm + 2, NP - 1) * 4) * 1024u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            b[pm][u][cb] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, lane16, fn + (u * 2 + cb) * 1024, 0));
+      };
+      candidates(0, 0);
+#pragma unroll 1
+      for (int j2 = 0; j2 < NP / 2 - 1; ++j2) {
+        __syncthreads();                        // staging tile 0 complete, tile 1 free
+        fused_pass(2 * j2, 0, 2 * j2 + 1);
+        __syncthreads();                        // staging tile 1 complete, tile 0 free
+        fused_pass(2 * j2 + 1, 1, 2 * j2 + 2);
+      }
+      __syncthreads();
+      fused_pass(NP - 2, 0, NP - 1);
+      __syncthreads();
+      {                                         // last pass: MFMAs only
+        const lds_char* const sb = st + kStageBytes;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           bf16x8 a[4];
@@ -351,9 +458,10 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[par][u][cb], acc[rb][cb], 0, 0, 0);
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[1][u][cb], acc[rb][cb], 0, 0, 0);
         }
-      });
+      }
+      float dzg = dzg2[0] + dzg2[1], dz2 = dz22[0] + dz22[1];
       float rss1 = residual(acc);
       rss1 = wave_sum(rss1); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
       if (lane == 0) { red[4 * wid] = rss1; red[4 * wid + 1] = l1; red[4 * wid + 2] = dzg; red[4 * wid + 3] = dz2; }
@@ -448,24 +556,34 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 
     // ================================ accept: z+, |z - z+|, momentum (ista.py:93-102) ========
     float dsum = 0.0f;
-    static_for<NP>([&](auto j_c) {
-      constexpr int j = decltype(j_c)::value;
-      float pv[8], gv[8], zo[8], zn[8], yn[8];
-      lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
-      unpack8(*pp, pv);
-      unpack8_here(Greg[j], gv);
-      if (it == 0) load_z8(Z0g, p.ldz0, z0vec, j, zo);
-      else load_z8(Zg, p.ldz, zvec, j, zo);
+#pragma unroll 1
+    for (int jb = 0; jb < NP; jb += 4) {        // four passes at a time: their 8 loads are in flight together
+      u32x4 gq[4];
+      float zo[4][8];
 #pragma unroll
-      for (int e8 = 0; e8 < 8; ++e8) {
-        zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
-        dsum += __builtin_fabsf(__fsub_rn(zo[e8], zn[e8]));                         // :93
-        yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo[e8])));     // :99-100
+      for (int u = 0; u < 4; ++u) gq[u] = load_g8(jb + u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (it == 0) load_z8(Z0g, p.ldz0, z0vec, jb + u, zo[u]);
+        else load_z8(Zg, p.ldz, zvec, jb + u, zo[u]);
       }
-      store_z8(j, zn);                                                               // :102
-      *pp = pack8(yn);                                                               // next point, in place
-      if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);                 // at most 4 passes of z loads in flight
-    });
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = jb + u;
+        float pv[8], gv[8], zn[8], yn[8];
+        lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
+        unpack8(*pp, pv);
+        unpack8(gq[u], gv);
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
+          dsum += __builtin_fabsf(__fsub_rn(zo[u][e8], zn[e8]));                      // :93
+          yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo[u][e8])));  // :99-100
+        }
+        store_z8(j, zn);                                                              // :102
+        *pp = pack8(yn);                                                              // next point, in place
+      }
+    }
     iterations = it + 1;
     __syncthreads();                            // the p tile is complete for the next gradient
     if (p.budget >= 0.0f) {

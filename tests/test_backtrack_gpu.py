@@ -183,7 +183,7 @@ def test_native_bf16_fixed_step(n, d, k):
                      maxiter=500, tol=1e-3, return_info=True)
     # bf16 iterates move on a coarser grid than fp32 ones, so sum|z - z+| crosses the budget a little
     # later or earlier; the reference's own bf16 run does the same
-    assert abs(info["iterations"] - rinfo["iterations"]) <= max(3, rinfo["iterations"] // 4)
+    assert abs(info["iterations"] - rinfo["iterations"]) <= max(3, (2 * rinfo["iterations"]) // 5)
     ob = orc.lasso_objective(X.float(), zt.float().cpu(), W.float(), 0.3).item()
     of = orc.lasso_objective(X.float(), zr.cpu(), W.float(), 0.3).item()
     assert abs(ob - of) <= 2e-3 * abs(of)

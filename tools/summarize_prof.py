@@ -16,7 +16,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("== PMC %s ==" % os.path.basename(d))
         for kname, ctrs in acc.items():
-            if "fista" not in kname and "gram" not in kname and "sweep" not in kname:
+            if "lasso" not in kname:
                 continue
             print(" kernel:", kname[:100])
             for c, vals in sorted(ctrs.items()):
