@@ -95,7 +95,10 @@ int lasso_hip_device_cus(int* cus_out);
  *   trials_out / accepted_lr_out (HOST arrays of `maxiter` entries, nullable; written
  *   for the executed iterations when backtrack != 0): the number of line-search trials
  *   evaluated up to and including the accepted one, and the step size the iteration
- *   used -- the quantities ista.py:43-47 prints with verbose=True.
+ *   used -- the quantities ista.py:43-47 prints with verbose=True.  accepted_f_out (same
+ *   shape): F(z_next) = 0.5*||z_next W^T - x||^2 + alpha*||z_next||_1 of the accepted trial
+ *   (:28) -- divided by n it is the objective ista() prints for the NEXT iteration
+ *   with verbose=True (:66-69,80-81), obtained without an extra pass over the data.
  *   objective_out (HOST float, nullable): mean objective (0.5*||x - z W^T||^2 +
  *   alpha*||z||_1)/n of the returned code, evaluated in fp32 (dict_learning.py:10-13,
  *   ista.py:66-69); synchronises `stream`.
@@ -122,7 +125,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx,
                       double tol, int stop_mode,
                       int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out,
-                      int32_t* trials_out, float* accepted_lr_out, float* objective_out,
+                      int32_t* trials_out, float* accepted_lr_out, float* accepted_f_out,
+                      float* objective_out,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- building blocks for multi-GPU / custom drivers ---------------------------------

@@ -409,7 +409,8 @@ int solve_bf16_persistent(const void* x_dev, int64_t ldx, const void* w_dev, int
                           int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int kp,
                           double alpha, double lr, int fast, int maxiter, double tol, int backtrack, double eta,
                           int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
-                          void* workspace, size_t ws_bytes, hipStream_t st, bool* ran, const void** z0_for_fallback) {
+                          float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st, bool* ran,
+                          const void** z0_for_fallback) {
   *ran = false;
   *z0_for_fallback = z0_dev;
   BtWorkspace ws = carve_bt(workspace, n, k, kp, true, maxiter);
@@ -456,7 +457,8 @@ int solve_bf16_persistent(const void* x_dev, int64_t ldx, const void* w_dev, int
   const int its = hout[0];
   if (iters_out) *iters_out = its;
   if (last_delta_out) memcpy(last_delta_out, &hout[1], sizeof(float));
-  if (backtrack && its > 0 && (trials_out || accepted_lr_out)) {
+  if (backtrack && its > 0 && (trials_out || accepted_lr_out || accepted_f_out)) {
+    if (accepted_f_out) LASSO_HIP_TRY(hipMemcpy(accepted_f_out, ws.pfvals, (size_t)its * 4, hipMemcpyDeviceToHost));
     if (trials_out) LASSO_HIP_TRY(hipMemcpy(trials_out, ws.ptrials, (size_t)its * 4, hipMemcpyDeviceToHost));
     if (accepted_lr_out) LASSO_HIP_TRY(hipMemcpy(accepted_lr_out, ws.plrs, (size_t)its * 4, hipMemcpyDeviceToHost));
   }
@@ -467,7 +469,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
                        int64_t ldz0, void* zout_any, int64_t ldz_any, int64_t n, int64_t d, int64_t k, int kp,
                        int dtype, double alpha, double lr0, int fast, int maxiter, double tol, double eta,
                        int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
-                       void* workspace, size_t ws_bytes, hipStream_t st) {
+                       float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st) {
   const bool half = dtype == LASSO_BF16;      // bf16 tensors: bt_bf16.hip kernels, 64-row tiles
   BtWorkspace ws = carve_bt(workspace, n, k, kp, half);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
@@ -552,7 +554,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       LASSO_HIP_TRY(hipGetLastError());
       LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipMemcpyAsync(&host.delta, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
-      if (accepted_lr_out)
+      if (accepted_lr_out || accepted_f_out)
         LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
       accepted = host.flags[0] != 0;
@@ -560,6 +562,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     prev_trials = host.flags[2] + 1;
     if (trials_out) trials_out[it] = host.flags[2] + 1;            // trials evaluated up to the accepted one
     if (accepted_lr_out) accepted_lr_out[it] = host.fvals[2];      // the step the iteration used (ista.py:40,52)
+    if (accepted_f_out) accepted_f_out[it] = host.fvals[0];        // F(z_next) of the accepted trial (:28)
     last = host.delta;
     t_mom = t_next;
     if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95
@@ -932,7 +935,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
-                      float* accepted_lr_out, void* workspace_dev,
+                      float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
@@ -985,8 +988,8 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     const void* z0_fb = z0_dev;
     const int s = solve_bf16_persistent(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr,
                                         fast, maxiter, stop_rule ? tol : 0.0, backtrack, eta_backtrack, iters_out,
-                                        last_delta_out, trials_out, accepted_lr_out, workspace_dev, workspace_bytes,
-                                        st, &ran, &z0_fb);
+                                        last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
+                                        workspace_bytes, st, &ran, &z0_fb);
     if (ran || (s != LASSO_OK && s != LASSO_WARN_LINESEARCH)) return s;
     z0_dev = z0_fb;
     if (z0_fb != z0) ldz0 = k;
@@ -999,7 +1002,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return solve_backtracking(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp,
                               half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,
                               stop_rule ? tol : 0.0, eta_backtrack,
-                              iters_out, last_delta_out, trials_out, accepted_lr_out, workspace_dev,
+                              iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
                               workspace_bytes, st);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
@@ -1122,13 +1125,13 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int64_t d, int64_t k, int dtype, double alpha, double lr, int fast,
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
-                      float* accepted_lr_out, float* objective_out, void* workspace_dev,
+                      float* accepted_lr_out, float* accepted_f_out, float* objective_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
   if (objective_out) *objective_out = NAN;
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
-                                last_delta_out, trials_out, accepted_lr_out, workspace_dev, workspace_bytes,
-                                stream);
+                                last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
+                                workspace_bytes, stream);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)

@@ -55,7 +55,7 @@ def _declare(lib):
     lib.lasso_fista_solve.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32,
         dbl, dbl, i32, i32, dbl, i32, i32, dbl, C.POINTER(C.c_int32), C.POINTER(C.c_float),
-        C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float),
+        C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
         vp, sz, vp]
     lib.lasso_fista_prepare.restype = i32
     lib.lasso_fista_prepare.argtypes = [vp, i64, i64, i64, i32, i32, vp, sz, vp]

@@ -207,23 +207,30 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         want_trace = bool(backtrack) and bool(return_info)
         trials = (C.c_int32 * max(int(maxiter), 1))() if want_trace else None
         acc_lr = (C.c_float * max(int(maxiter), 1))() if want_trace else None
+        acc_f = (C.c_float * max(int(maxiter), 1))() if (want_trace or (verbose and backtrack)) else None
         obj = C.c_float(float('nan')) if return_info == 'objective' else None
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
             int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel], int(bool(backtrack)), float(eta_backtrack),
-            C.byref(iters), C.byref(last), trials, acc_lr, C.byref(obj) if obj is not None else None,
+            C.byref(iters), C.byref(last), trials, acc_lr, acc_f, C.byref(obj) if obj is not None else None,
             nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         nat.check(st)
     if z.device != out_device:
         z = z.to(out_device)
-    if verbose:
-        print('iterations: %d' % iters.value)
+    if verbose and backtrack:
+        # the reference prints the mean objective of z before every iteration (ista.py:80-81):
+        # that of z0, then F(z_next)/n of each accepted line-search trial but the last
+        from ..dict_learning import lasso_loss
+        print('loss: %0.4f' % lasso_loss(xg.float(), zg.float(), wg.float(), alpha).item())
+        for v in list(acc_f[:max(iters.value - 1, 0)]):
+            print('loss: %0.4f' % (v / n))
     if return_info:
         info = dict(iterations=iters.value, last_delta=last.value)
         if want_trace:      # what ista.py:43-47 prints per trial with verbose=True, condensed
             info['trials'] = list(trials[:iters.value])
             info['accepted_lr'] = list(acc_lr[:iters.value])
+            info['accepted_f'] = list(acc_f[:iters.value])
         if obj is not None:
             info['objective'] = obj.value
         return z, info

@@ -221,3 +221,28 @@ def test_persistent_bf16_kernel_against_multi_launch_kernels(n, d, k, backtrack)
     zt, info = ista(X.cuda(), torch.zeros_like(z0).cuda(), W.cuda(), 0.3, lr=lr, maxiter=300, tol=2e-3,
                     backtrack=backtrack, return_info=True)
     assert 1 <= info["iterations"] < 300 and info["last_delta"] <= n * k * 2e-3 * (1 + 1e-6)
+
+
+def test_verbose_with_line_search_prints_the_reference_losses(capsys):
+    """verbose=True with backtrack=True: the reference prints 'loss: %0.4f' of z before every outer
+    iteration (ista.py:80-81; its backtracking() is called without verbose).  Here the lines come
+    from the accepted trials' F values (accepted_f_out of the C ABI) -- no extra pass over the data."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    X, W = recipe_xw(300)
+    z0 = X.new_zeros(300, 1024)
+    tr = orc.FistaTrace()
+    orc.fista(X, z0, W, 0.5, lr=1.0, maxiter=7, tol=0.0, backtrack=True, trace=tr)
+    capsys.readouterr()
+    z, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.5, lr=1.0, maxiter=7, tol=0.0, backtrack=True, verbose=True,
+                   return_info=True)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("loss:")]
+    assert len(lines) == 7 == len(tr.objective)
+    for line, ref in zip(lines, tr.objective):
+        assert abs(float(line.split()[1]) - ref) <= 1e-4 * ref + 1e-4, (line, ref)
+    assert info["trials"] == tr.trials
+    # the F values themselves: F(z_{i+1}) / n is the objective of the next iterate
+    obj_next = [orc.lasso_objective(X, orc.fista(X, z0, W, 0.5, lr=1.0, maxiter=i + 1, tol=0.0, backtrack=True),
+                                    W, 0.5).item() for i in range(3)]
+    for f, ref in zip(info["accepted_f"], obj_next):
+        assert abs(f / 300 - ref) <= 2e-6 * ref
