@@ -216,6 +216,19 @@ int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, i
 int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
                        const int32_t* degenerate_dev, void* stream);
 
+/* ---- unconstrained M-step: replaces update_dict_ridge, dict_learning.py:106-123 ----------
+ * V [d][k] (ldv) = ((A + lambda_n I)^-1 B)^T with A = Z^T Z, B = Z^T X from
+ * lasso_gram_accumulate (all-reduced by the caller across GPUs) and lambda_n = lambd * n
+ * (:119).  Blocked Cholesky + the two triangular solves on the library's own fp32-MFMA
+ * kernels (csrc/ridge.hip); k <= 2048.  A and B are not modified.  info_out (HOST, nullable):
+ * 0, or 1 + the index of the first non-positive pivot (then LASSO_ERR_BAD_ARG; torch raises
+ * in linalg.cholesky there); a non-NULL info_out makes the call synchronise `stream`.
+ */
+size_t lasso_ridge_workspace_bytes(int64_t d, int64_t k);
+int lasso_ridge_solve(const float* a_dev, const float* b_dev, void* v_dev, int64_t ldv,
+                      int64_t d, int64_t k, int dtype, double lambda_n, int32_t* info_out,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- greedy coordinate descent: replaces coord_descent(),
  *      lasso/linear/solvers/coordinate_descent.py:5-54 (sparse_encode.py:54-55) --------
  * Per row: b = x W (:19, independent of z0), tracked z = z0 or 0 (:10-14); per step

@@ -1320,6 +1320,34 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   return LASSO_OK;
 }
 
+// ---- unconstrained M-step: update_dict_ridge, dict_learning.py:106-123 ---------------------
+size_t lasso_ridge_workspace_bytes(int64_t d, int64_t k) {
+  if (d <= 0 || k <= 0 || k > 2048) return 0;
+  return ridge_workspace_bytes(d, k) + 256;
+}
+
+int lasso_ridge_solve(const float* a_dev, const float* b_dev, void* v_dev, int64_t ldv, int64_t d, int64_t k,
+                      int dtype, double lambda_n, int32_t* info_out, void* workspace_dev, size_t workspace_bytes,
+                      void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!a_dev || !b_dev || !v_dev || !workspace_dev || d <= 0 || k <= 0 || ldv < k)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (k > 2048) return fail(LASSO_ERR_UNSUPPORTED, "ridge solve: k=%lld > 2048", (long long)k);
+  if (workspace_bytes < lasso_ridge_workspace_bytes(d, k))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_ridge_workspace_bytes(d, k));
+  hipStream_t st = (hipStream_t)stream;
+  int* const info_dev = (int*)((char*)workspace_dev + ridge_workspace_bytes(d, k));
+  LASSO_HIP_TRY(launch_ridge_solve(a_dev, b_dev, (float*)v_dev, ldv, (int)d, (int)k, (float)lambda_n, workspace_dev,
+                                   info_dev, st));
+  if (info_out) {
+    LASSO_HIP_TRY(hipMemcpyAsync(info_out, info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    if (*info_out != 0)
+      return fail(LASSO_ERR_BAD_ARG, "Z^T Z + lambd*n*I is not positive definite (pivot %d)", *info_out);
+  }
+  return LASSO_OK;
+}
+
 int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
                                const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
                                int64_t pool_ld, int positive, void* stream) {

@@ -189,6 +189,10 @@ hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStre
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+// unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 2048
+size_t ridge_workspace_bytes(int64_t d, int64_t k);
+hipError_t launch_ridge_solve(const float* A, const float* B, float* V, int64_t ldv, int d, int k, float lam,
+                              void* workspace, int* info_dev, hipStream_t st);
 hipError_t launch_fill_degenerate(float* D, int64_t ldd, int d, int k, const int* degenerate, const float* pool,
                                   int pool_rows, int64_t pool_ld, int positive, hipStream_t stream);
 hipError_t launch_bw_prox(float* zb_next, float* zb_cur, const float* yb, const float* z_next, float* ub, float* gb,

@@ -173,10 +173,28 @@ class HipEngine:
             nat.check(self.lib.lasso_zero_columns(nat.ptr(Z), Z.stride(0), n, k, nat.LASSO_F32,
                                                   nat.ptr(mask), self._stream()))
 
-    def ridge(self, A, B, lam_n):
-        """V = ((A + lam_n I)^-1 B)^T  [d,k] (dict_learning.py:117-121).  k x k Cholesky via
-        torch.linalg (rocSOLVER) -- library call off the FISTA hot path."""
-        M = A.clone()
-        M.diagonal().add_(lam_n)
-        chol = torch.linalg.cholesky(M)
-        return torch.cholesky_solve(B, chol).T.contiguous()
+    def ridge(self, A, B, lam_n, check=False):
+        """V = ((A + lam_n I)^-1 B)^T  [d,k] (dict_learning.py:117-121): blocked Cholesky and
+        triangular solves of csrc/ridge.hip (lasso_ridge_solve).  `check` synchronises and raises
+        like torch.linalg.cholesky when the matrix is not positive definite.  Beyond k = 2048
+        (the kernel's LDS strip) the k x k factorisation goes to torch.linalg on the device."""
+        k, d = B.shape
+        L = self.lib
+        nbytes = L.lasso_ridge_workspace_bytes(d, k)
+        if nbytes == 0:
+            M = A.clone()
+            M.diagonal().add_(lam_n)
+            return torch.cholesky_solve(B, torch.linalg.cholesky(M)).T.contiguous()
+        with torch.cuda.device(self.device):
+            ws = self._ws(nbytes, "ridge")
+            V = torch.empty((d, k), dtype=torch.float32, device=self.device)
+            info = C.c_int32(0)
+            status = L.lasso_ridge_solve(nat.ptr(A), nat.ptr(B), nat.ptr(V), V.stride(0), d, k, nat.LASSO_F32,
+                                         float(lam_n), C.byref(info) if check else None, nat.ptr(ws), ws.numel(),
+                                         self._stream())
+            if info.value != 0:          # what torch.linalg.cholesky raises at dict_learning.py:120
+                raise torch.linalg.LinAlgError(
+                    "linalg.cholesky: The factorization could not be completed because the input is not "
+                    "positive-definite (the leading minor of order %d is not positive-definite)." % info.value)
+            nat.check(status)
+        return V

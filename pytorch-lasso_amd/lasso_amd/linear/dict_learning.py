@@ -64,7 +64,7 @@ def update_dict_ridge(x, z, lambd=1e-4):
     k = zg.shape[1]
     buf = torch.empty(k * k + k * d, dtype=torch.float32, device=eng.device)
     A, B = eng.gram(zg, xg, buf)
-    return eng.ridge(A, B, lambd * n).to(out_device)
+    return eng.ridge(A, B, lambd * n, check=True).to(out_device)
 
 
 def dict_learning(X, n_components, alpha=1.0, constrained=True, persist=False,

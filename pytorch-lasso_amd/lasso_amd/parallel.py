@@ -178,7 +178,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             if mask is not None:
                 engine.zero_columns(Z, mask)                                              # :98
         else:
-            weight = engine.ridge(A, B, lambd * n_total)                                  # :46-47
+            weight = engine.ridge(A, B, lambd * n_total, check=True)                                  # :46-47
         if bar is not None:
             bar.set_postfix(loss=losses[i].item())                                        # :50
             bar.update(1)

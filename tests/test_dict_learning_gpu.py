@@ -290,3 +290,38 @@ def test_dict_evaluate(golden, shape):
         g = golden("g1_readme")
         val = dict_evaluate(T(g["data"]).cuda(), T(g["D_auto"]).cuda(), 0.2, algorithm='ista')
         assert abs(val.item() - float(g["loss_z_auto"])) <= 1e-4
+
+
+@pytest.mark.parametrize("k,d,n", [(1024, 256, 4096), (64, 16, 200), (50, 10, 100), (200, 130, 500), (513, 64, 2000),
+                                   (1500, 300, 3000)])
+def test_ridge_solve_on_the_hip_kernels(k, d, n):
+    """lasso_ridge_solve (blocked Cholesky + triangular solves, csrc/ridge.hip) against torch.linalg in
+    fp64 on the same Gram matrices -- ragged k and d, the reference's lambd * n on the diagonal
+    (dict_learning.py:117-121)."""
+    from lasso_amd.engine import HipEngine
+    g = torch.Generator().manual_seed(k + d)
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)).cuda()
+    X = torch.randn(n, d, generator=g).cuda()
+    eng = HipEngine()
+    buf = torch.empty(k * k + k * d, device="cuda")
+    A, B = eng.gram(Z, X, buf)
+    lam = 1e-2 * n
+    V = eng.ridge(A, B, lam, check=True)
+    assert V.shape == (d, k) and V.is_contiguous()
+    M = A.double().clone()
+    M.diagonal().add_(lam)
+    ref = torch.cholesky_solve(B.double(), torch.linalg.cholesky(M)).T
+    err = (V.double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    # A, B untouched
+    A2, B2 = eng.gram(Z, X, torch.empty_like(buf))
+    assert torch.equal(A, A2) and torch.equal(B, B2)
+
+
+def test_ridge_solve_reports_a_non_positive_pivot():
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    A = -torch.eye(70, device="cuda")
+    B = torch.ones(70, 5, device="cuda")
+    with pytest.raises(torch.linalg.LinAlgError):
+        eng.ridge(A, B, 0.0, check=True)
