@@ -216,11 +216,19 @@ int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, i
 int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
                        const int32_t* degenerate_dev, void* stream);
 
+/* ---- init='transpose': replaces torch.matmul(x, weight), sparse_encode.py:24-25 ---------
+ * z0 [n][k] (ldz) = x [n][d] W [d][k] on the library's fp32-MFMA NT GEMM (csrc/gemm.hip).
+ */
+size_t lasso_init_transpose_workspace_bytes(int64_t d, int64_t k);
+int lasso_init_transpose(int64_t n, int64_t d, int64_t k, int dtype, const void* x_dev, int64_t ldx,
+                         const void* w_dev, int64_t ldw, void* z0_dev, int64_t ldz,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- unconstrained M-step: replaces update_dict_ridge, dict_learning.py:106-123 ----------
  * V [d][k] (ldv) = ((A + lambda_n I)^-1 B)^T with A = Z^T Z, B = Z^T X from
  * lasso_gram_accumulate (all-reduced by the caller across GPUs) and lambda_n = lambd * n
  * (:119).  Blocked Cholesky + the two triangular solves on the library's own fp32-MFMA
- * kernels (csrc/ridge.hip); k <= 2048.  A and B are not modified.  info_out (HOST, nullable):
+ * kernels (csrc/ridge.hip); k <= 4096 (lasso_ridge_workspace_bytes returns 0 beyond).  A and B are not modified.  info_out (HOST, nullable):
  * 0, or 1 + the index of the first non-positive pivot (then LASSO_ERR_BAD_ARG; torch raises
  * in linalg.cholesky there); a non-NULL info_out makes the call synchronise `stream`.
  */

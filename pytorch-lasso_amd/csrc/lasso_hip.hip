@@ -1320,9 +1320,34 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   return LASSO_OK;
 }
 
+// ---- init='transpose': z0 = x W, sparse_encode.py:24-25 --------------------------------------
+size_t lasso_init_transpose_workspace_bytes(int64_t d, int64_t k) {
+  if (d <= 0 || k <= 0) return 0;
+  return (size_t)k * (size_t)d * sizeof(float) + 256;
+}
+
+int lasso_init_transpose(int64_t n, int64_t d, int64_t k, int dtype, const void* x_dev, int64_t ldx,
+                         const void* w_dev, int64_t ldw, void* z0_dev, int64_t ldz, void* workspace_dev,
+                         size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (n < 0 || d <= 0 || k <= 0 || n > INT32_MAX || d > INT32_MAX || k > INT32_MAX)
+    return fail(LASSO_ERR_BAD_ARG, "bad shape");
+  if (!w_dev || !workspace_dev || (n > 0 && (!x_dev || !z0_dev))) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldx < d || ldw < k || ldz < k) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
+  if (workspace_bytes < lasso_init_transpose_workspace_bytes(d, k))
+    return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_init_transpose_workspace_bytes(d, k));
+  if (n == 0) return LASSO_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* const Wt = (float*)workspace_dev;                  // [k][d]: z0 = x Wt^T on the NT GEMM
+  LASSO_HIP_TRY(launch_transpose_pad((const float*)w_dev, ldw, (int)d, (int)k, Wt, d, (int)k, (int)d, st));
+  LASSO_HIP_TRY(launch_gemm_nt_sub((const float*)x_dev, ldx, Wt, d, nullptr, 0, (float*)z0_dev, ldz, (int)n, (int)k,
+                                   (int)d, st, /*add=*/1));
+  return LASSO_OK;
+}
+
 // ---- unconstrained M-step: update_dict_ridge, dict_learning.py:106-123 ---------------------
 size_t lasso_ridge_workspace_bytes(int64_t d, int64_t k) {
-  if (d <= 0 || k <= 0 || k > 2048) return 0;
+  if (d <= 0 || k <= 0 || k > 4096) return 0;
   return ridge_workspace_bytes(d, k) + 256;
 }
 
@@ -1332,7 +1357,7 @@ int lasso_ridge_solve(const float* a_dev, const float* b_dev, void* v_dev, int64
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!a_dev || !b_dev || !v_dev || !workspace_dev || d <= 0 || k <= 0 || ldv < k)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
-  if (k > 2048) return fail(LASSO_ERR_UNSUPPORTED, "ridge solve: k=%lld > 2048", (long long)k);
+  if (k > 4096) return fail(LASSO_ERR_UNSUPPORTED, "ridge solve: k=%lld > 4096", (long long)k);
   if (workspace_bytes < lasso_ridge_workspace_bytes(d, k))
     return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", lasso_ridge_workspace_bytes(d, k));
   hipStream_t st = (hipStream_t)stream;

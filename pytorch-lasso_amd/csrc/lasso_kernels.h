@@ -189,7 +189,7 @@ hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStre
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
-// unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 2048
+// unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 4096
 size_t ridge_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_ridge_solve(const float* A, const float* B, float* V, int64_t ldv, int d, int k, float lam,
                               void* workspace, int* info_dev, hipStream_t st);

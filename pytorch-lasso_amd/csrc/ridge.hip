@@ -33,7 +33,7 @@ namespace lasso {
 namespace {
 
 constexpr int kRB = 64;                       // block size
-constexpr int kRidgeMaxK = 2048;
+constexpr int kRidgeMaxK = 4096;
 
 // S[r][c] for r < kp: A + lam on the diagonal (identity on the padding); r >= kp: B^T
 __global__ __launch_bounds__(256) void ridge_setup_kernel(const float* __restrict__ A, const float* __restrict__ B,
@@ -395,7 +395,60 @@ __global__ __launch_bounds__(256) void ridge_backward_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// kp > 2048 (the 16-row strip of V no longer fits LDS): right-looking back substitution, one
+// launch per block column j from last to first, blocks (rb, c), c <= j:  V_j = Y_j Linv_j
+// (recomputed per block); c == j stores it, c < j applies Y_c -= V_j L_jc in place in F.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_block_t(const float* __restrict__ src, int64_t ld, float* __restrict__ t, int tid) {
+  for (int e = tid; e < kRB * kRB / 4; e += 256) {         // t[c][r] = src[r][c]
+    const int r = e / 16, c4 = (e % 16) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld + c4);
+    t[(c4 + 0) * 65 + r] = v[0]; t[(c4 + 1) * 65 + r] = v[1]; t[(c4 + 2) * 65 + r] = v[2]; t[(c4 + 3) * 65 + r] = v[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void ridge_backstep_kernel(float* __restrict__ F, const float* __restrict__ linv,
+                                                             float* __restrict__ V, int64_t ldv, int k, int d, int kp, int j) {
+  const int rb = blockIdx.x, c = blockIdx.y;
+  __shared__ float ta[kRB * 65], tb[kRB * 65], tl[kRB * 65];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  float* const yrow = F + (int64_t)(kp + kRB * rb) * kp;
+  load_block(yrow + kRB * j, kp, ta, tid);
+  load_block_t(linv + (int64_t)j * kRB * kRB, kRB, tl, tid);
+  if (c < j) load_block_t(F + (int64_t)(kRB * j) * kp + kRB * c, kp, tb, tid);
+  __syncthreads();
+  f32x4 vj[4] = {};
+  mma64_nt(ta, tl, vj, lane, w);                           // V_j = Y_j Linv_j
+  if (c == j) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = kRB * rb + 16 * w + 4 * q + rg, cc = kRB * j + 16 * nb + l15;
+        if (r < d && cc < k) V[(int64_t)r * ldv + cc] = vj[nb][rg];
+      }
+    return;
+  }
+  __syncthreads();
+  acc_to_tile(vj, ta, lane, w);
+  __syncthreads();
+  f32x4 upd[4] = {};
+  mma64_nt(ta, tb, upd, lane, w);                          // V_j L_jc
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) yrow[(int64_t)(16 * w + 4 * q + rg) * kp + kRB * c + 16 * nb + l15] -= upd[nb][rg];
+}
+
 hipError_t backward_k(const float* F, const float* linv, float* V, int64_t ldv, int k, int d, int kp, int dp, hipStream_t st) {
+  if (kp > 2048) {
+    for (int j = kp / kRB - 1; j >= 0; --j)
+      hipLaunchKernelGGL(ridge_backstep_kernel, dim3(dp / kRB, j + 1), dim3(256), 0, st, const_cast<float*>(F), linv, V, ldv, k,
+                         d, kp, j);
+    return hipGetLastError();
+  }
   const size_t fixed = (size_t)(16 * (kp + 1) + 16 * 65) * 4, budget = 160 * 1024 - 512;
   int ring = (int)std::min<size_t>(4, (budget - fixed) / (kTileFloats * 4));
   if (ring < 1) return hipErrorInvalidValue;
@@ -417,7 +470,7 @@ size_t ridge_workspace_bytes(int64_t d, int64_t k) {
 hipError_t launch_ridge_solve(const float* A, const float* B, float* V, int64_t ldv, int d, int k, float lam,
                               void* workspace, int* info_dev, hipStream_t st) {
   const int kp = (k + kRB - 1) / kRB * kRB, dp = (d + kRB - 1) / kRB * kRB;
-  if (kp > kRidgeMaxK) return hipErrorInvalidValue;       // the 16-row strip of V must fit LDS
+  if (kp > kRidgeMaxK) return hipErrorInvalidValue;
   float* const S = (float*)workspace;
   float* const F = S + (size_t)(kp + dp) * kp;             // the factor: L (lower blocks) over Y^T = B^T L^-T
   float* const linv = F + (size_t)(kp + dp) * kp;

@@ -81,6 +81,10 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_init_transpose_workspace_bytes.restype = sz
+    lib.lasso_init_transpose_workspace_bytes.argtypes = [i64, i64]
+    lib.lasso_init_transpose.restype = i32
+    lib.lasso_init_transpose.argtypes = [i64, i64, i64, i32, vp, i64, vp, i64, vp, i64, vp, sz, vp]
     lib.lasso_ridge_workspace_bytes.restype = sz
     lib.lasso_ridge_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_ridge_solve.restype = i32

@@ -173,11 +173,23 @@ class HipEngine:
             nat.check(self.lib.lasso_zero_columns(nat.ptr(Z), Z.stride(0), n, k, nat.LASSO_F32,
                                                   nat.ptr(mask), self._stream()))
 
+    def init_transpose(self, X, W):
+        """z0 = X W (sparse_encode.py:24-25) on the library's NT GEMM."""
+        n, d = X.shape
+        k = W.shape[1]
+        L = self.lib
+        with torch.cuda.device(self.device):
+            ws = self._ws(L.lasso_init_transpose_workspace_bytes(d, k), "init_t")
+            z0 = torch.empty((n, k), dtype=torch.float32, device=self.device)
+            nat.check(L.lasso_init_transpose(n, d, k, nat.LASSO_F32, nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0),
+                                             nat.ptr(z0), z0.stride(0), nat.ptr(ws), ws.numel(), self._stream()))
+        return z0
+
     def ridge(self, A, B, lam_n, check=False):
         """V = ((A + lam_n I)^-1 B)^T  [d,k] (dict_learning.py:117-121): blocked Cholesky and
         triangular solves of csrc/ridge.hip (lasso_ridge_solve).  `check` synchronises and raises
-        like torch.linalg.cholesky when the matrix is not positive definite.  Beyond k = 2048
-        (the kernel's LDS strip) the k x k factorisation goes to torch.linalg on the device."""
+        like torch.linalg.cholesky when the matrix is not positive definite.  Beyond k = 4096
+        (the kernels' limit) the k x k factorisation goes to torch.linalg on the device."""
         k, d = B.shape
         L = self.lib
         nbytes = L.lasso_ridge_workspace_bytes(d, k)

@@ -31,17 +31,22 @@ def _ridge_init(x, weight, alpha):
 
 def initialize_code(x, weight, alpha, mode):
     """sparse_encode.py:19-35.  'zero' (:22-23) is the hot-path default; the other modes
-    ('unif', 'transpose', 'lstsq', 'ridge') are one-off dense linear-algebra set-ups that
-    run as torch / torch.linalg calls (rocBLAS / rocSOLVER when the tensors are on the
-    GPU) -- library plumbing, not part of the HIP hot path."""
+    ('unif', 'lstsq', 'ridge') are one-off set-ups that run as torch / torch.linalg calls
+    (rocSOLVER when the tensors are on the GPU) -- library plumbing, not part of the HIP hot
+    path; 'transpose' is a product on the library's own GEMM (lasso_init_transpose)."""
     n_samples = x.size(0)
     n_components = weight.size(1)
     if mode == 'zero':
         z0 = x.new_zeros(n_samples, n_components)
     elif mode == 'unif':
         z0 = x.new(n_samples, n_components).uniform_(-0.1, 0.1)
-    elif mode == 'transpose':
-        z0 = torch.matmul(x, weight)
+    elif mode == 'transpose':                                        # :24-25, on the library's NT GEMM
+        from ..engine import HipEngine
+        from .. import _native as nat
+        nat.require_gpu()
+        eng = HipEngine(x.device if x.is_cuda else (weight.device if weight.is_cuda else None))
+        z0 = eng.init_transpose(eng.to_device(x).float().contiguous(),
+                                eng.to_device(weight).float().contiguous()).to(x.device)
     elif mode == 'lstsq':                                            # :26-27 (utils.py:13-25)
         z0 = _lstsq_init(x, weight)
     elif mode == 'ridge':                                            # :28-29 (utils.py:28-40)

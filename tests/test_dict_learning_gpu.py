@@ -293,7 +293,7 @@ def test_dict_evaluate(golden, shape):
 
 
 @pytest.mark.parametrize("k,d,n", [(1024, 256, 4096), (64, 16, 200), (50, 10, 100), (200, 130, 500), (513, 64, 2000),
-                                   (1500, 300, 3000)])
+                                   (1500, 300, 3000), (2300, 70, 4000)])
 def test_ridge_solve_on_the_hip_kernels(k, d, n):
     """lasso_ridge_solve (blocked Cholesky + triangular solves, csrc/ridge.hip) against torch.linalg in
     fp64 on the same Gram matrices -- ragged k and d, the reference's lambd * n on the diagonal
