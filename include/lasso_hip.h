@@ -44,7 +44,11 @@ typedef enum {
   LASSO_ERR_UNSUPPORTED = 2,  /* shape or dtype outside what the HIP path implements   */
   LASSO_ERR_WORKSPACE = 3,    /* workspace missing or too small                        */
   LASSO_ERR_HIP = 4,          /* HIP runtime error (no device, launch failure, ...)    */
-  LASSO_WARN_LINESEARCH = 5   /* backtracking failed, reverted to lr0 (ista.py:48-52)  */
+  LASSO_WARN_LINESEARCH = 5,  /* backtracking failed, reverted to lr0 (ista.py:48-52)  */
+  LASSO_PENDING = 6,          /* LASSO_SOLVE_ASYNC: enqueued; call lasso_fista_solve_finish */
+  LASSO_WARN_ABORTED = 7      /* lasso_fista_solve_finish: the in-kernel stop rule gave up
+                                 (a workgroup was not resident), z_out untouched: solve again
+                                 with LASSO_STOP_GLOBAL_CHUNKED                            */
 } lasso_status;
 
 typedef enum { LASSO_F32 = 0, LASSO_BF16 = 1 } lasso_dtype;
@@ -73,6 +77,15 @@ typedef enum {
 /* tuning knob: split-k with exactly T = 1, 2 or 4 tiles per workgroup group (default: by cost model) */
 #define LASSO_KERNEL_SPLITK_TILES(T) (0x200 | ((T) == 1 ? 0x1000 : (T) == 2 ? 0x2000 : 0x3000))
 #define LASSO_KERNEL_MASK 0x3F00
+/* OR into stop_mode of lasso_fista_solve (fp32, fixed step): do not wait for the stop rule's
+ * outcome.  Returns LASSO_PENDING when the single persistent launch was enqueued (then
+ * iters_out / last_delta_out are not written and lasso_fista_solve_finish collects them), or
+ * LASSO_OK when the solve completed inside the call (stop rule off, or the chunked path). */
+#define LASSO_SOLVE_ASYNC 0x4000
+/* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
+ * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device
+ * memory -- no host round trip; other paths synchronise once to fetch it. */
+#define LASSO_LR_AUTO (-1.0)
 
 int lasso_hip_abi_version(void);
 const char* lasso_hip_status_string(int status);
@@ -215,6 +228,21 @@ int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, i
                                int64_t pool_ld, int positive, void* stream);
 int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype,
                        const int32_t* degenerate_dev, void* stream);
+
+/* Second half of a LASSO_SOLVE_ASYNC solve that returned LASSO_PENDING (same n, d, k, dtype,
+ * maxiter, tol, workspace, stream): synchronises the stream, writes iters_out / last_delta_out
+ * (HOST, nullable).  LASSO_OK, or LASSO_WARN_ABORTED (see above).  Work enqueued between the
+ * two calls (lasso_objective, lasso_gram_accumulate on z_out ...) overlaps the wait. */
+/* The asynchronous form: only ENQUEUES the copy of {iterations, last delta (float bits), aborted
+ * != 0, 0} into out4_host (HOST; pinned memory keeps the copy asynchronous).  The caller waits
+ * on the stream -- or on an event recorded right behind this call, so that work enqueued after
+ * it keeps the GPU busy during the wait -- and decodes the four words itself. */
+int lasso_fista_solve_collect(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                              int32_t* out4_host, void* workspace_dev, size_t workspace_bytes,
+                              void* stream);
+int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                             int32_t* iters_out, float* last_delta_out, void* workspace_dev,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- init='transpose': replaces torch.matmul(x, weight), sparse_encode.py:24-25 ---------
  * z0 [n][k] (ldz) = x [n][d] W [d][k] on the library's fp32-MFMA NT GEMM (csrc/gemm.hip).

@@ -61,6 +61,8 @@ constexpr size_t lds_bytes(int T) {
 // STOP: compile the in-kernel global stop rule in (needs every tile in a resident group slot).
 template <int K, int T, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const FistaTileParams p) {
+  // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
+  const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
   constexpr int C = K / kSlice;
   constexpr int D = kFistaD;
   constexpr int NW = kFistaWaves;
@@ -387,8 +389,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
             for (int rg = 0; rg < 4; ++rg) {
               lds_f32* const yp = (lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n));
               const float zo = zreg[t][rg];
-              const float stp = __fmul_rn(p.lr, g2[rg]);                         // lr * grad
-              const float zn = soft_threshold(__fsub_rn(*yp, stp), p.lam);
+              const float stp = __fmul_rn(lr_, g2[rg]);                         // lr * grad
+              const float zn = soft_threshold(__fsub_rn(*yp, stp), lam_);
               dsum += __builtin_fabsf(__fsub_rn(zo, zn));                         // |z - z_next|
               const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));               // c (z_next - z)
               *yp = __fadd_rn(zn, mom);

@@ -34,6 +34,8 @@ namespace sp {
 // shape; M = 32 / 64 serve dictionaries with d <= 128 / 64 without padding d up to 256).
 template <int K, int M, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
+  // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
+  const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
   constexpr int D = 4096 / M;
   constexpr int NW = kFistaWaves;
   constexpr int S1 = K / 32;
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const float zo = zreg[ps][cb][rg];
-          const float stp = __fmul_rn(p.lr, g2[ps & 1][cb][rg]);              // lr * grad
-          const float zn = soft_threshold(__fsub_rn(yv[cb][rg], stp), p.lam);
+          const float stp = __fmul_rn(lr_, g2[ps & 1][cb][rg]);              // lr * grad
+          const float zn = soft_threshold(__fsub_rn(yv[cb][rg], stp), lam_);
           dsum += __builtin_fabsf(__fsub_rn(zo, zn));                          // |z - z_next|
           const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));                // c (z_next - z)
           yn[cb][rg] = __fadd_rn(zn, mom);

@@ -246,7 +246,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
              int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
              int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f,
-             int hint = LASSO_KERNEL_AUTO, bool* used_split = nullptr) {
+             int hint = LASSO_KERNEL_AUTO, bool* used_split = nullptr, const float* lr_dev = nullptr) {
   if (used_split) *used_split = false;
   if (n == 0) return LASSO_OK;
   const int dpad = pad_d(d, kp);
@@ -265,6 +265,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.ntiles = ntiles; p.iters = iters;
   p.lr = (float)lr;                 // ATen casts the python scalar to the tensor dtype
   p.lam = (float)(alpha * lr);      // softshrink(lambd = alpha*lr), product in double (ista.py:90)
+  p.lr_dev = lr_dev;                // LASSO_LR_AUTO: {lr, lam} read from device memory instead
   p.stop_on = stop_budget >= 0.0f;
   p.stop_budget = stop_budget;
   p.stop_gran = ws.gran;
@@ -836,6 +837,7 @@ int lasso_hip_device_cus(int* cus_out) {
 // bytes of the solver's own workspace (the objective_out region follows it)
 static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                                      int stop_mode, int backtrack) {
+  stop_mode &= 0xFF;                                   // kernel hint / LASSO_SOLVE_ASYNC bits ride above
   if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
@@ -851,6 +853,20 @@ static size_t objective_region_bytes(int64_t n, int64_t d, int64_t k, int dtype)
   if (dtype == LASSO_BF16)
     b += align_up((size_t)n * d * 4) + align_up((size_t)d * k * 4) + align_up((size_t)n * k * 4);
   return b;
+}
+
+// region behind that for lr = LASSO_LR_AUTO: the Lipschitz workspace, then {lr, alpha*lr} as floats
+static size_t lipschitz_region_bytes(int64_t d, int64_t k, int dtype) {
+  if (dtype != LASSO_F32 || std::min(d, k) > 2048) return 0;
+  return align_up(lipschitz_workspace_bytes(d, k)) + 256;
+}
+
+// {lr, alpha*lr} in fp32 from L (double) with the roundings of the host path: lr = 1/L in
+// double (ista.py:72-73), then the casts of run_impl()
+__global__ void step_from_lipschitz_kernel(const double* __restrict__ L, double alpha, float* __restrict__ out) {
+  const double lr = 1.0 / L[0];
+  out[0] = (float)lr;
+  out[1] = (float)(alpha * lr);
 }
 
 const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, int backtrack) {
@@ -887,7 +903,7 @@ size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, i
   if (n < 0 || d <= 0 || k <= 0) return 0;
   const size_t solver = solver_workspace_bytes(n, d, k, dtype, maxiter, tol, stop_mode, backtrack);
   if (solver == 0) return 0;
-  return align_up(solver) + objective_region_bytes(n, d, k, dtype);
+  return align_up(solver) + objective_region_bytes(n, d, k, dtype) + lipschitz_region_bytes(d, k, dtype);
 }
 
 int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, int dtype, int maxiter,
@@ -936,7 +952,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
-                      size_t workspace_bytes, void* stream) {
+                      size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1011,7 +1027,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
 
   if (!stop_rule) {
     if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
-                         alpha, lr, fast, 0, maxiter, nullptr, st, -1.0f, hint))
+                         alpha, lr, fast, 0, maxiter, nullptr, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     if (iters_out) *iters_out = maxiter;
     return LASSO_OK;
@@ -1039,8 +1055,9 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
       LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * std::max(ntiles, kSplitMaxParts) * 8, st));
       LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
       if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
-                           alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint))
+                           alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint, nullptr, lr_dev))
         return s;
+      if (async) return LASSO_PENDING;     // the caller collects {iterations, last delta, abort flag} later
       int hout[4] = {0, 0, 0, 0};
       LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -1068,7 +1085,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     float* ny = ws.state[2 * flip + 1];
     // the aliasing copy above used state[2]; first chunk writes state[0]/[1] (flip = 0)
     if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, nz, nldz, ny, k, n, d, k,
-                         alpha, lr, fast, done, c, ws.delta, st, -1.0f, hint))
+                         alpha, lr, fast, done, c, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     LASSO_HIP_TRY(hipMemcpyAsync(hdelta.data(), ws.delta, c * sizeof(float), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -1080,7 +1097,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     if (hit >= 0) {
       if (hit + 1 < c) {   // replay the chunk from its (intact) input state
         if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, zout, ldz, nullptr, 0,
-                             n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st, -1.0f, hint))
+                             n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st, -1.0f, hint, nullptr, lr_dev))
           return s;
       } else if (!final_chunk) {
         LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, nz, nldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
@@ -1128,10 +1145,43 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       float* accepted_lr_out, float* accepted_f_out, float* objective_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream) {
   if (objective_out) *objective_out = NAN;
+  const bool async = (stop_mode & LASSO_SOLVE_ASYNC) != 0;
+  stop_mode &= ~LASSO_SOLVE_ASYNC;
+  if (async && (objective_out || backtrack || dtype != LASSO_F32))
+    return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_ASYNC: fp32 fixed-step solves without objective_out only");
+  const float* lr_dev = nullptr;
+  if (lr == LASSO_LR_AUTO) {
+    // lr = 1/L, L = lambda_max(W^T W) (ista.py:72-73, :8-14) computed here on the stream.  The fp32
+    // fixed-step kernels read {lr, alpha*lr} from device memory -- no host round trip; the other
+    // paths need the step size on the host (line-search bookkeeping, the unfused driver).
+    if (dtype != LASSO_F32) return fail(LASSO_ERR_BAD_ARG, "lr = LASSO_LR_AUTO needs fp32 tensors (ista.py:12)");
+    if (!x_dev || !w_dev || d <= 0 || k <= 0 || n < 0 || ldw < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+    const size_t lip = lipschitz_region_bytes(d, k, dtype);
+    if (lip == 0) return fail(LASSO_ERR_UNSUPPORTED, "lr = LASSO_LR_AUTO: min(d,k) > 2048");
+    const size_t before = align_up(solver_workspace_bytes(n, d, k, dtype, maxiter, tol, stop_mode, backtrack)) +
+                          objective_region_bytes(n, d, k, dtype);
+    if (!workspace_dev || workspace_bytes < before + lip)
+      return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, before + lip);
+    hipStream_t st = (hipStream_t)stream;
+    char* const lip_ws = (char*)workspace_dev + before;
+    LASSO_HIP_TRY(launch_lipschitz((const float*)w_dev, ldw, d, k, lip_ws, 20, st));
+    if (fused_shape(d, k) && !backtrack && maxiter > 0 && n > 0) {
+      float* const slot = (float*)(lip_ws + align_up(lipschitz_workspace_bytes(d, k)));
+      hipLaunchKernelGGL(step_from_lipschitz_kernel, dim3(1), dim3(1), 0, st, (const double*)lip_ws, alpha, slot);
+      LASSO_HIP_TRY(hipGetLastError());
+      lr_dev = slot;
+      lr = 1.0;                                        // placeholder, never used by the kernels
+    } else {
+      double L = 0.0;
+      LASSO_HIP_TRY(hipMemcpyAsync(&L, lip_ws, sizeof(double), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      lr = 1.0 / L;
+    }
+  }
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream);
+                                workspace_bytes, stream, lr_dev, async);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
@@ -1164,6 +1214,45 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   LASSO_HIP_TRY(hipStreamSynchronize(st));
   memcpy(g_err, saved, sizeof(saved));
   return status;
+}
+
+// LASSO_SOLVE_ASYNC solve that returned LASSO_PENDING: enqueue the copy of what the persistent
+// kernel leaves behind -- no synchronisation
+int lasso_fista_solve_collect(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                              int32_t* out4_host, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || !(tol > 0.0) || !out4_host)
+    return fail(LASSO_ERR_BAD_ARG, "no pending solve of this shape");
+  const int kp = pad_k(k);
+  Workspace ws = carve(workspace_dev, n, k, kp, maxiter, true);
+  if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
+  LASSO_HIP_TRY(hipMemcpyAsync(out4_host, ws.stop_out, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+// the synchronous form: collect, wait, decode
+int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                             int32_t* iters_out, float* last_delta_out, void* workspace_dev,
+                             size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || !(tol > 0.0))
+    return fail(LASSO_ERR_BAD_ARG, "no pending solve of this shape");
+  const int kp = pad_k(k);
+  Workspace ws = carve(workspace_dev, n, k, kp, maxiter, true);
+  if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  int hout[4] = {0, 0, 0, 0};
+  LASSO_HIP_TRY(hipMemcpyAsync(hout, ws.stop_out, 16, hipMemcpyDeviceToHost, st));
+  LASSO_HIP_TRY(hipStreamSynchronize(st));
+  if (hout[2]) {
+    if (iters_out) *iters_out = 0;
+    if (last_delta_out) *last_delta_out = NAN;
+    snprintf(g_err, sizeof(g_err), "in-kernel stop rule gave up (a workgroup was not resident); z_out is unchanged");
+    return LASSO_WARN_ABORTED;
+  }
+  float lastf;
+  memcpy(&lastf, &hout[1], sizeof(float));
+  if (iters_out) *iters_out = hout[0];
+  if (last_delta_out) *last_delta_out = lastf;
+  return LASSO_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1275,7 +1364,8 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
 size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k) {
   if (d <= 0 || k <= 0 || d > kSweepMaxD || k > kSweepMaxK) return 0;
   const size_t dp = (size_t)(d + 255) / 256 * 256;
-  return align_up((size_t)k * dp * 4) * 2 + align_up((size_t)kSweepBlock * dp * 4) + 256;
+  return align_up((size_t)k * dp * 4) * 2 + align_up((size_t)kSweepBlock * dp * 4) + 256 +
+         (dp == 256 ? align_up(sweep_persist_extra_bytes((int)k)) : 0);
 }
 
 int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
@@ -1310,9 +1400,11 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
   p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
-  LASSO_HIP_TRY(launch_dict_sweep(p, st));
+  float* dt_new = Dt;
+  void* const extra = dp == 256 ? (void*)((char*)ndeg + 256) : nullptr;
+  LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
   // D[dd][j] = Dt[j][dd]
-  LASSO_HIP_TRY(launch_transpose_pad(Dt, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
+  LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
   if (ndeg_out) {
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));

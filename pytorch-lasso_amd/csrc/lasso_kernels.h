@@ -27,6 +27,7 @@ struct FistaTileParams {
   int n, d, k;                           // real sizes
   int ntiles, iters;
   float lr, lam;                         // step size, alpha*lr
+  const float* lr_dev;                   // nullable: {lr, lam} in device memory (LASSO_LR_AUTO), overrides the two above
   // in-kernel exact global stop rule (fista_tile_sp.hip; needs gridDim.x == ntiles):
   unsigned long long* stop_gran;         // [kStopRing][ntiles] {tag = it+1, |dz| partial} granules, zeroed per solve
   int* stop_out;                         // [0] iterations executed, [1] last delta (float bits), [2] abort flag
@@ -188,7 +189,11 @@ hipError_t launch_cd_init(const float* z0, int64_t ldz0, float* Zt, int kp, int 
 hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStream_t stream);
 hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_out, int64_t ldz,
                             float* zt_out, int64_t ldzt, int n, int k, float alpha, hipStream_t stream);
-hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream);
+// persist_extra (sweep_persist_extra_bytes(k) bytes) + dt_out: d <= 256 runs the single-launch sweep,
+// whose new atoms land in *dt_out (rows of 256 floats) instead of p.Dt
+size_t sweep_persist_extra_bytes(int k);
+hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* persist_extra = nullptr,
+                             float** dt_out = nullptr);
 // unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 4096
 size_t ridge_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_ridge_solve(const float* A, const float* B, float* V, int64_t ldv, int d, int k, float lam,

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 #include "lasso_kernels.h"
 #include "static_for.hpp"
 
@@ -169,37 +170,57 @@ __device__ __forceinline__ float counter_normal(unsigned long long seed, unsigne
 // overlap the deferred row updates of atom a with the reduction chain of atom a+1).
 // A degenerate atom (||u|| < eps, :92) leaves the model here (new atom = 0, dD = -old);
 // its replacement direction is written afterwards by degenerate_fixup_kernel.
-template <bool FULL, int NW>
+template <bool FULL, int NW, int F>
 __global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams p, int j0) {
   constexpr int JB = kSweepBlock;
-  constexpr int DP = 256 * NW;                                     // == p.dp
+  constexpr int DP = 64 * NW * F;                                  // == p.dp
   __shared__ __attribute__((aligned(16))) float sA[JB][JB];   // A[j0+a][j0+b] (symmetric)
   extern __shared__ __attribute__((aligned(16))) float sD_[];      // [JB][DP] old atoms of the block (rows of Dt)
   __shared__ float red[JB][NW];
   const int tid = threadIdx.x;
-  const int fo = 4 * tid;                                           // first feature of this lane
+  const int fo = F * tid;                                           // first feature of this lane
   const int nb = FULL ? JB : min(JB, p.k - j0);
+  // F consecutive floats at ptr (16-byte access for F == 4)
+  auto ld = [](const float* ptr, float (&v)[F]) {
+    if constexpr (F == 4) {
+      const f32x4 t = *(const f32x4*)ptr;
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[f] = ptr[f];
+    }
+  };
+  auto st = [](float* ptr, const float (&v)[F]) {
+    if constexpr (F == 4) {
+      *(f32x4*)ptr = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) ptr[f] = v[f];
+    }
+  };
   for (int e = tid; e < JB * JB; e += 64 * NW) {
     const int a = e / JB, b = e % JB;
     sA[a][b] = (a < nb && b < nb) ? p.A[(int64_t)(j0 + a) * p.lda + j0 + b] : 0.0f;
   }
   for (int a = 0; a < JB; ++a) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (a < nb) v = *(const f32x4*)(p.Dt + (int64_t)(j0 + a) * DP + fo);
-    *(f32x4*)(&sD_[a * DP + fo]) = v;
+    float v[F] = {};
+    if (a < nb) ld(p.Dt + (int64_t)(j0 + a) * DP + fo, v);
+    st(&sD_[a * DP + fo], v);
   }
-  float u[JB][4];
+  float u[JB][F];
 #pragma unroll
   for (int a = 0; a < JB; ++a) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (a < nb) v = *(const f32x4*)(p.U + (int64_t)(j0 + a) * p.ldu + fo);   // padded cols are 0
 #pragma unroll
-    for (int f = 0; f < 4; ++f) u[a][f] = v[f];
+    for (int f = 0; f < F; ++f) u[a][f] = 0.0f;
+    if (a < nb) ld(p.U + (int64_t)(j0 + a) * p.ldu + fo, u[a]);   // padded cols are 0
   }
   __syncthreads();
   const float lo = p.positive ? 0.0f : -INFINITY;                 // dict_learning.py:87-88
   const float eps2 = p.eps * p.eps;
   unsigned degmask = 0;
+#ifdef LASSO_ABL_NOSWEEP   // timing ablation only (results invalid): prologue + epilogue
+  if (p.k < 0)
+#endif
   static_for<JB>([&](auto a_c) {
     constexpr int a = decltype(a_c)::value;
     // the block's coefficients of atom a, A[j0+b][j0+a] = sA[a][b] by symmetry: one batch of
@@ -210,11 +231,11 @@ __global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams 
       const f32x4 t4 = *(const f32x4*)(&sA[a][4 * b4]);
       cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
     }
-    const f32x4 dc4 = *(const f32x4*)(&sD_[a * DP + fo]);
-    float v[4], dcur[4], ss = 0.0f;
+    float dcur[F];
+    ld(&sD_[a * DP + fo], dcur);
+    float v[F], ss = 0.0f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      dcur[f] = dc4[f];
+    for (int f = 0; f < F; ++f) {
       v[f] = fmaxf(fmaf(cf[a], dcur[f], u[a][f]), lo);            // u_j = U_j + A_jj d_j   (:85-88)
       ss = fmaf(v[f], v[f], ss);
     }
@@ -230,23 +251,401 @@ __global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams 
     // sqrt + divide pair of :91,:100 would put ~25 dependent instructions on the chain
     const bool deg = ss < eps2;                                     // uniform over the workgroup
     const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
-    f32x4 dnew, delta;
+    float dnew[F], delta[F];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dcur[f]; }
+    for (int f = 0; f < F; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dcur[f]; }
     if (FULL || a < nb) {
-      *(f32x4*)(p.Dt + (int64_t)(j0 + a) * DP + fo) = dnew;
-      *(f32x4*)(p.dD + (int64_t)a * DP + fo) = delta;
+      st(p.Dt + (int64_t)(j0 + a) * DP + fo, dnew);
+      st(p.dD + (int64_t)a * DP + fo, delta);
       degmask |= (deg ? 1u : 0u) << a;
     } else {
-      *(f32x4*)(p.dD + (int64_t)a * DP + fo) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float zero[F] = {};
+      st(p.dD + (int64_t)a * DP + fo, zero);
     }
 #pragma unroll
     for (int b = a + 1; b < JB; ++b) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
+      for (int f = 0; f < F; ++f) u[b][f] = fmaf(-cf[b], delta[f], u[b][f]);
     }
   });
   if (tid < nb) p.degenerate[j0 + tid] = (int)((degmask >> tid) & 1u);   // one store, no per-atom branch
+}
+
+// ---------------------------------------------------------------------------
+// The whole sweep in ONE launch (dp == 256): the multi-launch form above spends more than half
+// of its time in the fixed cost of its 2 k/32 dependent launches (~4.8 us each, against 8 us of
+// atom chain per block).  Workgroup 0 ("sweeper") walks the blocks; workgroup r - 2 owns the 32
+// U rows of block r >= 3 ("worker"): it keeps them in MFMA accumulators, applies
+// U_r -= A[r, b] dD_b for b = 0 .. r-3 as each dD_b is published, and hands the rows over.  The
+// sweeper applies the two newest deltas, dD_{r-2} and dD_{r-1}, itself (from LDS), so a worker
+// always has a block time of slack and the chain never waits for it.  Inside the sweeper wave 0
+// runs the chain of block b (U rows and old atoms in registers, no memory wait on the chain);
+// waves 1-3 meanwhile publish the deltas of block b - 1 (LDS -> global, written through, drained,
+// then the flag) and stage block b + 1 (A blocks, old atoms, U rows).
+// Hand-offs as in fista_splitk.hip: payload written through (sc1) and drained, then a flag;
+// consumers load past their L1/L2 (sc1).  Every spin is bounded: on a timeout (a workgroup is
+// not resident) the grid raises flags[1] and leaves; a stand-by launch of the same kernel in
+// solo mode (one workgroup doing the workers' updates itself, from the untouched U / Dt)
+// then runs -- it returns at once otherwise.  New atoms go to DtN, never over Dt.
+// Arithmetic of a row block is the same sequence in both modes (updates b = 0 .. r-1 in order,
+// each one v_mfma_f32_16x16x4_f32 chain over the 32 atoms of block b).
+// ---------------------------------------------------------------------------
+constexpr int kSpLdB = 272;     // row stride of the [32][256] LDS tiles: MFMA B-operand reads conflict-free
+constexpr int kSpLdA = 34;      // row stride of the negated off-diagonal A blocks (MFMA A operand)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool spin_until(const int* flag, int want, int* abort_flag) {
+  for (int spins = 0; spins < kStopSpinLimit; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+// acc[mt][nt] (rows 16 mt + 4 q + rg, columns 64 w + 16 nt + l15) += An[32][32] B[32][256];
+// the 32 B values of the lane are fetched up front (one memory latency when they come from HBM)
+template <typename BLoad>
+__device__ __forceinline__ void sp_mma(f32x4 (&acc)[2][4], const float* __restrict__ sAn, BLoad&& bload, int l15, int q) {
+  float b[8][4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[s][nt] = bload(4 * s + q, nt);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float a0 = sAn[l15 * kSpLdA + 4 * s + q], a1 = sAn[(16 + l15) * kSpLdA + 4 * s + q];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[s][nt], acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[s][nt], acc[1][nt], 0, 0, 0);
+    }
+  }
+}
+
+struct SweepPersist {
+  float* DtN;          // [k][256] new atoms
+  float* dDg;          // [nblk * 32][256] published deltas
+  float* Uw;           // [nblk * 32][256] worker results
+  int* flags;          // [0] blocks published, [1] abort, [8 + r] rows of block r handed over
+  int solo;            // 1: one workgroup, no workers
+  const int* run_if;   // nullable: run only if *run_if != 0 (the stand-by launch)
+};
+constexpr int kSpSelf = 1;      // newest deltas the sweeper applies itself
+static_assert(kSpSelf == 1, "the LDS delta buffers are shared with the next block's old atoms");
+
+__global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p, const SweepPersist x) {
+  constexpr int JB = kSweepBlock, DP = 256;
+  if (x.run_if && *x.run_if == 0) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nblk = (p.k + JB - 1) / JB;
+  int* const f_pub = x.flags, * const f_abort = x.flags + 1, * const f_rows = x.flags + 8;
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(x.dDg, 0, nblk * JB * DP * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(x.Uw, 0, nblk * JB * DP * 4, 0x00020000);
+  __shared__ int sh_ok;
+  // negated A[rb rows][cb columns] -> sAn (zero beyond k)
+  // (every load below is unconditional on a clamped address, the mask applied to the value: a
+  // load under a lane mask gets its own s_waitcnt and the batch degenerates into a chain of latencies)
+  const int kl = p.k - 1;
+  auto load_an = [&](float* sAn, int rb, int cb, int t0, int nt) {
+    for (int e = t0; e < JB * JB; e += nt) {
+      const int a = e >> 5, c = e & 31, r = JB * rb + a, cc = JB * cb + c;
+      const float v = p.A[(int64_t)min(r, kl) * p.lda + min(cc, kl)];
+      sAn[a * kSpLdA + c] = (r < p.k && cc < p.k) ? -v : 0.0f;
+    }
+  };
+  const auto dd_global = [&](int b) {
+    return [&, b](int kk, int nt) {
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+          drsrc, (unsigned)(((JB * b + kk) * DP + 64 * w + 16 * nt + l15) * 4), 0, 16));
+    };
+  };
+
+  if (blockIdx.x > 0) {
+    // ---------------- worker: rows of block r ------------------------------------------------
+    const int r = blockIdx.x + kSpSelf;
+    float* const sAn = smem;                                 // [2][32][34]
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = JB * r + 16 * mt + 4 * q + rg;
+          const float v = p.U[(int64_t)min(row, kl) * p.ldu + 64 * w + 16 * nt + l15];
+          acc[mt][nt][rg] = row < p.k ? v : 0.0f;
+        }
+    load_an(sAn, r, 0, tid, 256);
+    for (int b = 0; b <= r - kSpSelf - 1; ++b) {
+      float* const cur = sAn + (b & 1) * JB * kSpLdA;
+      if (w == 0) {
+        bool ok = true;
+        if (lane == 0) ok = spin_until(f_pub, b + 1, f_abort);
+        ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        if (lane == 0) sh_ok = ok;
+      } else if (b + 1 <= r - kSpSelf - 1) {
+        load_an(sAn + ((b + 1) & 1) * JB * kSpLdA, r, b + 1, tid - 64, 192);   // next block of A meanwhile
+      }
+      __syncthreads();
+      if (!sh_ok) return;
+      sp_mma(acc, cur, dd_global(b), l15, q);
+      __syncthreads();                                       // sAn / sh_ok reuse
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][rg]), ursrc,
+              (unsigned)(((JB * r + 16 * mt + 4 * q + rg) * DP + 64 * w + 16 * nt + l15) * 4), 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // written through
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(f_rows + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+
+  // ---------------- sweeper ----------------------------------------------------------------
+  float* const sA = smem;                                    // [2][32][32]     A[b][b]
+  float* const sAp = sA + 2 * JB * JB;                       // [2][2][32][34]  -A[b][b-1], -A[b][b-2]
+  // dDl[b & 1] holds the OLD atoms of block b until the chain replaces them, row by row, with the
+  // block's deltas (atom a reads its old row, then writes its delta there); dDl[(b & 1) ^ 1] the
+  // deltas of block b - 1 until wave 1 has published them, then the old atoms of block b + 1
+  float* const dDl = sAp + 4 * JB * kSpLdA;                  // [2][32][272]
+  float* const Ub = dDl + 2 * JB * kSpLdB;                   // [32][272]       U rows of the block
+  __shared__ volatile int pub_done;                          // blocks whose deltas wave 1 has copied out of dDl
+  __shared__ volatile int rows_taken;                        // blocks whose Ub rows wave 0 holds in registers
+  __shared__ int sh_abort;
+  // (loads first, LDS stores after: one memory latency per staging step, not one per loop trip)
+  auto stage_a = [&](int nb, int par, int t0, auto nt_c) {
+    constexpr int nt = decltype(nt_c)::value, kPer = (JB * JB + nt - 1) / nt;
+    float ra[kPer], rp[kSpSelf][kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = min(t0 + i * nt, JB * JB - 1), a = e >> 5, c = e & 31, r = JB * nb + a;
+      const float* const row = p.A + (int64_t)min(r, kl) * p.lda;
+      const float va = row[min(JB * nb + c, kl)];
+      ra[i] = va * ((r < p.k && JB * nb + c < p.k) ? 1.0f : 0.0f);
+#pragma unroll
+      for (int h = 0; h < kSpSelf; ++h) {
+        const float vp = row[max(JB * (nb - 1 - h), 0) + c];                                     // columns < k
+        rp[h][i] = vp * ((r < p.k && nb >= h + 1) ? -1.0f : 0.0f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = t0 + i * nt, a = e >> 5, c = e & 31;
+      if (e < JB * JB) {
+        sA[par * JB * JB + e] = ra[i];
+#pragma unroll
+        for (int h = 0; h < kSpSelf; ++h) sAp[(2 * par + h) * JB * kSpLdA + a * kSpLdA + c] = rp[h][i];
+      }
+    }
+  };
+  auto stage_rows = [&](int nb, bool from_worker, int t0, auto nt_c) {
+    constexpr int nt = decltype(nt_c)::value, kPer = (JB * DP / 4 + nt - 1) / nt;
+    f32x4 rv[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = min(t0 + i * nt, JB * DP / 4 - 1), a = e >> 6, c4 = (e & 63) * 4;
+      if (from_worker) {                                     // (wave-uniform)
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ursrc, (unsigned)(((JB * nb + a) * DP + c4) * 4), 0, 16);
+        rv[i] = __builtin_bit_cast(f32x4, t);
+      } else {
+        rv[i] = *(const f32x4*)(p.U + (int64_t)min(JB * nb + a, kl) * p.ldu + c4);
+        if (JB * nb + a >= p.k) rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = t0 + i * nt, a = e >> 6, c4 = (e & 63) * 4;
+      if (e < JB * DP / 4) *(f32x4*)(Ub + a * kSpLdB + c4) = rv[i];
+    }
+  };
+  auto stage_old = [&](int nb, int t0, auto nt_c, bool wait_pub) {
+    constexpr int nt = decltype(nt_c)::value, kPer = JB * DP / 4 / nt;
+    f32x4 rv[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = t0 + i * nt, a = e >> 6, c4 = (e & 63) * 4;
+      rv[i] = *(const f32x4*)(p.Dt + (int64_t)min(JB * nb + a, kl) * DP + c4);
+      if (JB * nb + a >= p.k) rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (wait_pub)
+      while (pub_done < nb - 1) __builtin_amdgcn_s_sleep(1); // wave 1 has copied the deltas of block nb - 2 + 1 out
+    float* const dst = dDl + (nb & 1) * JB * kSpLdB;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = t0 + i * nt, a = e >> 6, c4 = (e & 63) * 4;
+      *(f32x4*)(dst + a * kSpLdB + c4) = rv[i];
+    }
+  };
+  if (tid == 0) { rows_taken = 0; sh_abort = 0; pub_done = 0; }
+  using I64 = std::integral_constant<int, 64>;
+  using I128 = std::integral_constant<int, 128>;
+  using I256 = std::integral_constant<int, 256>;
+  stage_a(0, 0, tid, I256{});
+  stage_rows(0, false, tid, I256{});
+  stage_old(0, tid, I256{}, false);
+  const float lo = p.positive ? 0.0f : -INFINITY;            // dict_learning.py:87-88
+  const float eps2 = p.eps * p.eps;
+  const bool solo = x.solo != 0;
+
+#ifdef LASSO_SWEEP_TIMING
+  long long* const tlog = (long long*)(x.flags + 256);       // [nblk][16] wall_clock64 stamps (debug builds)
+#define SP_STAMP(slot) do { if (lane == 0) tlog[b * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SP_STAMP(slot) do {} while (0)
+#endif
+  for (int b = 0; b < nblk; ++b) {
+    const int par = b & 1;
+    // the staging code derives ~100 per-thread addresses from the thread index; opaque per trip, or
+    // hipcc hoists them all out of this loop and spills them (each reload then waits for vmcnt(0))
+    int tdyn = tid;
+    asm volatile("" : "+v"(tdyn));
+    __syncthreads();                                         // block b staged; dDl[par ^ 1] = deltas of block b - 1
+    if (sh_abort) return;
+    if (w == 0) SP_STAMP(0);
+    if (b > 0) {
+      // U_b -= A[b][b'] dD_b', b' ascending: (solo mode) every b' < b - 2 from the published deltas,
+      // then the two newest ones from LDS
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            acc[mt][nt][rg] = Ub[(16 * mt + 4 * q + rg) * kSpLdB + 64 * w + 16 * nt + l15];
+      if (solo) {
+        float* const sAn = sAp + (2 * (par ^ 1)) * JB * kSpLdA;   // free until block b + 1 is staged
+        for (int bb = 0; bb <= b - kSpSelf - 1; ++bb) {
+          __syncthreads();
+          load_an(sAn, b, bb, tid, 256);
+          __syncthreads();
+          sp_mma(acc, sAn, dd_global(bb), l15, q);
+        }
+        __syncthreads();
+      }
+      if (kSpSelf >= 2 && b >= 2)
+        sp_mma(acc, sAp + (2 * par + 1) * JB * kSpLdA,
+               [&](int kk, int nt) { return dDl[(par * JB + kk) * kSpLdB + 64 * w + 16 * nt + l15]; }, l15, q);
+      sp_mma(acc, sAp + (2 * par) * JB * kSpLdA,
+             [&](int kk, int nt) { return dDl[((par ^ 1) * JB + kk) * kSpLdB + 64 * w + 16 * nt + l15]; }, l15, q);
+      __syncthreads();                                       // all reads of Ub / dDl[par] done
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            Ub[(16 * mt + 4 * q + rg) * kSpLdB + 64 * w + 16 * nt + l15] = acc[mt][nt][rg];
+      __syncthreads();
+    }
+    if (w == 0) {
+      SP_STAMP(1);
+      // ---- the chain of block b (as sweep_block_kernel<.., 1, 4>), rows and old atoms in registers
+      const int j0 = JB * b, nb_at = min(JB, p.k - j0), fo = 4 * lane;
+      const float* const cA = sA + par * JB * JB;
+      float* const dOut = dDl + par * JB * kSpLdB;
+      f32x2 u[JB][2];
+#pragma unroll
+      for (int a = 0; a < JB; ++a) {
+        const f32x4 t = *(const f32x4*)(Ub + a * kSpLdB + fo);
+        u[a][0] = (f32x2){t[0], t[1]};
+        u[a][1] = (f32x2){t[2], t[3]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps hipcc from sinking the loads past the flag)
+      rows_taken = b + 1;
+      unsigned degmask = 0;
+      auto chain = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;       // all 32 atoms exist: no per-atom branch
+        static_for<JB>([&](auto a_c) {
+          constexpr int a = decltype(a_c)::value;
+          float cf[JB];
+#pragma unroll
+          for (int b4 = 0; b4 < JB / 4; ++b4) {
+            const f32x4 t4 = *(const f32x4*)(cA + a * JB + 4 * b4);
+            cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
+          }
+          const f32x4 dc4 = *(const f32x4*)(dOut + a * kSpLdB + fo);      // the old atom; its delta goes back here
+          float v[4], ss = 0.0f;
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            v[f] = fmaxf(fmaf(cf[a], dc4[f], u[a][f >> 1][f & 1]), lo);   // u_j = U_j + A_jj d_j   (:85-88)
+            ss = fmaf(v[f], v[f], ss);
+          }
+          ss = wave_sum_dpp(ss);
+          const bool deg = ss < eps2;
+          const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
+          f32x4 dnew, delta;
+#pragma unroll
+          for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dc4[f]; }
+          if (!FULL && a >= nb_at) delta = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (FULL || a < nb_at) {
+            *(f32x4*)(x.DtN + (int64_t)(j0 + a) * DP + fo) = dnew;
+            degmask |= (deg ? 1u : 0u) << a;
+          }
+          *(f32x4*)(dOut + a * kSpLdB + fo) = delta;
+          const f32x2 d01 = {delta[0], delta[1]}, d23 = {delta[2], delta[3]};
+#pragma unroll
+          for (int bb = a + 1; bb < JB; ++bb) {                // v_pk_fma_f32: two features per instruction
+            const f32x2 nc = {-cf[bb], -cf[bb]};
+            u[bb][0] = __builtin_elementwise_fma(nc, d01, u[bb][0]);
+            u[bb][1] = __builtin_elementwise_fma(nc, d23, u[bb][1]);
+          }
+        });
+      };
+      if (nb_at == JB) chain(std::true_type{});
+      else chain(std::false_type{});
+      if (lane < nb_at) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);
+      SP_STAMP(2);
+    } else if (w == 1) {
+      // ---- wave 1: publish the deltas of block b - 1, then stage the A blocks of block b + 1 ------
+      const int nb = b + 1;
+      SP_STAMP(4);
+      if (b >= 1) {
+        const float* const src = dDl + (par ^ 1) * JB * kSpLdB;
+#pragma unroll 8
+        for (int e = (tdyn & 63); e < JB * DP / 4; e += 64) {
+          const int a = e >> 6, c4 = (e & 63) * 4;
+          const f32x4 v = *(const f32x4*)(src + a * kSpLdB + c4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drsrc,
+                                                 (unsigned)(((JB * (b - 1) + a) * DP + c4) * 4), 0, 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads are done: the buffer may be refilled
+        pub_done = b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // written through
+        if (!solo && lane == 0) __hip_atomic_store(f_pub, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      SP_STAMP(5);
+      if (nb < nblk) stage_a(nb, par ^ 1, tdyn & 63, I64{});
+      SP_STAMP(6);
+    } else {
+      // ---- waves 2-3: old atoms and U rows of block b + 1 ---------------------------------------
+      const int ht = tdyn - 128, nb = b + 1;
+      if (nb < nblk) {
+        stage_old(nb, ht, I128{}, true);
+        while (rows_taken < nb) __builtin_amdgcn_s_sleep(1); // wave 0 holds the rows of block b in registers
+        if (w == 2) SP_STAMP(7);
+        bool ok = true;
+        const bool from_worker = !solo && nb > kSpSelf;
+        if (from_worker) {
+          if (lane == 0) ok = spin_until(f_rows + nb, 1, f_abort);
+          ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        }
+        if (w == 2) SP_STAMP(8);
+        if (!ok) sh_abort = 1;
+        else stage_rows(nb, from_worker, ht, I128{});
+        if (w == 2) SP_STAMP(9);
+      }
+    }
+  }
 }
 
 // Replacement directions for the degenerate atoms, in atom order: the i-th degenerate atom
@@ -450,34 +849,81 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
   return hipGetLastError();
 }
 
-template <int NW>
+template <int NW, int F>
 static hipError_t sweep_blocks(const SweepParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)kSweepBlock * 256 * NW * 4;
+  const size_t lds = (size_t)kSweepBlock * 64 * NW * F * 4;
   if (lds > 32 * 1024) {
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<true, NW>), lds);
-    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<false, NW>), lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<true, NW, F>), lds);
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_block_kernel<false, NW, F>), lds);
     if (e != hipSuccess) return e;
   }
   for (int j0 = 0; j0 < p.k; j0 += kSweepBlock) {
     if (j0 + kSweepBlock <= p.k)
-      hipLaunchKernelGGL((sweep_block_kernel<true, NW>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
+      hipLaunchKernelGGL((sweep_block_kernel<true, NW, F>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
     else
-      hipLaunchKernelGGL((sweep_block_kernel<false, NW>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
+      hipLaunchKernelGGL((sweep_block_kernel<false, NW, F>), dim3(1), dim3(64 * NW), lds, stream, p, j0);
     if (j0 + kSweepBlock < p.k) {
       const int rows = p.k - j0 - kSweepBlock;
-      hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256), NW), dim3(256), 0, stream, p, j0);
+      hipLaunchKernelGGL(trailing_update_kernel, dim3(std::min(rows, 256), p.dp / 256), dim3(256), 0, stream, p, j0);
     }
   }
   return hipGetLastError();
 }
 
-hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream) {
+size_t sweep_persist_extra_bytes(int k) {
+  const size_t nblk = (size_t)(k + kSweepBlock - 1) / kSweepBlock;
+  return 3 * nblk * kSweepBlock * 256 * 4 + 4096 + nblk * 128;   // DtN, dDg, Uw, flags (+ debug time stamps)
+}
+
+// dp == 256: the single-launch sweep (+ its stand-by).  `extra` = sweep_persist_extra_bytes(k)
+// bytes; on return *dt_out is where the new atoms are (rows of length 256).
+static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt_out, hipStream_t stream) {
+  const int nblk = (p.k + kSweepBlock - 1) / kSweepBlock;
+  const size_t rows = (size_t)nblk * kSweepBlock * 256;
+  SweepPersist x;
+  x.DtN = (float*)extra;
+  x.dDg = x.DtN + rows;
+  x.Uw = x.dDg + rows;
+  x.flags = (int*)(x.Uw + rows);
+  x.solo = nblk <= kSpSelf + 1;
+#ifdef LASSO_SWEEP_FORCE_SOLO   // debugging aid
+  x.solo = 1;
+#endif
+  x.run_if = nullptr;
+  const size_t lds = (size_t)(2 * kSweepBlock * kSweepBlock + 4 * kSweepBlock * kSpLdA + 3 * kSweepBlock * kSpLdB) * 4;
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_persist_kernel), lds);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(x.flags, 0, 4096, stream)) != hipSuccess) return e;
+  const int grid = x.solo ? 1 : nblk - kSpSelf;
+  hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(256), lds, stream, p, x);
+  if (!x.solo) {            // stand-by: runs only if the grid gave up (a workgroup was not resident)
+    SweepPersist y = x;
+    y.solo = 1;
+    y.run_if = x.flags + 1;
+    hipLaunchKernelGGL(sweep_persist_kernel, dim3(1), dim3(256), lds, stream, p, y);
+  }
+  *dt_out = x.DtN;
+  return hipGetLastError();
+}
+
+#ifndef LASSO_SWEEP_WAVES256
+#define LASSO_SWEEP_WAVES256 4
+#endif
+hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* persist_extra, float** dt_out) {
   hipError_t e;
+  if (dt_out) *dt_out = p.Dt;
+  if (p.dp == 256 && persist_extra && dt_out) {
+    if ((e = sweep_persistent(p, persist_extra, dt_out, stream)) != hipSuccess) return e;
+    SweepParams f = p;
+    f.Dt = *dt_out;
+    hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, f);
+    return hipGetLastError();
+  }
   switch (p.dp) {
-    case 256: e = sweep_blocks<1>(p, stream); break;
-    case 512: e = sweep_blocks<2>(p, stream); break;
-    case 768: e = sweep_blocks<3>(p, stream); break;
-    case 1024: e = sweep_blocks<4>(p, stream); break;
+    case 256: e = sweep_blocks<LASSO_SWEEP_WAVES256, 4 / LASSO_SWEEP_WAVES256>(p, stream); break;
+    case 512: e = sweep_blocks<2, 4>(p, stream); break;
+    case 768: e = sweep_blocks<3, 4>(p, stream); break;
+    case 1024: e = sweep_blocks<4, 4>(p, stream); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

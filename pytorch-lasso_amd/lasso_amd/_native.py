@@ -13,10 +13,13 @@ import torch
 
 LASSO_OK, LASSO_ERR_BAD_ARG, LASSO_ERR_UNSUPPORTED = 0, 1, 2
 LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
+LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
 ABI_VERSION = 2
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
+SOLVE_ASYNC = 0x4000
+LR_AUTO = -1.0
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -81,6 +84,11 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_fista_solve_collect.restype = i32
+    lib.lasso_fista_solve_collect.argtypes = [i64, i64, i64, i32, i32, dbl, vp, vp, sz, vp]
+    lib.lasso_fista_solve_finish.restype = i32
+    lib.lasso_fista_solve_finish.argtypes = [i64, i64, i64, i32, i32, dbl, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                             vp, sz, vp]
     lib.lasso_init_transpose_workspace_bytes.restype = sz
     lib.lasso_init_transpose_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_init_transpose.restype = i32

@@ -41,6 +41,44 @@ class HipEngine:
         from .linear.sparse_encode import sparse_encode
         return sparse_encode(X, W, alpha, z0, **solver_kwargs)
 
+    def encode_begin(self, X, W, alpha, z0, **solver_kwargs):
+        """sparse_encode that does not wait for the stop rule's outcome: returns (Z, pending);
+        ``pending`` is None (complete) or a callable that waits for the solve alone and returns
+        False when it has to be repeated with stop_mode='chunked' (solvers/ista.py PendingSolve)."""
+        from .linear.solvers import ista
+        kw = dict(solver_kwargs)
+        plain = (kw.pop('algorithm', 'ista') == 'ista' and kw.pop('init', None) is None and not kw.get('verbose')
+                 and not kw.get('backtrack') and not kw.get('return_info') and X.dtype == torch.float32
+                 and X.is_cuda and W.is_cuda and (z0 is None or z0.is_cuda))
+        if not plain:
+            return self.encode(X, W, alpha, z0, **solver_kwargs), None
+        if z0 is None:
+            z0 = X.new_zeros(X.shape[0], W.shape[1])
+        return ista(X, z0, W, alpha, begin=True, **kw)
+
+    def sweep_begin(self, A, B, D, eps, positive):
+        """The atom sweep without the host round trip for the number of degenerate atoms: returns
+        a callable giving (mask, ndeg) that waits only for the sweep itself."""
+        d, k = D.shape
+        L = self.lib
+        with torch.cuda.device(self.device):
+            ws = self._ws(L.lasso_dict_sweep_workspace_bytes(d, k), "sweep")
+            mask = torch.zeros(k, dtype=torch.int32, device=self.device)
+            nat.check(L.lasso_dict_sweep(
+                nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
+                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), None, nat.ptr(ws), ws.numel(), self._stream()))
+            if getattr(self, "_ndeg_host", None) is None:
+                self._ndeg_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host = self._ndeg_host
+            host.copy_(mask.sum(dtype=torch.int32).reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+
+        def result():
+            ev.synchronize()
+            return mask, int(host[0])
+        return result
+
     def lipschitz(self, W):
         from .linear.lipschitz import lipschitz_constant
         return lipschitz_constant(W)

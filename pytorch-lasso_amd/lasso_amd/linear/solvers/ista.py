@@ -92,9 +92,44 @@ class _UnrolledIsta(torch.autograd.Function):
         return gx, gz0, gw, None, None, None, None, None
 
 
+class PendingSolve:
+    """Outcome of a solve whose stop rule was left running on the GPU (``ista(..., begin=True)``):
+    calling it waits for the SOLVE only -- work enqueued behind it keeps the GPU busy -- and
+    returns True, or False when the in-kernel stop rule gave up (a workgroup of the persistent
+    kernel was not resident; z is then unchanged input and the caller solves again with
+    ``stop_mode='chunked'``).  ``iterations`` / ``last_delta`` are valid after a True call."""
+
+    def __init__(self, status, event):
+        self._status, self._event = status, event
+        self.iterations, self.last_delta = None, None
+
+    def __call__(self):
+        self._event.synchronize()
+        st = self._status
+        if int(st[2]) != 0:
+            return False
+        self.iterations = int(st[0])
+        self.last_delta = float(st[1:2].view(torch.float32)[0])
+        return True
+
+
+_PINNED = {}
+
+
+def _pinned_status(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    slots = _PINNED.setdefault(key, [])
+    # a small ring: a slot is reused only after several later solves on the same stream
+    if len(slots) < 4:
+        slots.append(torch.zeros(4, dtype=torch.int32).pin_memory())
+        return slots[-1]
+    slots.append(slots.pop(0))
+    return slots[-1]
+
+
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
-         return_info=False, stop_mode='global', kernel='auto'):
+         return_info=False, stop_mode='global', kernel='auto', begin=False):
     """Solve min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 on the GPU.
 
     x [n,d], z0 [n,k], weight [d,k]; returns a NEW tensor z [n,k] with the
@@ -106,6 +141,8 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     'chunked' = the same rule without the in-kernel handshake, 'none' = run maxiter iterations.
     ``kernel`` (extension): 'auto' | 'tile' | 'splitk' -- which fused kernel runs the batch
     (include/lasso_hip.h, LASSO_KERNEL_*); the code is bitwise the same either way.
+    ``begin`` (extension): return ``(z, pending)`` without waiting for the stop rule's outcome;
+    ``pending`` is a :class:`PendingSolve`, or None when the solve completed inside the call.
     Tensors that live on the CPU are staged through the current HIP device
     (the arithmetic still runs in the HIP kernels; there is no CPU fallback).
     """
@@ -139,10 +176,16 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         return out.to(x.dtype)
     if x.dtype not in _DT:
         raise NotImplementedError("lasso_amd: dtype %s is not implemented on the HIP path" % x.dtype)
+    if begin and (return_info or x.dtype != torch.float32):
+        raise ValueError("begin=True: fp32 tensors, return_info=False")
     if maxiter == 0:
+        if begin:
+            return z0, None
         return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
     if n == 0:      # empty batch: nothing to solve (the reference's loop stops at once: 0 <= 0)
         z = z0.clone()
+        if begin:
+            return z, None
         return (z, dict(iterations=1, last_delta=0.0)) if return_info else z
 
     out_device = z0.device
@@ -152,12 +195,20 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     wg = _to_device(weight.detach(), dev).contiguous()
     zg = _to_device(z0.detach(), dev).contiguous()
 
+    wants_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)
     if lr == 'auto':
-        from ..lipschitz import lipschitz_constant
-        lr = 1.0 / lipschitz_constant(wg)                          # ista.py:59-63
+        if not wants_grad and not verbose and not backtrack and d <= 256 and k <= 1024:
+            # the fused fp32 kernels read the step from device memory: lambda_max and 1/L are
+            # computed on the stream inside lasso_fista_solve, no host round trip (ista.py:72-73)
+            if wg.dtype != torch.float32:
+                raise TypeError("lasso_amd: lr='auto' needs an fp32 dictionary, got %s" % wg.dtype)
+            lr = nat.LR_AUTO
+        else:
+            from ..lipschitz import lipschitz_constant
+            lr = 1.0 / lipschitz_constant(wg)                      # ista.py:59-63
     lr = float(lr)
 
-    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad):
+    if wants_grad:
         # differentiable path (the reference's loop is autograd-traceable, README "autograd")
         if backtrack:
             raise NotImplementedError("lasso_amd: autograd through the backtracking line search is not implemented")
@@ -166,15 +217,19 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         if d > 256 or k > 1024:
             raise NotImplementedError("lasso_amd: the differentiable path is limited to d <= 256, k <= 1024")
         z = _UnrolledIsta.apply(x, z0, weight, float(alpha), bool(fast), lr, int(maxiter), float(tol))
+        if begin:
+            return z, None
         return (z, dict(iterations=None, last_delta=None)) if return_info else z
 
     if verbose and not backtrack:
         z, info = _ista_verbose(xg, zg, wg, alpha, fast, lr, maxiter, tol, dev)
         z = z if z.device == out_device else z.to(out_device)
+        if begin:
+            return z, None
         return (z, info) if return_info else z
 
     return _solve_native(xg, zg, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                         return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel)
+                         return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel, begin=begin)
 
 
 _STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
@@ -184,7 +239,7 @@ _KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNE
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                  return_info, out_device=None, stop_mode='global', kernel='auto'):
+                  return_info, out_device=None, stop_mode='global', kernel='auto', begin=False):
     """One call of lasso_fista_solve on tensors of one dtype (float32, or bfloat16 with the
     line search)."""
     n, d = x.shape
@@ -202,8 +257,10 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         nbytes = L.lasso_fista_workspace_bytes(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
                                                nat.STOP_GLOBAL, int(bool(backtrack)))
         ws = nat.workspace(dev, nbytes)
+        want_async = bool(begin) and not backtrack and x.dtype == torch.float32
         iters = C.c_int32(0)
         last = C.c_float(float('nan'))
+        want_host = bool(return_info) or bool(verbose)
         want_trace = bool(backtrack) and bool(return_info)
         trials = (C.c_int32 * max(int(maxiter), 1))() if want_trace else None
         acc_lr = (C.c_float * max(int(maxiter), 1))() if want_trace else None
@@ -212,10 +269,22 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
-            int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel], int(bool(backtrack)), float(eta_backtrack),
-            C.byref(iters), C.byref(last), trials, acc_lr, acc_f, C.byref(obj) if obj is not None else None,
-            nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
-        nat.check(st)
+            int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0),
+            int(bool(backtrack)), float(eta_backtrack),
+            C.byref(iters) if want_host else None, C.byref(last) if want_host else None, trials, acc_lr, acc_f,
+            C.byref(obj) if obj is not None else None, nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
+        pending = None
+        if st == nat.LASSO_PENDING:
+            status = _pinned_status(dev)
+            nat.check(L.lasso_fista_solve_collect(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
+                                                  status.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            pending = PendingSolve(status, ev)
+        else:
+            nat.check(st)
+    if begin:
+        return (z if z.device == out_device else z.to(out_device)), pending
     if z.device != out_device:
         z = z.to(out_device)
     if verbose and backtrack:

@@ -161,12 +161,42 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     if progbar and rank == 0:
         from tqdm import tqdm
         bar = tqdm(total=steps)
-    for i in range(steps):
-        Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, **solver_kwargs)   # :38
+    # One GPU: the step is enqueued without waiting on it -- the stop rule's outcome and the
+    # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
+    # objective and the Gram product are still queued, so the GPU does not idle behind the host.
+    overlap = world == 1 and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
+    deferred = None          # the previous step's sweep: callable -> (mask, ndeg)
+
+    def repair(mask, ndeg, Zprev):
+        cand = draw_directions(d, ndeg).to(weight.device)
+        engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
+        if Zprev is not None:
+            engine.zero_columns(Zprev, mask)                                              # :98
+
+    i, Zlast = 0, None
+    while i < steps:
+        pending = None
+        if overlap:
+            Z, pending = engine.encode_begin(X, weight, alpha, Z0, **solver_kwargs)       # :38
+        else:
+            Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, **solver_kwargs)
         loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
+        A, B = engine.gram(Z, X, buf)
+        if deferred is not None:
+            mask, ndeg = deferred()
+            deferred = None
+            if ndeg:     # rare: an atom degenerated in the previous sweep -- repair, redo this E-step
+                if pending is not None:
+                    pending()
+                repair(mask, ndeg, Zlast)
+                continue
+        if pending is not None and not pending():
+            # the in-kernel stop rule gave up (CUs held by other work): same rule, chunked
+            Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
+            loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
+            A, B = engine.gram(Z, X, buf)
         if persist:
             Z0 = Z                                                                        # :40-41
-        A, B = engine.gram(Z, X, buf)
         if world > 1:
             tail.copy_(sums)                 # the two objective sums ride in the Gram message
             _all_reduce(buf, group)
@@ -174,14 +204,23 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         else:
             losses[i] = loss_local
         if constrained:
-            mask = constrained_mstep(engine, A, B, weight, group=group)                   # :44-45
-            if mask is not None:
-                engine.zero_columns(Z, mask)                                              # :98
+            if overlap:
+                deferred = engine.sweep_begin(A, B, weight, 1e-10, False)                 # :44-45
+                Zlast = Z
+            else:
+                mask = constrained_mstep(engine, A, B, weight, group=group)
+                if mask is not None:
+                    engine.zero_columns(Z, mask)                                          # :98
         else:
-            weight = engine.ridge(A, B, lambd * n_total, check=True)                                  # :46-47
+            weight = engine.ridge(A, B, lambd * n_total, check=True)                      # :46-47
         if bar is not None:
             bar.set_postfix(loss=losses[i].item())                                        # :50
             bar.update(1)
+        i += 1
+    if deferred is not None:
+        mask, ndeg = deferred()
+        if ndeg:
+            repair(mask, ndeg, Zlast)
     if bar is not None:
         bar.close()
     return weight, losses

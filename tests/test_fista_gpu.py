@@ -216,3 +216,41 @@ def test_verbose_prints_reference_loss_lines(capsys):
     orc.fista(X, X.new_zeros(40, 60), W, 0.3, lr=lr, maxiter=6, tol=0.0, trace=tr)
     assert out == ["loss: %0.4f" % v for v in tr.objective]
     assert torch.equal(z, z_ref)
+
+
+def test_lr_auto_on_device_equals_host_step():
+    """lr='auto' (ista.py:72-73): the fused fp32 path computes lambda_max and 1/L on the stream and the
+    kernels read the step from device memory (LASSO_LR_AUTO) -- bitwise the solve with the host value."""
+    sparse_encode, ista, orc = _mods()
+    from lasso_amd.linear.lipschitz import lipschitz_constant
+    for (n, d, k) in ((300, 64, 200), (4096, 256, 1024), (100, 256, 1024)):
+        X, W = _case(n, d, k, seed=n)
+        Xg, Wg = X.cuda(), W.cuda()
+        z0 = torch.zeros(n, k, device="cuda")
+        lr = 1.0 / lipschitz_constant(Wg)
+        for tol in (0.0, 1e-4):
+            za, ia = ista(Xg, z0, Wg, alpha=0.2, lr="auto", maxiter=40, tol=tol, return_info=True)
+            zh, ih = ista(Xg, z0, Wg, alpha=0.2, lr=lr, maxiter=40, tol=tol, return_info=True)
+            assert ia["iterations"] == ih["iterations"]
+            assert torch.equal(za, zh)
+
+
+def test_begin_returns_before_the_stop_rule_and_collects_later():
+    """ista(begin=True): (z, pending) -- pending() waits for the solve alone and reports the stopping
+    iteration of the synchronous call; z is the same code."""
+    sparse_encode, ista, orc = _mods()
+    X, W = _case(2048, 256, 1024, seed=5)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(2048, 1024, device="cuda")
+    zs, info = ista(Xg, z0, Wg, alpha=0.3, maxiter=300, tol=1e-4, return_info=True)
+    z, pending = ista(Xg, z0, Wg, alpha=0.3, maxiter=300, tol=1e-4, begin=True)
+    assert pending is not None
+    busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # queued behind the solve
+    assert pending() is True
+    assert pending.iterations == info["iterations"] and pending.iterations < 300
+    assert abs(pending.last_delta - info["last_delta"]) <= 1e-6 * abs(info["last_delta"])
+    torch.cuda.synchronize()
+    assert torch.equal(z, zs) and busy.shape == (2048, 2048)
+    # no stop rule: complete inside the call
+    z2, p2 = ista(Xg, z0, Wg, alpha=0.3, maxiter=5, tol=0.0, begin=True)
+    assert p2 is None and torch.equal(z2, ista(Xg, z0, Wg, alpha=0.3, maxiter=5, tol=0.0))

@@ -1,12 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh <name> <extra hipcc flags...>  -> gpurun_variants/lib<name>.so (A/B kernel builds)
+# usage: tools/build_variant.sh <name> <file.hip> [-DFLAG ...]   ->  variants/liblasso_<name>.so
+# (an A/B build of ONE translation unit linked against the other objects of the product build)
 set -e
-NAME=$1; shift
-SRC=/root/repo/pytorch-lasso_amd/csrc
-OUT=/root/repo/variants; mkdir -p $OUT/obj_$NAME
-for f in $(cd $SRC && ls *.hip | sed "s/[.]hip\$//"); do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 "$@" -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/obj_$NAME/*.o -o $OUT/lib$NAME.so
-echo built $OUT/lib$NAME.so
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; SRC=$2; shift 2
+C=$ROOT/pytorch-lasso_amd/csrc
+make -s -C $C
+mkdir -p $ROOT/variants
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c $C/$SRC -o $ROOT/variants/${NAME}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/${SRC%.hip}.o") $ROOT/variants/${NAME}.o -o $ROOT/variants/liblasso_${NAME}.so
+echo built $ROOT/variants/liblasso_${NAME}.so
