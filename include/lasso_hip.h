@@ -233,6 +233,28 @@ int lasso_zero_columns(void* z_dev, int64_t ldz, int64_t n, int64_t k, int dtype
  * maxiter, tol, workspace, stream): synchronises the stream, writes iters_out / last_delta_out
  * (HOST, nullable).  LASSO_OK, or LASSO_WARN_ABORTED (see above).  Work enqueued between the
  * two calls (lasso_objective, lasso_gram_accumulate on z_out ...) overlaps the wait. */
+/* ---- line search on a ROW SHARD (one process per GPU): replaces the global reductions of
+ * ista.py:23,28,32-35 (F <= Q of each trial) and :93 (stop rule) -------------------------
+ * Same arguments as lasso_fista_solve with backtrack = 1 on the n rows this process holds
+ * (n_global = rows of the whole batch, for the stop budget).  Wherever the reference reduces over
+ * the batch the library hands `reduce` a small array of this rank's sums (doubles, HOST memory)
+ * to be replaced IN PLACE by their sum over all ranks (return 0; anything else aborts the solve
+ * with LASSO_ERR_HIP) -- e.g. an MPI_Allreduce / torch.distributed.all_reduce of `count`
+ * doubles.  Every rank must call with the same lr, eta, maxiter, tol: the callback is then
+ * invoked the same number of times with the same counts on every rank, and all ranks take the
+ * same decisions (trials_out / accepted_lr_out / accepted_f_out are identical everywhere).
+ * Workspace: lasso_fista_workspace_bytes(n, d, k, dtype, maxiter, tol, LASSO_STOP_GLOBAL, 1).
+ * Requires ldz == k. */
+typedef int (*lasso_allreduce_fn)(void* ctx, double* sums, int count);
+int lasso_fista_solve_sharded(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                              const void* z0_dev, int64_t ldz0, void* z_out_dev, int64_t ldz,
+                              int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype,
+                              double alpha, double lr, int fast, int maxiter, double tol,
+                              double eta_backtrack, lasso_allreduce_fn reduce, void* reduce_ctx,
+                              int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
+                              float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
+                              size_t workspace_bytes, void* stream);
+
 /* The asynchronous form: only ENQUEUES the copy of {iterations, last delta (float bits), aborted
  * != 0, 0} into out4_host (HOST; pinned memory keeps the copy asynchronous).  The caller waits
  * on the stream -- or on an event recorded right behind this call, so that work enqueued after

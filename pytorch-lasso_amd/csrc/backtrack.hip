@@ -172,7 +172,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
 __global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict__ partials, int ntiles,
                                                         float alpha, float half_over_lr, float lr, float lam,
                                                         int trial_index, int force,
-                                                        int* __restrict__ flags, float* __restrict__ fvals) {
+                                                        int* __restrict__ flags, float* __restrict__ fvals,
+                                                        double* __restrict__ sums_out) {
   if (!force && flags[0] != 0) return;
   __shared__ double sh[5][256];
   double acc[5] = {0, 0, 0, 0, 0};
@@ -187,6 +188,12 @@ __global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict_
 #pragma unroll
       for (int s = 0; s < 5; ++s) sh[s][threadIdx.x] += sh[s][threadIdx.x + st];
     __syncthreads();
+  }
+  if (threadIdx.x == 0 && sums_out) {
+    // row-sharded solve: this rank's five sums only; the host adds the ranks' and decides
+#pragma unroll
+    for (int s = 0; s < 5; ++s) sums_out[s] = sh[s][0];
+    return;
   }
   if (threadIdx.x == 0) {
     const float rss0 = (float)sh[0][0], rss1 = (float)sh[1][0], l1 = (float)sh[2][0];
@@ -292,7 +299,7 @@ hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t str
 }
 
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
-                           int trial_index, int force, hipStream_t stream) {
+                           int trial_index, int force, hipStream_t stream, double* sums_out) {
   const float lr_f = (float)lr, lam = (float)(alpha * lr);
   hipError_t e;
   switch (kpad) {
@@ -302,14 +309,14 @@ hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, 
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  return launch_bt_decide(p, alpha, lr, trial_index, force, stream);
+  return launch_bt_decide(p, alpha, lr, trial_index, force, stream, sums_out);
 }
 
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,
-                            hipStream_t stream) {
+                            hipStream_t stream, double* sums_out) {
   hipLaunchKernelGGL(bt_decide_kernel, dim3(1), dim3(256), 0, stream, p.partials, p.ntiles,
                      (float)alpha, (float)(0.5 / lr), (float)lr, (float)(alpha * lr), trial_index, force, p.flags,
-                     p.fvals);
+                     p.fvals, sums_out);
   return hipGetLastError();
 }
 

@@ -352,6 +352,7 @@ constexpr int kBtMaxTrials = 1000;   // ista.py:17 (maxiter=1000)
 
 struct BtWorkspace {
   float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
+  double* sums;    // [kBtMaxTrials][5] per-trial sums of a row-sharded solve
   float* G; float* C; float* Y;
   float* Zf;       // bf16 tensors: fp32 working copy of z
   // persistent bf16 solve (bt16_persist.hip)
@@ -381,6 +382,7 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
   w.delta = take(256);
   w.flags = reinterpret_cast<int*>(take(256));
   w.fvals = take(256);
+  w.sums = reinterpret_cast<double*>(take((size_t)kBtMaxTrials * 5 * sizeof(double)));
   w.G = take((size_t)n * k * 4);
   w.C = take((size_t)n * k * 4);
   w.Y = take((size_t)n * k * 4);
@@ -470,7 +472,12 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
                        int64_t ldz0, void* zout_any, int64_t ldz_any, int64_t n, int64_t d, int64_t k, int kp,
                        int dtype, double alpha, double lr0, int fast, int maxiter, double tol, double eta,
                        int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
-                       float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st) {
+                       float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st,
+                       lasso_allreduce_fn reduce = nullptr, void* reduce_ctx = nullptr, int64_t n_global = 0) {
+  // reduce != nullptr: this process holds a row shard.  The sums behind the two global decisions
+  // of an iteration -- F <= Q of every trial (ista.py:23,28,32-35) and sum |z_next - z| <= n k tol
+  // (:93) -- are added over the ranks by the caller's callback; every rank then takes the same
+  // decision from the same numbers.
   const bool half = dtype == LASSO_BF16;      // bf16 tensors: bt_bf16.hip kernels, 64-row tiles
   BtWorkspace ws = carve_bt(workspace, n, k, kp, half);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
@@ -507,11 +514,13 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   // candidates stay on chip and the finish kernel recomputes the accepted one whenever the
   // state is a flat [n][k] array (always for bf16 tensors; fp32: unless z_out is strided)
   const bool recompute = half || ldz == k;
+  if (reduce && !recompute) return fail(LASSO_ERR_UNSUPPORTED, "row-sharded line search needs ldz == k");
   p.G = ws.G; p.C = recompute ? nullptr : ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
-  const float budget = (float)((double)n * (double)k * tol);
+  const float budget = (float)((double)(reduce ? n_global : n) * (double)k * tol);
   bool warned = false;
   double t_mom = 1.0;   // ista.py:78 (python int 1; same arithmetic in double)
+  double hsums[kBtMaxTrials * 5];
   struct { int flags[4]; float fvals[4]; float delta; } host;
   int it = 0, prev_trials = kBtBatch - 1;
   float last = NAN;
@@ -532,17 +541,46 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       // (trials enqueued after the accepted one only cost their launch, but that adds up)
       const int want = t == 0 ? std::min(kBtBatch, std::max(2, prev_trials + 1)) : kBtBatch / 2;
       const int batch = give_up ? 1 : std::min(want, kBtMaxTrials - t);
+      double lr_batch[kBtMaxTrials];
       for (int b = 0; b < batch; ++b) {
         const double lr_t = give_up ? lr0 : lr;      // ista.py:48-52: warn and revert to the initial step size
         const int idx = give_up ? t : t + b, force = give_up ? 1 : 0;
+        double* const sums_dev = reduce ? ws.sums + 5 * b : nullptr;
+        lr_batch[b] = lr_t;
         if (half) {
           LASSO_HIP_TRY(launch_bt16_trial(p, kp, grid, (float)lr_t, (float)(alpha * lr_t), force, st));
-          LASSO_HIP_TRY(launch_bt_decide(p, alpha, lr_t, idx, force, st));
+          LASSO_HIP_TRY(launch_bt_decide(p, alpha, lr_t, idx, force, st, sums_dev));
         } else {
-          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr_t, idx, force, st));
+          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr_t, idx, force, st, sums_dev));
         }
         if (give_up) warned = true;
         else lr = lr / eta;                                                            // :47
+      }
+      if (reduce) {
+        // the batch's sums: all ranks add theirs, then the decision of bt_decide_kernel on the host,
+        // trial by trial in order -- same float arithmetic, same outcome on every rank
+        LASSO_HIP_TRY(hipMemcpyAsync(hsums, ws.sums, (size_t)batch * 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+        LASSO_HIP_TRY(hipStreamSynchronize(st));
+        if (reduce(reduce_ctx, hsums, batch * 5) != 0) return fail(LASSO_ERR_HIP, "all-reduce callback failed");
+        struct { int flags[4]; float fvals[4]; } dec = {{0, 0, 0, 0}, {0.f, 0.f, 0.f, 0.f}};
+        for (int b = 0; b < batch && !dec.flags[0]; ++b) {
+          const double* sm = hsums + 5 * b;
+          const float rss0 = (float)sm[0], rss1 = (float)sm[1], l1 = (float)sm[2], dzg = (float)sm[3], dz2 = (float)sm[4];
+          const float alpha_f = (float)alpha, half_over_lr = (float)(0.5 / lr_batch[b]);
+          const float f0 = 0.5f * rss0;                                              // ista.py:23
+          const float al1 = alpha_f * l1;
+          const float F = 0.5f * rss1 + al1;                                         // :28
+          const float Q = ((f0 + dzg) + half_over_lr * dz2) + al1;                   // :32-35
+          dec.fvals[0] = F; dec.fvals[1] = Q;
+          dec.flags[1] = (give_up ? t : t + b) + 1;
+          if (give_up || F <= Q) {                                                   // :45
+            dec.flags[0] = 1; dec.flags[2] = give_up ? t : t + b;
+            dec.fvals[2] = (float)lr_batch[b]; dec.fvals[3] = (float)(alpha * lr_batch[b]);
+          }
+        }
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.flags, dec.flags, sizeof(dec.flags), hipMemcpyHostToDevice, st));
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.fvals, dec.fvals, sizeof(dec.fvals), hipMemcpyHostToDevice, st));
+        LASSO_HIP_TRY(hipStreamSynchronize(st));     // (dec lives on this stack frame)
       }
       t += batch;
       if (recompute)   // P is Y (fast) or Z itself: element-wise in place is safe either way
@@ -559,6 +597,11 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
         LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
       accepted = host.flags[0] != 0;
+    }
+    if (reduce) {                                    // sum |z_next - z| over all ranks (:93)
+      double dsum = (double)host.delta;
+      if (reduce(reduce_ctx, &dsum, 1) != 0) return fail(LASSO_ERR_HIP, "all-reduce callback failed");
+      host.delta = (float)dsum;
     }
     prev_trials = host.flags[2] + 1;
     if (trials_out) trials_out[it] = host.flags[2] + 1;            // trials evaluated up to the accepted one
@@ -1214,6 +1257,30 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   LASSO_HIP_TRY(hipStreamSynchronize(st));
   memcpy(g_err, saved, sizeof(saved));
   return status;
+}
+
+// Line-search solve on a ROW SHARD of the batch: see include/lasso_hip.h
+int lasso_fista_solve_sharded(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* z0_dev,
+                              int64_t ldz0, void* z_out_dev, int64_t ldz, int64_t n, int64_t n_global, int64_t d,
+                              int64_t k, int dtype, double alpha, double lr, int fast, int maxiter, double tol,
+                              double eta_backtrack, lasso_allreduce_fn reduce, void* reduce_ctx, int32_t* iters_out,
+                              float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
+                              float* accepted_f_out, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32 && dtype != LASSO_BF16) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (!reduce) return fail(LASSO_ERR_BAD_ARG, "reduce callback is null");
+  if (n <= 0 || n_global < n || d <= 0 || k <= 0 || maxiter <= 0) return fail(LASSO_ERR_BAD_ARG, "bad shape");
+  if (!fused_shape(d, k)) return fail(LASSO_ERR_UNSUPPORTED, "line search needs d<=%d, k<=%d", kFistaD, kFistaMaxK);
+  if (!x_dev || !w_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
+  if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k)) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
+  if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
+  if (!(eta_backtrack > 1.0)) return fail(LASSO_ERR_BAD_ARG, "eta must be > 1.");
+  if (n > (int64_t)INT32_MAX - kTileM) return fail(LASSO_ERR_UNSUPPORTED, "n too large");
+  if (iters_out) *iters_out = 0;
+  if (last_delta_out) *last_delta_out = NAN;
+  return solve_backtracking(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, pad_k(k), dtype, alpha, lr,
+                            fast, maxiter, tol, eta_backtrack, iters_out, last_delta_out, trials_out, accepted_lr_out,
+                            accepted_f_out, workspace_dev, workspace_bytes, (hipStream_t)stream, reduce, reduce_ctx,
+                            n_global);
 }
 
 // LASSO_SOLVE_ASYNC solve that returned LASSO_PENDING: enqueue the copy of what the persistent

@@ -157,9 +157,9 @@ hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W,
 
 hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
-                           int trial_index, int force, hipStream_t stream);
+                           int trial_index, int force, hipStream_t stream, double* sums_out = nullptr);
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,
-                            hipStream_t stream);
+                            hipStream_t stream, double* sums_out = nullptr);
 hipError_t launch_bt16_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
 hipError_t launch_bt16_trial(const BtParams& p, int kpad, int grid, float lr, float lam, int force,
                              hipStream_t stream);

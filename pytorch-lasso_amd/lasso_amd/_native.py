@@ -36,6 +36,10 @@ def lib_path():
     return _LIB_PATH
 
 
+# int (*lasso_allreduce_fn)(void* ctx, double* sums, int count)   (include/lasso_hip.h)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
 def use_library(path):
     """Bind a different build of the library (A/B builds of the kernels under tools/); must be
     called before the first native call."""
@@ -84,6 +88,11 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_fista_solve_sharded.restype = i32
+    lib.lasso_fista_solve_sharded.argtypes = [
+        vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, dbl, dbl, i32, i32, dbl, dbl,
+        ALLREDUCE_FN, vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+        C.POINTER(C.c_float), vp, sz, vp]
     lib.lasso_fista_solve_collect.restype = i32
     lib.lasso_fista_solve_collect.argtypes = [i64, i64, i64, i32, i32, dbl, vp, vp, sz, vp]
     lib.lasso_fista_solve_finish.restype = i32

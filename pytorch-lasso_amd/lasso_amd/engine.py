@@ -56,6 +56,48 @@ class HipEngine:
             z0 = X.new_zeros(X.shape[0], W.shape[1])
         return ista(X, z0, W, alpha, begin=True, **kw)
 
+    def encode_sharded_backtrack(self, X, W, alpha, z0, lr, fast, maxiter, tol, eta, n_global, all_reduce):
+        """ISTA/FISTA with the backtracking line search on this rank's row shard
+        (lasso_fista_solve_sharded).  ``all_reduce(t)`` sums a float64 CPU tensor over the ranks in
+        place.  Returns (z, info) -- info holds the same trace on every rank."""
+        n, d = X.shape
+        k = W.shape[1]
+        dt = {torch.float32: nat.LASSO_F32, torch.bfloat16: nat.LASSO_BF16}[X.dtype]
+        L = self.lib
+        failure = []
+
+        def _cb(_ctx, buf, count):
+            try:
+                t = torch.tensor([buf[i] for i in range(count)], dtype=torch.float64)
+                all_reduce(t)
+                for i in range(count):
+                    buf[i] = float(t[i])
+                return 0
+            except Exception as e:          # never let an exception cross the C frame
+                failure.append(e)
+                return 1
+        cb = nat.ALLREDUCE_FN(_cb)
+        X, W = X.contiguous(), W.contiguous()
+        z0 = z0.contiguous() if z0 is not None else None
+        z = torch.empty((n, k), dtype=X.dtype, device=self.device)
+        iters, last = C.c_int32(0), C.c_float(float('nan'))
+        cap = max(int(maxiter), 1)
+        trials, acc_lr, acc_f = (C.c_int32 * cap)(), (C.c_float * cap)(), (C.c_float * cap)()
+        with torch.cuda.device(self.device):
+            nbytes = L.lasso_fista_workspace_bytes(n, d, k, dt, int(maxiter), float(tol), nat.STOP_GLOBAL, 1)
+            ws = nat.workspace(self.device, nbytes)
+            st = L.lasso_fista_solve_sharded(
+                nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0), nat.ptr(z0), z0.stride(0) if z0 is not None else 0,
+                nat.ptr(z), z.stride(0), n, int(n_global), d, k, dt, float(alpha), float(lr), int(bool(fast)),
+                int(maxiter), float(tol), float(eta), cb, None, C.byref(iters), C.byref(last), trials, acc_lr, acc_f,
+                nat.ptr(ws), ws.numel(), self._stream())
+        if failure:
+            raise failure[0]
+        nat.check(st)
+        it = iters.value
+        return z, dict(iterations=it, last_delta=last.value, trials=list(trials[:it]),
+                       accepted_lr=list(acc_lr[:it]), accepted_f=list(acc_f[:it]))
+
     def sweep_begin(self, A, B, D, eps, positive):
         """The atom sweep without the host round trip for the number of degenerate atoms: returns
         a callable giving (mask, ndeg) that waits only for the sweep itself."""

@@ -103,22 +103,41 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     maxiter = kw.pop('maxiter', 10)
     tol = kw.pop('tol', 1e-5)
     backtrack = kw.pop('backtrack', False)
-    kw.pop('eta_backtrack', None)
+    eta = kw.pop('eta_backtrack', 1.5)
     kw.pop('verbose', None)
+    return_info = kw.pop('return_info', False)
     if kw.get('algorithm', 'ista') != 'ista':
         raise NotImplementedError("sharded E-step supports algorithm='ista' and 'cd' only")
     kw.pop('algorithm', None)
     if kw:
         raise TypeError("ista() got unexpected keyword arguments %s" % sorted(kw))
-    if backtrack:
-        raise NotImplementedError("sharded E-step: backtrack=True is not implemented")
+    if backtrack and eta <= 1:
+        raise ValueError('eta must be > 1.')                                              # ista.py:18-19
     if lr == 'auto':
         lr = 1.0 / engine.lipschitz(W)
     n, k = X.shape[0], W.shape[1]
     if z0 is None:
         z0 = X.new_zeros(n, k)
     if maxiter == 0:
-        return z0
+        return (z0, dict(iterations=0)) if return_info else z0
+    if backtrack:
+        # the line search decides on sums over the WHOLE batch (ista.py:23,28,32-35,93): the HIP
+        # library hands this rank's sums to the callback below at every decision, all ranks add
+        # theirs and take the same decision (lasso_fista_solve_sharded)
+        n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
+        _all_reduce(n_glob, group)
+        def reduce_host(t):          # a few float64 words in host memory; RCCL reduces device buffers
+            if dist.get_backend(group) == "gloo":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                g = t.to(X.device)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(g)
+        z, info = engine.encode_sharded_backtrack(X, W, alpha, z0, lr, fast, maxiter, tol, eta, int(n_glob.item()),
+                                                  reduce_host)
+        return (z, info) if return_info else z
+    if return_info:
+        raise NotImplementedError("sharded E-step: return_info needs backtrack=True")
     if not tol > 0:
         z, _, _ = engine.fista_run(X, W, z0, None, alpha, lr, fast, 0, maxiter, False)
         return z

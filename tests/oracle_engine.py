@@ -18,6 +18,42 @@ class OracleEngine:
     def encode(self, X, W, alpha, z0, **kw):
         return orc.sparse_encode(X, W, alpha, z0, **kw)
 
+    def encode_sharded_backtrack(self, X, W, alpha, z0, lr, fast, maxiter, tol, eta, n_global, all_reduce):
+        """The line search on a row shard with the five batch sums of ista.py:23,28,32-35 and the
+        stop-rule sum (:93) added over the ranks -- the protocol of lasso_fista_solve_sharded."""
+        z = z0.clone()
+        y, t = z.clone(), 1.0
+        info = dict(trials=[], accepted_lr=[], accepted_f=[], iterations=0, last_delta=float("nan"))
+        for _ in range(int(maxiter)):
+            p = y if fast else z
+            r0 = p @ W.T - X
+            g = r0 @ W
+            lr_t, ntr = float(lr), 0
+            while True:
+                zn = orc.soft_threshold(p - lr_t * g, alpha * lr_t)
+                r1, dz = zn @ W.T - X, zn - p
+                s = torch.stack([r0.pow(2).sum(), r1.pow(2).sum(), zn.abs().sum(), (dz * g).sum(),
+                                 dz.pow(2).sum()]).double()
+                all_reduce(s)
+                s = s.float()
+                F = 0.5 * s[1] + alpha * s[2]
+                Q = 0.5 * s[0] + s[3] + (0.5 / lr_t) * s[4] + alpha * s[2]
+                ntr += 1
+                if F <= Q:
+                    break
+                lr_t /= eta
+            d = (z - zn).abs().sum().double().reshape(1)
+            all_reduce(d)
+            t_next = (1.0 + (1.0 + 4.0 * t * t) ** 0.5) / 2.0
+            y = zn + ((t - 1.0) / t_next) * (zn - z) if fast else zn
+            z, t = zn, t_next
+            info["trials"].append(ntr); info["accepted_lr"].append(lr_t); info["accepted_f"].append(float(F))
+            info["iterations"] += 1
+            info["last_delta"] = float(d)
+            if tol > 0 and float(d) <= n_global * W.shape[1] * tol:
+                break
+        return z, info
+
     def lipschitz(self, W):
         return orc.lipschitz_constant(W, "exact")
 

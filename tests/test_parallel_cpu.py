@@ -103,3 +103,35 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert np.array_equal(r0[tag + "_l"], r1[tag + "_l"])
         assert np.abs(r0[tag + "_l"] - lref.numpy()).max() < 2e-5, tag
         assert np.abs(r0[tag + "_D"] - Dref.numpy()).max() < 2e-4, tag
+
+
+def _bt_worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from lasso_amd.parallel import sharded_encode
+    from oracle_engine import OracleEngine as Eng
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, D0 = _problem(n=100, d=12, k=40)
+    lo, hi = (0, 37) if rank == 0 else (37, 100)
+    z, info = sharded_encode(Eng(), X[lo:hi], D0, 0.3, None, lr=1.5, maxiter=12, tol=0.0, backtrack=True,
+                             eta_backtrack=1.5, return_info=True)
+    np.savez(os.path.join(tmp, "bt%d.npz" % rank), z=z.numpy(), trials=np.array(info["trials"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_line_search_equals_the_whole_batch(tmp_path):
+    """sharded_encode(backtrack=True) over gloo: the F <= Q decisions use the sums of both ranks
+    (ista.py:23,28,32-35), so the trial trace equals the oracle's on the whole batch."""
+    port = 27500 + (os.getpid() % 2000)
+    mp.start_processes(_bt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "bt0.npz"), np.load(tmp_path / "bt1.npz")
+    X, D0 = _problem(n=100, d=12, k=40)
+    tr = orc.FistaTrace()
+    zo = orc.fista(X, torch.zeros(100, 40), D0, alpha=0.3, lr=1.5, maxiter=12, tol=0.0, backtrack=True,
+                  eta_backtrack=1.5, trace=tr)
+    assert list(r0["trials"]) == list(r1["trials"]) == list(tr.trials)
+    assert max(tr.trials) > 1                                   # the search did backtrack
+    assert np.abs(np.concatenate([r0["z"], r1["z"]]) - zo.numpy()).max() <= 1e-5

@@ -66,3 +66,71 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
                                    device="cuda", **kw)
         assert np.abs(r0[tag + "_l"] - lref.cpu().numpy()).max() <= 1e-4, tag
         assert np.abs(r0[tag + "_D"] - Dref.cpu().numpy()).max() <= 1e-4, tag
+
+
+# ---- row-sharded line search (ista.py:23-52 on two ranks) -------------------------------------
+BT = dict(n=700, d=64, k=200, split=263, alpha=0.25, lr=0.6, maxiter=8, eta=1.5)
+
+
+def _bt_problem():
+    g = torch.Generator().manual_seed(33)
+    X = torch.randn(BT["n"], BT["d"], generator=g)
+    W = torch.nn.functional.normalize(torch.randn(BT["d"], BT["k"], generator=g), dim=0)
+    return X, W
+
+
+def _bt_worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from lasso_amd.parallel import sharded_encode
+    from lasso_amd.engine import HipEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, W = _bt_problem()
+    lo, hi = (0, BT["split"]) if rank == 0 else (BT["split"], BT["n"])
+    out = {}
+    for tag, dt, tol in (("f32", torch.float32, 0.0), ("f32tol", torch.float32, 3e-3), ("bf16", torch.bfloat16, 0.0)):
+        z, info = sharded_encode(HipEngine(), X[lo:hi].cuda().to(dt), W.cuda().to(dt), BT["alpha"], None, lr=BT["lr"],
+                                 maxiter=40 if tol else BT["maxiter"], tol=tol, backtrack=True,
+                                 eta_backtrack=BT["eta"], return_info=True)
+        out[tag + "_z"] = z.float().cpu().numpy()
+        out[tag + "_trials"] = np.array(info["trials"])
+        out[tag + "_lr"] = np.array(info["accepted_lr"])
+    np.savez(os.path.join(tmp, "bt%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_line_search_on_two_row_shards_equals_the_whole_batch(tmp_path):
+    """sharded_encode(backtrack=True): every F <= Q decision and the stop rule on sums over BOTH
+    ranks (lasso_fista_solve_sharded).  The trial trace equals the oracle's on the whole batch and
+    the single-process HIP solve; the code matches row for row."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lasso_oracle as orc
+    from lasso_amd.linear.solvers import ista
+    port = 33500 + (os.getpid() % 2000)
+    mp.start_processes(_bt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "bt0.npz"), np.load(tmp_path / "bt1.npz")
+    X, W = _bt_problem()
+    for tag, tol, iters in (("f32", 0.0, BT["maxiter"]), ("f32tol", 3e-3, 40)):
+        tr = orc.FistaTrace()
+        zo = orc.fista(X, torch.zeros(BT["n"], BT["k"]), W, alpha=BT["alpha"], lr=BT["lr"], maxiter=iters, tol=tol,
+                      backtrack=True, eta_backtrack=BT["eta"], trace=tr)
+        assert list(r0[tag + "_trials"]) == list(r1[tag + "_trials"]) == list(tr.trials), tag
+        assert np.array_equal(r0[tag + "_lr"], r1[tag + "_lr"]), tag
+        z = np.concatenate([r0[tag + "_z"], r1[tag + "_z"]])
+        assert np.abs(z - zo.numpy()).max() <= 1e-4, tag
+        zs, info = ista(X.cuda(), torch.zeros(BT["n"], BT["k"], device="cuda"), W.cuda(), alpha=BT["alpha"], lr=BT["lr"],
+                        maxiter=iters, tol=tol, backtrack=True, eta_backtrack=BT["eta"], return_info=True)
+        assert info["trials"] == list(r0[tag + "_trials"]), tag
+        assert np.abs(z - zs.cpu().numpy()).max() <= 1e-5, tag
+    # bf16 tensors: same decisions on both ranks; the trace of the single-process bf16 multi-launch solve
+    assert list(r0["bf16_trials"]) == list(r1["bf16_trials"])
+    zs, info = ista(X.cuda().bfloat16(), torch.zeros(BT["n"], BT["k"], device="cuda").bfloat16(), W.cuda().bfloat16(),
+                    alpha=BT["alpha"], lr=BT["lr"], maxiter=BT["maxiter"], tol=0.0, backtrack=True,
+                    eta_backtrack=BT["eta"], return_info=True, kernel="tile")
+    assert info["trials"] == list(r0["bf16_trials"])
+    z = np.concatenate([r0["bf16_z"], r1["bf16_z"]])
+    assert np.abs(z - zs.float().cpu().numpy()).max() <= 2e-2
