@@ -32,12 +32,15 @@ namespace sp {
 // fixed-iteration kernel keeps its register allocation).
 // M: rows per tile; the padded feature count is D = 4096 / M (M = 16 / D = 256 is the flagship
 // shape; M = 32 / 64 serve dictionaries with d <= 128 / 64 without padding d up to 256).
-template <int K, int M, bool STOP>
-__global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
+// NW: waves per workgroup.  8 (two per SIMD) is the tuned form; 4 with M halved is the same
+// per-wave work in a workgroup of half the height and half the LDS, two of which share a CU:
+// small batches of short rows (d <= 128) then spread over twice as many CUs.
+template <int K, int M, bool STOP, int NW = kFistaWaves>
+__global__ __launch_bounds__(64 * NW, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
   // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
   const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
-  constexpr int D = 4096 / M;
-  constexpr int NW = kFistaWaves;
+  constexpr int D = 512 * NW / M;
+  constexpr int NT = 64 * NW;
   constexpr int S1 = K / 32;
   constexpr int KW = TileCtx<K, D>::KW;
   constexpr int NP = KW / 32;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   constexpr int S2 = NP * T2;
   constexpr int YT_BYTES = M * K * 4;
   constexpr int RT_BYTES = M * D * 4;
-  static_assert(M * D == 4096 && M % 16 == 0 && D % 32 == 0, "tile shape");
+  static_assert(M * D == 512 * NW && M % 16 == 0 && D % 32 == 0, "tile shape");
   static_assert(S1 % 2 == 0 && S2 % 2 == 0 && S1 >= 6 && S2 >= 4 && NP >= 1, "geometry");
   static_assert(YT_BYTES <= 65536, "y tile must fit beside the rings");
 
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     {
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
-      visit_tile4<K, kFistaThreads, M>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+      visit_tile4<K, NT, M>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
         *(lds_f32x4*)(yt + tile_chunk_off<K>(r, cc)) = v;
       });
     }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
     }
     if (p.y_out) {
       const bool yvec = vec4_ok(p.y_out, p.ldy_out, p.k);
-      for (int idx = tid; idx < M * (K / 4); idx += kFistaThreads) {
+      for (int idx = tid; idx < M * (K / 4); idx += NT) {
         const int r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
         const f32x4 v = *(const lds_f32x4*)(yt + tile_chunk_off<K>(r, cc));
         store_row4(p.y_out, p.ldy_out, row0 + r, p.n, p.k, cc, v, yvec);
@@ -396,32 +399,44 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_tile_sp_kernel(const F
   LASSO_WAIT_VMCNT(0);
 }
 
-template <int K, int M, bool STOP>
+template <int K, int M, bool STOP, int NW>
 static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)M * K * 4 + (size_t)M * (4096 / M) * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP>), lds);
+  const size_t lds = (size_t)M * K * 4 + (size_t)512 * NW * 4 + (size_t)NW * kRingBytesPerWave + 64;
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP, NW>), lds);
       e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP, NW>), dim3(grid), dim3(64 * NW), lds, stream, p);
   return hipGetLastError();
 }
 
-template <int K, int M>
+template <int K, int M, int NW = kFistaWaves>
 static hipError_t occupancy_k(int* blocks_per_cu) {
-  const size_t lds = (size_t)M * K * 4 + (size_t)M * (4096 / M) * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 64;
-  const void* fn = reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, true>);
+  const size_t lds = (size_t)M * K * 4 + (size_t)512 * NW * 4 + (size_t)NW * kRingBytesPerWave + 64;
+  const void* fn = reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, true, NW>);
   if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kFistaThreads, lds);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 64 * NW, lds);
 }
 
-template <int K, int M>
+template <int K, int M, int NW = kFistaWaves>
 static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
-  return p.stop_on ? launch_ks<K, M, true>(p, grid, stream) : launch_ks<K, M, false>(p, grid, stream);
+  return p.stop_on ? launch_ks<K, M, true, NW>(p, grid, stream) : launch_ks<K, M, false, NW>(p, grid, stream);
 }
 
 }  // namespace sp
 
-hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu) {
+// waves = 8: tiles of 4096 / dpad rows; waves = 4 (dpad <= 128): half-height tiles, two workgroups per CU
+hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int waves) {
+  if (waves == 4) {
+    if (dpad == 128) {
+      switch (kpad) {
+        case 256: return sp::occupancy_k<256, 16, 4>(blocks_per_cu);
+        case 512: return sp::occupancy_k<512, 16, 4>(blocks_per_cu);
+      }
+    } else if (dpad == 64) {
+      if (kpad == 256) return sp::occupancy_k<256, 32, 4>(blocks_per_cu);
+    }
+    return hipErrorInvalidValue;
+  }
   if (dpad == 256) {
     switch (kpad) {
       case 256: return sp::occupancy_k<256, 16>(blocks_per_cu);
@@ -439,8 +454,19 @@ hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu) {
   return hipErrorInvalidValue;
 }
 
-// rows per tile for a padded feature count (256 -> 16, 128 -> 32, 64 -> 64)
-hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream) {
+// rows per tile: 512 * waves / dpad  (8 waves: 256 -> 16, 128 -> 32, 64 -> 64; 4 waves: 128 -> 16, 64 -> 32)
+hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream, int waves) {
+  if (waves == 4) {
+    if (dpad == 128) {
+      switch (kpad) {
+        case 256: return sp::launch_k<256, 16, 4>(p, grid, stream);
+        case 512: return sp::launch_k<512, 16, 4>(p, grid, stream);
+      }
+    } else if (dpad == 64) {
+      if (kpad == 256) return sp::launch_k<256, 32, 4>(p, grid, stream);
+    }
+    return hipErrorInvalidValue;
+  }
   if (dpad == 256) {
     switch (kpad) {
       case 256: return sp::launch_k<256, 16>(p, grid, stream);

@@ -172,10 +172,27 @@ int device_cus() {
 bool fused_shape(int64_t d, int64_t k) { return d <= kFistaD && k <= kFistaMaxK; }
 
 // workgroups of the fused kernel that can be resident at once (occupancy query x CUs)
-int fista_resident_workgroups(int kp, int dpad) {
+int fista_resident_workgroups(int kp, int dpad, int waves = kFistaWaves) {
   int per_cu = 0;
-  if (fista_tile_sp_occupancy(kp, dpad, &per_cu) != hipSuccess) return 0;
+  if (fista_tile_sp_occupancy(kp, dpad, &per_cu, waves) != hipSuccess) return 0;
   return per_cu * device_cus();
+}
+
+// Tile geometry of the one-workgroup-per-tile kernel for a batch of n rows: 8-wave workgroups on
+// tiles of 4096 / dpad rows, or -- short rows (dpad <= 128) whose tiles would not give every CU
+// its share -- 4-wave workgroups on half-height tiles, two per CU (the same waves per CU on twice
+// as many tiles; per CU the longest queue of rows is what counts).
+struct TilePlan { int waves, rows, ntiles; };
+TilePlan plan_tiles(int64_t n, int dpad) {
+  TilePlan t = {kFistaWaves, 4096 / dpad, 0};
+  t.ntiles = (int)((n + t.rows - 1) / t.rows);
+  if (dpad >= kFistaD || n <= 0) return t;
+  const int cus = std::max(device_cus(), 1);
+  const int64_t full_rows = (int64_t)((t.ntiles + cus - 1) / cus) * t.rows;       // rows queued on the busiest CU
+  const int half = t.rows / 2, nh = (int)((n + half - 1) / half);
+  const int64_t half_rows = (int64_t)((nh + cus - 1) / cus) * half;
+  if (half_rows * 10 <= full_rows * 9) { t.waves = 4; t.rows = half; t.ntiles = nh; }
+  return t;
 }
 
 int pad_d(int64_t d, int kp) {
@@ -250,8 +267,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   if (used_split) *used_split = false;
   if (n == 0) return LASSO_OK;
   const int dpad = pad_d(d, kp);
-  const int tile_rows = 4096 / dpad;
-  const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
+  const TilePlan tp = plan_tiles(n, dpad);
+  const int ntiles = tp.ntiles;
   FistaTileParams p;
   p.X = x; p.ldx = ldx;
   p.Wp = ws.wp; p.Wtp = ws.wtp;
@@ -302,11 +319,12 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
       f.run_if = ws.stop_out + 2;
       f.part_stride = ntiles;
       if (f.partials) f.partials = ws.partials;
-      LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(ntiles, cus), stream));
+      LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(ntiles, cus), stream, tp.waves));
     }
   } else {
-    const int grid = std::min(ntiles, cus);   // one workgroup per CU (LDS bound), persistent over tiles
-    LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream));
+    // persistent over tiles: one 8-wave workgroup per CU (LDS bound), or two 4-wave ones
+    const int grid = std::min(ntiles, cus * (tp.waves == 4 ? 2 : 1));
+    LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream, tp.waves));
   }
   if (delta && iters > 0) {
     if (plan.split)
@@ -931,14 +949,10 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
     snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
     return name;
   }
-  switch (dpad) {
-    case 256: return kp == 1024 ? "lasso::sp::fista_tile_sp_kernel<1024, 16, false>"
-                   : kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 16, false>"
-                               : "lasso::sp::fista_tile_sp_kernel<256, 16, false>";
-    case 128: return kp == 512 ? "lasso::sp::fista_tile_sp_kernel<512, 32, false>"
-                               : "lasso::sp::fista_tile_sp_kernel<256, 32, false>";
-    default: return "lasso::sp::fista_tile_sp_kernel<256, 64, false>";
-  }
+  const TilePlan tp = plan_tiles(n, dpad);
+  static thread_local char tname[96];
+  snprintf(tname, sizeof(tname), "lasso::sp::fista_tile_sp_kernel<%d, %d, false, %d>", kp, tp.rows, tp.waves);
+  return tname;
 }
 
 size_t lasso_fista_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter,
@@ -1087,14 +1101,15 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     cur_z = ws.state[2]; cur_ldz = k;
   }
   if (stop_mode == LASSO_STOP_GLOBAL) {
-    const int tile_rows = 4096 / pad_d(d, kp);
-    const int ntiles = (int)((n + tile_rows - 1) / tile_rows);
+    const TilePlan tp = plan_tiles(n, pad_d(d, kp));
+    const int ntiles = tp.ntiles;
     // The handshake needs every workgroup of the grid resident at once: one workgroup per CU
     // (LDS-bound), so the grid must not exceed what the occupancy query admits.  CUs held by
     // OTHER work (a second stream, another process) are invisible to that query: then the
     // handshake times out, the kernel aborts as a whole without touching z_out, and the solve
     // is repeated on the chunked path below.
-    if (ntiles <= fista_resident_workgroups(kp, pad_d(d, kp))) {
+    // (the rule's granule fetch covers 256 tiles: four per lane of one wave)
+    if (ntiles <= std::min(fista_resident_workgroups(kp, pad_d(d, kp), tp.waves), 256)) {
       LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * std::max(ntiles, kSplitMaxParts) * 8, st));
       LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
       if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,

@@ -137,9 +137,10 @@ struct ConvGeom {
 // (kernel, device); thread-safe, cheap on the repeat path.  Defined in lasso_hip.hip.
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
-hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream);
+hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream,
+                                int waves = kFistaWaves);
 // workgroups of the stop-rule instantiation the occupancy query admits per CU
-hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu);
+hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int waves = kFistaWaves);
 // small-batch variant: a 16-row tile shared by Kpad/128 workgroups (fista_splitk.hip); needs
 // p.xch / p.xflags / p.groups / p.stop_out, flags and stop_out zeroed on the stream before the launch
 hipError_t launch_fista_splitk(const FistaTileParams& p, int kpad, int tiles, hipStream_t stream);
