@@ -120,6 +120,201 @@ __global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused gradient + proximal step (ista.py:20,29,42,44):  g = conv2d(R, W) as an IMPLICIT GEMM --
+// the patch matrix RC [M][C kh kw] of conv_patches_kernel is never formed, the G matrix never
+// written -- and z, y updated in the epilogue.
+// One workgroup = 4 waves = a tile of 64 code pixels (TU x TV of one image) x 128 atoms; it is
+// persistent over pixel tiles (blockIdx.y = block of 128 atoms), so that each wave keeps the B
+// fragments of its 32 atoms -- W [K][C kh kw], contraction order (c, a, b) like the reference --
+// in registers for the whole launch.  Per tile the receptive field of the 64 pixels,
+// C x ((TU-1) sh + kh) x ((TV-1) sw + kw) residual values (zero outside the image), is staged in
+// LDS once; the A operand of MFMA step s is read from it at  tap_offset[4 s + q] + pixel_offset
+// (two small tables: stride and padding live only in those).  Epilogue: the 64 x 128 block of g
+// goes through LDS so that z, y are read and written as 16-byte row-contiguous pieces; sum|z - z+|
+// per workgroup in a fixed order (deterministic).
+// ---------------------------------------------------------------------------
+struct ConvGradProx {
+  const float* R; const float* Wp; int ldr;
+  float* Zm; float* Ym;
+  float lr, lam, coef;
+  float* dpart;
+  ConvGeom g;
+  int TU, TV, tiles_u, tiles_v, RH, RW;
+};
+constexpr int kCgpGtLd = 132;
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global
+// load / store in flight (vmcnt(0)), which would serialise the HBM phases with the MFMA phase
+#define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+
+template <int S4>
+__global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradProx p) {
+  extern __shared__ __attribute__((aligned(16))) float cg_smem[];
+  float* const Gt = cg_smem;                                // [64][132]
+  int* const toff = (int*)(Gt + 64 * kCgpGtLd);             // [4 * S4]
+  float* const S = (float*)(toff + 4 * S4);                 // [C][RH][RW]
+  __shared__ float red[256];
+  const ConvGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int ckk = g.C * g.kh * g.kw, K = g.K;
+  const int kcol0 = 128 * blockIdx.y + 32 * w;
+  // B fragments of this wave's 32 atoms: B[k][e], e = 4 s + q, zero beyond ckk / K
+  float bf[S4][2];
+#pragma unroll
+  for (int s = 0; s < S4; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int k = kcol0 + 16 * nt + l15, e = 4 * s + q;
+      const float v = p.Wp[(int64_t)min(k, K - 1) * p.ldr + min(e, p.ldr - 1)];
+      bf[s][nt] = (k < K && e < ckk) ? v : 0.0f;
+    }
+  for (int e = tid; e < 4 * S4; e += 256) {
+    int off = 0;
+    if (e < ckk) {
+      const int b = e % g.kw, a = (e / g.kw) % g.kh, c = e / (g.kw * g.kh);
+      off = (c * p.RH + a) * p.RW + b;
+    }
+    toff[e] = off;
+  }
+  __syncthreads();
+  int toffr[S4];                                            // this lane's tap offsets, one per MFMA step
+#pragma unroll
+  for (int s = 0; s < S4; ++s) toffr[s] = toff[4 * s + q];
+  int base_p[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int pix = 16 * mt + l15, tu = pix / p.TV, tv = pix - tu * p.TV;
+    base_p[mt] = tu * g.sh * p.RW + tv * g.sw;
+  }
+  const int tiles_img = p.tiles_u * p.tiles_v, ntiles = g.N * tiles_img;
+  const int region = g.C * p.RH * p.RW, plane = p.RH * p.RW;
+  const bool kvec = (K & 3) == 0;
+  float dsum = 0.0f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tiles_img, tt = tile - n * tiles_img;
+    const int u0 = (tt / p.tiles_v) * p.TU, v0 = (tt % p.tiles_v) * p.TV;
+    const int i0 = u0 * g.sh - g.ph, j0 = v0 * g.sw - g.pw;
+    const float* const Rn = p.R + (int64_t)n * g.C * g.H * g.W;
+    // (opaque per trip: otherwise hipcc hoists the index arithmetic of the unrolled staging and
+    // epilogue loops out of the tile loop and spills it)
+    int tdyn = tid;
+    asm volatile("" : "+v"(tdyn));
+    int bp[4] = {base_p[0], base_p[1], base_p[2], base_p[3]};     // (likewise: 4 * S4 operand addresses)
+    asm volatile("" : "+v"(bp[0]), "+v"(bp[1]), "+v"(bp[2]), "+v"(bp[3]));
+    for (int e0 = tdyn; e0 < region; e0 += 256 * 8) {        // 8 independent loads in flight per thread
+      float sv[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int e = min(e0 + 256 * h, region - 1);
+        const int c = e / plane, rem = e - c * plane, rr = rem / p.RW, cc = rem - rr * p.RW;
+        const int i = i0 + rr, j = j0 + cc;
+        const float v = Rn[((int64_t)c * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)];
+        sv[h] = v * ((i >= 0 && i < g.H && j >= 0 && j < g.W) ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        if (e0 + 256 * h < region) S[e0 + 256 * h] = sv[h];
+    }
+    // z, y of the tile do not depend on g: fetched now, so that the HBM latency runs under the MFMAs
+    f32x4 zo[8], yo[8];
+    if (kvec) {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
+        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
+        const int col = 128 * blockIdx.y + c4;
+        const int64_t off = (((int64_t)n * g.Hz + min(u, g.Hz - 1)) * g.Wz + min(v, g.Wz - 1)) * K + min(col, K - 4);
+#ifdef LASSO_ABL_CONV_NOMEM    // timing ablation only (results invalid)
+        zo[h] = (f32x4){0.f, 0.f, 0.f, (float)off}; yo[h] = zo[h];
+#else
+        zo[h] = *(const f32x4*)(p.Zm + off);
+        yo[h] = *(const f32x4*)(p.Ym + off);
+#endif
+      }
+    }
+    LDS_BARRIER();
+    f32x4 acc[4][2] = {};
+#ifdef LASSO_ABL_CONV_NOMFMA   // timing ablation only (results invalid)
+    if (p.lr < -1e30f)
+#endif
+#pragma unroll
+    for (int s = 0; s < S4; ++s) {
+      const int off = toffr[s];
+      float a[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = S[off + bp[mt]];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bf[s][nt], acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Gt[(16 * mt + 4 * q + rg) * kCgpGtLd + 32 * w + 16 * nt + l15] = acc[mt][nt][rg];
+    LDS_BARRIER();
+    if (kvec) {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
+        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
+        const int col = 128 * blockIdx.y + c4;
+        const bool ok = u < g.Hz && v < g.Wz && col < K;
+        const int64_t off = (((int64_t)n * g.Hz + min(u, g.Hz - 1)) * g.Wz + min(v, g.Wz - 1)) * K + min(col, K - 4);
+        const f32x4 gv = *(const f32x4*)(Gt + pix * kCgpGtLd + c4);
+        f32x4 zn, yn;
+        float ds = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = __fsub_rn(yo[h][e], __fmul_rn(p.lr, gv[e]));
+          zn[e] = __fsub_rn(t, __builtin_amdgcn_fmed3f(t, -p.lam, p.lam));
+          ds += __builtin_fabsf(__fsub_rn(zo[h][e], zn[e]));
+          yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo[h][e])));
+        }
+#ifdef LASSO_ABL_CONV_NOMEM
+        if (ok) dsum += ds + yn[0];
+#else
+        if (ok) {
+          dsum += ds;
+          *(f32x4*)(p.Zm + off) = zn;
+          *(f32x4*)(p.Ym + off) = yn;
+        }
+#endif
+      }
+    } else {
+      for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int pix = idx >> 5, c4 = (idx & 31) * 4;
+        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
+        const int col = 128 * blockIdx.y + c4;
+        if (u >= g.Hz || v >= g.Wz || col >= K) continue;
+        const int64_t m = ((int64_t)n * g.Hz + u) * g.Wz + v;
+        float* const zp = p.Zm + m * K + col;
+        float* const yp = p.Ym + m * K + col;
+        const f32x4 gv = *(const f32x4*)(Gt + pix * kCgpGtLd + c4);
+        for (int e = 0; e < 4 && col + e < K; ++e) {
+          const float zo = zp[e];
+          const float t = __fsub_rn(yp[e], __fmul_rn(p.lr, gv[e]));
+          const float zn = __fsub_rn(t, __builtin_amdgcn_fmed3f(t, -p.lam, p.lam));
+          dsum += __builtin_fabsf(__fsub_rn(zo, zn));
+          yp[e] = __fadd_rn(zn, __fmul_rn(p.coef, __fsub_rn(zn, zo)));
+          zp[e] = zn;
+        }
+      }
+    }
+    LDS_BARRIER();
+  }
+  red[tid] = dsum;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) p.dpart[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
 // Wp[k][t] = w[k][t] with the row stride padded like RC (zeros in the padding)
 __global__ __launch_bounds__(256) void conv_pad_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
                                                          int ckk, int ldr) {
@@ -287,6 +482,44 @@ hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_gemm_nt_sub(rc, ldr, Wp, ldr, nullptr, 0, G, g.K, (int)M, g.K, ldr, stream, /*add=*/1);
+}
+
+// The fused implicit-GEMM gradient + prox step, when the geometry fits (C kh kw <= 192 and the
+// receptive field of a 64-pixel tile <= 64 KiB); *count = number of dpart entries written, 0 when
+// the caller has to take the explicit path.
+hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
+                                 float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
+                                 hipStream_t stream) {
+  *count = 0;
+  const int ckk = g.C * g.kh * g.kw;
+  if (ckk > 192) return hipSuccess;
+  ConvGradProx p;
+  p.TV = g.Wz >= 48 ? 64 : g.Wz >= 24 ? 32 : g.Wz >= 12 ? 16 : 8;
+  p.TU = 64 / p.TV;
+  p.RH = (p.TU - 1) * g.sh + g.kh;
+  p.RW = (p.TV - 1) * g.sw + g.kw;
+  if ((int64_t)g.C * p.RH * p.RW > 16384) return hipSuccess;
+  p.tiles_u = (g.Hz + p.TU - 1) / p.TU;
+  p.tiles_v = (g.Wz + p.TV - 1) / p.TV;
+  p.R = r; p.Wp = Wp; p.ldr = ldr; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
+  const int64_t ntiles = (int64_t)g.N * p.tiles_u * p.tiles_v;
+  const int gy = (g.K + 127) / 128;
+  if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
+  const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, 2 * cus / gy)));
+  const int s4 = ckk <= 64 ? 16 : ckk <= 96 ? 24 : ckk <= 144 ? 36 : 48;
+  const size_t lds = (size_t)(64 * kCgpGtLd + 4 * s4 + g.C * p.RH * p.RW) * 4;
+  const void* fn = s4 == 16 ? (const void*)&conv_grad_prox_kernel<16> : s4 == 24 ? (const void*)&conv_grad_prox_kernel<24>
+                 : s4 == 36 ? (const void*)&conv_grad_prox_kernel<36> : (const void*)&conv_grad_prox_kernel<48>;
+  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  const dim3 grid(gx, gy);
+  switch (s4) {
+    case 16: hipLaunchKernelGGL(conv_grad_prox_kernel<16>, grid, dim3(256), lds, stream, p); break;
+    case 24: hipLaunchKernelGGL(conv_grad_prox_kernel<24>, grid, dim3(256), lds, stream, p); break;
+    case 36: hipLaunchKernelGGL(conv_grad_prox_kernel<36>, grid, dim3(256), lds, stream, p); break;
+    default: hipLaunchKernelGGL(conv_grad_prox_kernel<48>, grid, dim3(256), lds, stream, p); break;
+  }
+  *count = gx * gy;
+  return hipGetLastError();
 }
 
 hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,

@@ -1686,6 +1686,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Zm, (size_t)M * g.K * 4, hipMemcpyDeviceToDevice, st));
   const float budget = (float)((double)M * (double)g.K * tol);     // ista.py:16, compared in fp32
   const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  const int cus = std::max(device_cus(), 1);
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
@@ -1693,12 +1694,19 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
     LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));   // :19
-    LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wp, ws.PT, ldr, ws.G, g, st));                    // :20
-    LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,
-                                      kGenGrid, st));                                             // :29,:42,:44
+    // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
+    int dcount = 0;
+    LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
+                                        &dcount, st));                                            // :20,:29,:42,:44
+    if (dcount == 0) {
+      LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wp, ws.PT, ldr, ws.G, g, st));                  // :20
+      LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,
+                                        kGenGrid, st));                                           // :29,:42,:44
+      dcount = kGenGrid;
+    }
     t_mom = t_next;
     if (tol > 0.0) {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, ws.delta);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, dcount, ws.delta);
       LASSO_HIP_TRY(hipGetLastError());
       LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));

@@ -210,6 +210,9 @@ hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int 
 hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int ckk, int ldr, hipStream_t stream);
 hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
                                 const ConvGeom& g, hipStream_t stream);
+hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
+                                 float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
+                                 hipStream_t stream);
 hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int ldr, float* G, const ConvGeom& g,
                                 hipStream_t stream);
 hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,

@@ -4,9 +4,14 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
 import torch
+from lasso_amd import _native as nat
+if '--lib' in sys.argv:
+    nat.use_library(sys.argv[sys.argv.index('--lib') + 1])
 from lasso_amd.conv2d import ista_conv2d
 out = []
 cases = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64)]
+if '--last' in sys.argv:
+    cases = cases[-1:]
 for (N, C, K, ks, st, pd, Hz) in cases:
     g = torch.Generator().manual_seed(0)
     w = torch.randn(K, C, ks, ks, generator=g) / ks
