@@ -60,9 +60,12 @@ def hbm_traffic_from_profiles():
     profile's, and the JSON says which."""
     best, src = None, None
     pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+    names = sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []
+    # the headline kernel's profile of the latest round: profiles/rNN_fista (older rounds: rNNx)
+    names = [n for n in names if not n.endswith("_fista")] + [n for n in names if n.endswith("_fista")]
+    for name in names:
         f = os.path.join(pdir, name, "hbm_traffic.json")
-        if os.path.exists(f):
+        if os.path.exists(f) and not name.endswith("_splitk"):
             with open(f) as fh:
                 best, src = json.load(fh).get("hbm_bytes_per_launch"), "profiles/%s/hbm_traffic.json" % name
     return best, src

@@ -118,6 +118,137 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
       }
 }
 
+// ---------------------------------------------------------------------------
+// The same product on 128 x 128 output blocks (the 16-byte-aligned case with at least one
+// full block): 4 waves x (64 x 64) = 16 accumulators per wave, so a k-step of 4 samples is
+// 4 + 4 LDS operand reads for 16 MFMAs (the 64 x 64 kernel above: 2 + 2 for 4); samples in
+// chunks of 32 through a double-buffered LDS stage (row stride 144 floats: the operand read
+// "16 consecutive floats of 4 consecutive rows" is conflict-free per half-wave), the next
+// chunk's global loads in flight in registers meanwhile -- one barrier per chunk.
+// sym: only the blocks bj >= bi exist (blockIdx.x enumerates them); the mirror image is written
+// by sum_splits_sym_kernel, which also folds the sample splits.
+// ---------------------------------------------------------------------------
+constexpr int kG2B = 128, kG2S = 32, kG2Ld = 144;
+
+__global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restrict__ P, int64_t ldp, int pc,
+                                                            const float* __restrict__ Q, int64_t ldq, int qc, int n,
+                                                            float* __restrict__ C, int64_t ldc, int sym,
+                                                            int rows_per_split, int64_t split_stride) {
+  int bi, bj;
+  if (sym) {                                   // blockIdx.x -> (bi, bj), bj >= bi, row by row
+    const int nb = (pc + kG2B - 1) / kG2B;
+    int rem = blockIdx.x;
+    bi = 0;
+    while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+    bj = bi + rem;
+  } else {
+    const int nbq = (qc + kG2B - 1) / kG2B;
+    bi = blockIdx.x / nbq;
+    bj = blockIdx.x - bi * nbq;
+  }
+  const int n_lo = blockIdx.z * rows_per_split;
+  P += (int64_t)n_lo * ldp;
+  Q += (int64_t)n_lo * ldq;
+  n = min(rows_per_split, n - n_lo);
+  C += (int64_t)blockIdx.z * split_stride;
+  extern __shared__ __attribute__((aligned(16))) float g2_smem[];
+  float* const sp = g2_smem;                               // [2][32][144]
+  float* const sq = g2_smem + 2 * kG2S * kG2Ld;            // [2][32][144]
+  const int i0 = bi * kG2B, j0 = bj * kG2B;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1, l15 = lane & 15, q = lane >> 4;
+  f32x4 acc[4][4] = {};
+  // staging map: thread -> sample row srow + 8 h (h = 0..3), 4 consecutive columns of each operand
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  f32x4 stg[2][4];
+  const bool pin = i0 + scol < pc, qin = j0 + scol < qc;   // columns are multiples of 4: whole groups
+  auto load_chunk = [&](int s0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int r = min(s0 + srow + 8 * h, n - 1);
+      const f32x4 vp = *(const f32x4*)(P + (int64_t)r * ldp + (pin ? i0 + scol : 0));
+      const f32x4 vq = *(const f32x4*)(Q + (int64_t)r * ldq + (qin ? j0 + scol : 0));
+      const float mp = (pin && s0 + srow + 8 * h < n) ? 1.0f : 0.0f, mq = (qin && s0 + srow + 8 * h < n) ? 1.0f : 0.0f;
+      stg[0][h] = vp * mp;
+      stg[1][h] = vq * mq;
+    }
+  };
+  auto put_chunk = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      *(f32x4*)(sp + (buf * kG2S + srow + 8 * h) * kG2Ld + scol) = stg[0][h];
+      *(f32x4*)(sq + (buf * kG2S + srow + 8 * h) * kG2Ld + scol) = stg[1][h];
+    }
+  };
+  if (n > 0) {
+    load_chunk(0);
+    put_chunk(0);
+    if (kG2S < n) load_chunk(kG2S);
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = 0; s0 < n; s0 += kG2S, buf ^= 1) {
+      const float* const ap = sp + buf * kG2S * kG2Ld + 64 * wr + l15;
+      const float* const bp = sq + buf * kG2S * kG2Ld + 64 * wc + l15;
+#pragma unroll
+      for (int ks = 0; ks < kG2S / 4; ++ks) {
+        float a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = ap[(4 * ks + q) * kG2Ld + 16 * m];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] = bp[(4 * ks + q) * kG2Ld + 16 * m];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj)
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+      }
+      if (s0 + kG2S < n) {
+        put_chunk(buf ^ 1);                                // the other buffer: its last readers passed the barrier below
+        if (s0 + 2 * kG2S < n) load_chunk(s0 + 2 * kG2S);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = i0 + 64 * wr + 16 * mi + 4 * q + rg, cc = j0 + 64 * wc + 16 * nj + l15;
+        if (r < pc && cc < qc) C[(int64_t)r * ldc + cc] = acc[mi][nj][rg];
+      }
+}
+
+// sym product of gram_tn128_kernel: C = sum of the splits' upper 128-blocks, mirrored.  One workgroup
+// per 32 x 32 tile (tr, tc), tc >= tr, of the upper triangle: coalesced reads, the transposed copy
+// through LDS.  (Tiles below the diagonal inside a diagonal 128-block are computed values too, but
+// bitwise equal to their mirror image -- the same products in the same order.)
+__global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __restrict__ part, int splits,
+                                                             int64_t split_stride, int64_t ldpart, int pc,
+                                                             float* __restrict__ C, int64_t ldc) {
+  __shared__ float t[32][33];
+  const int nt = (pc + 31) / 32;
+  int rem = blockIdx.x, tr = 0;
+  while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
+  const int tc = tr + rem;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = 32 * tr + i, c = 32 * tc + tx;
+    float acc = 0.0f;
+    if (r < pc && c < pc)
+      for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + (int64_t)r * ldpart + c];
+    t[i][tx] = acc;
+    if (r < pc && c < pc) C[(int64_t)r * ldc + c] = acc;
+  }
+  __syncthreads();
+  if (tr != tc)
+    for (int i = ty; i < 32; i += 8) {
+      const int r = 32 * tc + i, c = 32 * tr + tx;          // the mirror tile
+      if (r < pc && c < pc) C[(int64_t)r * ldc + c] = t[tx][i];
+    }
+}
+
 // C[r][c] = sum_s part[s][r][c]  (fixed order)
 __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict__ part, int splits,
                                                          int64_t split_stride, int rows, int cols,
@@ -815,9 +946,21 @@ __global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, i
 
 // Number of sample splits that gives the chip ~3 workgroups per CU (the output has only
 // (pc/64)*(qc/64) blocks), each split keeping at least 512 samples.
+static bool gram_use128(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc) {
+  return pc >= kG2B && qc >= kG2B && pc % 4 == 0 && qc % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 &&
+         ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
+}
+
 int gram_splits(int pc, int qc, int n, int sym, int cus) {
   int blocks = ((qc + kGB - 1) / kGB) * ((pc + kGB - 1) / kGB);
   if (sym) blocks = blocks / 2 + (pc + kGB - 1) / kGB / 2 + 1;
+  if (pc >= kG2B && qc >= kG2B) {               // 128 x 128 blocks, two workgroups per CU
+    const int nbp = (pc + kG2B - 1) / kG2B, nbq = (qc + kG2B - 1) / kG2B;
+    blocks = sym ? nbp * (nbp + 1) / 2 : nbp * nbq;
+    int s2 = (2 * cus + blocks - 1) / std::max(blocks, 1);
+    s2 = std::min(s2, std::max(n / 512, 1));
+    return std::max(1, std::min(s2, 16));
+  }
   int s = (3 * cus + blocks - 1) / std::max(blocks, 1);
   s = std::min(s, std::max(n / 512, 1));
   return std::max(1, std::min(s, 16));
@@ -827,6 +970,28 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
                           int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
                           hipStream_t stream) {
   if (!scratch) splits = 1;
+  if (gram_use128(P, ldp, pc, Q, ldq, qc) && (!sym || scratch)) {
+    const int rps = ((n + splits - 1) / splits + kG2S - 1) / kG2S * kG2S;
+    const int sp = std::max(1, (n + rps - 1) / std::max(rps, 1));
+    const int nbp = (pc + kG2B - 1) / kG2B, nbq = (qc + kG2B - 1) / kG2B;
+    const int blocks = sym ? nbp * (nbp + 1) / 2 : nbp * nbq;
+    const size_t lds = (size_t)4 * kG2S * kG2Ld * 4;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_tn128_kernel), lds); e != hipSuccess) return e;
+    const bool to_scratch = sym || sp > 1;
+    float* const out = to_scratch ? scratch : C;
+    const int64_t old_ = to_scratch ? qc : ldc, stride128 = (int64_t)pc * qc;
+    hipLaunchKernelGGL(gram_tn128_kernel, dim3(blocks, 1, sp), dim3(256), lds, stream, P, ldp, pc, Q, ldq, qc, n, out,
+                       old_, sym, rps, stride128);
+    if (sym) {
+      const int nt = (pc + 31) / 32;
+      hipLaunchKernelGGL(sum_splits_sym_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, scratch, sp, stride128,
+                         (int64_t)qc, pc, C, ldc);
+    } else if (sp > 1) {
+      hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((stride128 + 255) / 256)), dim3(256), 0, stream, scratch, sp,
+                         stride128, pc, qc, C, ldc);
+    }
+    return hipGetLastError();
+  }
   const int rows_per_split = ((n + splits - 1) / splits + kGS - 1) / kGS * kGS;
   splits = std::max(1, (n + rows_per_split - 1) / std::max(rows_per_split, 1));
   const dim3 grid((qc + kGB - 1) / kGB, (pc + kGB - 1) / kGB, splits);
