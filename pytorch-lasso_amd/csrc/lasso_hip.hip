@@ -143,6 +143,54 @@ __global__ void momentum_table_kernel(float* __restrict__ coef, float* __restric
   }
 }
 
+// Everything a solve needs before its persistent launch, in ONE launch (the EM step is made of
+// ~10 such 5-us launches otherwise): pack W (pack_w_kernel), the momentum table
+// (momentum_table_kernel, by the last block), zero the stop rule's granule ring and result words,
+// and -- lr = LASSO_LR_AUTO -- turn lambda_max into {lr, alpha*lr} (step_from_lipschitz_kernel).
+struct PrepareExtras {
+  unsigned long long* zero_a; int words_a;      // nullable
+  unsigned long long* zero_b; int words_b;      // nullable
+  const double* lip; double alpha; float* lr_slot;   // nullable
+};
+__global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, int d, int k, int kp,
+                                     float* __restrict__ wp, float* __restrict__ wtp, int dpad, float* __restrict__ coef,
+                                     float* __restrict__ zeros, int count, const PrepareExtras x) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < d && c < k) ? W[(int64_t)r * ldw + c] : 0.0f;
+    tile[i][tx] = v;
+    wp[(size_t)r * kp + c] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    wtp[(size_t)c * dpad + r] = tile[tx][i];
+  }
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y, tid = ty * 32 + tx;
+  for (int i = bid * 256 + tid; i < x.words_a; i += nb * 256) x.zero_a[i] = 0ull;
+  for (int i = bid * 256 + tid; i < x.words_b; i += nb * 256) x.zero_b[i] = 0ull;
+  if (tid != 0) return;
+  if (bid == 0 && x.lip) {
+    const double lr = 1.0 / x.lip[0];
+    x.lr_slot[0] = (float)lr;
+    x.lr_slot[1] = (float)(x.alpha * lr);
+  }
+  if (bid == nb - 1) {
+    double t = 1.0;
+    for (int i = 0; i < count; ++i) {
+      const double tt = __dmul_rn(t, t);
+      const double s = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(4.0, tt)));
+      const double tn = __ddiv_rn(__dadd_rn(1.0, s), 2.0);
+      coef[i] = (float)__ddiv_rn(__dsub_rn(t, 1.0), tn);
+      zeros[i] = 0.0f;
+      t = tn;
+    }
+  }
+}
+
 // delta[i] = sum_t partials[i][t], fixed summation order (deterministic).  `alt` (nullable):
 // the rows of the stand-by launch, taken instead when *alt_if != 0 (the split-k kernel gave up).
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles,
@@ -349,13 +397,12 @@ int splitk_aborted(const Workspace& ws, hipStream_t stream, bool* aborted) {
 }
 
 int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k,
-                 int coef_cap, hipStream_t stream) {
+                 int coef_cap, hipStream_t stream, const PrepareExtras* extras = nullptr) {
   const int dpad = pad_d(d, kp);
-  hipLaunchKernelGGL(pack_w_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0, stream, w, ldw,
-                     (int)d, (int)k, kp, ws.wp, ws.wtp, dpad);
-  LASSO_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(momentum_table_kernel, dim3(1), dim3(64), 0, stream, ws.coef, ws.zeros,
-                     std::max(coef_cap, 1));
+  PrepareExtras x = {nullptr, 0, nullptr, 0, nullptr, 0.0, nullptr};
+  if (extras) x = *extras;
+  hipLaunchKernelGGL(prepare_solve_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0, stream, w, ldw, (int)d, (int)k, kp,
+                     ws.wp, ws.wtp, dpad, ws.coef, ws.zeros, std::max(coef_cap, 1), x);
   LASSO_HIP_TRY(hipGetLastError());
   return LASSO_OK;
 }
@@ -1009,7 +1056,8 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int maxiter, double tol, int stop_mode, int backtrack, double eta_backtrack,
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
-                      size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false) {
+                      size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
+                      const double* lip_dev = nullptr) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1080,7 +1128,15 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
     return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
-  if (int s = prepare_impl(ws, kp, (const float*)w_dev, ldw, d, k, maxiter, st)) return s;
+  // one launch: pack W, momentum table, {lr, alpha*lr} from lambda_max (lr = LASSO_LR_AUTO), and the
+  // zeroing of the in-kernel stop rule's granule ring and result words
+  PrepareExtras px = {nullptr, 0, nullptr, 0, lip_dev, alpha, const_cast<float*>(lr_dev)};
+  const TilePlan tp0 = plan_tiles(n, pad_d(d, kp));
+  if (stop_rule && stop_mode == LASSO_STOP_GLOBAL) {
+    px.zero_a = ws.gran; px.words_a = kStopRing * std::max(tp0.ntiles, kSplitMaxParts);
+    px.zero_b = reinterpret_cast<unsigned long long*>(ws.stop_out); px.words_b = 2;
+  }
+  if (int s = prepare_impl(ws, kp, (const float*)w_dev, ldw, d, k, maxiter, st, &px)) return s;
 
   if (!stop_rule) {
     if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
@@ -1110,8 +1166,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     // is repeated on the chunked path below.
     // (the rule's granule fetch covers 256 tiles: four per lane of one wave)
     if (ntiles <= std::min(fista_resident_workgroups(kp, pad_d(d, kp), tp.waves), 256)) {
-      LASSO_HIP_TRY(hipMemsetAsync(ws.gran, 0, (size_t)kStopRing * std::max(ntiles, kSplitMaxParts) * 8, st));
-      LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, st));
+      // (granule ring and stop_out were zeroed by the prepare launch)
       if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                            alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint, nullptr, lr_dev))
         return s;
@@ -1208,6 +1263,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   if (async && (objective_out || backtrack || dtype != LASSO_F32))
     return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_ASYNC: fp32 fixed-step solves without objective_out only");
   const float* lr_dev = nullptr;
+  const double* lip_dev = nullptr;
   if (lr == LASSO_LR_AUTO) {
     // lr = 1/L, L = lambda_max(W^T W) (ista.py:72-73, :8-14) computed here on the stream.  The fp32
     // fixed-step kernels read {lr, alpha*lr} from device memory -- no host round trip; the other
@@ -1225,8 +1281,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     LASSO_HIP_TRY(launch_lipschitz((const float*)w_dev, ldw, d, k, lip_ws, 20, st));
     if (fused_shape(d, k) && !backtrack && maxiter > 0 && n > 0) {
       float* const slot = (float*)(lip_ws + align_up(lipschitz_workspace_bytes(d, k)));
-      hipLaunchKernelGGL(step_from_lipschitz_kernel, dim3(1), dim3(1), 0, st, (const double*)lip_ws, alpha, slot);
-      LASSO_HIP_TRY(hipGetLastError());
+      lip_dev = (const double*)lip_ws;                 // the prepare launch of the solve fills the slot
       lr_dev = slot;
       lr = 1.0;                                        // placeholder, never used by the kernels
     } else {
@@ -1239,7 +1294,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async);
+                                workspace_bytes, stream, lr_dev, async, lip_dev);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)

@@ -957,7 +957,7 @@ int gram_splits(int pc, int qc, int n, int sym, int cus) {
   if (pc >= kG2B && qc >= kG2B) {               // 128 x 128 blocks, two workgroups per CU
     const int nbp = (pc + kG2B - 1) / kG2B, nbq = (qc + kG2B - 1) / kG2B;
     blocks = sym ? nbp * (nbp + 1) / 2 : nbp * nbq;
-    int s2 = (2 * cus + blocks - 1) / std::max(blocks, 1);
+    int s2 = std::max(1, 2 * cus / std::max(blocks, 1));   // one round of resident workgroups, no tail
     s2 = std::min(s2, std::max(n / 512, 1));
     return std::max(1, std::min(s2, 16));
   }
