@@ -14,6 +14,10 @@
 //     step of pass p+1 (two alternating accumulator sets).
 #include "tile_device.hpp"
 
+#ifndef LASSO_SLICE_UNROLL
+#define LASSO_SLICE_UNROLL 2
+#endif
+
 namespace lasso {
 namespace sp {
 
@@ -163,24 +167,38 @@ __global__ __launch_bounds__(64 * NW, 2) void fista_tile_sp_kernel(const FistaTi
       // order in which the split-k kernel (fista_splitk.hip, one slice per workgroup) can
       // form the same r -- a row's code is bitwise independent of the kernel that computed it.
       f32x4 run[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-      for (int s2 = 0; s2 < S1 / 2 - 2; ++s2) {
+      auto fetch_granules = [&](int s2) {
         if (STOP && check && wid == 0 && s2 == S1 / 8) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (lane + 64 * e < p.ntiles)
               gr[e] = __hip_atomic_load(grow + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      };
+      // one loop trip = one slice = two trips of the step machinery; slice 0 is peeled (run = p_0), so the
+      // loop body is straight-line code
+      static_assert((S1 / 2 - 2) % 2 == 0 && S1 / 2 - 2 >= 2, "whole slices in the regular part");
+      fetch_granules(0);
+      trip(0, c.w1 + 96, c.voff1, c.w1 + 128, c.voff1, F{});
+      fetch_granules(1);
+      trip(1, c.w1 + 64 + 96, c.voff1, c.w1 + 64 + 128, c.voff1, F{});
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) { run[cb][rg] = acc[cb][rg]; acc[cb][rg] = 0.0f; }
+#pragma unroll LASSO_SLICE_UNROLL
+      for (int s2 = 2; s2 < S1 / 2 - 2; s2 += 2) {
+        fetch_granules(s2);
         trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
-        if (s2 & 1) {                                  // end of slice s2 / 2
+        fetch_granules(s2 + 1);
+        trip(s2 + 1, c.w1 + 64 * (s2 + 1) + 96, c.voff1, c.w1 + 64 * (s2 + 1) + 128, c.voff1, F{});
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              run[cb][rg] = (s2 == 1) ? acc[cb][rg] : __fadd_rn(run[cb][rg], acc[cb][rg]);
-              acc[cb][rg] = 0.0f;
-            }
-        }
+          for (int rg = 0; rg < 4; ++rg) {
+            run[cb][rg] = __fadd_rn(run[cb][rg], acc[cb][rg]);
+            acc[cb][rg] = 0.0f;
+          }
       }
       // steps S1-4, S1-3: refills are W step S1-1 and W^T step 0
       trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, c.w2, c.voff2, F{});
