@@ -12,7 +12,7 @@ bash $R/tools/prof_pmc.sh ${T}_fista > $O/${T}_fista_summary.txt 2>&1
 bash $R/tools/prof_pmc.sh ${T}_splitk --rows 512 > $O/${T}_splitk_summary.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 python $R/tools/bench_matrix.py 2>/dev/null | tail -1 > $O/${T}_fista_shapes.json
-python $R/tools/bench_small.py 2>/dev/null | tail -1 > $O/${T}_small_batches.json
+python $R/tools/bench_small.py 2>/dev/null | grep "^{" > $O/${T}_small_batches.jsonl
 python $R/tools/bench_em.py 2>/dev/null | grep '^{' > $O/${T}_em.jsonl
 python $R/tools/bench_c3.py 2>/dev/null | grep '^{' > $O/${T}_c3.jsonl
 python $R/tools/bench_c5.py 2>/dev/null | grep '^{' > $O/${T}_c5.jsonl
