@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the tile kernels (fista_tile.hip,
+// Device-side building blocks shared by the tile kernels (fista_tile_sp.hip, fista_splitk.hip,
 // objective.hip, backtrack.hip): LDS layouts, the per-wave LDS-DMA ring that streams
 // W / W^T from L2, and the MFMA GEMM-1 loop  acc = A_tile * W^T.
 #pragma once
