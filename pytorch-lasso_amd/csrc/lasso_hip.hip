@@ -270,9 +270,9 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 // split-k kernel with T tiles per group runs ceil(ntiles / (groups * T)) rounds of split_us[T].
 struct KernelCost { double tile_us, split_us[3]; };   // split_us: T = 1, 2, 4
 KernelCost kernel_cost(int kp) {
-  if (kp >= 1024) return {31.7, {5.9, 10.6, 20.7}};
-  if (kp >= 512) return {16.1, {5.45, 9.9, 19.4}};
-  return {8.35, {5.2, 9.6, 18.9}};
+  if (kp >= 1024) return {31.0, {5.9, 10.7, 20.7}};
+  if (kp >= 512) return {15.9, {5.45, 9.9, 19.4}};
+  return {8.3, {5.2, 9.6, 18.9}};
 }
 struct KernelPlan { bool split; int groups, tiles; };
 
