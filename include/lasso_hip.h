@@ -21,10 +21,10 @@
  *     fp32 accumulation and state; fixed step or line search) and LASSO_ERR_UNSUPPORTED
  *     elsewhere;
  *   - shapes: d <= 256 and k <= 1024 run the fused kernels; beyond that lasso_fista_solve
- *     (fixed step), lasso_objective and lasso_gram_accumulate take any d, k (unfused
- *     MFMA GEMM paths), lasso_dict_sweep d <= 1024 and k <= 4096, lasso_cd_* k <= 4096;
- *     the line search (backtrack != 0) and lasso_fista_prepare/_run are fused-shape only
- *     (LASSO_ERR_UNSUPPORTED otherwise).
+ *     (fixed step, and the line search on fp32 tensors), lasso_objective and
+ *     lasso_gram_accumulate take any d, k (unfused MFMA GEMM paths), lasso_dict_sweep
+ *     d <= 1024 and k <= 4096, lasso_cd_* k <= 4096; lasso_fista_prepare/_run and
+ *     lasso_fista_solve_sharded are fused-shape only (LASSO_ERR_UNSUPPORTED otherwise).
  */
 #ifndef LASSO_HIP_H_
 #define LASSO_HIP_H_

@@ -320,6 +320,64 @@ hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int tria
   return hipGetLastError();
 }
 
+// ---- unfused line search (d > 256 or k > 1024): element-wise halves around the general GEMM ------
+// part[b] = sum over this block's grid-stride elements of v^2 (fixed grid => deterministic)
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ v, int64_t total,
+                                                             float* __restrict__ part) {
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    acc = fmaf(v[i], v[i], acc);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// candidate z_next = S_lam(p - lr g) -> Cand, and the block's sums of |z_next|, dz.g, dz^2
+// (dz = z_next - p; ista.py:31-35,40) -> l1[b], dzg[b], dz2[b]
+__global__ __launch_bounds__(256) void generic_trial_kernel(const float* __restrict__ P, const float* __restrict__ G,
+                                                            float* __restrict__ Cand, int64_t total, float lr, float lam,
+                                                            float* __restrict__ l1p, float* __restrict__ dzgp,
+                                                            float* __restrict__ dz2p) {
+  __shared__ float sh[3][256];
+  float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float pv = P[i], g = G[i];
+    const float zn = soft_threshold(__fsub_rn(pv, __fmul_rn(lr, g)), lam);
+    const float dz = __fsub_rn(zn, pv);
+    Cand[i] = zn;
+    l1 += __builtin_fabsf(zn);
+    dzg = __fadd_rn(dzg, __fmul_rn(dz, g));
+    dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+  }
+  sh[0][threadIdx.x] = l1; sh[1][threadIdx.x] = dzg; sh[2][threadIdx.x] = dz2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { l1p[blockIdx.x] = sh[0][0]; dzgp[blockIdx.x] = sh[1][0]; dz2p[blockIdx.x] = sh[2][0]; }
+}
+
+hipError_t launch_sumsq_partials(const float* v, int64_t total, float* part, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(grid), dim3(256), 0, stream, v, total, part);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic_trial(const float* P, const float* G, float* Cand, int64_t total, float lr, float lam,
+                                float* partials, int grid, hipStream_t stream) {
+  // partials layout of bt_decide_kernel: [0] rss0, [1] rss1, [2] l1, [3] dz.g, [4] dz^2, each [grid]
+  hipLaunchKernelGGL(generic_trial_kernel, dim3(grid), dim3(256), 0, stream, P, G, Cand, total, lr, lam,
+                     partials + 2 * (size_t)grid, partials + 3 * (size_t)grid, partials + 4 * (size_t)grid);
+  return hipGetLastError();
+}
+
 hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
                                       const int* flags, const float* fvals, float* dpart, int grid,
                                       hipStream_t stream) {

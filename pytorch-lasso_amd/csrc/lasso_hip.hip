@@ -742,9 +742,11 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
 // like the reference does.  Correctness path, not tuned.
 // ---------------------------------------------------------------------------
 constexpr int kGenGrid = 1024;
-struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; float* delta; size_t bytes; };
+struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; float* delta;
+                      float* C; float* part; int* flags; float* fvals;      // line search only
+                      size_t bytes; };
 
-GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k) {
+GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool backtrack = false) {
   GenWorkspace w;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -759,6 +761,13 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k) {
   w.G = take((size_t)n * k * 4);
   w.dpart = take((size_t)kGenGrid * 4);
   w.delta = take(256);
+  w.C = w.part = w.fvals = nullptr; w.flags = nullptr;
+  if (backtrack) {
+    w.C = take((size_t)n * k * 4);
+    w.part = take((size_t)5 * kGenGrid * 4);
+    w.flags = reinterpret_cast<int*>(take(256));
+    w.fvals = take(256);
+  }
   w.bytes = off;
   return w;
 }
@@ -803,6 +812,77 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
   if (iters_out) *iters_out = it;
   if (last_delta_out) *last_delta_out = last;
   return LASSO_OK;
+}
+
+// The line search of ista.py:17-54 for shapes beyond the fused kernels: per outer iteration two
+// launches of the general GEMM for the gradient at p, then per trial one element-wise launch
+// (candidate + three of the sums), one GEMM (its residual), the sum of squares and the decision
+// kernel of backtrack.hip, one host synchronisation per trial -- the reference's own structure on
+// HIP kernels.  Correctness path, not tuned.
+int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* z0,
+                               int64_t ldz0, float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, double alpha,
+                               double lr0, int fast, int maxiter, double tol, double eta, int32_t* iters_out,
+                               float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
+                               float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st) {
+  GenWorkspace ws = carve_generic(workspace, n, d, k, true);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  if (n > INT32_MAX || d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+  LASSO_HIP_TRY(launch_transpose_pad(w, ldw, (int)d, (int)k, ws.Wt, d, (int)k, (int)d, st));
+  if (z0) {
+    if (z0 != zout)
+      LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  } else {
+    LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
+  }
+  LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  BtParams bp;                                             // only what bt_decide_kernel reads
+  bp.partials = ws.part; bp.ntiles = kGenGrid; bp.flags = ws.flags; bp.fvals = ws.fvals;
+  const float budget = (float)((double)n * (double)k * tol);
+  bool warned = false;
+  double t_mom = 1.0;
+  float last = NAN;
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;             // :98
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;                 // :99 (ISTA: y == z)
+    LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
+    // NR = x - p W^T (= -r0, :22);  G = r0 W (:24);  partials[0] = sum r0^2 (:23)
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Y, k, w, ldw, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.NR, d, ws.Wt, d, nullptr, 0, ws.G, k, (int)n, (int)k, (int)d, st));
+    LASSO_HIP_TRY(launch_sumsq_partials(ws.NR, n * d, ws.part, kGenGrid, st));
+    double lr = lr0;
+    int t = 0, accepted_at = -1;
+    struct { int flags[4]; float fvals[4]; } host;
+    for (;;) {
+      const bool give_up = t >= kBtMaxTrials;
+      const double lr_t = give_up ? lr0 : lr;                                           // :48-52
+      LASSO_HIP_TRY(launch_generic_trial(ws.Y, ws.G, ws.C, n * k, (float)lr_t, (float)(alpha * lr_t), ws.part,
+                                         kGenGrid, st));                                // :40, :31-35
+      LASSO_HIP_TRY(launch_gemm_nt_sub(ws.C, k, w, ldw, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));   // :27
+      LASSO_HIP_TRY(launch_sumsq_partials(ws.NR, n * d, ws.part + kGenGrid, kGenGrid, st));
+      LASSO_HIP_TRY(launch_bt_decide(bp, alpha, lr_t, t, give_up ? 1 : 0, st));         // :28, :32-35, :45
+      LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, sizeof(host.flags), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, sizeof(host.fvals), hipMemcpyDeviceToHost, st));
+      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      if (give_up) warned = true;
+      if (host.flags[0]) { accepted_at = t; break; }
+      lr = lr / eta;                                                                    // :47
+      ++t;
+    }
+    LASSO_HIP_TRY(launch_bt_finish(zout, ldz, ws.Y, ws.C, (int)n, (int)k, coef, ws.flags, ws.dpart, kGenGrid, st));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, ws.delta);
+    LASSO_HIP_TRY(hipGetLastError());
+    LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    if (trials_out) trials_out[it] = accepted_at + 1;
+    if (accepted_lr_out) accepted_lr_out[it] = host.fvals[2];
+    if (accepted_f_out) accepted_f_out[it] = host.fvals[0];
+    t_mom = t_next;
+    if (tol > 0.0 && last <= budget) { ++it; break; }                                   // :93-95
+  }
+  if (iters_out) *iters_out = it;
+  if (last_delta_out) *last_delta_out = last;
+  return warned ? fail(LASSO_WARN_LINESEARCH, "backtracking line search failed; reverted to lr0") : LASSO_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -946,7 +1026,7 @@ int lasso_hip_device_cus(int* cus_out) {
 static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                                      int stop_mode, int backtrack) {
   stop_mode &= 0xFF;                                   // kernel hint / LASSO_SOLVE_ASYNC bits ride above
-  if (!fused_shape(d, k)) return backtrack ? 0 : carve_generic(nullptr, n, d, k).bytes;
+  if (!fused_shape(d, k)) return carve_generic(nullptr, n, d, k, backtrack != 0).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
   if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16, maxiter).bytes;
@@ -1064,8 +1144,8 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   if (int s = check_common(n, d, k, half_any ? LASSO_F32 : dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !z_out_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "maxiter < 0");
-  if (!fused_shape(d, k) && backtrack)
-    return fail(LASSO_ERR_UNSUPPORTED, "backtrack=1 needs d<=%d, k<=%d", kFistaD, kFistaMaxK);
+  if (!fused_shape(d, k) && backtrack && dtype != LASSO_F32)
+    return fail(LASSO_ERR_UNSUPPORTED, "backtrack=1 beyond d<=%d, k<=%d needs fp32 tensors", kFistaD, kFistaMaxK);
   if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k))
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
@@ -1097,6 +1177,10 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
+  if (!fused_shape(d, k) && backtrack)
+    return solve_generic_backtracking(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
+                                      maxiter, stop_rule ? tol : 0.0, eta_backtrack, iters_out, last_delta_out,
+                                      trials_out, accepted_lr_out, accepted_f_out, workspace_dev, workspace_bytes, st);
   if (!fused_shape(d, k))
     return solve_generic(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
                          maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,

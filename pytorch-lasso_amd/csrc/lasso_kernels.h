@@ -171,6 +171,10 @@ hipError_t launch_cvt_bf16(const void* src, int64_t ld_src, void* dst, int64_t l
 hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
                                       const int* flags, const float* fvals, float* dpart, int grid,
                                       hipStream_t stream);
+// unfused line search (backtrack.hip): element-wise halves around launch_gemm_nt_sub
+hipError_t launch_sumsq_partials(const float* v, int64_t total, float* part, int grid, hipStream_t stream);
+hipError_t launch_generic_trial(const float* P, const float* G, float* Cand, int64_t total, float lr, float lam,
+                                float* partials, int grid, hipStream_t stream);
 hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
                             float coef, const int* flags, float* dpart, int grid, hipStream_t stream);
 

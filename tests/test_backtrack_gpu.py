@@ -274,3 +274,28 @@ def test_native_bf16_paths_against_the_oracle(n, d, k, backtrack):
         o = obj(z.cpu())
         assert abs(o - ref32) <= 1e-3 * ref32, (kern, o, ref32)
         assert abs(o - ref16) <= 2e-3 * ref16, (kern, o, ref16)
+
+
+@pytest.mark.parametrize("n,d,k,fast", [(60, 300, 40, True), (45, 64, 1500, True), (30, 512, 1100, False)])
+def test_line_search_beyond_the_fused_shapes(n, d, k, fast):
+    """d > 256 or k > 1024: the line search on the general GEMM + element-wise kernels
+    (solve_generic_backtracking) -- trial trace, accepted steps and code against the oracle."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    g = torch.Generator().manual_seed(n + d)
+    W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+    X = torch.randn(n, d, generator=g)
+    z0 = torch.zeros(n, k)
+    tr = orc.FistaTrace()
+    ref = orc.fista(X, z0, W, 0.3, fast=fast, lr=2.0, maxiter=7, tol=0.0, backtrack=True, trace=tr)
+    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, fast=fast, lr=2.0, maxiter=7, tol=0.0, backtrack=True,
+                     return_info=True)
+    assert info["trials"] == list(tr.trials) and max(tr.trials) > 1
+    assert np.allclose(info["accepted_lr"], tr.accepted_lr, rtol=1e-6)
+    assert (got.cpu() - ref).abs().max().item() <= 5e-5
+    # with the stop rule
+    tr2 = orc.FistaTrace()
+    orc.fista(X, z0, W, 0.3, fast=fast, lr=2.0, maxiter=60, tol=2e-3, backtrack=True, trace=tr2)
+    _, info2 = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, fast=fast, lr=2.0, maxiter=60, tol=2e-3, backtrack=True,
+                    return_info=True)
+    assert info2["iterations"] == tr2.iterations < 60

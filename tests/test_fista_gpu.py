@@ -162,8 +162,9 @@ def test_errors_and_unsupported():
         sparse_encode(x, w, z0=torch.zeros(4, 4).cuda())
     with pytest.raises(TypeError):
         sparse_encode(x, w, bogus=1)
-    with pytest.raises(NotImplementedError):      # line search is fused-kernel only
-        sparse_encode(torch.randn(4, 300).cuda(), torch.randn(300, 5).cuda(), lr=0.1, backtrack=True)
+    # (the line search beyond the fused shapes runs on the unfused kernels: test_backtrack_gpu.py)
+    z = sparse_encode(torch.randn(4, 300).cuda(), torch.randn(300, 5).cuda(), lr=0.1, backtrack=True)
+    assert z.shape == (4, 5) and torch.isfinite(z).all()
 
 
 @pytest.mark.parametrize("n,d,k", [(50, 300, 40), (33, 64, 1500), (20, 784, 1100), (0, 10, 50)])
