@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert L.lasso_hip_status_string(0) == b"ok"
     assert L.lasso_fista_workspace_bytes(4096, 256, 1024, 0, 100, 0.0, 0, 0) > 2 * 1024 * 1024
     assert L.lasso_fista_workspace_bytes(4096, 256, 4096, 0, 100, 0.0, 0, 0) > 0    # unfused path
-    assert L.lasso_fista_workspace_bytes(4096, 256, 4096, 0, 100, 0.0, 0, 1) == 0    # no line search there
+    assert L.lasso_fista_workspace_bytes(4096, 256, 4096, 0, 100, 0.0, 0, 1) > L.lasso_fista_workspace_bytes(4096, 256, 4096, 0, 100, 0.0, 0, 0)    # unfused line search: + the candidate matrix
 
 
 def test_signatures_match_reference():
