@@ -325,3 +325,36 @@ def test_ridge_solve_reports_a_non_positive_pivot():
     B = torch.ones(70, 5, device="cuda")
     with pytest.raises(torch.linalg.LinAlgError):
         eng.ridge(A, B, 0.0, check=True)
+
+
+def test_atom_sweep_and_ridge_survive_a_busy_gpu():
+    """The single-launch atom sweep (sweeper + row-block workers) and the look-ahead Cholesky hand
+    data between workgroups; with a second stream holding the CUs they either still find each
+    other or give up as a whole and the stand-by launch redoes the sweep -- same dictionary
+    bit for bit, no error, no hang."""
+    from lasso_amd.engine import HipEngine
+    from lasso_amd.parallel import constrained_mstep
+    g = torch.Generator().manual_seed(4)
+    n, d, k = 4096, 256, 1024
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)).cuda()
+    X = torch.randn(n, d, generator=g).cuda()
+    D0 = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+    eng = HipEngine()
+    A, B = eng.gram(Z, X, torch.empty(k * k + k * d, device="cuda"))
+    Dref = D0.clone()
+    constrained_mstep(eng, A, B, Dref)
+    Vref = eng.ridge(A, B, 1e-2 * n, check=True)
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    b = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4 + 3 * trial):
+                a = torch.mm(a, b) * 1e-2
+        D = D0.clone()
+        constrained_mstep(eng, A, B, D)
+        V = eng.ridge(A, B, 1e-2 * n, check=True)
+        torch.cuda.synchronize()
+        assert torch.equal(D, Dref), trial
+        assert torch.equal(V, Vref), trial
