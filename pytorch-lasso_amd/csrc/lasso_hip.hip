@@ -744,6 +744,7 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
 constexpr int kGenGrid = 1024;
 struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; float* delta;
                       float* C; float* part; int* flags; float* fvals;      // line search only
+                      float* Wc;                                            // [d][k] copy of W (lasso_fista_prepare / _run)
                       size_t bytes; };
 
 GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool backtrack = false) {
@@ -756,6 +757,7 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool bac
     return reinterpret_cast<float*>(r);
   };
   w.Wt = take((size_t)k * d * 4);
+  w.Wc = take((size_t)d * k * 4);             // (both dictionary copies first: their place does not depend on n)
   w.Y = take((size_t)n * k * 4);
   w.NR = take((size_t)n * d * 4);
   w.G = take((size_t)n * k * 4);
@@ -811,6 +813,45 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
   }
   if (iters_out) *iters_out = it;
   if (last_delta_out) *last_delta_out = last;
+  return LASSO_OK;
+}
+
+// `iters` iterations it0 .. of the unfused solve from a given (z, y) state: the resumable form behind
+// lasso_fista_run for shapes beyond the fused kernels (traced forward pass of the autograd path,
+// verbose mode).  Wt must have been prepared in the workspace (lasso_fista_prepare).
+int run_generic(const float* x, int64_t ldx, const float* z_in, int64_t ldz_in,
+                const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out, float* y_out, int64_t ldy_out,
+                int64_t n, int64_t d, int64_t k, double alpha, double lr, int fast, int it0, int iters, float* delta_dev,
+                void* workspace, size_t ws_bytes, hipStream_t st) {
+  GenWorkspace ws = carve_generic(workspace, n, d, k);
+  if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
+  if (n == 0) return LASSO_OK;
+  if (z_in) {
+    if (z_in != z_out)
+      LASSO_HIP_TRY(hipMemcpy2DAsync(z_out, ldz_out * 4, z_in, ldz_in * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  } else {
+    LASSO_HIP_TRY(hipMemset2DAsync(z_out, ldz_out * 4, 0, k * 4, n, st));
+  }
+  const float* ysrc = y_in ? y_in : z_out;
+  LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, ysrc, (y_in ? ldy_in : ldz_out) * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
+  double t_mom = 1.0;
+  for (int i = 0; i < it0; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+  for (int i = 0; i < iters; ++i) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+    const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Y, k, ws.Wc, k, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));
+    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.NR, d, ws.Wt, d, nullptr, 0, ws.G, k, (int)n, (int)k, (int)d, st));
+    LASSO_HIP_TRY(launch_generic_prox(z_out, ldz_out, ws.Y, ws.G, (int)n, (int)k, lr_f, lam, coef, ws.dpart,
+                                      kGenGrid, st));
+    if (delta_dev) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, delta_dev + i);
+      LASSO_HIP_TRY(hipGetLastError());
+    }
+    t_mom = t_next;
+  }
+  if (y_out)
+    LASSO_HIP_TRY(hipMemcpy2DAsync(y_out, ldy_out * 4, ws.Y, k * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
   return LASSO_OK;
 }
 
@@ -1094,9 +1135,18 @@ int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, in
                         void* workspace_dev, size_t workspace_bytes, void* stream) {
   // packs W and builds the momentum table for iterations 0 .. maxiter-1 (the workspace must
   // come from lasso_fista_workspace_bytes with the same maxiter)
-  if (int s = check_common(0, d, k, dtype)) return s;
+  if (int s = check_common(0, d, k, dtype, /*allow_large=*/true)) return s;
   if (!w_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (ldw < k || maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "ldw < k or maxiter < 0");
+  if (!fused_shape(d, k)) {          // unfused path: W^T for the second GEMM (the workspace of solve_generic)
+    if (d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
+    GenWorkspace gw = carve_generic(workspace_dev, 0, d, k);
+    if (workspace_bytes < gw.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", gw.bytes);
+    LASSO_HIP_TRY(launch_transpose_pad((const float*)w_dev, ldw, (int)d, (int)k, gw.Wt, d, (int)k, (int)d,
+                                       (hipStream_t)stream));
+    LASSO_HIP_TRY(hipMemcpy2DAsync(gw.Wc, k * 4, w_dev, ldw * 4, k * 4, d, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return LASSO_OK;
+  }
   const int kp = pad_k(k);
   Workspace ws = carve(workspace_dev, 0, k, kp, maxiter, false);
   if (workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
@@ -1108,9 +1158,17 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
                     void* y_out_dev, int64_t ldy_out, int64_t n, int64_t d, int64_t k, int dtype,
                     double alpha, double lr, int fast, int it0, int iters, int maxiter, int kernel_hint,
                     float* delta_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
-  if (int s = check_common(n, d, k, dtype)) return s;
+  if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (it0 < 0 || iters < 0) return fail(LASSO_ERR_BAD_ARG, "negative iteration range");
+  if (!fused_shape(d, k)) {
+    if (it0 + iters > maxiter) return fail(LASSO_ERR_BAD_ARG, "it0 + iters = %d > maxiter = %d", it0 + iters, maxiter);
+    if (ldx < d || ldz_out < k || (z_in_dev && ldz_in < k) || (y_in_dev && ldy_in < k) || (y_out_dev && ldy_out < k))
+      return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
+    return run_generic((const float*)x_dev, ldx, (const float*)z_in_dev, ldz_in,
+                       (const float*)y_in_dev, ldy_in, (float*)z_out_dev, ldz_out, (float*)y_out_dev, ldy_out, n, d, k,
+                       alpha, lr, fast, it0, iters, delta_dev, workspace_dev, workspace_bytes, (hipStream_t)stream);
+  }
   if (delta_dev && iters > kChunkMax)
     return fail(LASSO_ERR_BAD_ARG, "iters=%d > %d with delta recording", iters, kChunkMax);
   if (ldx < d || ldz_out < k || (z_in_dev && ldz_in < k) || (y_in_dev && ldy_in < k) ||

@@ -214,8 +214,6 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
             raise NotImplementedError("lasso_amd: autograd through the backtracking line search is not implemented")
         if not (x.is_cuda and weight.is_cuda and z0.is_cuda):
             raise NotImplementedError("lasso_amd: the differentiable path needs x, weight, z0 on the HIP device")
-        if d > 256 or k > 1024:
-            raise NotImplementedError("lasso_amd: the differentiable path is limited to d <= 256, k <= 1024")
         z = _UnrolledIsta.apply(x, z0, weight, float(alpha), bool(fast), lr, int(maxiter), float(tol))
         if begin:
             return z, None

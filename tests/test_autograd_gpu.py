@@ -34,7 +34,8 @@ def _grads(fn, X, W, Z0, G, dev):
     return z.detach().cpu(), x.grad.cpu(), w.grad.cpu(), z0.grad.cpu()
 
 
-@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (130, 128, 512), (16, 64, 256)])
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (130, 128, 512), (16, 64, 256),
+                                   (40, 300, 70), (24, 96, 1300)])     # the last two: beyond the fused shapes
 @pytest.mark.parametrize("fast", [True, False])
 def test_gradients_match_autograd_through_the_oracle(n, d, k, fast):
     _, ista, orc = _mods()

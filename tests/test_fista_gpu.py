@@ -255,3 +255,26 @@ def test_begin_returns_before_the_stop_rule_and_collects_later():
     # no stop rule: complete inside the call
     z2, p2 = ista(Xg, z0, Wg, alpha=0.3, maxiter=5, tol=0.0, begin=True)
     assert p2 is None and torch.equal(z2, ista(Xg, z0, Wg, alpha=0.3, maxiter=5, tol=0.0))
+
+
+def test_resumable_runs_beyond_the_fused_shapes():
+    """lasso_fista_prepare / lasso_fista_run for d > 256 or k > 1024 (unfused, state in HBM): three
+    chunks of iterations with the (z, y) state handed over equal one solve; per-iteration deltas
+    equal the oracle trace."""
+    sparse_encode, ista, orc = _mods()
+    from lasso_amd.engine import HipEngine
+    for (n, d, k) in ((50, 300, 90), (33, 80, 1200)):
+        X, W = _case(n, d, k, seed=d)
+        lr = 0.9 / orc.lipschitz_constant(W, "exact")
+        eng = HipEngine()
+        Xg, Wg = X.cuda(), W.cuda()
+        ws = eng.fista_workspace(n, d, k, 9)
+        z, y, deltas = torch.zeros(n, k, device="cuda"), None, []
+        for it0, iters in ((0, 2), (2, 3), (5, 4)):
+            z, y, dl = eng.fista_run(Xg, Wg, z, y, 0.3, lr, True, it0, iters, True, ws=ws)
+            deltas += dl.cpu().tolist()
+        tr = orc.FistaTrace()
+        ref = orc.fista(X, torch.zeros(n, k), W, 0.3, lr=lr, maxiter=9, tol=0.0, trace=tr)
+        assert (z.cpu() - ref).abs().max().item() <= 5e-5
+        assert torch.equal(z, sparse_encode(Xg, Wg, 0.3, lr=lr, maxiter=9, tol=0.0))
+        assert np.allclose(deltas, tr.delta, rtol=1e-4)
