@@ -97,6 +97,7 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     if world == 1 or kw.get('algorithm', 'ista') == 'cd':
         # coordinate descent stops every row on its own (coordinate_descent.py:45-48): a row
         # shard needs no collective and reproduces the full batch exactly
+        kw.pop('n_global', None)
         return engine.encode(X, W, alpha, z0, **kw)
     fast = kw.pop('fast', True)
     lr = kw.pop('lr', 'auto')
@@ -106,6 +107,7 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     eta = kw.pop('eta_backtrack', 1.5)
     kw.pop('verbose', None)
     return_info = kw.pop('return_info', False)
+    n_global = kw.pop('n_global', None)
     if kw.get('algorithm', 'ista') != 'ista':
         raise NotImplementedError("sharded E-step supports algorithm='ista' and 'cd' only")
     kw.pop('algorithm', None)
@@ -124,8 +126,10 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
         # the line search decides on sums over the WHOLE batch (ista.py:23,28,32-35,93): the HIP
         # library hands this rank's sums to the callback below at every decision, all ranks add
         # theirs and take the same decision (lasso_fista_solve_sharded)
-        n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
-        _all_reduce(n_glob, group)
+        if n_global is None:
+            n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
+            _all_reduce(n_glob, group)
+            n_global = n_glob.item()
         def reduce_host(t):          # a few float64 words in host memory; RCCL reduces device buffers
             if dist.get_backend(group) == "gloo":
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -133,7 +137,7 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
                 g = t.to(X.device)
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
                 t.copy_(g)
-        z, info = engine.encode_sharded_backtrack(X, W, alpha, z0, lr, fast, maxiter, tol, eta, int(n_glob.item()),
+        z, info = engine.encode_sharded_backtrack(X, W, alpha, z0, lr, fast, maxiter, tol, eta, int(n_global),
                                                   reduce_host)
         return (z, info) if return_info else z
     if return_info:
@@ -141,9 +145,11 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     if not tol > 0:
         z, _, _ = engine.fista_run(X, W, z0, None, alpha, lr, fast, 0, maxiter, False)
         return z
-    n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
-    _all_reduce(n_glob, group)
-    budget = torch.tensor(n_glob.item() * k * tol, dtype=torch.float32).item()
+    if n_global is None:          # (the EM driver passes the row count of the whole batch)
+        n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
+        _all_reduce(n_glob, group)
+        n_global = n_glob.item()
+    budget = torch.tensor(float(n_global) * k * tol, dtype=torch.float32).item()
     chunk, done = 64, 0
     z, y = z0, None
     while done < maxiter:
@@ -184,10 +190,16 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
     # objective and the Gram product are still queued, so the GPU does not idle behind the host.
     overlap = world == 1 and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
+    # Any number of ranks: the sweep's count of degenerate atoms is not waited for -- it is looked at
+    # after the NEXT E-step has been enqueued (every rank holds the same A, B, D bit for bit, so every
+    # rank sees the same count and takes the same branch).
+    defer = hasattr(engine, 'sweep_begin')
     deferred = None          # the previous step's sweep: callable -> (mask, ndeg)
 
     def repair(mask, ndeg, Zprev):
-        cand = draw_directions(d, ndeg).to(weight.device)
+        cand = draw_directions(d, ndeg).to(weight.device)       # every rank advances its generator alike
+        if world > 1:
+            _broadcast(cand, group)                              # ... and uses rank 0's directions
         engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
         if Zprev is not None:
             engine.zero_columns(Zprev, mask)                                              # :98
@@ -198,7 +210,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         if overlap:
             Z, pending = engine.encode_begin(X, weight, alpha, Z0, **solver_kwargs)       # :38
         else:
-            Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, **solver_kwargs)
+            Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
         loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
         A, B = engine.gram(Z, X, buf)
         if deferred is not None:
@@ -223,7 +235,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         else:
             losses[i] = loss_local
         if constrained:
-            if overlap:
+            if defer:
                 deferred = engine.sweep_begin(A, B, weight, 1e-10, False)                 # :44-45
                 Zlast = Z
             else:
