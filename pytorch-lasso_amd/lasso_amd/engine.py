@@ -53,7 +53,8 @@ class HipEngine:
         if not plain:
             return self.encode(X, W, alpha, z0, **solver_kwargs), None
         if z0 is None:
-            z0 = X.new_zeros(X.shape[0], W.shape[1])
+            from .linear.solvers.ista import lazy_zeros
+            z0 = lazy_zeros(X, X.shape[0], W.shape[1])
         return ista(X, z0, W, alpha, begin=True, **kw)
 
     def encode_sharded_backtrack(self, X, W, alpha, z0, lr, fast, maxiter, tol, eta, n_global, all_reduce):

@@ -20,6 +20,17 @@ def _to_device(t, device):
     return t if t.device == device else t.to(device)
 
 
+def lazy_zeros(like, n, k):
+    """An all-zero [n,k] start that costs no memory: a (0,0)-stride view of one element.  The
+    solvers recognise it and hand the C ABI a NULL z0 (= zeros, no fill and no read of n*k floats);
+    anything else that touches it sees an ordinary read-only zeros tensor."""
+    return like.new_zeros(1, 1).expand(n, k)
+
+
+def _is_lazy_zeros(z0):
+    return z0 is not None and z0.dim() == 2 and z0.numel() > 1 and z0.stride(0) == 0 and z0.stride(1) == 0
+
+
 def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
     """verbose=True: the reference prints the mean objective of z before every iteration
     (ista.py:80-81, 'loss: %0.4f').  Same here, one HIP iteration at a time (the state
@@ -179,6 +190,8 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     if begin and (return_info or x.dtype != torch.float32):
         raise ValueError("begin=True: fp32 tensors, return_info=False")
     if maxiter == 0:
+        if _is_lazy_zeros(z0):
+            z0 = z0.contiguous()
         if begin:
             return z0, None
         return (z0, dict(iterations=0, last_delta=float('nan'))) if return_info else z0
@@ -193,7 +206,7 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
                                       (z0.device if z0.is_cuda else torch.device('cuda', torch.cuda.current_device())))
     xg = _to_device(x.detach(), dev).contiguous()
     wg = _to_device(weight.detach(), dev).contiguous()
-    zg = _to_device(z0.detach(), dev).contiguous()
+    zg = None if _is_lazy_zeros(z0) else _to_device(z0.detach(), dev).contiguous()   # None: zeros, never materialised
 
     wants_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or z0.requires_grad)
     if lr == 'auto':
@@ -220,14 +233,16 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         return (z, dict(iterations=None, last_delta=None)) if return_info else z
 
     if verbose and not backtrack:
+        if zg is None:
+            zg = torch.zeros((n, k), dtype=xg.dtype, device=dev)
         z, info = _ista_verbose(xg, zg, wg, alpha, fast, lr, maxiter, tol, dev)
         z = z if z.device == out_device else z.to(out_device)
         if begin:
             return z, None
         return (z, info) if return_info else z
 
-    return _solve_native(xg, zg, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                         return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel, begin=begin)
+    return _solve_native(xg, zg if zg is not None else z0, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack,
+                         verbose, return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel, begin=begin)
 
 
 _STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
@@ -248,7 +263,7 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
                                       (z0.device if z0.is_cuda else torch.device('cuda', torch.cuda.current_device())))
     xg = _to_device(x.detach(), dev).contiguous()
     wg = _to_device(weight.detach(), dev).contiguous()
-    zg = _to_device(z0.detach(), dev).contiguous()
+    zg = None if _is_lazy_zeros(z0) else _to_device(z0.detach(), dev).contiguous()     # None -> NULL z0 = zeros
     L = nat.lib()
     z = torch.empty((n, k), dtype=x.dtype, device=dev)
     with torch.cuda.device(dev):
@@ -265,7 +280,7 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         acc_f = (C.c_float * max(int(maxiter), 1))() if (want_trace or (verbose and backtrack)) else None
         obj = C.c_float(float('nan')) if return_info == 'objective' else None
         st = L.lasso_fista_solve(
-            nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0),
+            nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0) if zg is not None else 0,
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
             int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0),
             int(bool(backtrack)), float(eta_backtrack),
@@ -289,7 +304,8 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         # the reference prints the mean objective of z before every iteration (ista.py:80-81):
         # that of z0, then F(z_next)/n of each accepted line-search trial but the last
         from ..dict_learning import lasso_loss
-        print('loss: %0.4f' % lasso_loss(xg.float(), zg.float(), wg.float(), alpha).item())
+        z_start = zg.float() if zg is not None else torch.zeros((n, k), dtype=torch.float32, device=dev)
+        print('loss: %0.4f' % lasso_loss(xg.float(), z_start, wg.float(), alpha).item())
         for v in list(acc_f[:max(iters.value - 1, 0)]):
             print('loss: %0.4f' % (v / n))
     if return_info:

@@ -69,7 +69,11 @@ def sparse_encode(x, weight, alpha=1.0, z0=None, algorithm='ista', init=None,
     else:
         if init is None:
             init = _init_defaults.get(algorithm, 'zero')             # :47-48
-        z0 = initialize_code(x, weight, alpha, mode=init)            # :51
+        if init == 'zero' and algorithm == 'ista' and kwargs.get('maxiter', 10) != 0 and n_samples * n_components > 1:
+            from .solvers.ista import lazy_zeros
+            z0 = lazy_zeros(x, n_samples, n_components)              # :22-23 without the n*k fill (and read)
+        else:
+            z0 = initialize_code(x, weight, alpha, mode=init)        # :51
     if algorithm == 'ista':
         z = ista(x, z0, weight, alpha, **kwargs)                     # :62-63
     elif algorithm == 'cd':
