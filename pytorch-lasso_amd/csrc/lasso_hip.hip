@@ -1617,7 +1617,8 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
 // ---------------------------------------------------------------------------
 size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k) {
   if (n < 0 || d <= 0 || k <= 0) return 0;
-  return (size_t)16 * (size_t)k * (size_t)std::max(k, d) * 4 + 256;   // up to 16 sample splits
+  // up to 16 sample splits of the larger product; the fused [A | B] kernel keeps up to 32 splits of k x (k + d)
+  return std::max((size_t)16 * (size_t)k * (size_t)std::max(k, d) * 4, gram_ab_scratch_bytes(d, k)) + 256;
 }
 
 int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
@@ -1633,6 +1634,14 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
   float* scratch = (workspace_dev && workspace_bytes >= lasso_gram_workspace_bytes(n, d, k))
                        ? (float*)workspace_dev : nullptr;
   const int cus = device_cus();
+  if (scratch) {
+    hipError_t e = hipSuccess;
+    if (launch_gram_ab(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, a_dev, b_dev, scratch,
+                       workspace_bytes - 256, cus, st, &e)) {
+      LASSO_HIP_TRY(e);
+      return LASSO_OK;
+    }
+  }
   const int sa = gram_splits((int)k, (int)k, (int)n, 1, cus), sb = gram_splits((int)k, (int)d, (int)n, 0, cus);
   LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, scratch, sa, st));
   LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, b_dev, d, 0,

@@ -183,6 +183,11 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
                             int squarings, hipStream_t stream);
 
 int gram_splits(int pc, int qc, int n, int sym, int cus);
+// [A | B] = Z^T [Z | X] in one launch on 256 x 256 blocks (k, d multiples of 256, large n); false = not applicable
+constexpr int kGramAbMaxSplits = 128;
+size_t gram_ab_scratch_bytes(int64_t d, int64_t k);
+bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
+                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err);
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
                           int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
                           hipStream_t stream);

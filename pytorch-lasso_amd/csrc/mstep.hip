@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
 // sym: only the blocks bj >= bi exist (blockIdx.x enumerates them); the mirror image is written
 // by sum_splits_sym_kernel, which also folds the sample splits.
 // ---------------------------------------------------------------------------
+// barrier that orders LDS traffic only: __syncthreads() would also drain the global loads in flight
+#define LASSO_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 constexpr int kG2B = 128, kG2S = 32, kG2Ld = 144;
 
 __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restrict__ P, int64_t ldp, int pc,
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restr
     load_chunk(0);
     put_chunk(0);
     if (kG2S < n) load_chunk(kG2S);
-    __syncthreads();
+    LASSO_LDS_BARRIER();
     int buf = 0;
     for (int s0 = 0; s0 < n; s0 += kG2S, buf ^= 1) {
       const float* const ap = sp + buf * kG2S * kG2Ld + 64 * wr + l15;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restr
         put_chunk(buf ^ 1);                                // the other buffer: its last readers passed the barrier below
         if (s0 + 2 * kG2S < n) load_chunk(s0 + 2 * kG2S);
       }
-      __syncthreads();
+      LASSO_LDS_BARRIER();
     }
   }
 #pragma unroll
@@ -247,6 +249,118 @@ __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __rest
       const int r = 32 * tc + i, c = 32 * tr + tx;          // the mirror tile
       if (r < pc && c < pc) C[(int64_t)r * ldc + c] = t[tx][i];
     }
+}
+
+// ---------------------------------------------------------------------------
+// Both M-step products in ONE launch on 256 x 256 blocks:  [A | B] = Z^T [Z | X].
+// At n = 65536 the 128 x 128 kernel above is HBM-bound, not MFMA-bound: Z (268 MB) does not stay
+// in L2 / MALL and every block pair streams its 2 x 128 columns of all n rows -- 3.5 GB per Gram
+// step.  A 256 x 256 block reads 512 columns for four times the flops (half the bytes per flop),
+// and treating X as further column blocks of the right operand puts A's 10 upper blocks and B's
+// k/256 x d/256 blocks into one grid that fills the chip (k = 1024, d = 256: 14 blocks x 18
+// sample splits = 252 workgroups).  8 waves x (64 x 128) = 32 accumulators per wave, a k-step of 4
+// samples = 4 + 8 LDS operand reads for 32 MFMAs; samples in chunks of 32, double-buffered LDS
+// (row stride 272 floats: conflict-free operand reads), next chunk's loads in registers.
+// Output: partial [split][k][k + d] (A's block (bi, bj) at columns 256 bj, B behind column k);
+// folded by sum_splits_sym_kernel (A, mirrored) and sum_splits_ld_kernel (B).
+// ---------------------------------------------------------------------------
+constexpr int kG3B = 256, kG3S = 32, kG3Ld = 272;
+
+__global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict__ Z, int64_t ldz, int k,
+                                                         const float* __restrict__ X, int64_t ldx, int d, int n,
+                                                         float* __restrict__ part, int rows_per_split) {
+  const int nb = k / kG3B, nsym = nb * (nb + 1) / 2;
+  int bi, bj;                                     // bj < nb: A block (bj >= bi);  bj >= nb: B block, X columns 256 (bj - nb)
+  if ((int)blockIdx.x < nsym) {
+    int rem = blockIdx.x;
+    bi = 0;
+    while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+    bj = bi + rem;
+  } else {
+    const int e = blockIdx.x - nsym, nbx = d / kG3B;
+    bi = e / nbx;
+    bj = nb + e % nbx;
+  }
+  const int n_lo = blockIdx.z * rows_per_split;
+  n = min(rows_per_split, n - n_lo);
+  const float* const P = Z + (int64_t)n_lo * ldz + kG3B * bi;
+  const float* const Q = bj < nb ? Z + (int64_t)n_lo * ldz + kG3B * bj : X + (int64_t)n_lo * ldx + kG3B * (bj - nb);
+  const int64_t ldq = bj < nb ? ldz : ldx;
+  const int64_t ldc = k + d;
+  float* const C = part + (int64_t)blockIdx.z * k * ldc + (int64_t)(kG3B * bi) * ldc + kG3B * bj;   // (bj >= nb lands behind column k)
+  extern __shared__ __attribute__((aligned(16))) float g3_smem[];
+  float* const sp = g3_smem;                               // [2][32][272]
+  float* const sq = g3_smem + 2 * kG3S * kG3Ld;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1, l15 = lane & 15, q = lane >> 4;
+  f32x4 acc[4][8] = {};
+  // staging map: thread -> sample rows srow + 8 h (h = 0..3), 4 consecutive columns of each operand
+  const int srow = tid >> 6, scol = (tid & 63) * 4;
+  f32x4 stg[2][4];
+  auto load_chunk = [&](int s0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int r = min(s0 + srow + 8 * h, n - 1);
+      const float m = (s0 + srow + 8 * h < n) ? 1.0f : 0.0f;
+      stg[0][h] = *(const f32x4*)(P + (int64_t)r * ldz + scol) * m;
+      stg[1][h] = *(const f32x4*)(Q + (int64_t)r * ldq + scol) * m;
+    }
+  };
+  auto put_chunk = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      *(f32x4*)(sp + (buf * kG3S + srow + 8 * h) * kG3Ld + scol) = stg[0][h];
+      *(f32x4*)(sq + (buf * kG3S + srow + 8 * h) * kG3Ld + scol) = stg[1][h];
+    }
+  };
+  if (n > 0) {
+    load_chunk(0);
+    put_chunk(0);
+    if (kG3S < n) load_chunk(kG3S);
+    LASSO_LDS_BARRIER();
+    int buf = 0;
+    for (int s0 = 0; s0 < n; s0 += kG3S, buf ^= 1) {
+      const float* const ap = sp + buf * kG3S * kG3Ld + 64 * wr + l15;
+      const float* const bp = sq + buf * kG3S * kG3Ld + 128 * wc + l15;
+#pragma unroll
+      for (int ks = 0; ks < kG3S / 4; ++ks) {
+        float a[4], b[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = ap[(4 * ks + q) * kG3Ld + 16 * m];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) b[m] = bp[(4 * ks + q) * kG3Ld + 16 * m];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj)
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+      }
+      if (s0 + kG3S < n) {
+        put_chunk(buf ^ 1);
+        if (s0 + 2 * kG3S < n) load_chunk(s0 + 2 * kG3S);
+      }
+      LASSO_LDS_BARRIER();
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 8; ++nj)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        C[(int64_t)(64 * wr + 16 * mi + 4 * q + rg) * ldc + 128 * wc + 16 * nj + l15] = acc[mi][nj][rg];
+}
+
+// C[r][c] = sum_s part[s][r * ldpart + c]  (fixed order): the B part of gram_ab256_kernel's partials
+__global__ __launch_bounds__(256) void sum_splits_ld_kernel(const float* __restrict__ part, int splits,
+                                                            int64_t split_stride, int64_t ldpart, int rows, int cols,
+                                                            float* __restrict__ C, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  const int64_t r = idx / cols, c = idx - r * cols;
+  float acc = 0.0f;
+  for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + r * ldpart + c];
+  C[r * ldc + c] = acc;
 }
 
 // C[r][c] = sum_s part[s][r][c]  (fixed order)
@@ -946,6 +1060,54 @@ __global__ void zero_columns_kernel(float* __restrict__ Z, int64_t ldz, int n, i
 
 // Number of sample splits that gives the chip ~3 workgroups per CU (the output has only
 // (pc/64)*(qc/64) blocks), each split keeping at least 512 samples.
+// [A | B] = Z^T [Z | X] in one launch on 256 x 256 blocks (see gram_ab256_kernel): k, d multiples of 256,
+// aligned operands, a batch that gives every split at least 512 rows, scratch for the partials.
+// Returns false when the shape does not qualify (the caller takes the two-launch path).
+size_t gram_ab_scratch_bytes(int64_t d, int64_t k) {
+  if (k < kG3B || d < kG3B || k % kG3B || d % kG3B) return 0;
+  const int64_t nb = k / kG3B, blocks = nb * (nb + 1) / 2 + nb * (d / kG3B);
+  const size_t one = (size_t)k * (size_t)(k + d) * 4;
+  // up to four rounds of workgroups on an MI355X's 256 CUs, at most 512 MB
+  const int64_t splits = std::min<int64_t>(std::min<int64_t>(kGramAbMaxSplits, std::max<int64_t>(1, 1024 / blocks)),
+                                           std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / one)));
+  return (size_t)splits * one;
+}
+
+bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
+                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err) {
+  *err = hipSuccess;
+  if (k < kG3B || d < kG3B || k % kG3B || d % kG3B || (ldz & 3) || (ldx & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)X & 15) ||
+      !scratch || n < 8 * 512)
+    return false;
+  const int nb = k / kG3B, blocks = nb * (nb + 1) / 2 + nb * (d / kG3B);
+  // Sample splits: one workgroup per CU at a time (LDS), so the launch runs in ceil(blocks * s / cus) rounds; every
+  // split also writes and re-reads k (k + d) partial sums.  Pick the s with the least modelled time.
+  const int smax = (int)std::min<size_t>(std::min(n / 512, kGramAbMaxSplits), scratch_bytes / ((size_t)k * (k + d) * 4));
+  if (smax < 1) return false;
+  const double work = (double)blocks * kG3B * kG3B * 2.0 * n / 130e12, fold = (double)k * (k + d) * 8.0 / 3e12;
+  int splits = 1;
+  double best = 1e30, best_eff = 0.0;
+  for (int sidx = 1; sidx <= smax && blocks * sidx <= 4 * cus + blocks; ++sidx) {
+    const int wgs = blocks * sidx;
+    const double eff = (double)wgs / ((double)((wgs + cus - 1) / cus) * cus), t = work / eff + sidx * fold;
+    if (t < best) { best = t; best_eff = eff; splits = sidx; }
+  }
+  if (best_eff < 0.75) return false;                       // would leave over a quarter of the chip idle
+  const int rps = ((n + splits - 1) / splits + kG3S - 1) / kG3S * kG3S;
+  const int sp = (n + rps - 1) / rps;
+  const size_t lds = (size_t)4 * kG3S * kG3Ld * 4;
+  if ((*err = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_ab256_kernel), lds)) != hipSuccess) return true;
+  hipLaunchKernelGGL(gram_ab256_kernel, dim3(blocks, 1, sp), dim3(512), lds, stream, Z, ldz, k, X, ldx, d, n, scratch, rps);
+  const int64_t stride = (int64_t)k * (k + d);
+  const int nt = (k + 31) / 32;
+  hipLaunchKernelGGL(sum_splits_sym_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, scratch, sp, stride,
+                     (int64_t)(k + d), k, A, (int64_t)k);
+  hipLaunchKernelGGL(sum_splits_ld_kernel, dim3((unsigned)(((int64_t)k * d + 255) / 256)), dim3(256), 0, stream,
+                     scratch + k, sp, stride, (int64_t)(k + d), k, d, B, (int64_t)d);
+  *err = hipGetLastError();
+  return true;
+}
+
 static bool gram_use128(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc) {
   return pc >= kG2B && qc >= kG2B && pc % 4 == 0 && qc % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 &&
          ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
