@@ -40,6 +40,27 @@
 // multi-launch kernels.
 #include "bf16_device.hpp"
 
+#ifndef LASSO_BT16_G2RING
+#define LASSO_BT16_G2RING 4   // GEMM-2 of the gradient: W fragment ring depth in steps
+#endif
+#ifndef LASSO_BT16_ACCEPT_BATCH
+#define LASSO_BT16_ACCEPT_BATCH 8   // passes of the accept step whose loads are in flight together
+#endif
+#ifndef LASSO_BT16_CHECK
+#define LASSO_BT16_CHECK 2     // double passes of a speculative trial before its predecessor's verdict is read
+#endif
+
+#ifdef LASSO_BT16_TIMING
+// debug build (tools/bt16_timeline.py): wall-clock stamps of ONE outer iteration, 16 per workgroup
+__device__ unsigned long long lasso_bt16_stamps[1024 * 16];
+extern "C" int lasso_debug_bt16_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_bt16_stamps), sizeof(lasso_bt16_stamps));
+}
+#define BT16_STAMP(slot) do { if (it == LASSO_BT16_TIMING && tid == 0) lasso_bt16_stamps[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define BT16_STAMP(slot) do { } while (0)
+#endif
+
 namespace lasso {
 namespace {
 
@@ -170,6 +191,8 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
   // compiler materialises ~100 loop-invariant addresses and spills them.
   const __amdgpu_buffer_rsrc_t w1rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(wq1), 0, (K / 32) * 2 * 64 * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(wq2), 0, S2 * NAB * 64 * 16, 0x00020000);
   const unsigned lane16 = lane * 16;
   auto wfrag1 = [&](int frag) {                 // fragment index (step * 2 + col block) of this wave's pack
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, lane16, frag * 1024, 0));
@@ -195,6 +218,17 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       for (int e = 0; e < 8; ++e)
         if (a0 + e < p.k) v[e] = (float)src[e];
     }
+  };
+  // the same 8 values, still packed (exact: they are bf16 in memory)
+  auto load_z8p = [&](const __bf16* base, int64_t ld, bool vec, int j) -> u32x4 {
+    const int a0 = kPass * j + 8 * ec8;
+    if (!base || !erow_ok || a0 >= p.k) return (u32x4){0u, 0u, 0u, 0u};
+    const __bf16* src = base + (int64_t)(row0 + erow) * ld + a0;
+    if (vec) return *reinterpret_cast<const u32x4*>(src);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (a0 + e < p.k) ? (float)src[e] : 0.0f;
+    return pack8(v);
   };
   auto store_z8 = [&](int j, const float (&v)[8]) {
     const int a0 = kPass * j + 8 * ec8;
@@ -264,6 +298,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 
   for (int it = 0; it < p.maxiter && !aborted; ++it) {
     const float coef = p.fast ? p.coef[it] : 0.0f;
+    BT16_STAMP(0);
     // ================================ gradient at p (ista.py:22-24 / 72-73) =================
     float rss0;
     {
@@ -273,6 +308,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       gemm1_bf16_deep<K>(pt, w1rsrc, lane16, lane, acc);
+      BT16_STAMP(11);
       rss0 = residual(acc);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
@@ -285,6 +321,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           }
     }
     __syncthreads();                            // residual tile complete
+    BT16_STAMP(12);
     // g^T = W^T r^T for the wave's K/8 atoms, NB atom blocks (16 NB atoms) at a time, W fragments
     // three steps ahead through a 4-deep ring; stored as bf16.  Which atom an MFMA output row
     // stands for is free: block a, row i is atom 4 NB (i >> 2) + 4 a + (i & 3) of the group, so
@@ -295,38 +332,57 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     static_for<NAB / NB>([&](auto h_c) {
       constexpr int h = decltype(h_c)::value;
       f32x4 gt[NB][4];
-      int gidx[NB];
+      unsigned gofs[NB];                         // lane part of the gather (bytes); step and group go into the scalar offset
 #pragma unroll
       for (int a = 0; a < NB; ++a) {
         const int ag = 4 * NB * (cl >> 2) + 4 * a + (cl & 3);            // atom of (block a, row cl) inside the group
-        gidx[a] = (NB * h + (ag >> 4)) * 64 + (ag & 15) + 16 * q;
+        gofs[a] = (unsigned)(((ag >> 4) * 64 + (ag & 15) + 16 * q) * 16);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) gt[a][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      bf16x8 wf[4][NB];
+      // (descriptor + lane offset + uniform offset: with 64-bit per-fragment addresses the compiler sank every
+      // load to just before its MFMAs to save the address registers -- the ring was gone, 13.6 us)
+      auto wfrag2 = [&](int step, int a) __attribute__((always_inline)) {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                              w2rsrc, gofs[a], (unsigned)((step * NAB + NB * h) * 1024), 0));
+      };
+      constexpr int RD = LASSO_BT16_G2RING;      // ring depth (steps): RD - 1 steps of W fragments in flight
+      static_assert(S2 % RD == 0, "ring depth must divide the steps");
+      bf16x8 wf[RD][NB];
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < RD - 1; ++s)
 #pragma unroll
-        for (int a = 0; a < NB; ++a) wf[s][a] = wq2[s * NAB * 64 + gidx[a]];
+        for (int a = 0; a < NB; ++a) wf[s][a] = wfrag2(s, a);
+      static_assert(RD % 2 == 0, "even ring depth (residual fragment parity)");
+      bf16x8 rf[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) rf[0][rb] = *(const lds_bf16x8*)(st + tile16_off<kFistaD * 2>(16 * rb + cl, q));
 #pragma unroll 1
-      for (int j = 0; j < S2 / 4; ++j) {
-        static_for<4>([&](auto u_c) {
+      for (int j = 0; j < S2 / RD; ++j) {
+        static_for<RD>([&](auto u_c) {
           constexpr int u = decltype(u_c)::value;
-          const int s = 4 * j + u;
-          const int sp = min(s + 3, S2 - 1);
+          const int s = RD * j + u;
+          const int sp = min(s + RD - 1, S2 - 1);
 #pragma unroll
-          for (int a = 0; a < NB; ++a) wf[(u + 3) & 3][a] = wq2[sp * NAB * 64 + gidx[a]];
-          bf16x8 rf[4];
+#ifndef LASSO_BT16_ABL_NOW2
+          for (int a = 0; a < NB; ++a) wf[(u + RD - 1) % RD][a] = wfrag2(sp, a);
+#else
+          for (int a = 0; a < NB; ++a) asm volatile("" : "+v"(wf[(u + RD - 1) % RD][a]));
+#endif
+          const int sn = min(s + 1, S2 - 1);       // the residual fragments run one step ahead
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
-            rf[rb] = *(const lds_bf16x8*)(st + tile16_off<kFistaD * 2>(16 * rb + cl, 4 * s + q));
+            rf[(u + 1) & 1][rb] = *(const lds_bf16x8*)(st + tile16_off<kFistaD * 2>(16 * rb + cl, 4 * sn + q));
+          __builtin_amdgcn_sched_barrier(0);       // prefetches first, in this order (left alone, the loads sink to their uses)
 #pragma unroll
           for (int a = 0; a < NB; ++a)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
-              gt[a][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][a], rf[rb], gt[a][rb], 0, 0, 0);
+              gt[a][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][a], rf[u & 1][rb], gt[a][rb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         });
       }
+      if (h == NAB / NB - 1) BT16_STAMP(13);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         // lane: atoms (K/8) w + 16 NB h + 4 NB q + (0 .. 4 NB - 1) of row 16 rb + cl (padded atoms are exact zeros)
@@ -335,11 +391,16 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         for (int a2 = 0; a2 < NB / 2; ++a2) {
           const float v[8] = {gt[2 * a2][rb][0], gt[2 * a2][rb][1], gt[2 * a2][rb][2], gt[2 * a2][rb][3],
                               gt[2 * a2 + 1][rb][0], gt[2 * a2 + 1][rb][1], gt[2 * a2 + 1][rb][2], gt[2 * a2 + 1][rb][3]};
+#ifndef LASSO_BT16_ABL_NOGST
           *reinterpret_cast<u32x4*>(dst + 8 * a2) = pack8(v);
+#else
+          { u32x4 pk = pack8(v); asm volatile("" :: "v"(pk), "v"(dst)); }
+#endif
         }
       }
     });
     __syncthreads();                            // g is in memory (this CU reads it back); the residual tile is dead
+    BT16_STAMP(1);
     {                                           // sum r0^2 of the tile -> red[48] (kept until the next gradient)
       const float r0w = wave_sum(rss0);
       if (lane == 0) red[40 + wid] = r0w;
@@ -352,8 +413,80 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       }
     }
 
-    // trial with step (lr, lam): candidate passes -> staging -> GEMM-1, sums published as epoch e
-    auto run_trial = [&](float lr, float lam, unsigned e) {
+    // Decision of the trial published as epoch e with 0.5 / step (every workgroup: same data, same
+    // order, same verdict): 0 = rejected, 1 = accepted, 2 = handshake timed out.  Thread t reads
+    // workgroup t's two granules; the loads are issued one double pass before the verdict is
+    // taken (sweep_issue), so their round trip hides behind that pass; a granule that had not
+    // arrived by then is polled (bounded).  Sums in double: per wave in butterfly order, then
+    // the waves' partial sums in index order.
+    const unsigned gran_lane = (unsigned)min(tid, p.ntiles - 1) * 32u;   // clamped: every lane loads, spare lanes add 0
+    const int sweep_waves = (p.ntiles + 63) >> 6;
+    lds_f32* const vote = red + 56;                // [8] per-wave "all granules arrived"
+    double* const dpart = (double*)(st + 2 * kStageBytes + 256);   // [8][5]
+    auto sweep_issue = [&](unsigned e, u32x4& ga, u32x4& gb) {
+      const unsigned off = (unsigned)((e % kRing) * p.ntiles * 32) + gran_lane;
+      ga = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off, 0, 16);
+      gb = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 16, 0, 16);
+    };
+    auto decide = [&](unsigned e, u32x4 ga, u32x4 gb, float half_over_lr, float& f_out) {
+      if (wid < sweep_waves) {
+        const unsigned off = (unsigned)((e % kRing) * p.ntiles * 32) + gran_lane;
+        bool ok = true;
+        int spins = 0;
+        while (ga[0] != e || gb[0] != e) {
+          if (++spins >= kStopSpinLimit ||
+              ((spins & 63) == 63 && __hip_atomic_load(p.out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            ok = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          ga = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off, 0, 16);
+          gb = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 16, 0, 16);
+        }
+        const bool mine = tid < p.ntiles;
+        double sv[5] = {(double)__uint_as_float(ga[1]), (double)__uint_as_float(ga[2]), (double)__uint_as_float(ga[3]),
+                        (double)__uint_as_float(gb[1]), (double)__uint_as_float(gb[2])};
+        ok = __all(ok);
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) sv[jj] = wave_sum_f64(mine ? sv[jj] : 0.0);
+        if (lane == 0) {
+#pragma unroll
+          for (int jj = 0; jj < 5; ++jj) dpart[5 * wid + jj] = sv[jj];
+          vote[wid] = ok ? 1.0f : 0.0f;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double sv[5] = {0., 0., 0., 0., 0.};
+        bool ok = true;
+        for (int w = 0; w < sweep_waves; ++w) {
+#pragma unroll
+          for (int jj = 0; jj < 5; ++jj) sv[jj] += dpart[5 * w + jj];
+          ok = ok && vote[w] != 0.0f;
+        }
+        const float rss1 = (float)sv[0], l1 = (float)sv[1], dzg = (float)sv[2], dz2 = (float)sv[3], rss0t = (float)sv[4];
+        const float f0 = __fmul_rn(0.5f, rss0t);                                     // ista.py:23
+        const float al1 = __fmul_rn((float)p.alpha, l1);
+        const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                      // :28
+        const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(half_over_lr, dz2)), al1);   // :32-35
+        red[32] = !ok ? 2.0f : (F <= Q ? 1.0f : 0.0f);                              // :45
+        red[34] = F;
+        if (!ok) abort_now();
+      }
+      __syncthreads();
+      f_out = red[34];
+      return red[32];                               // rewritten at the earliest a barrier later (the next pass / accept)
+    };
+
+    [[maybe_unused]] const unsigned trial_e0 = epoch + 1;           // epoch of this outer iteration's first trial
+    // trial with step (lr, lam): candidate passes -> staging -> GEMM-1, sums published as epoch e.
+    // A trial after the first is speculative -- it is needed only if the previous one (epoch
+    // check_e, 0 = none) gets rejected: that verdict is taken kCheck double passes into this
+    // trial (its granules have had that long to arrive) and an accepted predecessor ends the
+    // trial there instead of after all NP passes.  Returns the verdict (-1: none taken).
+    constexpr int kIssue = (NP / 2 - 1) < LASSO_BT16_CHECK ? (NP / 2 - 1) : LASSO_BT16_CHECK;
+    constexpr int kCheck = (NP / 2 - 1) < LASSO_BT16_CHECK + 1 ? (NP / 2 - 1) : LASSO_BT16_CHECK + 1;
+    auto run_trial = [&](float lr, float lam, unsigned e, unsigned check_e, float hol_check, float& f_check) -> float {
       float l1 = 0.0f;
       f32x2 dzg2 = {0.f, 0.f}, dz22 = {0.f, 0.f};
       const f32x2 lr2 = {lr, lr};
@@ -436,9 +569,35 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
             b[pm][u][cb] = __builtin_bit_cast(
                 bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, lane16, fn + (u * 2 + cb) * 1024, 0));
       };
+      if (e == trial_e0 + 1) BT16_STAMP(2);
+      if (e == trial_e0 + 2) BT16_STAMP(8);
       candidates(0, 0);
+      float verdict = -1.0f;
+      u32x4 ga = {0u, 0u, 0u, 0u}, gb = {0u, 0u, 0u, 0u};
 #pragma unroll 1
-      for (int j2 = 0; j2 < NP / 2 - 1; ++j2) {
+      for (int j2 = 0; j2 < kIssue; ++j2) {
+        __syncthreads();                        // staging tile 0 complete, tile 1 free
+        fused_pass(2 * j2, 0, 2 * j2 + 1);
+        __syncthreads();                        // staging tile 1 complete, tile 0 free
+        fused_pass(2 * j2 + 1, 1, 2 * j2 + 2);
+      }
+      if (check_e) sweep_issue(check_e, ga, gb);
+      if (e == trial_e0 + 1) BT16_STAMP(3);
+#pragma unroll 1
+      for (int j2 = kIssue; j2 < kCheck; ++j2) {
+        __syncthreads();
+        fused_pass(2 * j2, 0, 2 * j2 + 1);
+        __syncthreads();
+        fused_pass(2 * j2 + 1, 1, 2 * j2 + 2);
+      }
+      if (check_e) {
+        if (e == trial_e0 + 1) BT16_STAMP(4);
+        verdict = decide(check_e, ga, gb, hol_check, f_check);
+        if (e == trial_e0 + 1) BT16_STAMP(5);
+        if (verdict != 0.0f) return verdict;    // accepted (or timed out): nobody will ask for this trial
+      }
+#pragma unroll 1
+      for (int j2 = kCheck; j2 < NP / 2 - 1; ++j2) {
         __syncthreads();                        // staging tile 0 complete, tile 1 free
         fused_pass(2 * j2, 0, 2 * j2 + 1);
         __syncthreads();                        // staging tile 1 complete, tile 0 free
@@ -461,6 +620,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
               acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[1][u][cb], acc[rb][cb], 0, 0, 0);
         }
       }
+      if (e == trial_e0 + 1) BT16_STAMP(6);
       float dzg = dzg2[0] + dzg2[1], dz2 = dz22[0] + dz22[1];
       float rss1 = residual(acc);
       rss1 = wave_sum(rss1); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
@@ -478,67 +638,29 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         __builtin_amdgcn_raw_buffer_store_b128(g0, grsrc, off, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(g1, grsrc, off + 16, 0, 16);
       }
+      if (e == trial_e0 + 1) BT16_STAMP(7);
+      return verdict;
     };
-    // decision of the trial published as epoch e with 0.5 / step (every workgroup: same data,
-    // same order, same verdict): 0 = rejected, 1 = accepted, 2 = handshake timed out
-    auto decide = [&](unsigned e, float half_over_lr, float& f_out) {
-      if (wid == 0) {
-        double s[5] = {0., 0., 0., 0., 0.};
-        const unsigned base = (unsigned)((e % kRing) * p.ntiles * 32);
-        bool ok = true;
-        for (int wg = lane; wg < p.ntiles; wg += 64) {
-          u32x4 a, b;
-          int spins = 0;
-          for (;;) {
-            a = __builtin_amdgcn_raw_buffer_load_b128(grsrc, base + wg * 32, 0, 16);
-            b = __builtin_amdgcn_raw_buffer_load_b128(grsrc, base + wg * 32 + 16, 0, 16);
-            if (a[0] == e && b[0] == e) break;
-            if (++spins >= kStopSpinLimit ||
-                ((spins & 63) == 63 &&
-                 __hip_atomic_load(p.out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              ok = false;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-          }
-          s[0] += __uint_as_float(a[1]); s[1] += __uint_as_float(a[2]); s[2] += __uint_as_float(a[3]);
-          s[3] += __uint_as_float(b[1]); s[4] += __uint_as_float(b[2]);
-        }
-        ok = __all(ok);
-#pragma unroll
-        for (int jj = 0; jj < 5; ++jj) s[jj] = wave_sum_f64(s[jj]);
-        if (lane == 0) {
-          const float rss1 = (float)s[0], l1 = (float)s[1], dzg = (float)s[2], dz2 = (float)s[3], rss0t = (float)s[4];
-          const float f0 = __fmul_rn(0.5f, rss0t);                                     // ista.py:23
-          const float al1 = __fmul_rn((float)p.alpha, l1);
-          const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                      // :28
-          const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(half_over_lr, dz2)), al1);   // :32-35
-          red[32] = !ok ? 2.0f : (F <= Q ? 1.0f : 0.0f);                              // :45
-          red[34] = F;
-          if (!ok) abort_now();
-        }
-      }
-      __syncthreads();
-      const float v = red[32];
-      f_out = red[34];
-      __syncthreads();                          // red[32] may be rewritten by the next decision
-      return v;
-    };
-
     // ================================ step size (ista.py:86-90) =============================
     float lr_acc = (float)p.lr0, lam_acc = (float)(p.alpha * p.lr0), f_acc = __builtin_nanf("");
     int t_acc = 0;
     if (p.backtrack) {
       // step s computes trial s (step / eta^s, in double like the reference's python floats, :47)
-      // and then decides trial s-1: the sweep of a trial's granules is taken one GEMM later
+      // and, a few passes into it, decides trial s-1
       double lr_d = p.lr0;
       float lr_prev = 0.f, lam_prev = 0.f, hol_prev = 0.f;
       for (int s = 0;; ++s) {
         const float lr_s = (float)lr_d, lam_s = (float)(p.alpha * lr_d), hol_s = (float)(0.5 / lr_d);
-        if (s < kMaxTrials) run_trial(lr_s, lam_s, ++epoch);      // for s >= 1 speculative: wasted only if s-1 is accepted
+        float fv = 0.f, verdict;
+        if (s < kMaxTrials) {
+          const unsigned e_prev = s >= 1 ? epoch : 0u;
+          verdict = run_trial(lr_s, lam_s, ++epoch, e_prev, hol_prev, fv);
+        } else {
+          u32x4 ga, gb;
+          sweep_issue(epoch, ga, gb);
+          verdict = decide(epoch, ga, gb, hol_prev, fv);
+        }
         if (s >= 1) {
-          float fv;
-          const float verdict = decide(epoch - (s < kMaxTrials ? 1u : 0u), hol_prev, fv);
           if (verdict == 2.0f) { aborted = true; break; }
           if (verdict == 1.0f) { lr_acc = lr_prev; lam_acc = lam_prev; t_acc = s - 1; f_acc = fv; break; }
           if (s >= kMaxTrials) { warned = true; t_acc = kMaxTrials - 1; break; }   // :48-52: revert to lr0
@@ -555,30 +677,32 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     }
 
     // ================================ accept: z+, |z - z+|, momentum (ista.py:93-102) ========
+    BT16_STAMP(9);
     float dsum = 0.0f;
+    // AB passes at a time, ALL their g and z loads in flight together (kept packed: 8 registers per pass): the
+    // phase is a chain of memory round trips, and with four passes per trip it took 14.8 us at K = 1024
+    constexpr int AB = NP < LASSO_BT16_ACCEPT_BATCH ? NP : LASSO_BT16_ACCEPT_BATCH;
+    static_assert(NP % AB == 0, "accept batch must divide the passes");
 #pragma unroll 1
-    for (int jb = 0; jb < NP; jb += 4) {        // four passes at a time: their 8 loads are in flight together
-      u32x4 gq[4];
-      float zo[4][8];
+    for (int jb = 0; jb < NP; jb += AB) {
+      u32x4 gq[AB], zq[AB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) gq[u] = load_g8(jb + u);
+      for (int u = 0; u < AB; ++u) gq[u] = load_g8(jb + u);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (it == 0) load_z8(Z0g, p.ldz0, z0vec, jb + u, zo[u]);
-        else load_z8(Zg, p.ldz, zvec, jb + u, zo[u]);
-      }
+      for (int u = 0; u < AB; ++u) zq[u] = it == 0 ? load_z8p(Z0g, p.ldz0, z0vec, jb + u) : load_z8p(Zg, p.ldz, zvec, jb + u);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < AB; ++u) {
         const int j = jb + u;
-        float pv[8], gv[8], zn[8], yn[8];
+        float pv[8], gv[8], zn[8], yn[8], zo1[8];
         lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
         unpack8(*pp, pv);
         unpack8(gq[u], gv);
+        unpack8(zq[u], zo1);
 #pragma unroll
         for (int e8 = 0; e8 < 8; ++e8) {
           zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
-          dsum += __builtin_fabsf(__fsub_rn(zo[u][e8], zn[e8]));                      // :93
-          yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo[u][e8])));  // :99-100
+          dsum += __builtin_fabsf(__fsub_rn(zo1[e8], zn[e8]));                        // :93
+          yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo1[e8])));    // :99-100
         }
         store_z8(j, zn);                                                              // :102
         *pp = pack8(yn);                                                              // next point, in place
@@ -586,6 +710,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     }
     iterations = it + 1;
     __syncthreads();                            // the p tile is complete for the next gradient
+    BT16_STAMP(10);
     if (p.budget >= 0.0f) {
       // global stop rule: one 8-byte granule per workgroup, swept by wave 0 of every workgroup
       dsum = wave_sum(dsum);

@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
 import torch  # noqa: E402
 
+if '--lib' in sys.argv:                       # an A/B build (tools/build_variant.sh)
+    from lasso_amd import _native as _nat
+    _nat.use_library(os.path.abspath(sys.argv[sys.argv.index('--lib') + 1]))
 from lasso_amd.linear.solvers import ista  # noqa: E402
 from recipes import recipe_xw  # noqa: E402
 
