@@ -461,9 +461,15 @@ hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int c
   return hipGetLastError();
 }
 
-// R = conv_transpose2d(rows Ym) - x :  GEMM into COLSt, then the gather
-hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
-                                const ConvGeom& g, hipStream_t stream) {
+// R = conv_transpose2d(rows Ym) - x :  one implicit-GEMM kernel, or GEMM into COLSt, then the gather
+// (w = the caller's weight [K][C][kh][kw]; null forces the explicit path)
+hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w, const float* x, float* colst, float* r,
+                                const ConvGeom& g, int cus, hipStream_t stream) {
+  if (w) {                                      // the implicit-GEMM kernel (conv_synth.hip) when the geometry is covered
+    bool done = false;
+    if (hipError_t e = launch_conv_synth(Ym, w, x, r, g, cus, &done, stream); e != hipSuccess) return e;
+    if (done) return hipSuccess;
+  }
   const int ckk = g.C * g.kh * g.kw;
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;
   hipError_t e = launch_gemm_nt_sub(Wt, g.K, Ym, g.K, nullptr, 0, colst, M, ckk, (int)M, g.K, stream, /*add=*/1);

@@ -1893,13 +1893,14 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   const float budget = (float)((double)M * (double)g.K * tol);     // ista.py:16, compared in fp32
   const float lr_f = (float)lr, lam = (float)(alpha * lr);
   const int cus = std::max(device_cus(), 1);
+  const float* const conv_w = (const float*)w_dev;
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
   for (; it < maxiter; ++it) {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
-    LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));   // :19
+    LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
     // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
     int dcount = 0;
     LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
@@ -1941,7 +1942,8 @@ int lasso_conv_objective(const void* x_dev, const void* w_dev, const void* z_dev
   const int64_t M = (int64_t)g.N * P;
   LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, ws.Wp, g.K, ckk, (ckk + 3) / 4 * 4, st));
   LASSO_HIP_TRY(launch_conv_relayout((const float*)z_dev, ws.Zm, g.N, g.K, P, 1, st));
-  LASSO_HIP_TRY(launch_conv_residual(ws.Zm, ws.Wt, (const float*)x_dev, ws.PT, ws.R, g, st));
+  LASSO_HIP_TRY(launch_conv_residual(ws.Zm, ws.Wt, (const float*)w_dev, (const float*)x_dev, ws.PT, ws.R, g,
+                                     std::max(device_cus(), 1), st));
   LASSO_HIP_TRY(launch_objective_reduce(ws.R, (int64_t)g.N * g.C * g.H * g.W, ws.Zm, g.K, (int)M, g.K, ws.dpart,
                                         kGenGrid, alpha, (double)g.N, ws.sums, loss_dev, st));
   return LASSO_OK;

@@ -217,8 +217,12 @@ hipError_t launch_bw_axpy(float* a, const float* b, float s1, const float* c, fl
                           hipStream_t stream);
 hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream);
 hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int ckk, int ldr, hipStream_t stream);
-hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* x, float* colst, float* r,
-                                const ConvGeom& g, hipStream_t stream);
+hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w, const float* x, float* colst, float* r,
+                                const ConvGeom& g, int cus, hipStream_t stream);
+// conv_synth.hip: the same residual as one implicit-GEMM kernel (stride 1, C <= 16, square kernels 3/5/7 with
+// an instantiated atom count); *done = false -> not covered
+hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
+                             bool* done, hipStream_t stream);
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
                                  hipStream_t stream);

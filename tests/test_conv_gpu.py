@@ -107,7 +107,15 @@ def test_auto_step_and_stop_rule(golden):
 
 @pytest.mark.parametrize("N,C,K,kh,kw,stride,padding,Hz,Wz", [
     (1, 1, 1, 1, 1, 1, 0, 1, 1), (2, 1, 3, 3, 5, (1, 2), (1, 0), 6, 5), (3, 2, 70, 3, 3, 1, 1, 10, 12),
-    (2, 5, 4, 5, 5, 3, 2, 4, 6), (64, 1, 32, 7, 7, 1, 0, 22, 22), (0, 1, 4, 3, 3, 1, 0, 5, 5)])
+    (2, 5, 4, 5, 5, 3, 2, 4, 6), (64, 1, 32, 7, 7, 1, 0, 22, 22), (0, 1, 4, 3, 3, 1, 0, 5, 5),
+    # 8 <= C <= 16, stride 1, square 3/5/7 kernels: the implicit-GEMM synthesis kernel (conv_synth.hip), every
+    # instantiation, image sizes that are not multiples of the 4 x 16 pixel tile, paddings 0 .. ks-1, K % 32 != 0
+    (2, 16, 256, 3, 3, 1, 1, 21, 35), (3, 8, 20, 3, 3, 1, 0, 9, 30), (2, 12, 64, 3, 3, 1, 2, 17, 18),
+    (2, 9, 100, 3, 3, 1, 1, 16, 16), (1, 16, 200, 3, 3, 1, 0, 7, 40), (2, 8, 32, 5, 5, 1, 2, 13, 19),
+    (2, 16, 64, 5, 5, 1, 0, 9, 21), (1, 10, 128, 5, 5, 1, 4, 12, 17), (2, 8, 24, 7, 7, 1, 3, 14, 20),
+    (1, 16, 64, 7, 7, 1, 0, 8, 25),
+    # same channel counts where it does not apply (stride 2, non-square kernel, C > 16): explicit path
+    (2, 16, 32, 3, 3, 2, 1, 8, 9), (2, 8, 16, 3, 5, 1, 1, 9, 9), (1, 17, 8, 3, 3, 1, 1, 6, 6)])
 def test_shapes_match_oracle(N, C, K, kh, kw, stride, padding, Hz, Wz):
     ista_conv2d, _, _, _, orc = _mods()
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
