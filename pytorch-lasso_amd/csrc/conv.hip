@@ -28,6 +28,7 @@ namespace lasso {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Zm[(n,u,v)][k] <- z[n][k][u][v]   (to_rows != 0)   or the inverse: per image a K x P
 // matrix transpose through a 32 x 33 LDS tile (both sides coalesced); blockIdx.z = image.
@@ -141,6 +142,8 @@ struct ConvGradProx {
   float* dpart;
   ConvGeom g;
   int TU, TV, tiles_u, tiles_v, RH, RW;
+  int tv_shift;                 // TV = 1 << tv_shift
+  float inv_plane, inv_rw;      // 1 / (RH RW), 1 / RW: exact index splits of e < 2^14 without integer division
 };
 constexpr int kCgpGtLd = 132;
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global
@@ -183,12 +186,17 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
   int base_p[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int pix = 16 * mt + l15, tu = pix / p.TV, tv = pix - tu * p.TV;
+    const int pix = 16 * mt + l15, tu = pix >> p.tv_shift, tv = pix & (p.TV - 1);
     base_p[mt] = tu * g.sh * p.RW + tv * g.sw;
   }
   const int tiles_img = p.tiles_u * p.tiles_v, ntiles = g.N * tiles_img;
   const int region = g.C * p.RH * p.RW, plane = p.RH * p.RW;
   const bool kvec = (K & 3) == 0;
+  // z, y rows through buffer descriptors: 32-bit offsets (the launcher checks M K 4 < 2^32), out-of-range pieces
+  // read as zero and are not written
+  const unsigned zbytes = (unsigned)((int64_t)g.N * g.Hz * g.Wz * K * 4);
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(p.Zm, 0, (int)zbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.Ym, 0, (int)zbytes, 0x00020000);
   float dsum = 0.0f;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / tiles_img, tt = tile - n * tiles_img;
@@ -206,7 +214,11 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         const int e = min(e0 + 256 * h, region - 1);
-        const int c = e / plane, rem = e - c * plane, rr = rem / p.RW, cc = rem - rr * p.RW;
+        // e = (c, rr, cc): floor((e + 1/2) / d) in fp32 is exact for e < 2^14 (the distance to the next integer
+        // is at least 1/(2d), the rounding error below 2e-3/d) -- two runtime integer divisions per element were
+        // a third of this kernel's instructions
+        const int c = (int)(((float)e + 0.5f) * p.inv_plane), rem = e - c * plane;
+        const int rr = (int)(((float)rem + 0.5f) * p.inv_rw), cc = rem - rr * p.RW;
         const int i = i0 + rr, j = j0 + cc;
         const float v = Rn[((int64_t)c * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)];
         sv[h] = v * ((i >= 0 && i < g.H && j >= 0 && j < g.W) ? 1.0f : 0.0f);
@@ -217,18 +229,20 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
     }
     // z, y of the tile do not depend on g: fetched now, so that the HBM latency runs under the MFMAs
     f32x4 zo[8], yo[8];
+    unsigned zoff[8];                                         // byte offset of this thread's pieces (~0u: outside -> reads 0, writes dropped)
     if (kvec) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
-        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
+        const int u = u0 + (pix >> p.tv_shift), v = v0 + (pix & (p.TV - 1));
         const int col = 128 * blockIdx.y + c4;
-        const int64_t off = (((int64_t)n * g.Hz + min(u, g.Hz - 1)) * g.Wz + min(v, g.Wz - 1)) * K + min(col, K - 4);
+        const bool ok = u < g.Hz && v < g.Wz && col < K;
+        zoff[h] = ok ? (unsigned)(((n * g.Hz + u) * g.Wz + v) * K + col) * 4u : ~0u;
 #ifdef LASSO_ABL_CONV_NOMEM    // timing ablation only (results invalid)
-        zo[h] = (f32x4){0.f, 0.f, 0.f, (float)off}; yo[h] = zo[h];
+        zo[h] = (f32x4){0.f, 0.f, 0.f, (float)zoff[h]}; yo[h] = zo[h];
 #else
-        zo[h] = *(const f32x4*)(p.Zm + off);
-        yo[h] = *(const f32x4*)(p.Ym + off);
+        zo[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zoff[h], 0, 0));
+        yo[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, zoff[h], 0, 0));
 #endif
       }
     }
@@ -260,10 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
-        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
-        const int col = 128 * blockIdx.y + c4;
-        const bool ok = u < g.Hz && v < g.Wz && col < K;
-        const int64_t off = (((int64_t)n * g.Hz + min(u, g.Hz - 1)) * g.Wz + min(v, g.Wz - 1)) * K + min(col, K - 4);
+        const bool ok = zoff[h] != ~0u;
         const f32x4 gv = *(const f32x4*)(Gt + pix * kCgpGtLd + c4);
         f32x4 zn, yn;
         float ds = 0.0f;
@@ -279,15 +290,15 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
 #else
         if (ok) {
           dsum += ds;
-          *(f32x4*)(p.Zm + off) = zn;
-          *(f32x4*)(p.Ym + off) = yn;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zn), zrsrc, zoff[h], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yn), yrsrc, zoff[h], 0, 0);
         }
 #endif
       }
     } else {
       for (int idx = tid; idx < 64 * 32; idx += 256) {
         const int pix = idx >> 5, c4 = (idx & 31) * 4;
-        const int tu = pix / p.TV, tv = pix - tu * p.TV, u = u0 + tu, v = v0 + tv;
+        const int u = u0 + (pix >> p.tv_shift), v = v0 + (pix & (p.TV - 1));
         const int col = 128 * blockIdx.y + c4;
         if (u >= g.Hz || v >= g.Wz || col >= K) continue;
         const int64_t m = ((int64_t)n * g.Hz + u) * g.Wz + v;
@@ -505,6 +516,10 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   p.RH = (p.TU - 1) * g.sh + g.kh;
   p.RW = (p.TV - 1) * g.sw + g.kw;
   if ((int64_t)g.C * p.RH * p.RW > 16384) return hipSuccess;
+  p.tv_shift = p.TV == 64 ? 6 : p.TV == 32 ? 5 : p.TV == 16 ? 4 : 3;
+  p.inv_plane = 1.0f / (float)(p.RH * p.RW);
+  p.inv_rw = 1.0f / (float)p.RW;
+  if ((int64_t)g.N * g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31)) return hipSuccess;   // 32-bit row offsets in the kernel
   p.tiles_u = (g.Hz + p.TU - 1) / p.TU;
   p.tiles_v = (g.Wz + p.TV - 1) / p.TV;
   p.R = r; p.Wp = Wp; p.ldr = ldr; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
