@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LASSO_HIP_ABI_VERSION 2
+#define LASSO_HIP_ABI_VERSION 3
 
 typedef enum {
   LASSO_OK = 0,
@@ -372,6 +372,17 @@ int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int6
                          int64_t n, int64_t d, int64_t k, int dtype, double lr, int fast, int iterations,
                          void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same with one step size per iteration: lr_steps_host[i] (HOST array, `iterations` entries) is the
+ * step iteration i was taken with -- the derivative of a line-search solve (ista.py:17-54: the accepted
+ * step is a python float, i.e. a constant of the autograd graph; lasso_fista_solve reports the steps in
+ * accepted_lr_out[], lasso_fista_run replays them one iteration per call to produce the trace).
+ * lr_steps_host == NULL: every iteration used `lr`. */
+int lasso_fista_backward_steps(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                               const void* trace_dev, const void* grad_z_dev,
+                               int64_t n, int64_t d, int64_t k, int dtype, double lr,
+                               const float* lr_steps_host, int fast, int iterations,
+                               void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
+                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- patch front end: image -> patches -> centre -> dict_learning ->
  * reconstruct.  The reference's notebook that did this (examples/dict_learning_omniglot.ipynb)

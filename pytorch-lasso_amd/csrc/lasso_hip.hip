@@ -2023,6 +2023,16 @@ int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int6
                          const void* grad_z_dev, int64_t n, int64_t d, int64_t k, int dtype, double lr, int fast,
                          int iterations, void* grad_x_dev, void* grad_w_dev, void* grad_z0_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return lasso_fista_backward_steps(x_dev, ldx, w_dev, ldw, trace_dev, grad_z_dev, n, d, k, dtype, lr, nullptr, fast,
+                                    iterations, grad_x_dev, grad_w_dev, grad_z0_dev, workspace_dev, workspace_bytes,
+                                    stream);
+}
+
+int lasso_fista_backward_steps(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw, const void* trace_dev,
+                               const void* grad_z_dev, int64_t n, int64_t d, int64_t k, int dtype, double lr,
+                               const float* lr_steps_host, int fast, int iterations, void* grad_x_dev,
+                               void* grad_w_dev, void* grad_z0_dev, void* workspace_dev, size_t workspace_bytes,
+                               void* stream) {
   if (int s = check_common(n, d, k, dtype, /*allow_large=*/true)) return s;
   if (!x_dev || !w_dev || !trace_dev || !grad_z_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (ldx < d || ldw < k || iterations < 0) return fail(LASSO_ERR_BAD_ARG, "bad argument");
@@ -2061,7 +2071,8 @@ int lasso_fista_backward(const void* x_dev, int64_t ldx, const void* w_dev, int6
     const float* z_next = trace + (int64_t)(i + 1) * nk;
     const float* z_i = trace + (int64_t)i * nk;
     // c_i formed y_{i+1}; for the last iteration y_{i+1} was never used (yb == 0)
-    LASSO_HIP_TRY(launch_bw_prox(zb_next, zb_cur, ws.yb, z_next, ws.ub, ws.gb, nk, coef[i], (float)lr, st));
+    LASSO_HIP_TRY(launch_bw_prox(zb_next, zb_cur, ws.yb, z_next, ws.ub, ws.gb, nk, coef[i],
+                                 lr_steps_host ? lr_steps_host[i] : (float)lr, st));
     // the point of iteration i:  y_i = z_i + c_{i-1} (z_i - z_{i-1}),  y_0 = z_0
     LASSO_HIP_TRY(launch_bw_point(z_i, (i > 0 && fast) ? trace + (int64_t)(i - 1) * nk : nullptr, ws.y, nk,
                                   i > 0 ? coef[i - 1] : 0.0f, st));

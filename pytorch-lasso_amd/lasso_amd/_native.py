@@ -16,7 +16,7 @@ LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
 LR_AUTO = -1.0
@@ -136,6 +136,9 @@ def _declare(lib):
     lib.lasso_fista_backward.restype = i32
     lib.lasso_fista_backward.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, dbl, i32, i32,
                                          vp, vp, vp, vp, sz, vp]
+    lib.lasso_fista_backward_steps.restype = i32
+    lib.lasso_fista_backward_steps.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i32, dbl, C.POINTER(C.c_float),
+                                               i32, i32, vp, vp, vp, vp, sz, vp]
     lib.lasso_patches_extract.restype = i32
     lib.lasso_patches_extract.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp]
     lib.lasso_patches_reconstruct.restype = i32

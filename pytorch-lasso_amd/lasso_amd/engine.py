@@ -173,8 +173,9 @@ class HipEngine:
         return z, y, delta
 
     def fista_backward(self, X, W, trace, grad_z, lr, fast, need_x, need_w, need_z0):
-        """Reverse pass through the unrolled fixed-step solve (lasso_fista_backward);
-        trace [T+1,n,k] holds z_0..z_T.  Returns (gx, gw, gz0), None where not needed."""
+        """Reverse pass through the unrolled solve (lasso_fista_backward_steps); trace [T+1,n,k] holds
+        z_0..z_T, `lr` is the step or the list of the T steps of a line-search solve.
+        Returns (gx, gw, gz0), None where not needed."""
         n, d = X.shape
         k = W.shape[1]
         T = trace.shape[0] - 1
@@ -184,10 +185,15 @@ class HipEngine:
             gx = torch.empty((n, d), dtype=torch.float32, device=self.device) if need_x else None
             gw = torch.empty((d, k), dtype=torch.float32, device=self.device) if need_w else None
             gz0 = torch.empty((n, k), dtype=torch.float32, device=self.device) if need_z0 else None
-            nat.check(L.lasso_fista_backward(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0), nat.ptr(trace),
-                                             nat.ptr(grad_z), n, d, k, nat.LASSO_F32, float(lr), int(bool(fast)),
-                                             int(T), nat.ptr(gx), nat.ptr(gw), nat.ptr(gz0), nat.ptr(ws),
-                                             ws.numel(), self._stream()))
+            steps = None
+            if isinstance(lr, (list, tuple)):
+                if len(lr) != T:
+                    raise ValueError("fista_backward: %d steps for %d iterations" % (len(lr), T))
+                steps, lr = (C.c_float * max(T, 1))(*lr), (lr[0] if T else 1.0)
+            nat.check(L.lasso_fista_backward_steps(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0), nat.ptr(trace),
+                                                   nat.ptr(grad_z), n, d, k, nat.LASSO_F32, float(lr), steps,
+                                                   int(bool(fast)), int(T), nat.ptr(gx), nat.ptr(gw), nat.ptr(gz0),
+                                                   nat.ptr(ws), ws.numel(), self._stream()))
         return gx, gw, gz0
 
     # -- objective ---------------------------------------------------------------

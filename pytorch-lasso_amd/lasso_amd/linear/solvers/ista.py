@@ -52,10 +52,12 @@ def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
 
 
 class _UnrolledIsta(torch.autograd.Function):
-    """Differentiable fixed-step solve: the reference's loop is plain
-    torch code, so torch.autograd differentiates through its unrolled iterations
-    (ista.py:79-102).  Forward: the HIP kernel one iteration per launch, keeping the
-    iterates z_0..z_T; backward: lasso_fista_backward (csrc/autograd.hip)."""
+    """Differentiable solve: the reference's loop is plain torch code, so
+    torch.autograd differentiates through its unrolled iterations (ista.py:79-102).  Forward: the
+    HIP kernel one iteration per launch, keeping the iterates z_0..z_T; backward:
+    lasso_fista_backward_steps (csrc/autograd.hip).  `lr` is the fixed step, or the list of the
+    steps a line-search solve accepted (ista.py:17-54: python floats, constants of the graph) --
+    then exactly len(lr) iterations are replayed."""
 
     @staticmethod
     def forward(ctx, x, z0, weight, alpha, fast, lr, maxiter, tol):
@@ -80,8 +82,8 @@ class _UnrolledIsta(torch.autograd.Function):
                 src, cur, pos = cur[pos], nxt, -1
             else:
                 src = cur[pos]
-            _, y, delta = eng.fista_run(xg, wg, src, y, alpha, lr, fast, it, 1, tol > 0, ws=ws,
-                                        z_out=cur[pos + 1])
+            _, y, delta = eng.fista_run(xg, wg, src, y, alpha, lr[it] if isinstance(lr, list) else lr, fast, it, 1,
+                                        tol > 0, ws=ws, z_out=cur[pos + 1])
             pos += 1
             done = it + 1
             if tol > 0 and delta[0].item() <= budget:                    # ista.py:93-95
@@ -223,10 +225,21 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
 
     if wants_grad:
         # differentiable path (the reference's loop is autograd-traceable, README "autograd")
-        if backtrack:
-            raise NotImplementedError("lasso_amd: autograd through the backtracking line search is not implemented")
         if not (x.is_cuda and weight.is_cuda and z0.is_cuda):
             raise NotImplementedError("lasso_amd: the differentiable path needs x, weight, z0 on the HIP device")
+        if x.dtype != torch.float32 or weight.dtype != torch.float32:
+            raise NotImplementedError("lasso_amd: the differentiable path computes in float32")
+        if backtrack:
+            # the line search picks the steps (one ordinary solve, no graph); the accepted steps are constants of the
+            # reference's graph (python floats, ista.py:40,47), so the derivative is that of the replayed iterations
+            _, binfo = _solve_native(xg, zg if zg is not None else z0, wg, alpha, fast, lr, maxiter, tol, True,
+                                     eta_backtrack, False, True, out_device=dev, stop_mode=stop_mode, kernel=kernel)
+            steps = [float(v) for v in binfo['accepted_lr']]
+            z = _UnrolledIsta.apply(x, z0, weight, float(alpha), bool(fast), steps, len(steps), 0.0)
+            if begin:
+                return z, None
+            return (z, dict(iterations=binfo['iterations'], last_delta=binfo['last_delta'], trials=binfo['trials'],
+                            accepted_lr=steps)) if return_info else z
         z = _UnrolledIsta.apply(x, z0, weight, float(alpha), bool(fast), lr, int(maxiter), float(tol))
         if begin:
             return z, None

@@ -72,11 +72,32 @@ def test_early_stop_and_partial_requires_grad():
         assert not sparse_encode(X.cuda(), w, alpha=0.5, lr=lr, maxiter=5, tol=0.0).requires_grad
 
 
+@pytest.mark.parametrize("n,d,k", [(37, 10, 50), (64, 256, 1024), (40, 300, 70)])   # the last: beyond the fused shapes
+@pytest.mark.parametrize("fast", [True, False])
+def test_gradients_through_the_line_search(n, d, k, fast):
+    """backtrack=True (ista.py:17-54): the accepted steps are python floats, i.e. constants of the reference's
+    graph; the derivative is that of the iterations taken with those steps."""
+    _, ista, orc = _mods()
+    X, W, Z0, G = _problem(n, d, k, seed=5)
+    trace = orc.FistaTrace()
+    orc.fista(X, Z0, W, 0.3, fast=fast, lr=1.0, maxiter=5, tol=0.0, backtrack=True, trace=trace)
+    assert max(trace.trials) > 1                      # the search really shrinks the step
+    ref = _grads(lambda x, z0, w: orc.fista(x, z0, w, 0.3, fast=fast, lr=1.0, maxiter=5, tol=0.0, backtrack=True),
+                 X, W, Z0, G, "cpu")
+    got = _grads(lambda x, z0, w: ista(x, z0, w, 0.3, fast=fast, lr=1.0, maxiter=5, tol=0.0, backtrack=True),
+                 X, W, Z0, G, "cuda")
+    assert (got[0] - ref[0]).abs().max().item() <= 5e-5
+    for name, a, b in zip(("dx", "dW", "dz0"), got[1:], ref[1:]):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-3), name
+    # return_info reports the search next to a result that carries the graph
+    x = X.cuda().requires_grad_(True)
+    z, info = ista(x, Z0.cuda(), W.cuda(), 0.3, fast=fast, lr=1.0, maxiter=5, tol=0.0, backtrack=True, return_info=True)
+    assert z.requires_grad and info["trials"] == trace.trials
+    assert max(abs(a - b) for a, b in zip(info["accepted_lr"], trace.accepted_lr)) <= 1e-6
+
+
 def test_unsupported_combinations_fail_loudly():
     _, ista, _ = _mods()
     X, W, Z0, _ = _problem(8, 16, 32)
-    w = W.cuda().requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        ista(X.cuda(), Z0.cuda(), w, 0.3, lr=1.0, maxiter=3, backtrack=True)
     with pytest.raises(NotImplementedError):
         ista(X, Z0, W.clone().requires_grad_(True), 0.3, lr=0.1, maxiter=3)      # CPU tensors
