@@ -24,8 +24,8 @@
  *     (fixed step, and the line search on fp32 tensors), lasso_objective and
  *     lasso_gram_accumulate take any d, k (unfused MFMA GEMM paths), lasso_dict_sweep
  *     d <= 1024 and k <= 4096, lasso_cd_* k <= 4096; lasso_fista_prepare/_run take any
- *     d, k too (unfused: state in HBM, kernel_hint ignored); lasso_fista_solve_sharded is
- *     fused-shape only (LASSO_ERR_UNSUPPORTED otherwise).
+ *     d, k too (unfused: state in HBM, kernel_hint ignored); lasso_fista_solve_sharded takes
+ *     any d, k on fp32 tensors (bf16: fused shapes only).
  */
 #ifndef LASSO_HIP_H_
 #define LASSO_HIP_H_

@@ -744,6 +744,7 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
 constexpr int kGenGrid = 1024;
 struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; float* delta;
                       float* C; float* part; int* flags; float* fvals;      // line search only
+                      double* sums;                                         // (its five sums of a trial: row shards)
                       float* Wc;                                            // [d][k] copy of W (lasso_fista_prepare / _run)
                       size_t bytes; };
 
@@ -763,12 +764,13 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool bac
   w.G = take((size_t)n * k * 4);
   w.dpart = take((size_t)kGenGrid * 4);
   w.delta = take(256);
-  w.C = w.part = w.fvals = nullptr; w.flags = nullptr;
+  w.C = w.part = w.fvals = nullptr; w.flags = nullptr; w.sums = nullptr;
   if (backtrack) {
     w.C = take((size_t)n * k * 4);
     w.part = take((size_t)5 * kGenGrid * 4);
     w.flags = reinterpret_cast<int*>(take(256));
     w.fvals = take(256);
+    w.sums = reinterpret_cast<double*>(take(256));
   }
   w.bytes = off;
   return w;
@@ -864,7 +866,10 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
                                int64_t ldz0, float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, double alpha,
                                double lr0, int fast, int maxiter, double tol, double eta, int32_t* iters_out,
                                float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
-                               float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st) {
+                               float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st,
+                               lasso_allreduce_fn reduce = nullptr, void* reduce_ctx = nullptr, int64_t n_global = 0) {
+  // reduce != nullptr: a row shard -- the five sums of every trial and sum|z - z+| are added over the ranks and the
+  // decision of bt_decide_kernel is taken on the host, as in solve_backtracking
   GenWorkspace ws = carve_generic(workspace, n, d, k, true);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   if (n > INT32_MAX || d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
@@ -878,7 +883,7 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
   LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
   BtParams bp;                                             // only what bt_decide_kernel reads
   bp.partials = ws.part; bp.ntiles = kGenGrid; bp.flags = ws.flags; bp.fvals = ws.fvals;
-  const float budget = (float)((double)n * (double)k * tol);
+  const float budget = (float)((double)(reduce ? n_global : n) * (double)k * tol);
   bool warned = false;
   double t_mom = 1.0;
   float last = NAN;
@@ -901,10 +906,30 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
                                          kGenGrid, st));                                // :40, :31-35
       LASSO_HIP_TRY(launch_gemm_nt_sub(ws.C, k, w, ldw, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));   // :27
       LASSO_HIP_TRY(launch_sumsq_partials(ws.NR, n * d, ws.part + kGenGrid, kGenGrid, st));
-      LASSO_HIP_TRY(launch_bt_decide(bp, alpha, lr_t, t, give_up ? 1 : 0, st));         // :28, :32-35, :45
-      LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, sizeof(host.flags), hipMemcpyDeviceToHost, st));
-      LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, sizeof(host.fvals), hipMemcpyDeviceToHost, st));
-      LASSO_HIP_TRY(hipStreamSynchronize(st));
+      LASSO_HIP_TRY(launch_bt_decide(bp, alpha, lr_t, t, give_up ? 1 : 0, st, reduce ? ws.sums : nullptr));   // :28, :32-35, :45
+      if (reduce) {
+        double hs[5];
+        LASSO_HIP_TRY(hipMemcpyAsync(hs, ws.sums, sizeof(hs), hipMemcpyDeviceToHost, st));
+        LASSO_HIP_TRY(hipStreamSynchronize(st));
+        if (reduce(reduce_ctx, hs, 5) != 0) return fail(LASSO_ERR_HIP, "all-reduce callback failed");
+        const float rss0 = (float)hs[0], rss1 = (float)hs[1], l1 = (float)hs[2], dzg = (float)hs[3], dz2 = (float)hs[4];
+        const float f0 = 0.5f * rss0, al1 = (float)alpha * l1;                          // ista.py:23
+        const float F = 0.5f * rss1 + al1;                                              // :28
+        const float Q = ((f0 + dzg) + (float)(0.5 / lr_t) * dz2) + al1;                 // :32-35
+        memset(&host, 0, sizeof(host));
+        host.fvals[0] = F; host.fvals[1] = Q; host.flags[1] = t + 1;
+        if (give_up || F <= Q) {                                                        // :45
+          host.flags[0] = 1; host.flags[2] = t;
+          host.fvals[2] = (float)lr_t; host.fvals[3] = (float)(alpha * lr_t);
+        }
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.flags, host.flags, sizeof(host.flags), hipMemcpyHostToDevice, st));
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.fvals, host.fvals, sizeof(host.fvals), hipMemcpyHostToDevice, st));
+        LASSO_HIP_TRY(hipStreamSynchronize(st));
+      } else {
+        LASSO_HIP_TRY(hipMemcpyAsync(host.flags, ws.flags, sizeof(host.flags), hipMemcpyDeviceToHost, st));
+        LASSO_HIP_TRY(hipMemcpyAsync(host.fvals, ws.fvals, sizeof(host.fvals), hipMemcpyDeviceToHost, st));
+        LASSO_HIP_TRY(hipStreamSynchronize(st));
+      }
       if (give_up) warned = true;
       if (host.flags[0]) { accepted_at = t; break; }
       lr = lr / eta;                                                                    // :47
@@ -915,6 +940,11 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
     LASSO_HIP_TRY(hipGetLastError());
     LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
+    if (reduce) {                                    // sum |z_next - z| over all ranks (:93)
+      double dsum = (double)last;
+      if (reduce(reduce_ctx, &dsum, 1) != 0) return fail(LASSO_ERR_HIP, "all-reduce callback failed");
+      last = (float)dsum;
+    }
     if (trials_out) trials_out[it] = accepted_at + 1;
     if (accepted_lr_out) accepted_lr_out[it] = host.fvals[2];
     if (accepted_f_out) accepted_f_out[it] = host.fvals[0];
@@ -1481,11 +1511,19 @@ int lasso_fista_solve_sharded(const void* x_dev, int64_t ldx, const void* w_dev,
   if (dtype != LASSO_F32 && dtype != LASSO_BF16) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!reduce) return fail(LASSO_ERR_BAD_ARG, "reduce callback is null");
   if (n <= 0 || n_global < n || d <= 0 || k <= 0 || maxiter <= 0) return fail(LASSO_ERR_BAD_ARG, "bad shape");
-  if (!fused_shape(d, k)) return fail(LASSO_ERR_UNSUPPORTED, "line search needs d<=%d, k<=%d", kFistaD, kFistaMaxK);
   if (!x_dev || !w_dev || !z_out_dev || !workspace_dev) return fail(LASSO_ERR_BAD_ARG, "null pointer");
   if (ldx < d || ldw < k || ldz < k || (z0_dev && ldz0 < k)) return fail(LASSO_ERR_BAD_ARG, "leading dimension too small");
   if (!(lr > 0.0) || !(alpha >= 0.0)) return fail(LASSO_ERR_BAD_ARG, "need lr > 0 and alpha >= 0");
   if (!(eta_backtrack > 1.0)) return fail(LASSO_ERR_BAD_ARG, "eta must be > 1.");
+  if (!fused_shape(d, k)) {                     // beyond the fused shapes: the unfused line search (fp32 tensors)
+    if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "bf16 line search needs d<=%d, k<=%d", kFistaD, kFistaMaxK);
+    if (iters_out) *iters_out = 0;
+    if (last_delta_out) *last_delta_out = NAN;
+    return solve_generic_backtracking((const float*)x_dev, ldx, (const float*)w_dev, ldw, (const float*)z0_dev, ldz0,
+                                      (float*)z_out_dev, ldz, n, d, k, alpha, lr, fast, maxiter, tol, eta_backtrack,
+                                      iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out,
+                                      workspace_dev, workspace_bytes, (hipStream_t)stream, reduce, reduce_ctx, n_global);
+  }
   if (n > (int64_t)INT32_MAX - kTileM) return fail(LASSO_ERR_UNSUPPORTED, "n too large");
   if (iters_out) *iters_out = 0;
   if (last_delta_out) *last_delta_out = NAN;
