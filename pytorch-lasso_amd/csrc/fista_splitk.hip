@@ -32,6 +32,17 @@
 // on the one-workgroup-per-tile kernel.
 #include "tile_device.hpp"
 
+#ifdef LASSO_SPLITK_TIMING
+// debug build (tools/splitk_timeline.py): wall-clock stamps of ONE iteration, 32 per workgroup
+__device__ unsigned long long lasso_splitk_stamps[2048 * 32];
+extern "C" int lasso_debug_splitk_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_splitk_stamps), sizeof(lasso_splitk_stamps));
+}
+#define SK_STAMP(slot) do { if (it == LASSO_SPLITK_TIMING && tid == 0) lasso_splitk_stamps[blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SK_STAMP(slot) do { } while (0)
+#endif
+
 namespace lasso {
 namespace splitk {
 
@@ -218,6 +229,15 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       const unsigned par_off = (epoch & 1u) * parity_stride;
 
       // ============ GEMM-1 of every tile: p_mem = y[:, slice] W[:, slice]^T (- x), published ====
+      SK_STAMP(0);
+      int pending = -1;                                  // tile whose partial is stored but not yet flagged
+      auto raise_flag = [&](int tp) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in the XCD's L2 / written through
+        if (lane == 0) {
+          if (local) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off + tp * 4, 0, 0);
+          else __hip_atomic_store(my_flag + tp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
       static_for<T>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         if (t < nt) {
@@ -240,23 +260,25 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
                 for (int cb = 0; cb < 2; ++cb)
                   acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b1[s][ss][cb][jj], acc[cb], 0, 0, 0);
           }
-          // publish: two 16-byte stores per lane, drained, then the wave's flag for this slot
+          // publish: two 16-byte stores per lane; they drain under the NEXT tile's MFMAs, only then the wave's
+          // flag for this slot goes out (the drain of the last tile is the only one that is waited for in the open)
+          SK_STAMP(1 + t);                               // tile t: GEMM-1 issued
+          if (pending >= 0) raise_flag(pending);
+      SK_STAMP(5);                                       // all partials flagged
           const unsigned dst = my_part + par_off + t * (C * kPartBytes);
           if (local) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
               __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // in the XCD's L2
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off + t * 4, 0, 0);
           } else {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
               __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 16);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through
-            if (lane == 0) __hip_atomic_store(my_flag + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          pending = t;
         }
       });
+      if (pending >= 0) raise_flag(pending);
 
       // in-kernel stop rule: fetch the previous iteration's |dz| granules (one per workgroup)
       // now, look at them once the first tile's partials have arrived
@@ -274,30 +296,33 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       float dsum = 0.0f;
       bool leave = false;
       // ============ per tile: gather the partials, r, GEMM-2 on the wave's 16 atoms, prox ========
+      // ONE poll for the flags of all T tiles (lane = peer + C * tile: the same wave of every peer, L1-bypassing):
+      // a poll is a round trip of 0.8 us even when the flags are long set (tools/splitk_timeline.py).
+      {
+        int spins = 0;
+        bool ok;
+        const int fpeer = lane & (C - 1), ftile = lane / C;
+        do {
+          unsigned v = epoch;
+          if (ftile < nt && fpeer != mem)
+            v = __hip_atomic_load(peer_flag + (size_t)fpeer * NW * T + ftile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = __all(v == epoch);
+          if (!ok) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63) == 63 &&
+                __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+              break;
+          }
+        } while (!ok && ++spins < kStopSpinLimit * 4);
+        if (!ok && lane == 0) {       // a peer is not resident: the whole grid gives up
+          __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          red[NW + 2] = 1.0f;
+        }
+      }
+      SK_STAMP(6);                                         // flags of every tile seen
       static_for<T>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         if (t < nt && !leave) {
-          // wait for the same wave of every peer (L1-bypassing polls), then read their partials
-          {
-            int spins = 0;
-            bool ok;
-            do {
-              unsigned v = epoch;
-              if (lane < C && lane != mem)
-                v = __hip_atomic_load(peer_flag + (size_t)lane * NW * T + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok = __all(v == epoch);
-              if (!ok) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 63) == 63 &&
-                    __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                  break;
-              }
-            } while (!ok && ++spins < kStopSpinLimit * 4);
-            if (!ok && lane == 0) {       // a peer is not resident: the whole grid gives up
-              __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              red[NW + 2] = 1.0f;
-            }
-          }
           if (t == 0 && STOP && check && wid == 0) {
             const unsigned want = (unsigned)it;
             float partsum = 0.0f;
@@ -352,6 +377,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
                 for (int rg = 0; rg < 4; ++rg) rsum[cb][rg] = __fadd_rn(rsum[cb][rg], part[pe][cb][rg]);
             }
           });
+          SK_STAMP(7 + 5 * t);                           // partials summed
           lds_char* const rbuf = rt + (t & 1) * RT_BYTES;
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb)
@@ -360,6 +386,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
               *(lds_f32*)(rbuf + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = rsum[cb][rg];
           LASSO_WAIT_LGKM0();
           __builtin_amdgcn_s_barrier();                  // r tile complete (and, at t = 0, the verdicts)
+          SK_STAMP(8 + 5 * t);
           if (red[NW + 2] != 0.0f || (t == 0 && STOP && check && red[NW] == 2.0f)) {
             aborted = true;
             leave = true;
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
                 for (int jj = 0; jj < 4; ++jj)
                   g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b2[tt][ss][jj], g2, 0, 0, 0);
             }
+            SK_STAMP(9 + 5 * t);                         // GEMM-2 issued
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               lds_f32* const yp = (lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n));
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
           }
         }
       });
+      SK_STAMP(26);
       if (leave) break;
       dsum = wave_sum(dsum);
       if (lane == 0) red[wid] = dsum;
