@@ -270,7 +270,7 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 // split-k kernel with T tiles per group runs ceil(ntiles / (groups * T)) rounds of split_us[T].
 struct KernelCost { double tile_us, split_us[3]; };   // split_us: T = 1, 2, 4
 KernelCost kernel_cost(int kp) {
-  if (kp >= 1024) return {31.0, {5.9, 10.7, 20.7}};
+  if (kp >= 1024) return {31.0, {5.9, 10.7, 20.0}};
   if (kp >= 512) return {15.9, {5.45, 9.9, 19.4}};
   return {8.3, {5.2, 9.6, 18.9}};
 }
@@ -301,7 +301,11 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bit
     const int groups = std::min(gmax, (ntiles + T - 1) / T);
     const int rounds = (ntiles + groups * T - 1) / (groups * T);
     if (lockstep && rounds > 1) continue;             // the in-kernel stop rule needs every tile in a resident slot
-    const double us = cost.split_us[ti] * rounds;
+    // the kernel's cost is linear in the tile slots a group works on, and the last round may fill fewer of them
+    const int last_tiles = ntiles - (rounds - 1) * groups * T, last_slots = (last_tiles + groups - 1) / groups;
+    const double slot_us[5] = {0.0, cost.split_us[0], cost.split_us[1], 0.5 * (cost.split_us[1] + cost.split_us[2]),
+                               cost.split_us[2]};
+    const double us = cost.split_us[ti] * (rounds - 1) + slot_us[std::min(last_slots, 4)];
     if (us < best) { best = us; plan.split = true; plan.groups = groups; plan.tiles = T; }
   }
   return plan;
