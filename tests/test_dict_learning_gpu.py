@@ -358,3 +358,29 @@ def test_atom_sweep_and_ridge_survive_a_busy_gpu():
         torch.cuda.synchronize()
         assert torch.equal(D, Dref), trial
         assert torch.equal(V, Vref), trial
+
+
+@pytest.mark.parametrize("n,d,k", [(4096, 256, 256), (4097, 256, 1024), (9000, 512, 512), (8192, 256, 768),
+                                   (5000, 256, 2048), (4095, 256, 1024), (6001, 300, 1024), (70000, 256, 1024)])
+def test_gram_products_against_fp64(n, d, k):
+    """Z^T Z and Z^T X of the M-step (dict_learning.py:69-70,117-118) on every path of lasso_gram_accumulate: the
+    one-launch [A | B] kernel on 256 x 256 blocks (k, d multiples of 256, n >= 4096; ragged n, several split
+    counts), the 128-block kernels otherwise.  A exactly symmetric, bitwise reproducible, <= 2e-6 of the fp64
+    products."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    g = torch.Generator().manual_seed(n + k)
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.15)).cuda()
+    X = torch.randn(n, d, generator=g).cuda()
+    A, B = eng.gram(Z, X, torch.empty(k * k + k * d, device="cuda"))
+    A2, B2 = eng.gram(Z, X, torch.empty(k * k + k * d, device="cuda"))
+    assert torch.equal(A, A2) and torch.equal(B, B2)
+    assert torch.equal(A, A.T)
+    Ar, Br = Z.double().T @ Z.double(), Z.double().T @ X.double()
+    assert ((A.double() - Ar).abs().max() / Ar.abs().max()).item() <= 2e-6
+    assert ((B.double() - Br).abs().max() / Br.abs().max()).item() <= 2e-6
+    # a strided view of the samples (leading dimension > k)
+    Zs = torch.zeros(n, k + 8, device="cuda")[:, :k]
+    Zs.copy_(Z)
+    A3, B3 = eng.gram(Zs, X, torch.empty(k * k + k * d, device="cuda"))
+    assert torch.equal(A3, A) and torch.equal(B3, B)
