@@ -110,16 +110,10 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
     const int row0 = tile * kTileM;
     float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
     const bool gvec = vec4_ok(p.G, p.k, p.k);   // G and C are internal [n][k] buffers
-    visit_tile4<K, kFistaThreads>(p.P, p.ldp, row0, p.n, p.k, [&](int r, int cc, const f32x4& pv) {
+    // p and g of the tile: all 16 pieces of a thread in flight together (one memory round trip per tile)
+    visit_tile4x2<K, kFistaThreads>(p.P, p.ldp, p.G, p.k, row0, p.n, p.k, [&](int r, int cc, const f32x4& pv, const f32x4& g) {
       f32x4 zn = {0.f, 0.f, 0.f, 0.f};
       if ((row0 + r) < p.n && cc < p.k) {
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        const float* gp = p.G + (int64_t)(row0 + r) * p.k + cc;
-        if (gvec) g = *reinterpret_cast<const f32x4*>(gp);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (cc + e < p.k) g[e] = gp[e];
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (cc + e < p.k) {

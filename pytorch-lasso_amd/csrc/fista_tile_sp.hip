@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fista_tile_sp_kernel(const FistaTi
     {
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
-      visit_tile4<K, NT, M>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
+      // (rolled loads: once per tile and launch, and the batched form costs this kernel registers it does not have)
+      visit_tile4<K, NT, M, false>(ysrc, ldy, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
         *(lds_f32x4*)(yt + tile_chunk_off<K>(r, cc)) = v;
       });
     }

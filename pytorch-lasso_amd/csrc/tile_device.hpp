@@ -88,10 +88,31 @@ __device__ __forceinline__ void dma_step(const float* src, const unsigned (&voff
 // f(r, c, v) with c a multiple of 4 and v = src[row0+r][c..c+3] (0 beyond n / k).  Uses
 // 16-byte loads when the layout allows (k, ld multiples of 4 and a 16-B aligned base),
 // else masked scalar loads.  K is the padded tile width, NT the workgroup size.
-template <int K, int NT, int ROWS = kTileM, typename F>
+template <int K, int NT, int ROWS = kTileM, bool BATCH = true, typename F>
 __device__ __forceinline__ void visit_tile4(const float* __restrict__ src, int64_t ld, int row0, int n,
                                             int k, F&& f) {
   const bool vec = src && (k & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)src) & 15) == 0;
+  if constexpr (BATCH && (ROWS * (K / 4)) % NT == 0 && ROWS * (K / 4) / NT <= 16) {
+    // The usual case: ALL of the thread's 16-byte loads are issued before the first one is used (clamped
+    // addresses, values masked afterwards).  As a rolled loop with the loads under their bounds checks this was
+    // one memory round trip per piece -- eight in a row per 16 x 1024 tile.
+    if (vec && n > 0 && k >= 4) {
+      constexpr int ITER = ROWS * (K / 4) / NT;
+      f32x4 v[ITER];
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int idx = threadIdx.x + NT * i, r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+        v[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(row0 + r, n - 1) * ld + min(c, k - 4));
+      }
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int idx = threadIdx.x + NT * i, r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+        const bool ok = (row0 + r) < n && c < k;
+        f(r, c, ok ? v[i] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+      return;
+    }
+  }
   for (int idx = threadIdx.x; idx < ROWS * (K / 4); idx += NT) {
     const int r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -106,6 +127,49 @@ __device__ __forceinline__ void visit_tile4(const float* __restrict__ src, int64
       }
     }
     f(r, c, v);
+  }
+}
+
+// The same over TWO matrices with the same tile geometry (the line search's point p and gradient g):
+// f(r, c, a, b).  All loads of both are in flight together when both layouts allow 16-byte loads.
+template <int K, int NT, int ROWS = kTileM, typename F>
+__device__ __forceinline__ void visit_tile4x2(const float* __restrict__ sa, int64_t lda, const float* __restrict__ sb,
+                                              int64_t ldb, int row0, int n, int k, F&& f) {
+  constexpr int ITER = ROWS * (K / 4) / NT;
+  static_assert((ROWS * (K / 4)) % NT == 0 && ITER <= 16, "tile geometry");
+  const bool va = sa && (k & 3) == 0 && (lda & 3) == 0 && (((uintptr_t)sa) & 15) == 0;
+  const bool vb = sb && (k & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)sb) & 15) == 0;
+  if (va && vb && n > 0 && k >= 4) {
+    f32x4 a[ITER], b[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = threadIdx.x + NT * i, r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+      const int64_t rr = min(row0 + r, n - 1);
+      const int cc = min(c, k - 4);
+      a[i] = *reinterpret_cast<const f32x4*>(sa + rr * lda + cc);
+      b[i] = *reinterpret_cast<const f32x4*>(sb + rr * ldb + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = threadIdx.x + NT * i, r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+      const bool ok = (row0 + r) < n && c < k;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      f(r, c, ok ? a[i] : zero, ok ? b[i] : zero);
+    }
+    return;
+  }
+  for (int idx = threadIdx.x; idx < ROWS * (K / 4); idx += NT) {
+    const int r = idx / (K / 4), c = (idx - r * (K / 4)) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if ((row0 + r) < n) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < k) {
+          if (sa) a[e] = sa[(int64_t)(row0 + r) * lda + c + e];
+          if (sb) b[e] = sb[(int64_t)(row0 + r) * ldb + c + e];
+        }
+    }
+    f(r, c, a, b);
   }
 }
 
