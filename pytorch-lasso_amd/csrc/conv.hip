@@ -146,12 +146,15 @@ struct ConvGradProx {
   float inv_plane, inv_rw;      // 1 / (RH RW), 1 / RW: exact index splits of e < 2^14 without integer division
 };
 constexpr int kCgpGtLd = 132;
+#ifndef LASSO_CGP_OCC
+#define LASSO_CGP_OCC 3      // workgroups (4 waves) per SIMD-quad the kernel is compiled for: 3 -> 168 registers
+#endif
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global
 // load / store in flight (vmcnt(0)), which would serialise the HBM phases with the MFMA phase
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 template <int S4>
-__global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradProx p) {
+__global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(const ConvGradProx p) {
   extern __shared__ __attribute__((aligned(16))) float cg_smem[];
   float* const Gt = cg_smem;                                // [64][132]
   int* const toff = (int*)(Gt + 64 * kCgpGtLd);             // [4 * S4]
@@ -180,9 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
     toff[e] = off;
   }
   __syncthreads();
-  int toffr[S4];                                            // this lane's tap offsets, one per MFMA step
-#pragma unroll
-  for (int s = 0; s < S4; ++s) toffr[s] = toff[4 * s + q];
+  // (this lane's tap offset of MFMA step s is read from the table where it is used: 36 registers that a third
+  // resident workgroup needs more)
   int base_p[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
         if (e0 + 256 * h < region) S[e0 + 256 * h] = sv[h];
     }
     // z, y of the tile do not depend on g: fetched now, so that the HBM latency runs under the MFMAs
-    f32x4 zo[8], yo[8];
+    f32x4 yo[8];                                              // (z is fetched in the epilogue: registers)
     unsigned zoff[8];                                         // byte offset of this thread's pieces (~0u: outside -> reads 0, writes dropped)
     if (kvec) {
 #pragma unroll
@@ -239,9 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
         const bool ok = u < g.Hz && v < g.Wz && col < K;
         zoff[h] = ok ? (unsigned)(((n * g.Hz + u) * g.Wz + v) * K + col) * 4u : ~0u;
 #ifdef LASSO_ABL_CONV_NOMEM    // timing ablation only (results invalid)
-        zo[h] = (f32x4){0.f, 0.f, 0.f, (float)zoff[h]}; yo[h] = zo[h];
+        yo[h] = (f32x4){0.f, 0.f, 0.f, (float)zoff[h]};
 #else
-        zo[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zoff[h], 0, 0));
         yo[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, zoff[h], 0, 0));
 #endif
       }
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
 #endif
 #pragma unroll
     for (int s = 0; s < S4; ++s) {
-      const int off = toffr[s];
+      const int off = toff[4 * s + q];
       float a[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) a[mt] = S[off + bp[mt]];
@@ -271,6 +272,14 @@ __global__ __launch_bounds__(256, 2) void conv_grad_prox_kernel(const ConvGradPr
         for (int rg = 0; rg < 4; ++rg) Gt[(16 * mt + 4 * q + rg) * kCgpGtLd + 32 * w + 16 * nt + l15] = acc[mt][nt][rg];
     LDS_BARRIER();
     if (kvec) {
+      f32x4 zo[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+#ifdef LASSO_ABL_CONV_NOMEM
+        zo[h] = yo[h];
+#else
+        zo[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zoff[h], 0, 0));
+#endif
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
@@ -526,7 +535,7 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   const int64_t ntiles = (int64_t)g.N * p.tiles_u * p.tiles_v;
   const int gy = (g.K + 127) / 128;
   if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
-  const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, 2 * cus / gy)));
+  const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, LASSO_CGP_OCC * cus / gy)));
   const int s4 = ckk <= 64 ? 16 : ckk <= 96 ? 24 : ckk <= 144 ? 36 : 48;
   const size_t lds = (size_t)(64 * kCgpGtLd + 4 * s4 + g.C * p.RH * p.RW) * 4;
   const void* fn = s4 == 16 ? (const void*)&conv_grad_prox_kernel<16> : s4 == 24 ? (const void*)&conv_grad_prox_kernel<24>
