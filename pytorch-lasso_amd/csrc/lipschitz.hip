@@ -99,6 +99,71 @@ __global__ __launch_bounds__(256) void syrk_f64_kernel(const TIn* __restrict__ A
     Cz[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
 }
 
+// One squaring  C = (P / tr P)(P / tr P)^T  of the m x m iterate, m = mp <= 256: the same arithmetic as
+// syrk_f64_kernel<double, true> (scaled operands, contraction in ascending order, the same reduction tree for
+// the trace: bitwise the same C), laid out for latency -- a squaring is 33 MFLOP on 64 workgroups, and the
+// general kernel spent 8.6 us on it: the trace reduction in front of the operand loads, then eight staged
+// chunks with two barriers each.  Here all operand loads (32 x mp doubles per operand, 16-byte pieces) and the
+// diagonal are issued at once, the trace is reduced while they fly (two barriers, then shuffles), both operand
+// tiles go to LDS whole (132 KB at mp = 256) and the 64 fp64 MFMA steps run without a barrier in between.
+// NB = ceil(mp / 64): 16-byte column groups per thread and row.
+template <int NB>
+__global__ __launch_bounds__(256) void square_f64_kernel(const double* __restrict__ A, int mp, double* __restrict__ C) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) double sq_smem[];
+  const int RS = mp + 1;
+  double* const sa = sq_smem;                 // [32][RS]
+  double* const sb = sq_smem + 32 * RS;       // [32][RS]
+  double* const sh = sq_smem + 64 * RS;       // [256]
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;
+  f64x2 ra[4][NB], rb[4][NB];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int r = ty + 8 * a, t = min(2 * (tx + 32 * b), mp - 2);
+      ra[a][b] = *reinterpret_cast<const f64x2*>(A + (int64_t)(i0 + r) * mp + t);
+      rb[a][b] = *reinterpret_cast<const f64x2*>(A + (int64_t)(j0 + r) * mp + t);
+    }
+  // tr A: the tree of syrk_f64_kernel (sh[t] += sh[t + s], s = 128 .. 1), its last six levels inside wave 0
+  sh[tid] = tid < mp ? A[(int64_t)tid * mp + tid] : 0.0;
+  __syncthreads();
+  if (tid < 128) sh[tid] += sh[tid + 128];
+  __syncthreads();
+  if (tid < 64) {
+    double v = sh[tid] + sh[tid + 64];
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+    if (tid == 0) sh[0] = v;
+  }
+  __syncthreads();
+  const double inv = 1.0 / sh[0];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int r = ty + 8 * a, t = 2 * (tx + 32 * b);
+      if (t < mp) {
+        sa[r * RS + t] = ra[a][b][0] * inv; sa[r * RS + t + 1] = ra[a][b][1] * inv;
+        sb[r * RS + t] = rb[a][b][0] * inv; sb[r * RS + t + 1] = rb[a][b][1] * inv;
+      }
+    }
+  __syncthreads();
+  const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const double* const pa = sa + (iw + l15) * RS + q;
+  const double* const pb = sb + (jw + l15) * RS + q;
+  for (int c = 0; c < mp / 32; ++c)          // (mp is a multiple of 32)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[32 * c + 4 * ks], pb[32 * c + 4 * ks], acc, 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) C[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
+}
+
 // C[e] = sum_z part[z][e]  (fixed order)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double* __restrict__ part, int splits, int64_t mm,
                                                             double* __restrict__ C) {
@@ -172,6 +237,26 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
                      W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
   if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G);
   const double* src = G;
+  if (mp <= 256) {                         // the usual case (d or k <= 256): the low-latency squaring kernel
+    const size_t lds = (size_t)(64 * (mp + 1) + 256) * sizeof(double);
+    const int nb = (mp + 63) / 64;
+    const void* fn = nb == 1 ? (const void*)&square_f64_kernel<1> : nb == 2 ? (const void*)&square_f64_kernel<2>
+                   : nb == 3 ? (const void*)&square_f64_kernel<3> : (const void*)&square_f64_kernel<4>;
+    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+    const dim3 grid(mp / kLipTile, mp / kLipTile);
+    for (int p = 0; p < squarings; ++p) {
+      double* const dst = P[p & 1];
+      switch (nb) {
+        case 1: hipLaunchKernelGGL(square_f64_kernel<1>, grid, dim3(256), lds, stream, src, mp, dst); break;
+        case 2: hipLaunchKernelGGL(square_f64_kernel<2>, grid, dim3(256), lds, stream, src, mp, dst); break;
+        case 3: hipLaunchKernelGGL(square_f64_kernel<3>, grid, dim3(256), lds, stream, src, mp, dst); break;
+        default: hipLaunchKernelGGL(square_f64_kernel<4>, grid, dim3(256), lds, stream, src, mp, dst); break;
+      }
+      src = dst;
+    }
+    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, src, mp, out);
+    return hipGetLastError();
+  }
   for (int p = 0; p < squarings; ++p) {
     hipLaunchKernelGGL((syrk_f64_kernel<double, true>), dim3(mp / kLipTile, mp / kLipTile, ps), dim3(256), 0,
                        stream, src, (int64_t)mp, (int64_t)1, mp, mp, mp, pspans, ps > 1 ? part : P[p & 1]);
