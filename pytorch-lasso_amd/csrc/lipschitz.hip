@@ -191,7 +191,19 @@ __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __re
   __syncthreads();
   double acc = 0.0;
   const size_t total = (size_t)mp * mp;
-  for (size_t e = threadIdx.x; e < total; e += 1024) acc = fma(G[e], P[e], acc);
+  // (same chain of fmas per thread; the loads of eight links are issued together instead of one round trip each)
+  for (size_t e0 = threadIdx.x; e0 < total; e0 += 8 * 1024) {
+    double gv[8], pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t e = e0 + (size_t)1024 * u < total ? e0 + (size_t)1024 * u : total - 1;
+      gv[u] = G[e];
+      pv[u] = P[e];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + (size_t)1024 * u < total) acc = fma(gv[u], pv[u], acc);
+  }
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) {
