@@ -1657,10 +1657,16 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
 }
 
 // ---------------------------------------------------------------------------
+static int gram_max_splits(int64_t d, int64_t k) {
+  const int64_t one = k * std::max(k, d) * 4;
+  return (int)std::min<int64_t>(128, std::max<int64_t>(16, ((int64_t)64 << 20) / std::max<int64_t>(one, 1)));
+}
+
 size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k) {
   if (n < 0 || d <= 0 || k <= 0) return 0;
-  // up to 16 sample splits of the larger product; the fused [A | B] kernel keeps up to 32 splits of k x (k + d)
-  return std::max((size_t)16 * (size_t)k * (size_t)std::max(k, d) * 4, gram_ab_scratch_bytes(d, k)) + 256;
+  // sample splits of the larger product: 16, more for small dictionaries (few output blocks: the splits are what
+  // fills the chip -- k = 256, d = 64 ran on 48 workgroups with 16) up to 64 MB; the fused [A | B] kernel sizes its own
+  return std::max((size_t)gram_max_splits(d, k) * (size_t)k * (size_t)std::max(k, d) * 4, gram_ab_scratch_bytes(d, k)) + 256;
 }
 
 int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
@@ -1684,7 +1690,8 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
       return LASSO_OK;
     }
   }
-  const int sa = gram_splits((int)k, (int)k, (int)n, 1, cus), sb = gram_splits((int)k, (int)d, (int)n, 0, cus);
+  const int smax = scratch ? gram_max_splits(d, k) : 1;
+  const int sa = gram_splits((int)k, (int)k, (int)n, 1, cus, smax), sb = gram_splits((int)k, (int)d, (int)n, 0, cus, smax);
   LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, scratch, sa, st));
   LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, b_dev, d, 0,
                                scratch, sb, st));

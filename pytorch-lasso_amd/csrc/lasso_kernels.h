@@ -182,7 +182,8 @@ size_t lipschitz_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,
                             int squarings, hipStream_t stream);
 
-int gram_splits(int pc, int qc, int n, int sym, int cus);
+// (max_splits: what the caller's scratch holds -- 16 unless it was sized for more)
+int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits = 16);
 // [A | B] = Z^T [Z | X] in one launch on 256 x 256 blocks (k, d multiples of 256, large n); false = not applicable
 constexpr int kGramAbMaxSplits = 128;
 size_t gram_ab_scratch_bytes(int64_t d, int64_t k);

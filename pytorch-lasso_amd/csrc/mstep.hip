@@ -222,6 +222,21 @@ __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restr
       }
 }
 
+// sum_s base[s * stride], s = 0 .. splits-1, added in that order; the loads of eight terms are in flight together
+// (with many splits -- small dictionaries -- a load per dependent add was a memory round trip per split)
+__device__ __forceinline__ float ordered_split_sum(const float* __restrict__ base, int64_t stride, int splits) {
+  float acc = 0.0f;
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s0 + u, splits - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < splits) acc += v[u];
+  }
+  return acc;
+}
+
 // sym product of gram_tn128_kernel: C = sum of the splits' upper 128-blocks, mirrored.  One workgroup
 // per 32 x 32 tile (tr, tc), tc >= tr, of the upper triangle: coalesced reads, the transposed copy
 // through LDS.  (Tiles below the diagonal inside a diagonal 128-block are computed values too, but
@@ -235,13 +250,28 @@ __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __rest
   while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
   const int tc = tr + rem;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    const int r = 32 * tr + i, c = 32 * tc + tx;
-    float acc = 0.0f;
-    if (r < pc && c < pc)
-      for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + (int64_t)r * ldpart + c];
-    t[i][tx] = acc;
-    if (r < pc && c < pc) C[(int64_t)r * ldc + c] = acc;
+  // this thread's four elements (rows ty + 8 a), each summed over the splits in order; 4 x 8 loads in flight
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cc = min(32 * tc + tx, pc - 1);
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float v[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[a][u] = part[(int64_t)min(s0 + u, splits - 1) * split_stride + (int64_t)min(32 * tr + ty + 8 * a, pc - 1) * ldpart + cc];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < splits) acc[a] += v[a][u];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = ty + 8 * a, r = 32 * tr + i, c = 32 * tc + tx;
+    const bool ok = r < pc && c < pc;
+    t[i][tx] = ok ? acc[a] : 0.0f;
+    if (ok) C[(int64_t)r * ldc + c] = acc[a];
   }
   __syncthreads();
   if (tr != tc)
@@ -358,9 +388,7 @@ __global__ __launch_bounds__(256) void sum_splits_ld_kernel(const float* __restr
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
   const int64_t r = idx / cols, c = idx - r * cols;
-  float acc = 0.0f;
-  for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + r * ldpart + c];
-  C[r * ldc + c] = acc;
+  C[r * ldc + c] = ordered_split_sum(part + r * ldpart + c, split_stride, splits);
 }
 
 // C[r][c] = sum_s part[s][r][c]  (fixed order)
@@ -369,9 +397,7 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(const float* __restrict
                                                          float* __restrict__ C, int64_t ldc) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)rows * cols) return;
-  float acc = 0.0f;
-  for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * split_stride + idx];
-  C[(idx / cols) * ldc + idx % cols] = acc;
+  C[(idx / cols) * ldc + idx % cols] = ordered_split_sum(part + idx, split_stride, splits);
 }
 
 // Wave-wide sum on the ALU path (no LDS crossbar): DPP row_shr 1,2,4,8 leaves each
@@ -1113,7 +1139,7 @@ static bool gram_use128(const float* P, int64_t ldp, int pc, const float* Q, int
          ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
 }
 
-int gram_splits(int pc, int qc, int n, int sym, int cus) {
+int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits) {
   int blocks = ((qc + kGB - 1) / kGB) * ((pc + kGB - 1) / kGB);
   if (sym) blocks = blocks / 2 + (pc + kGB - 1) / kGB / 2 + 1;
   if (pc >= kG2B && qc >= kG2B) {               // 128 x 128 blocks, two workgroups per CU
@@ -1121,11 +1147,11 @@ int gram_splits(int pc, int qc, int n, int sym, int cus) {
     blocks = sym ? nbp * (nbp + 1) / 2 : nbp * nbq;
     int s2 = std::max(1, 2 * cus / std::max(blocks, 1));   // one round of resident workgroups, no tail
     s2 = std::min(s2, std::max(n / 512, 1));
-    return std::max(1, std::min(s2, 16));
+    return std::max(1, std::min(s2, max_splits));
   }
   int s = (3 * cus + blocks - 1) / std::max(blocks, 1);
   s = std::min(s, std::max(n / 512, 1));
-  return std::max(1, std::min(s, 16));
+  return std::max(1, std::min(s, max_splits));
 }
 
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
