@@ -147,8 +147,20 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
   auto pad = [](int v, int b) { return (v + b - 1) / b * b; };
   const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
   const bool roomy = big_blocks >= 192;
-  const int bm = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
-  const int bn = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+  int bm = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
+  int bn = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+  // Small products (U = B - A D^T of the M-step: 1024 x 256 outputs = 64 blocks of 64 x 64 on 256 CUs): 32-wide
+  // sides until every CU has a workgroup.  The accumulation order of an output element does not depend on the
+  // block shape, so the result is bitwise the same.
+  if (bm == 64 && bn == 64) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 1;
+    auto blocks = [&](int a, int b) { return (int64_t)((m + a - 1) / a) * ((nn + b - 1) / b); };
+    if (blocks(64, 64) < cus && m > 32) bm = 32;
+    if (blocks(bm, 64) < cus && nn > 32) bn = 32;
+  }
 #define LASSO_GEMM_CASE(BM_, BN_)                                                                              \
   if (bm == BM_ && bn == BN_)                                                                                   \
     return vec ? launch_tile<BM_, BN_, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)         \
@@ -157,6 +169,9 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
   LASSO_GEMM_CASE(128, 64);
   LASSO_GEMM_CASE(64, 128);
   LASSO_GEMM_CASE(64, 64);
+  LASSO_GEMM_CASE(32, 64);
+  LASSO_GEMM_CASE(64, 32);
+  LASSO_GEMM_CASE(32, 32);
 #undef LASSO_GEMM_CASE
   return hipErrorInvalidValue;
 }
