@@ -1732,7 +1732,7 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   float* D = (float*)d_dev;
   LASSO_HIP_TRY(hipMemsetAsync(ndeg, 0, sizeof(int), st));
   // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, zero padded to dp columns)
-  LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));
+  if (dp != d) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
   LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st));
   // Dt[j][dd] = D[dd][j]  (zero padded to dp features)
   LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
