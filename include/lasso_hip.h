@@ -47,9 +47,11 @@ typedef enum {
   LASSO_ERR_HIP = 4,          /* HIP runtime error (no device, launch failure, ...)    */
   LASSO_WARN_LINESEARCH = 5,  /* backtracking failed, reverted to lr0 (ista.py:48-52)  */
   LASSO_PENDING = 6,          /* LASSO_SOLVE_ASYNC: enqueued; call lasso_fista_solve_finish */
-  LASSO_WARN_ABORTED = 7      /* lasso_fista_solve_finish: the in-kernel stop rule gave up
-                                 (a workgroup was not resident), z_out untouched: solve again
-                                 with LASSO_STOP_GLOBAL_CHUNKED                            */
+  LASSO_WARN_ABORTED = 7      /* lasso_fista_solve_finish: the asynchronous solve must be repeated
+                                 with LASSO_STOP_GLOBAL_CHUNKED -- the in-kernel stop rule gave up
+                                 (a workgroup was not resident; z_out untouched), or the rule fired
+                                 before the end of an asynchronously enqueued chunk (z_out holds a
+                                 later iterate)                                            */
 } lasso_status;
 
 typedef enum { LASSO_F32 = 0, LASSO_BF16 = 1 } lasso_dtype;
@@ -79,9 +81,11 @@ typedef enum {
 #define LASSO_KERNEL_SPLITK_TILES(T) (0x200 | ((T) == 1 ? 0x1000 : (T) == 2 ? 0x2000 : 0x3000))
 #define LASSO_KERNEL_MASK 0x3F00
 /* OR into stop_mode of lasso_fista_solve (fp32, fixed step): do not wait for the stop rule's
- * outcome.  Returns LASSO_PENDING when the single persistent launch was enqueued (then
- * iters_out / last_delta_out are not written and lasso_fista_solve_finish collects them), or
- * LASSO_OK when the solve completed inside the call (stop rule off, or the chunked path). */
+ * outcome.  Returns LASSO_PENDING when the solve was enqueued without a wait -- the single
+ * persistent launch with the in-kernel rule, or, with more tiles than resident workgroups, one
+ * chunk of maxiter <= 64 iterations whose deltas are judged on the device -- (then iters_out /
+ * last_delta_out are not written and lasso_fista_solve_finish / _collect fetch them), or
+ * LASSO_OK when the solve completed inside the call (stop rule off, longer chunked solves). */
 #define LASSO_SOLVE_ASYNC 0x4000
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
  * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device

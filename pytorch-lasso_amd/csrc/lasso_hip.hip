@@ -210,6 +210,19 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
   if (threadIdx.x == 0) delta[blockIdx.x] = sh[0];
 }
 
+// the stop rule over one chunk's per-iteration deltas (ista.py:93-95): out = {iterations, last delta, redo, 0};
+// redo = the rule fired before the chunk's last iteration
+__global__ void chunk_verdict_kernel(const float* __restrict__ delta, int c, float budget, int* __restrict__ out) {
+  int hit = -1;
+  float last = delta[c - 1];
+  for (int i = 0; i < c; ++i)
+    if (delta[i] <= budget) { hit = i; last = delta[i]; break; }
+  out[0] = hit >= 0 ? hit + 1 : c;
+  out[1] = __float_as_int(last);
+  out[2] = (hit >= 0 && hit + 1 < c) ? 1 : 0;
+  out[3] = 0;
+}
+
 int device_cus() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
@@ -1360,6 +1373,20 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
       hint = LASSO_KERNEL_TILE;      // some workgroup was not resident: no cross-workgroup traffic from here on
     }
   }
+  // ---- LASSO_SOLVE_ASYNC beyond the in-kernel rule (more tiles than resident workgroups) when maxiter fits
+  // one chunk: the chunk is enqueued, a one-thread kernel turns its per-iteration deltas into the words the
+  // collect call copies -- {iterations, last delta, redo} -- and the call returns without waiting.  "redo" is
+  // set when the rule fired BEFORE the last iteration (z_out is then one of the later iterates): the caller
+  // repeats the solve synchronously, exactly like after an aborted handshake.  The E-step of an EM loop
+  // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
+  if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
+    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+                         alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
+      return s;
+    hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out);
+    LASSO_HIP_TRY(hipGetLastError());
+    return LASSO_PENDING;
+  }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
   // replay the chunk up to the stopping iteration if one fired ----------
   int done = 0, flip = 0;
@@ -1566,7 +1593,7 @@ int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int max
   if (hout[2]) {
     if (iters_out) *iters_out = 0;
     if (last_delta_out) *last_delta_out = NAN;
-    snprintf(g_err, sizeof(g_err), "in-kernel stop rule gave up (a workgroup was not resident); z_out is unchanged");
+    snprintf(g_err, sizeof(g_err), "asynchronous solve must be repeated (handshake gave up, or the rule fired before the end of the chunk)");
     return LASSO_WARN_ABORTED;
   }
   float lastf;

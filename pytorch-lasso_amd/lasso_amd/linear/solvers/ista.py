@@ -108,9 +108,10 @@ class _UnrolledIsta(torch.autograd.Function):
 class PendingSolve:
     """Outcome of a solve whose stop rule was left running on the GPU (``ista(..., begin=True)``):
     calling it waits for the SOLVE only -- work enqueued behind it keeps the GPU busy -- and
-    returns True, or False when the in-kernel stop rule gave up (a workgroup of the persistent
-    kernel was not resident; z is then unchanged input and the caller solves again with
-    ``stop_mode='chunked'``).  ``iterations`` / ``last_delta`` are valid after a True call."""
+    returns True, or False when the solve has to be repeated with ``stop_mode='chunked'``: the
+    in-kernel stop rule gave up (a workgroup of the persistent kernel was not resident), or -- batches
+    with more tiles than resident workgroups, enqueued as one chunk -- the rule fired before the last
+    iteration (z then holds a later iterate).  ``iterations`` / ``last_delta`` are valid after a True call."""
 
     def __init__(self, status, event):
         self._status, self._event = status, event

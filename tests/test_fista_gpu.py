@@ -257,6 +257,31 @@ def test_begin_returns_before_the_stop_rule_and_collects_later():
     assert p2 is None and torch.equal(z2, ista(Xg, z0, Wg, alpha=0.3, maxiter=5, tol=0.0))
 
 
+def test_begin_with_more_tiles_than_resident_workgroups():
+    """n = 8192 rows are 512 tiles: no in-kernel stop rule.  With maxiter within one chunk the solve is still
+    enqueued without a wait (the E-step of the EM loop): pending() reports the synchronous call's outcome, and
+    asks for a repeat -- False -- when the rule fired before the last iteration (z is then a later iterate)."""
+    sparse_encode, ista, orc = _mods()
+    X, W = _case(8192, 256, 1024, seed=7)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(8192, 1024, device="cuda")
+    zs, info = ista(Xg, z0, Wg, alpha=0.3, maxiter=10, tol=1e-5, return_info=True)
+    z, pending = ista(Xg, z0, Wg, alpha=0.3, maxiter=10, tol=1e-5, begin=True)
+    assert pending is not None and pending() is True
+    assert pending.iterations == info["iterations"] == 10
+    assert abs(pending.last_delta - info["last_delta"]) <= 1e-6 * abs(info["last_delta"])
+    assert torch.equal(z, zs)
+    # a tolerance that stops the loop early: the synchronous call replays to the stopping iteration, the
+    # asynchronous one reports that it has to be repeated
+    zs, info = ista(Xg, z0, Wg, alpha=0.3, maxiter=40, tol=3e-3, return_info=True)
+    assert 1 < info["iterations"] < 40
+    z, pending = ista(Xg, z0, Wg, alpha=0.3, maxiter=40, tol=3e-3, begin=True)
+    assert pending is not None and pending() is False
+    # stopping exactly at the last iteration of the chunk is a plain success
+    z, pending = ista(Xg, z0, Wg, alpha=0.3, maxiter=info["iterations"], tol=3e-3, begin=True)
+    assert pending() is True and pending.iterations == info["iterations"] and torch.equal(z, zs)
+
+
 def test_resumable_runs_beyond_the_fused_shapes():
     """lasso_fista_prepare / lasso_fista_run for d > 256 or k > 1024 (unfused, state in HBM): three
     chunks of iterations with the (z, y) state handed over equal one solve; per-iteration deltas

@@ -7,6 +7,9 @@ for p in (ROOT, os.path.join(ROOT, 'pytorch-lasso_amd'), os.path.join(ROOT, 'tes
     sys.path.insert(0, p)
 import torch
 from recipes import recipe_xw, recipe_c4_init, LAMBDA_MAX_C4
+if '--lib' in sys.argv:                       # an A/B build (tools/build_variant.sh)
+    from lasso_amd import _native as _nat
+    _nat.use_library(os.path.abspath(sys.argv[sys.argv.index('--lib') + 1]))
 from lasso_amd.engine import HipEngine
 from lasso_amd.linear import sparse_encode, dict_learning
 from lasso_amd.parallel import constrained_mstep
