@@ -361,7 +361,8 @@ def test_atom_sweep_and_ridge_survive_a_busy_gpu():
 
 
 @pytest.mark.parametrize("n,d,k", [(4096, 256, 256), (4097, 256, 1024), (9000, 512, 512), (8192, 256, 768),
-                                   (5000, 256, 2048), (4095, 256, 1024), (6001, 300, 1024), (70000, 256, 1024)])
+                                   (5000, 256, 2048), (4095, 256, 1024), (6001, 300, 1024), (70000, 256, 1024),
+                                   (70000, 64, 256), (33000, 100, 300), (9000, 64, 128)])   # small dictionaries: up to 128 sample splits
 def test_gram_products_against_fp64(n, d, k):
     """Z^T Z and Z^T X of the M-step (dict_learning.py:69-70,117-118) on every path of lasso_gram_accumulate: the
     one-launch [A | B] kernel on 256 x 256 blocks (k, d multiples of 256, n >= 4096; ragged n, several split
