@@ -22,6 +22,7 @@ namespace {
 constexpr int kLipTile = 32;   // output tile per workgroup (256 threads, 2x2 per thread)
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int kLipSpan = 256;      // contraction elements whose loads one workgroup keeps in flight together
 constexpr int kLipMaxSplits = 16;  // partial products along the contraction (blockIdx.z)
@@ -164,6 +165,74 @@ __global__ __launch_bounds__(256) void square_f64_kernel(const double* __restric
   for (int rg = 0; rg < 4; ++rg) C[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
 }
 
+// The Gram matrix of W over ONE 256-element span of the contraction per workgroup (split z = span z), laid out
+// like square_f64_kernel: all loads of both 32 x 256 operand tiles in flight at once (16-byte pieces of fp32),
+// converted to fp64 on their way into LDS, 64 MFMA steps without a barrier in between.  Same contraction order
+// per split as syrk_f64_kernel<float, false> -- bitwise the same partial products.
+// ROWS: elem(i, t) = W[i * ld + t] (G = W W^T), else elem(i, t) = W[t * ld + i] (G = W^T W).
+// Needs m % 4 == 0 or ROWS, len % 4 == 0 or !ROWS, ld % 4 == 0, a 16-byte aligned base.
+template <bool ROWS>
+__global__ __launch_bounds__(256) void gram_span_f64_kernel(const float* __restrict__ W, int64_t ld, int m, int len,
+                                                            int mp, double* __restrict__ C) {
+  constexpr int RS = 257;
+  extern __shared__ __attribute__((aligned(16))) double gs_smem[];
+  double* const sa = gs_smem;                 // [32][RS]
+  double* const sb = gs_smem + 32 * RS;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tbase = blockIdx.z * 256;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  f32x4v ra[8], rb[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int e = tid + 256 * h;
+    if constexpr (ROWS) {
+      const int r = e >> 6, t = tbase + 4 * (e & 63);
+      const int tc = min(t, len - 4);
+      ra[h] = *reinterpret_cast<const f32x4v*>(W + (int64_t)min(i0 + r, m - 1) * ld + tc);
+      rb[h] = *reinterpret_cast<const f32x4v*>(W + (int64_t)min(j0 + r, m - 1) * ld + tc);
+    } else {
+      const int tl = e >> 3, i4 = 4 * (e & 7);
+      const int64_t tc = min(tbase + tl, len - 1);
+      ra[h] = *reinterpret_cast<const f32x4v*>(W + tc * ld + min(i0 + i4, m - 4));
+      rb[h] = *reinterpret_cast<const f32x4v*>(W + tc * ld + min(j0 + i4, m - 4));
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int e = tid + 256 * h;
+    if constexpr (ROWS) {
+      const int r = e >> 6, tl = 4 * (e & 63);
+      const bool okt = tbase + tl < len;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sa[r * RS + tl + u] = (okt && i0 + r < m) ? (double)ra[h][u] : 0.0;
+        sb[r * RS + tl + u] = (okt && j0 + r < m) ? (double)rb[h][u] : 0.0;
+      }
+    } else {
+      const int tl = e >> 3, i4 = 4 * (e & 7);
+      const bool okt = tbase + tl < len;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sa[(i4 + u) * RS + tl] = (okt && i0 + i4 < m) ? (double)ra[h][u] : 0.0;
+        sb[(i4 + u) * RS + tl] = (okt && j0 + i4 < m) ? (double)rb[h][u] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const double* const pa = sa + (iw + l15) * RS + q;
+  const double* const pb = sb + (jw + l15) * RS + q;
+  const int chunks = min(8, (len - tbase + 31) / 32);       // like syrk_f64_kernel: chunks beyond len are skipped
+  for (int c = 0; c < chunks; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[32 * c + 4 * ks], pb[32 * c + 4 * ks], acc, 0, 0, 0);
+  double* const Cz = C + (int64_t)blockIdx.z * mp * mp;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Cz[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
+}
+
 // ALL squarings of a small iterate (m = mp <= 64: dictionaries with d or k <= 64, e.g. 8 x 8 patches) in ONE
 // launch of one workgroup: the iterate lives in LDS (two 64 x 65 buffers), wave w owns the 16 x 16 output block
 // (w / nb, w % nb), per squaring {trace by the tree of square_f64_kernel, 16 fp64 MFMA steps on operands scaled
@@ -291,8 +360,19 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   lip_splits(len, &gs, &gspans);
   lip_splits(mp, &ps, &pspans);
   const dim3 fold_grid((unsigned)((mm + 255) / 256));
-  hipLaunchKernelGGL((syrk_f64_kernel<float, false>), dim3(mp / kLipTile, mp / kLipTile, gs), dim3(256), 0, stream,
-                     W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
+  const bool span_ok = gspans == 1 && (ldw & 3) == 0 && (((uintptr_t)W) & 15) == 0 && (rows ? (len & 3) == 0 : (m & 3) == 0) &&
+                       len >= 4 && m >= 4;
+  if (span_ok) {                            // one span per workgroup: the low-latency kernel
+    const size_t lds = (size_t)64 * 257 * sizeof(double);
+    const void* fn = rows ? (const void*)&gram_span_f64_kernel<true> : (const void*)&gram_span_f64_kernel<false>;
+    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+    const dim3 grid(mp / kLipTile, mp / kLipTile, gs);
+    if (rows) hipLaunchKernelGGL(gram_span_f64_kernel<true>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G);
+    else hipLaunchKernelGGL(gram_span_f64_kernel<false>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G);
+  } else {
+    hipLaunchKernelGGL((syrk_f64_kernel<float, false>), dim3(mp / kLipTile, mp / kLipTile, gs), dim3(256), 0, stream,
+                       W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
+  }
   if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G);
   const double* src = G;
   if (mp <= 64 && squarings > 0) {         // small iterate: every squaring in one launch of one workgroup
