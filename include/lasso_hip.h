@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LASSO_HIP_ABI_VERSION 3
+#define LASSO_HIP_ABI_VERSION 4
 
 typedef enum {
   LASSO_OK = 0,
@@ -87,6 +87,17 @@ typedef enum {
  * last_delta_out are not written and lasso_fista_solve_finish / _collect fetch them), or
  * LASSO_OK when the solve completed inside the call (stop rule off, longer chunked solves). */
 #define LASSO_SOLVE_ASYNC 0x4000
+/* OR into stop_mode together with LASSO_SOLVE_ASYNC when the batch is a ROW SHARD of a larger one
+ * (one process per GPU): the stop rule of ista.py:93 sums over the rows of ALL shards, so nothing
+ * on this device can judge it alone.  The solve is enqueued as one chunk of maxiter <= 64 iterations
+ * (LASSO_ERR_UNSUPPORTED beyond) that leaves this shard's per-iteration sums |z - z_next| in the
+ * workspace and returns LASSO_PENDING; the caller all-reduces the `maxiter` floats at
+ * lasso_fista_solve_deltas() across the ranks ON THE STREAM (RCCL), enqueues
+ * lasso_fista_solve_verdict(n_global, ...) -- the one-thread kernel that applies the rule to the
+ * summed vector -- and then lasso_fista_solve_collect() as for any other asynchronous solve.  No
+ * host wait anywhere: every rank reads the same verdict ("redo" when the rule fired before the last
+ * iteration) at its one synchronisation per EM step. */
+#define LASSO_SOLVE_SHARDED 0x8000
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
  * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device
  * memory -- no host round trip; other paths synchronise once to fetch it. */
@@ -266,6 +277,18 @@ int lasso_fista_solve_sharded(const void* x_dev, int64_t ldx, const void* w_dev,
  * it keeps the GPU busy during the wait -- and decodes the four words itself. */
 int lasso_fista_solve_collect(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                               int32_t* out4_host, void* workspace_dev, size_t workspace_bytes,
+                              void* stream);
+/* LASSO_SOLVE_SHARDED: the device address (inside the workspace) of the pending solve's `maxiter`
+ * per-iteration sums, to be all-reduced in place; NULL when the arguments describe no such solve. */
+float* lasso_fista_solve_deltas(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                                void* workspace_dev, size_t workspace_bytes);
+/* LASSO_SOLVE_SHARDED: enqueue the stop rule over the (all-reduced) sums with the budget
+ * n_global * k * tol of the whole batch (ista.py:64); lasso_fista_solve_collect fetches its words.
+ * sums_dev: the `maxiter` all-reduced sums, or NULL when they were reduced in place at
+ * lasso_fista_solve_deltas() (a driver may carry them in the tail of its M-step message instead: the
+ * EM step then has ONE collective). */
+int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter,
+                              double tol, const float* sums_dev, void* workspace_dev, size_t workspace_bytes,
                               void* stream);
 int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                              int32_t* iters_out, float* last_delta_out, void* workspace_dev,

@@ -1242,7 +1242,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
-                      const double* lip_dev = nullptr) {
+                      const double* lip_dev = nullptr, bool sharded = false) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1344,6 +1344,18 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   if (z0 && z0 == zout) {     // aliasing: keep the initial state intact for a replay / a second attempt
     LASSO_HIP_TRY(hipMemcpy2DAsync(ws.state[2], k * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
     cur_z = ws.state[2]; cur_ldz = k;
+  }
+  if (sharded) {
+    // LASSO_SOLVE_SHARDED: this batch is a row shard -- the rule needs the other ranks' sums.  One chunk, its
+    // per-iteration sums left in ws.delta for the caller's all-reduce; lasso_fista_solve_verdict judges them.
+    if (!async || stop_mode != LASSO_STOP_GLOBAL)
+      return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_SHARDED needs LASSO_SOLVE_ASYNC | LASSO_STOP_GLOBAL");
+    if (maxiter > kChunkMax)
+      return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: maxiter=%d > %d", maxiter, kChunkMax);
+    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+                         alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
+      return s;
+    return LASSO_PENDING;
   }
   if (stop_mode == LASSO_STOP_GLOBAL) {
     const TilePlan tp = plan_tiles(n, pad_d(d, kp));
@@ -1462,7 +1474,10 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       size_t workspace_bytes, void* stream) {
   if (objective_out) *objective_out = NAN;
   const bool async = (stop_mode & LASSO_SOLVE_ASYNC) != 0;
-  stop_mode &= ~LASSO_SOLVE_ASYNC;
+  const bool sharded = (stop_mode & LASSO_SOLVE_SHARDED) != 0;
+  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED);
+  if (sharded && !(async && tol > 0.0 && maxiter > 0 && n > 0 && fused_shape(d, k)))
+    return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: asynchronous fp32 solves with tol > 0 on the fused shapes only");
   if (async && (objective_out || backtrack || dtype != LASSO_F32))
     return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_ASYNC: fp32 fixed-step solves without objective_out only");
   const float* lr_dev = nullptr;
@@ -1497,7 +1512,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async, lip_dev);
+                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
@@ -1574,6 +1589,29 @@ int lasso_fista_solve_collect(int64_t n, int64_t d, int64_t k, int dtype, int ma
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, true);
   if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   LASSO_HIP_TRY(hipMemcpyAsync(out4_host, ws.stop_out, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+float* lasso_fista_solve_deltas(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                                void* workspace_dev, size_t workspace_bytes) {
+  if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || maxiter > kChunkMax || !(tol > 0.0) ||
+      !workspace_dev)
+    return nullptr;
+  Workspace ws = carve(workspace_dev, n, k, pad_k(k), maxiter, true);
+  return workspace_bytes < ws.bytes ? nullptr : ws.delta;
+}
+
+int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                              const float* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || n_global < n || maxiter <= 0 || maxiter > kChunkMax ||
+      !(tol > 0.0))
+    return fail(LASSO_ERR_BAD_ARG, "no pending sharded solve of this shape");
+  Workspace ws = carve(workspace_dev, n, k, pad_k(k), maxiter, true);
+  if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
+  const float budget = (float)((double)n_global * (double)k * tol);   // ista.py:64 on the whole batch
+  hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums_dev ? sums_dev : ws.delta,
+                     maxiter, budget, ws.stop_out);
+  LASSO_HIP_TRY(hipGetLastError());
   return LASSO_OK;
 }
 

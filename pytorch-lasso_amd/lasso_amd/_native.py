@@ -4,6 +4,7 @@ This is the binding a maintainer of the reference would add next to
 lasso/linear/solvers/ista.py; see INTEGRATION.md.  The library is built in-tree
 by ``__graft_entry__.build()`` / ``make -C pytorch-lasso_amd/csrc``.
 """
+import collections
 import ctypes as C
 import os
 import threading
@@ -16,9 +17,10 @@ LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
+SOLVE_SHARDED = 0x8000
 LR_AUTO = -1.0
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -95,6 +97,10 @@ def _declare(lib):
         C.POINTER(C.c_float), vp, sz, vp]
     lib.lasso_fista_solve_collect.restype = i32
     lib.lasso_fista_solve_collect.argtypes = [i64, i64, i64, i32, i32, dbl, vp, vp, sz, vp]
+    lib.lasso_fista_solve_deltas.restype = vp
+    lib.lasso_fista_solve_deltas.argtypes = [i64, i64, i64, i32, i32, dbl, vp, sz]
+    lib.lasso_fista_solve_verdict.restype = i32
+    lib.lasso_fista_solve_verdict.argtypes = [i64, i64, i64, i64, i32, i32, dbl, vp, vp, sz, vp]
     lib.lasso_fista_solve_finish.restype = i32
     lib.lasso_fista_solve_finish.argtypes = [i64, i64, i64, i32, i32, dbl, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                              vp, sz, vp]
@@ -198,15 +204,33 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-_WS = {}
+_WS = collections.OrderedDict()       # key -> buffer, least recently used first
 _WS_LOCK = threading.Lock()
+_WS_MAX_ENTRIES = 64                   # (device, stream, thread, purpose) combinations kept
+_WS_MAX_BYTES = 8 << 30                # ... and their total size; beyond either the oldest entries go
+
+
+def _ws_evict(keep):
+    total = sum(b.numel() for b in _WS.values())
+    while len(_WS) > 1 and (len(_WS) > _WS_MAX_ENTRIES or total > _WS_MAX_BYTES):
+        key = next(iter(_WS))
+        if key == keep:                 # never the buffer being handed out
+            _WS.move_to_end(key)
+            key = next(iter(_WS))
+            if key == keep:
+                break
+        total -= _WS.pop(key).numel()
 
 
 def workspace(device, nbytes, tag='fista'):
     """A cached device scratch buffer (caller-owned memory of the C ABI).  One buffer per
     (device, HIP stream, host thread, purpose): calls enqueued on one stream are ordered, so
     they may share scratch; different streams or threads never do (the C library itself is
-    re-entrant -- all state lives in the workspace the caller passes)."""
+    re-entrant -- all state lives in the workspace the caller passes).  The cache is bounded
+    (least recently used entries are dropped beyond `_WS_MAX_ENTRIES` keys or `_WS_MAX_BYTES`
+    bytes): thread pools with churn or code that creates many streams do not pin one workspace
+    set each for ever.  A dropped buffer goes back to torch's caching allocator, which keeps
+    it alive for the kernels already enqueued on its stream."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream,
            threading.get_ident(), tag)
     with _WS_LOCK:
@@ -214,6 +238,8 @@ def workspace(device, nbytes, tag='fista'):
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
             _WS[key] = buf
+        _WS.move_to_end(key)
+        _ws_evict(key)
     return buf
 
 

@@ -41,6 +41,30 @@ class HipEngine:
         from .linear.sparse_encode import sparse_encode
         return sparse_encode(X, W, alpha, z0, **solver_kwargs)
 
+    def encode_begin_sharded(self, X, W, alpha, z0, **solver_kwargs):
+        """E-step on a ROW SHARD without a host wait: returns (Z, pending) with ``pending`` a
+        PendingShardedSolve (its ``deltas`` are to be all-reduced, then ``judge``d), None when the solve
+        needs no verdict (stop rule off), or returns None when these arguments have no asynchronous
+        sharded form (line search, maxiter > 64, shapes beyond the fused kernels, ...): the caller then
+        takes the synchronous sharded path."""
+        from .linear.solvers import ista
+        kw = dict(solver_kwargs)
+        kw.pop('n_global', None)
+        d, k = W.shape
+        plain = (kw.pop('algorithm', 'ista') == 'ista' and kw.pop('init', None) is None and not kw.get('verbose')
+                 and not kw.get('backtrack') and not kw.get('return_info') and X.dtype == torch.float32
+                 and X.is_cuda and W.is_cuda and (z0 is None or z0.is_cuda) and d <= 256 and k <= 1024
+                 and X.shape[0] > 0 and kw.get('stop_mode', 'global') == 'global')
+        maxiter, tol = kw.get('maxiter', 10), kw.get('tol', 1e-5)
+        if not plain or not (0 < maxiter <= 64):
+            return None
+        if z0 is None:
+            from .linear.solvers.ista import lazy_zeros
+            z0 = lazy_zeros(X, X.shape[0], W.shape[1])
+        if not tol > 0:
+            return ista(X, z0, W, alpha, begin=True, **kw)          # no rule: nothing to agree on
+        return ista(X, z0, W, alpha, begin=True, shard=True, **kw)
+
     def encode_begin(self, X, W, alpha, z0, **solver_kwargs):
         """sparse_encode that does not wait for the stop rule's outcome: returns (Z, pending);
         ``pending`` is None (complete) or a callable that waits for the solve alone and returns

@@ -21,14 +21,20 @@ def _to_device(t, device):
 
 
 def lazy_zeros(like, n, k):
-    """An all-zero [n,k] start that costs no memory: a (0,0)-stride view of one element.  The
-    solvers recognise it and hand the C ABI a NULL z0 (= zeros, no fill and no read of n*k floats);
-    anything else that touches it sees an ordinary read-only zeros tensor."""
-    return like.new_zeros(1, 1).expand(n, k)
+    """An all-zero [n,k] start that costs no memory: a (0,0)-stride view of one element, MARKED as
+    the library's own sentinel.  The solvers recognise the marked object and hand the C ABI a NULL z0
+    (= zeros, no fill and no read of n*k floats); anything else that touches it sees an ordinary
+    read-only zeros tensor.  The mark lives on this python object only -- views, clones and a
+    caller's own broadcast tensors (``torch.full((1, 1), c).expand(n, k)``) never carry it and are
+    read like any other z0 (sparse_encode.py:44-45)."""
+    z = like.new_zeros(1, 1).expand(n, k)
+    z._lasso_lazy_zeros = True
+    return z
 
 
 def _is_lazy_zeros(z0):
-    return z0 is not None and z0.dim() == 2 and z0.numel() > 1 and z0.stride(0) == 0 and z0.stride(1) == 0
+    return (z0 is not None and getattr(z0, '_lasso_lazy_zeros', False) is True and z0.dim() == 2
+            and z0.stride(0) == 0 and z0.stride(1) == 0)
 
 
 def _ista_verbose(x, z0, weight, alpha, fast, lr, maxiter, tol, dev):
@@ -66,30 +72,24 @@ class _UnrolledIsta(torch.autograd.Function):
         eng = HipEngine(dev)
         n, k = z0.shape
         xg, wg = x.detach().contiguous(), weight.detach().contiguous()
-        # the iterates z_0 .. z_T are kept for the reverse pass; the trace grows in blocks so an
-        # early stop by the tol rule never pays for maxiter iterates
-        block = 32
-        chunks = [torch.empty((min(block, maxiter) + 1, n, k), dtype=torch.float32, device=dev)]
-        chunks[0][0].copy_(z0.detach())
-        budget = torch.tensor(float(n * k) * tol, dtype=torch.float32).item()
-        ws = eng.fista_workspace(n, xg.shape[1], k, maxiter)
-        y, done = None, 0
-        cur, pos = chunks[0], 0          # z_done lives in cur[pos]
-        for it in range(maxiter):
-            if pos + 1 == cur.shape[0]:
-                nxt = torch.empty((min(block, maxiter - it), n, k), dtype=torch.float32, device=dev)
-                chunks.append(nxt)
-                src, cur, pos = cur[pos], nxt, -1
-            else:
-                src = cur[pos]
-            _, y, delta = eng.fista_run(xg, wg, src, y, alpha, lr[it] if isinstance(lr, list) else lr, fast, it, 1,
-                                        tol > 0, ws=ws, z_out=cur[pos + 1])
-            pos += 1
-            done = it + 1
-            if tol > 0 and delta[0].item() <= budget:                    # ista.py:93-95
-                break
-        trace = chunks[0][:pos + 1] if len(chunks) == 1 else \
-            torch.cat([c if i + 1 < len(chunks) else c[:pos + 1] for i, c in enumerate(chunks)])
+        # The iterates z_0 .. z_T are kept for the reverse pass in ONE buffer of exactly T+1 iterates.
+        # With the stop rule active T is not known in advance: an ordinary (untraced, single-launch) solve
+        # finds the stopping iteration first -- the solve is bitwise deterministic, so the replay below lands
+        # on the same iterate -- instead of growing the trace in blocks and concatenating them (twice the
+        # memory at the end) with a host synchronisation per iteration.
+        steps = int(maxiter)
+        if tol > 0 and steps > 0:
+            _, info = _solve_native(xg, z0.detach(), wg, alpha, fast, lr, steps, tol, False, 1.5, False, True,
+                                    out_device=dev)
+            steps = int(info['iterations'])
+        trace = torch.empty((steps + 1, n, k), dtype=torch.float32, device=dev)
+        trace[0].copy_(z0.detach())
+        ws = eng.fista_workspace(n, xg.shape[1], k, max(steps, 1))
+        y = None
+        for it in range(steps):
+            _, y, _ = eng.fista_run(xg, wg, trace[it], y, alpha, lr[it] if isinstance(lr, list) else lr, fast, it, 1,
+                                    False, ws=ws, z_out=trace[it + 1])
+        done = steps
         ctx.save_for_backward(xg, wg, trace)
         ctx.lr, ctx.fast = lr, fast
         return trace[done].clone()
@@ -127,6 +127,23 @@ class PendingSolve:
         return True
 
 
+class PendingShardedSolve(PendingSolve):
+    """A LASSO_SOLVE_SHARDED solve (this rank's row shard of a larger batch): the stop rule of ista.py:93
+    sums over ALL shards, so the outcome exists only after the ranks' per-iteration sums met.
+    ``deltas`` is a device view (inside the solve's workspace) of this shard's `maxiter` sums; the
+    driver all-reduces them -- in place, or carried in the tail of another message -- and calls
+    ``judge(reduced_or_None, n_global)``, which enqueues the rule on the summed vector and the copy of
+    its words.  Calling the object then waits like PendingSolve (False: the rule fired before the last
+    iteration -- repeat the E-step on the chunked path)."""
+
+    def __init__(self, deltas, judge):
+        super().__init__(None, None)
+        self.deltas, self._judge = deltas, judge
+
+    def judge(self, reduced, n_global):
+        self._status, self._event = self._judge(reduced, int(n_global))
+
+
 _PINNED = {}
 
 
@@ -143,7 +160,7 @@ def _pinned_status(dev):
 
 def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
          tol=1e-5, backtrack=False, eta_backtrack=1.5, verbose=False,
-         return_info=False, stop_mode='global', kernel='auto', begin=False):
+         return_info=False, stop_mode='global', kernel='auto', begin=False, shard=False):
     """Solve min_z 0.5*||z W^T - x||^2 + alpha*||z||_1 on the GPU.
 
     x [n,d], z0 [n,k], weight [d,k]; returns a NEW tensor z [n,k] with the
@@ -157,6 +174,8 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     (include/lasso_hip.h, LASSO_KERNEL_*); the code is bitwise the same either way.
     ``begin`` (extension): return ``(z, pending)`` without waiting for the stop rule's outcome;
     ``pending`` is a :class:`PendingSolve`, or None when the solve completed inside the call.
+    ``shard`` (extension, with ``begin``): x is one rank's row shard of a larger batch -- ``pending`` is a
+    :class:`PendingShardedSolve` whose sums the multi-GPU driver all-reduces (lasso_amd/parallel.py).
     Tensors that live on the CPU are staged through the current HIP device
     (the arithmetic still runs in the HIP kernels; there is no CPU fallback).
     """
@@ -192,6 +211,9 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         raise NotImplementedError("lasso_amd: dtype %s is not implemented on the HIP path" % x.dtype)
     if begin and (return_info or x.dtype != torch.float32):
         raise ValueError("begin=True: fp32 tensors, return_info=False")
+    if shard and not (begin and tol > 0 and not backtrack and not verbose and 0 < maxiter <= 64 and d <= 256 and k <= 1024):
+        raise NotImplementedError("shard=True: asynchronous fixed-step fp32 solves with 0 < maxiter <= 64 and tol > 0 "
+                                  "on the fused shapes")
     if maxiter == 0:
         if _is_lazy_zeros(z0):
             z0 = z0.contiguous()
@@ -256,7 +278,8 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
         return (z, info) if return_info else z
 
     return _solve_native(xg, zg if zg is not None else z0, wg, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack,
-                         verbose, return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel, begin=begin)
+                         verbose, return_info, out_device=out_device, stop_mode=stop_mode, kernel=kernel, begin=begin,
+                         shard=shard)
 
 
 _STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
@@ -266,7 +289,7 @@ _KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNE
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,
-                  return_info, out_device=None, stop_mode='global', kernel='auto', begin=False):
+                  return_info, out_device=None, stop_mode='global', kernel='auto', begin=False, shard=False):
     """One call of lasso_fista_solve on tensors of one dtype (float32, or bfloat16 with the
     line search)."""
     n, d = x.shape
@@ -296,12 +319,32 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         st = L.lasso_fista_solve(
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0) if zg is not None else 0,
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
-            int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0),
+            int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0) |
+            (nat.SOLVE_SHARDED if shard else 0),
             int(bool(backtrack)), float(eta_backtrack),
             C.byref(iters) if want_host else None, C.byref(last) if want_host else None, trials, acc_lr, acc_f,
             C.byref(obj) if obj is not None else None, nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         pending = None
-        if st == nat.LASSO_PENDING:
+        if st == nat.LASSO_PENDING and shard:
+            shape = (n, d, k, _DT[x.dtype], int(maxiter), float(tol))
+            dptr = L.lasso_fista_solve_deltas(*shape, nat.ptr(ws), ws.numel())
+            if not dptr:
+                raise nat.NativeError("lasso_fista_solve_deltas: no pending sharded solve")
+            off = int(dptr) - ws.data_ptr()
+            deltas = ws[off:off + 4 * int(maxiter)].view(torch.float32)
+
+            def judge(reduced, n_global, ws=ws, shape=shape, dev=dev):
+                with torch.cuda.device(dev):
+                    status = _pinned_status(dev)
+                    nat.check(L.lasso_fista_solve_verdict(shape[0], n_global, *shape[1:], nat.ptr(reduced), nat.ptr(ws),
+                                                          ws.numel(), nat.stream_ptr(dev)))
+                    nat.check(L.lasso_fista_solve_collect(*shape, status.data_ptr(), nat.ptr(ws), ws.numel(),
+                                                          nat.stream_ptr(dev)))
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                return status, ev
+            pending = PendingShardedSolve(deltas, judge)
+        elif st == nat.LASSO_PENDING:
             status = _pinned_status(dev)
             nat.check(L.lasso_fista_solve_collect(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
                                                   status.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))

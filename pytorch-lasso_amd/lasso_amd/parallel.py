@@ -130,6 +130,14 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
             n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
             _all_reduce(n_glob, group)
             n_global = n_glob.item()
+        # a rank without rows would fail its argument check before the first collective and leave its peers
+        # blocked in the line search's all-reduce: agree on that up front and fail on EVERY rank instead
+        empty = torch.tensor([1.0 if n == 0 else 0.0], dtype=torch.float64, device=X.device)
+        _all_reduce(empty, group)
+        if empty.item() > 0:
+            raise ValueError("sharded line search: %d rank(s) hold an empty row shard; give every rank at least "
+                             "one row (or run those rows elsewhere)" % int(empty.item()))
+
         def reduce_host(t):          # a few float64 words in host memory; RCCL reduces device buffers
             if dist.get_backend(group) == "gloo":
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -178,23 +186,34 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     _all_reduce(n_glob, group)
     n_total = n_glob.item()
     losses = torch.zeros(steps, device=X.device)
-    # ONE message per EM step: [A = Z^T Z | B = Z^T X | sum r^2, sum |z|]
-    buf = torch.empty(k * k + k * d + 2, dtype=torch.float32, device=X.device)
-    tail = buf[k * k + k * d:]
+    # One GPU: the step is enqueued without waiting on it -- the stop rule's outcome and the
+    # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
+    # objective and the Gram product are still queued, so the GPU does not idle behind the host.
+    overlap = world == 1 and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
+    # Several ranks: the same, with the stop rule's per-iteration sums (ista.py:93 sums over the rows of ALL
+    # ranks) riding in the tail of the M-step message -- E-step (lr='auto' and the solve on the stream),
+    # objective, Gram product, ONE all-reduce, the rule judged on the device from the summed vector -- and
+    # the one host wait per step behind all of it.  (RCCL reduces on the stream; gloo, used when ranks
+    # share a GPU in tests, stages the message through the host -- that copy is then the wait.)
+    shard_async = world > 1 and hasattr(engine, 'encode_begin_sharded') and hasattr(engine, 'sweep_begin')
+    ndelta = int(solver_kwargs.get('maxiter', 10)) if shard_async else 0
+    if not 0 < ndelta <= 64:
+        ndelta = 0
+    # ONE message per EM step: [A = Z^T Z | B = Z^T X | sum r^2, sum |z| | stop-rule sums]
+    buf = torch.zeros(k * k + k * d + 2 + ndelta, dtype=torch.float32, device=X.device)
+    tail = buf[k * k + k * d:k * k + k * d + 2]
+    dtail = buf[k * k + k * d + 2:]
     Z0 = None
     bar = None
     if progbar and rank == 0:
         from tqdm import tqdm
         bar = tqdm(total=steps)
-    # One GPU: the step is enqueued without waiting on it -- the stop rule's outcome and the
-    # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
-    # objective and the Gram product are still queued, so the GPU does not idle behind the host.
-    overlap = world == 1 and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
     # Any number of ranks: the sweep's count of degenerate atoms is not waited for -- it is looked at
     # after the NEXT E-step has been enqueued (every rank holds the same A, B, D bit for bit, so every
     # rank sees the same count and takes the same branch).
     defer = hasattr(engine, 'sweep_begin')
     deferred = None          # the previous step's sweep: callable -> (mask, ndeg)
+    stats = getattr(engine, 'em_stats', None)     # optional counters (tests, tools/bench_em.py)
 
     def repair(mask, ndeg, Zprev):
         cand = draw_directions(d, ndeg).to(weight.device)       # every rank advances its generator alike
@@ -204,36 +223,59 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         if Zprev is not None:
             engine.zero_columns(Zprev, mask)                                              # :98
 
+    def encode_sync():
+        return sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
+
     i, Zlast = 0, None
     while i < steps:
-        pending = None
+        pending, sharded = None, False
         if overlap:
             Z, pending = engine.encode_begin(X, weight, alpha, Z0, **solver_kwargs)       # :38
         else:
-            Z = sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
+            began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs) if ndelta else None
+            if began is None:
+                Z = encode_sync()
+            else:
+                Z, pending = began
+                sharded = pending is not None
+                if stats is not None:
+                    stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
         loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
         A, B = engine.gram(Z, X, buf)
         if deferred is not None:
             mask, ndeg = deferred()
             deferred = None
             if ndeg:     # rare: an atom degenerated in the previous sweep -- repair, redo this E-step
-                if pending is not None:
+                if pending is not None and not sharded:
                     pending()
                 repair(mask, ndeg, Zlast)
                 continue
-        if pending is not None and not pending():
+        if pending is not None and not sharded and not pending():
             # the in-kernel stop rule gave up (CUs held by other work): same rule, chunked
             Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
             loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
             A, B = engine.gram(Z, X, buf)
-        if persist:
-            Z0 = Z                                                                        # :40-41
         if world > 1:
             tail.copy_(sums)                 # the two objective sums ride in the Gram message
+            if sharded:
+                dtail.copy_(pending.deltas)  # ... and so do this shard's stop-rule sums
             _all_reduce(buf, group)
+            if sharded:
+                pending.judge(dtail, n_total)
+                if not pending():            # the step's host wait; every rank reads the same verdict
+                    # the rule fired before the last iteration (rare in an EM loop): exact rule, chunked replay
+                    Z = encode_sync()
+                    loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
+                    A, B = engine.gram(Z, X, buf)
+                    tail.copy_(sums)
+                    _all_reduce(buf, group)
+                    if stats is not None:
+                        stats['replayed_steps'] = stats.get('replayed_steps', 0) + 1
             losses[i] = (0.5 * tail[0] + alpha * tail[1]) / n_total
         else:
             losses[i] = loss_local
+        if persist:
+            Z0 = Z                                                                        # :40-41
         if constrained:
             if defer:
                 deferred = engine.sweep_begin(A, B, weight, 1e-10, False)                 # :44-45

@@ -303,3 +303,98 @@ def test_resumable_runs_beyond_the_fused_shapes():
         assert (z.cpu() - ref).abs().max().item() <= 5e-5
         assert torch.equal(z, sparse_encode(Xg, Wg, 0.3, lr=lr, maxiter=9, tol=0.0))
         assert np.allclose(deltas, tr.delta, rtol=1e-4)
+
+
+def test_a_callers_broadcast_z0_is_read_not_taken_for_the_zero_sentinel():
+    """sparse_encode.py:44-45 reads the values of a given z0.  The library's own all-zero start is a MARKED
+    (0,0)-stride view (lazy_zeros); a caller's broadcast tensor with the same strides -- zero or not -- is an
+    ordinary z0 (round 2 keyed the sentinel on the strides alone and silently started such solves from 0)."""
+    sparse_encode, ista, orc = _mods()
+    from lasso_amd.linear.solvers.ista import lazy_zeros, _is_lazy_zeros
+    X, W = _case(48, 40, 96, seed=5)
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    Xg, Wg = X.cuda(), W.cuda()
+    for c in (0.1, -0.05):
+        z0 = torch.full((1, 1), c, device="cuda").expand(48, 96)
+        assert z0.stride() == (0, 0) and not _is_lazy_zeros(z0)
+        ref = orc.fista(X, torch.full((48, 96), c), W, alpha=0.3, lr=lr, maxiter=4, tol=0.0)
+        for fn in (lambda: ista(Xg, z0, Wg, alpha=0.3, lr=lr, maxiter=4, tol=0.0),
+                   lambda: sparse_encode(Xg, Wg, alpha=0.3, z0=z0, lr=lr, maxiter=4, tol=0.0),
+                   lambda: ista(X, torch.full((1, 1), c).expand(48, 96), W, alpha=0.3, lr=lr, maxiter=4, tol=0.0)):
+            assert (fn().cpu() - ref).abs().max().item() <= Z_ATOL
+        assert torch.equal(ista(Xg, z0, Wg, alpha=0.3, lr=lr, maxiter=0), z0)       # maxiter=0 returns z0 itself
+    lz = lazy_zeros(Xg, 48, 96)
+    assert _is_lazy_zeros(lz) and not _is_lazy_zeros(lz.detach()) and not _is_lazy_zeros(lz[:])
+    zz = torch.zeros(1, 1, device="cuda").expand(48, 96)                            # unmarked zeros: same result
+    assert torch.equal(ista(Xg, zz, Wg, alpha=0.3, lr=lr, maxiter=4, tol=0.0),
+                       ista(Xg, lz, Wg, alpha=0.3, lr=lr, maxiter=4, tol=0.0))
+
+
+def test_transpose_init_keeps_dtype_and_autograd_graph():
+    """init='transpose' (sparse_encode.py:24-25 is torch.matmul(x, weight)): z0 has x's dtype -- bf16 inputs solve
+    natively -- and stays part of the autograd graph, so dL/dz0 reaches x and the dictionary."""
+    sparse_encode, ista, orc = _mods()
+    from lasso_amd.linear import initialize_code
+    X, W = _case(64, 32, 128, seed=6)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = initialize_code(Xg.bfloat16(), Wg.bfloat16(), 0.3, "transpose")
+    assert z0.dtype == torch.bfloat16 and z0.shape == (64, 128)
+    zb = sparse_encode(Xg.bfloat16(), Wg.bfloat16(), alpha=0.3, init="transpose", lr=0.05, maxiter=5, tol=0.0)
+    assert zb.dtype == torch.bfloat16
+    zr = orc.fista(X, X @ W, W, alpha=0.3, lr=0.05, maxiter=5, tol=0.0)
+    assert (zb.float().cpu() - zr).abs().max().item() <= 0.15      # bf16 operands
+    # gradients through z0 = x W: compare with torch.autograd through the oracle
+    xa, wa = Xg.clone().requires_grad_(True), Wg.clone().requires_grad_(True)
+    z = sparse_encode(xa, wa, alpha=0.3, init="transpose", lr=0.05, maxiter=3, tol=0.0)
+    z.square().sum().backward()
+    xc, wc = X.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    zc = orc.fista(xc, xc @ wc, wc, alpha=0.3, lr=0.05, maxiter=3, tol=0.0)
+    zc.square().sum().backward()
+    for got, ref in ((xa.grad.cpu(), xc.grad), (wa.grad.cpu(), wc.grad)):
+        assert (got - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    # ... and differs from the gradient with z0 cut out of the graph (what round 2 computed)
+    xd = Xg.clone().requires_grad_(True)
+    zd = sparse_encode(xd, Wg, alpha=0.3, z0=(Xg @ Wg), lr=0.05, maxiter=3, tol=0.0)
+    zd.square().sum().backward()
+    assert (xd.grad - xa.grad).abs().max().item() > 1e-3
+
+
+def test_ridge_and_lstsq_inits_on_the_library_kernels():
+    """init='ridge' / 'lstsq' (sparse_encode.py:26-29, utils.py:13-40) on lasso_gram_accumulate +
+    lasso_ridge_solve: against fp64 solves on ragged shapes, under- and over-complete dictionaries; a
+    rank-deficient dictionary takes the QR route; a singular ridge system raises like the reference."""
+    from lasso_amd.linear import initialize_code
+    for (n, d, k) in ((37, 10, 50), (300, 96, 320), (64, 256, 1024), (500, 200, 120), (33, 64, 64), (4096, 256, 1024)):
+        X, W = _case(n, d, k, seed=n + k)
+        Xd, Wd = X.double(), W.double()
+        ridge = torch.linalg.solve(Wd.T @ Wd + 0.3 * torch.eye(k, dtype=torch.float64), Wd.T @ Xd.T).T
+        got = initialize_code(X.cuda(), W.cuda(), 0.3, "ridge")
+        assert got.shape == (n, k) and got.dtype == torch.float32
+        assert (got.cpu().double() - ridge).abs().max().item() <= 2e-5 * max(1.0, ridge.abs().max().item())
+        lst = torch.linalg.lstsq(Wd, Xd.T).solution.T if d >= k else (torch.linalg.pinv(Wd) @ Xd.T).T
+        got = initialize_code(X.cuda(), W.cuda(), 0.3, "lstsq")
+        assert (got.cpu().double() - lst).abs().max().item() <= 5e-5 * max(1.0, lst.abs().max().item()), (n, d, k)
+    # rank-deficient: duplicated rows make W W^T singular -> QR route (finite result, consistent system solved)
+    X, W = _case(20, 8, 30, seed=9)
+    W[4] = W[3]
+    z0 = initialize_code(X.cuda(), W.cuda(), 0.3, "lstsq")
+    assert z0.shape == (20, 30)
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        initialize_code(X.cuda(), torch.zeros(8, 30, device="cuda"), 0.0, "ridge")           # utils.py:36-38
+
+
+def test_workspace_cache_is_bounded():
+    """The scratch cache keyed by (device, stream, thread, purpose) evicts least-recently-used entries."""
+    from lasso_amd import _native as nat
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nat.release_workspaces()
+    old = nat._WS_MAX_ENTRIES
+    try:
+        nat._WS_MAX_ENTRIES = 4
+        bufs = [nat.workspace(dev, 1024, tag="t%d" % i) for i in range(10)]
+        assert len(nat._WS) == 4
+        assert nat.workspace(dev, 1024, tag="t9") is bufs[9]          # the newest survive
+        assert nat.workspace(dev, 512, tag="t0") is not bufs[0]       # the oldest were dropped
+    finally:
+        nat._WS_MAX_ENTRIES = old
+        nat.release_workspaces()

@@ -18,6 +18,7 @@ CASES = {"bcd": dict(constrained=True, lr=0.08, maxiter=12, tol=0.0),
          "ridge": dict(constrained=False, lr=0.08, maxiter=12, tol=0.0),
          "tol": dict(constrained=True, lr=0.08, maxiter=200, tol=2e-3),
          "auto": dict(constrained=True, maxiter=10),                      # lr='auto', default tol
+         "tol_short": dict(constrained=True, lr=0.08, maxiter=40, tol=5e-3),   # the rule fires at ~19 of 40: replay
          "persist": dict(constrained=True, persist=True, lr=0.08, maxiter=8, tol=0.0)}
 
 
@@ -43,9 +44,12 @@ def _worker(rank, world, port, tmp):
     for tag, kw in CASES.items():
         kw = dict(kw)
         torch.manual_seed(1)
+        eng = HipEngine()
+        eng.em_stats = {}
         Dl, losses = dict_learning_sharded(X[lo:hi], K, alpha=0.3, steps=4, init_weight=D0,
-                                           engine=HipEngine(), **kw)
+                                           engine=eng, **kw)
         out[tag + "_D"], out[tag + "_l"] = Dl.cpu().numpy(), losses.cpu().numpy()
+        out[tag + "_stats"] = np.array([eng.em_stats.get("overlapped_steps", 0), eng.em_stats.get("replayed_steps", 0)])
     np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -57,6 +61,13 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
     mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     X, D0 = _problem()
+    # the multi-rank step takes the no-host-wait path (E-step enqueued with lr='auto' on the stream, stop-rule sums
+    # in the tail of the ONE all-reduce, verdict on the device) whenever maxiter <= 64; "tol" (maxiter = 200) is the
+    # synchronous chunked path, "tol_short" stops early in every step and replays
+    for tag in CASES:
+        assert np.array_equal(r0[tag + "_stats"], r1[tag + "_stats"]), tag
+        assert (int(r0[tag + "_stats"][0]) >= 4) == (tag != "tol"), (tag, r0[tag + "_stats"])
+    assert int(r0["tol_short_stats"][1]) >= 1 and int(r0["auto_stats"][1]) == 0
     for tag, kw in CASES.items():
         # both ranks hold the same replicated dictionary and the same global objective, bit for bit
         assert np.array_equal(r0[tag + "_D"], r1[tag + "_D"]), tag
