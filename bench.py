@@ -293,6 +293,35 @@ def run_fista(args, ranks):
                                   "iterations": info["iterations"], "tol": 1e-5, "rows": r["rows"],
                                   "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), exact global over the "
                                           "rows of rank 0"}
+        if not args.no_extras and world == 1:
+            # SURVEY 8d's other figures for this configuration, each with its own timed region
+            Xg, Wg, z0 = r["Xg"], r["Wg"], r["z0"]
+            el, _ = timed_steps(ranks, lambda: ista(Xg, z0, Wg, ALPHA, fast=False, lr=lr, maxiter=args.iters, tol=0.0),
+                                args.steps, args.warmup)
+            out["ista_iterations_per_sec"] = {"value": args.steps * args.iters / el, "fast": False,
+                                              "ms_per_step": 1e3 * el / args.steps,
+                                              "note": "plain ISTA (ista.py:84 z_prev = z): same kernel, momentum coefficient 0"}
+            from lasso_amd.engine import HipEngine
+            eng = HipEngine(dev)
+            el, _ = timed_steps(ranks, lambda: eng.lipschitz(Wg), args.steps, args.warmup, events=False)
+            out["lipschitz_ms"] = {"value": 1e3 * el / args.steps,
+                                   "note": "lasso_lipschitz (ista.py:8-14) incl. its host synchronisation: the "
+                                           "reference returns a python float the same way"}
+            ista(Xg, z0, Wg, ALPHA, lr="auto", maxiter=2000, tol=1e-5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, info = ista(Xg, z0, Wg, ALPHA, lr="auto", maxiter=2000, tol=1e-5, return_info=True)
+            torch.cuda.synchronize()
+            out["time_to_tol_lr_auto"] = {"ms": 1e3 * (time.perf_counter() - t1), "iterations": info["iterations"],
+                                          "tol": 1e-5, "note": "lr='auto': lambda_max on the stream inside the call "
+                                          "(LASSO_LR_AUTO), Lipschitz time included"}
+            long_iters = 10 * args.iters
+            el, kms = timed_steps(ranks, lambda: ista(Xg, z0, Wg, ALPHA, fast=True, lr=lr, maxiter=long_iters, tol=0.0),
+                                  10, 1)
+            out["sustained"] = {"iterations_per_s": 10 * long_iters / el, "iters_per_launch": long_iters, "launches": 10,
+                                "seconds": el, "tflops": 4.0 * r["rows"] * D * K * long_iters * 10 / el / 1e12,
+                                "note": "the same kernel held busy ~10x longer than the headline region (clock under "
+                                        "sustained load)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(r["X"], r["W"], lr)
         elif not args.no_cpu_baseline:
@@ -374,8 +403,9 @@ def run_em(args, ranks):
                        "rows_per_gpu": rows, "rows_total": N_EM,
                        "parallelism": "row-sharded x%d, one all-reduce of [A|B|sums] per step" % world},
             "all_reduce_ms": {"median": ar[len(ar) // 2] if ar else 0.0, "max": ar[-1] if ar else 0.0,
-                              "bytes": 4 * (K * K + K * D + 2), "note": "device time of the one RCCL all-reduce per "
-                              "EM step (0 at N=1: no collective)"},
+                              "bytes": 4 * (K * K + K * D + 2 + 10), "note": "device time of the one RCCL all-reduce "
+                              "per EM step -- [A | B | objective sums | the E-step's 10 stop-rule sums] -- (0 at N=1: "
+                              "no collective)"},
             "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "kernel": "whole EM step (E-step kernel dominates)",
@@ -412,6 +442,7 @@ def main():
                          "the shard one rank of an 8-GPU strong-scaling run works on)")
     ap.add_argument("--no-shards", action="store_true", help="skip the per-shard timings of the N=1 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ISTA / Lipschitz / lr='auto' / sustained legs")
     ap.add_argument("--no-time-to-tol", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
