@@ -79,6 +79,9 @@ typedef enum {
 #define LASSO_KERNEL_SPLITK 0x200
 /* tuning knob: split-k with exactly T = 1, 2 or 4 tiles per workgroup group (default: by cost model) */
 #define LASSO_KERNEL_SPLITK_TILES(T) (0x200 | ((T) == 1 ? 0x1000 : (T) == 2 ? 0x2000 : 0x3000))
+/* tuning knob (A/B measurements): split-k with the register-gather exchange for every T (the default streams the
+ * partials of T >= 2 tiles through an LDS-DMA ring, csrc/fista_splitk.hip) */
+#define LASSO_KERNEL_SPLITK_GATHER (0x200 | 0x400)
 #define LASSO_KERNEL_MASK 0x3F00
 /* OR into stop_mode of lasso_fista_solve (fp32, fixed step): do not wait for the stop rule's
  * outcome.  Returns LASSO_PENDING when the solve was enqueued without a wait -- the single

@@ -45,12 +45,24 @@ __device__ __forceinline__ f32x4 load_chunk4(const float* __restrict__ src, int6
   return v;
 }
 
-template <int BM, int BN, bool VEC>
+// Epilogue of the unfused FISTA path's second GEMM (EPI = true): the block of g = -(A B^T) never goes to
+// memory -- the proximal step runs on the accumulators: z_next = softshrink(y - lr*g, lam), the block's
+// sum |z - z_next|, y = z_next + c (z_next - z), z = z_next (ista.py:90,93,98-102; each product and sum rounded
+// on its own like the reference's separate ATen ops, the arithmetic of generic_prox_kernel).  Z and Y are
+// updated in place: every element belongs to exactly one block and neither is an operand of this GEMM.
+struct ProxEpilogue {
+  float* Z; int64_t ldz;
+  float* Y; int64_t ldy;
+  float lr, lam, coef;
+  float* dpart;                 // [gridDim.y * gridDim.x] per-block sums of |z - z_next|
+};
+
+template <int BM, int BN, bool VEC, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ B, int64_t ldb,
                                                          const float* __restrict__ C0, int64_t ldc0,
                                                          float* __restrict__ C, int64_t ldc, int m, int nn,
-                                                         int kk, int add) {
+                                                         int kk, int add, ProxEpilogue ep = ProxEpilogue()) {
   constexpr int MI = BM / 32, NJ = BN / 32;          // 16x16 blocks per wave: MI x NJ
   constexpr int PA = BM / 32, PB = BN / 32;          // staged 16-byte chunks per thread and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,18 +116,58 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     __syncthreads();
     buf ^= 1;
   }
+  if constexpr (EPI) {
+    float dsum = 0.0f;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      // all of a row block's z, y values in flight before the first is used
+      float zo[NJ][4], yo[NJ][4];
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj)
+      for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
-        if (r < m && cc < nn) {
-          const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
-          C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+          const bool in = r < m && cc < nn;
+          zo[nj][rg] = in ? ep.Z[(int64_t)r * ep.ldz + cc] : 0.0f;
+          yo[nj][rg] = in ? ep.Y[(int64_t)r * ep.ldy + cc] : 0.0f;
         }
-      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+          if (r < m && cc < nn) {
+            const float g = 0.0f - acc[mi][nj][rg];
+            const float v = __fsub_rn(yo[nj][rg], __fmul_rn(ep.lr, g));
+            const float zn = __fsub_rn(v, __builtin_amdgcn_fmed3f(v, -ep.lam, ep.lam));
+            dsum += __builtin_fabsf(__fsub_rn(zo[nj][rg], zn));
+            ep.Y[(int64_t)r * ep.ldy + cc] = __fadd_rn(zn, __fmul_rn(ep.coef, __fsub_rn(zn, zo[nj][rg])));
+            ep.Z[(int64_t)r * ep.ldz + cc] = zn;
+          }
+        }
+    }
+    // block sum in a fixed order: lanes (butterfly over the wave), then the four waves
+    __syncthreads();                                   // the staging buffers are free
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+    if (lane == 0) red[w] = dsum;
+    __syncthreads();
+    if (tid == 0) ep.dpart[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+          if (r < m && cc < nn) {
+            const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
+            C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
+          }
+        }
+  }
 }
 
 template <int BM, int BN, bool VEC>
@@ -133,7 +185,58 @@ hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb,
   return hipGetLastError();
 }
 
+template <int BM, int BN, bool VEC>
+hipError_t launch_tile_prox(const float* A, int64_t lda, const float* B, int64_t ldb, int m, int nn, int kk,
+                            const ProxEpilogue& ep, hipStream_t stream) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  if (lds > 48 * 1024)
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, VEC, true>), lds);
+        e != hipSuccess)
+      return e;
+  const dim3 grid((nn + BN - 1) / BN, (m + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC, true>), grid, dim3(256), lds, stream, A, lda, B, ldb, nullptr, 0,
+                     nullptr, 0, m, nn, kk, 0, ep);
+  return hipGetLastError();
+}
+
 }  // namespace
+
+// blocks the fused GEMM-2 + prox launch uses for an [m x nn] result (= partial sums it writes)
+static void prox_blocks(int m, int nn, int* bm_out, int* bn_out) {
+  auto pad = [](int v, int b) { return (v + b - 1) / b * b; };
+  const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
+  const bool roomy = big_blocks >= 192;
+  *bm_out = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
+  *bn_out = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+}
+
+int gemm_nt_prox_parts(int m, int nn) {
+  int bm, bn;
+  prox_blocks(m, nn, &bm, &bn);
+  return ((m + bm - 1) / bm) * ((nn + bn - 1) / bn);
+}
+
+// G = -(A B^T) consumed in the epilogue: Z, Y [m x nn] updated in place, dpart[gemm_nt_prox_parts(m, nn)] written
+hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int64_t ldb, float* Z, int64_t ldz,
+                               float* Y, int64_t ldy, int m, int nn, int kk, float lr, float lam, float coef,
+                               float* dpart, hipStream_t stream) {
+  if (m <= 0 || nn <= 0) return hipSuccess;
+  const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
+                   ((uintptr_t)B & 15) == 0;
+  int bm, bn;
+  prox_blocks(m, nn, &bm, &bn);
+  const ProxEpilogue ep = {Z, ldz, Y, ldy, lr, lam, coef, dpart};
+#define LASSO_PROX_CASE(BM_, BN_)                                                                 \
+  if (bm == BM_ && bn == BN_)                                                                      \
+    return vec ? launch_tile_prox<BM_, BN_, true>(A, lda, B, ldb, m, nn, kk, ep, stream)          \
+               : launch_tile_prox<BM_, BN_, false>(A, lda, B, ldb, m, nn, kk, ep, stream)
+  LASSO_PROX_CASE(128, 128);
+  LASSO_PROX_CASE(128, 64);
+  LASSO_PROX_CASE(64, 128);
+  LASSO_PROX_CASE(64, 64);
+#undef LASSO_PROX_CASE
+  return hipErrorInvalidValue;
+}
 
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
                               int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk,

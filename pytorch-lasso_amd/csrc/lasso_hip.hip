@@ -299,7 +299,7 @@ int splitk_max_groups(int kp) {
 
 KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bits) {
   KernelPlan plan = {false, 0, 1};
-  const int hint = hint_bits & 0xF00;
+  const int hint = hint_bits & 0x300;
   if (dpad != kFistaD || hint == LASSO_KERNEL_TILE || ntiles <= 0) return plan;
   const int gmax = splitk_max_groups(kp);
   if (gmax <= 0) return plan;
@@ -354,6 +354,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.stop_out = ws.stop_out;
   p.xch = nullptr; p.xflags = nullptr; p.groups = 0;
   p.run_if = nullptr; p.part_stride = ntiles;
+  p.variant = (hint & 0x400) ? 1 : (hint & 0x800) ? 2 : 0;       // A/B knobs: register gather for every T / streamed for every T
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   // in-place launches keep the tile kernel: a split-k launch that gives up is redone from its
@@ -779,7 +780,8 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool bac
   w.Y = take((size_t)n * k * 4);
   w.NR = take((size_t)n * d * 4);
   w.G = take((size_t)n * k * 4);
-  w.dpart = take((size_t)kGenGrid * 4);
+  // per-block sums of |z - z_next|: the fused GEMM-2 + prox launch writes one per 64 x 64 (or larger) block
+  w.dpart = take(std::max<size_t>((size_t)kGenGrid, (size_t)((n + 63) / 64) * (size_t)((k + 63) / 64)) * 4);
   w.delta = take(256);
   w.C = w.part = w.fvals = nullptr; w.flags = nullptr; w.sums = nullptr;
   if (backtrack) {
@@ -817,13 +819,14 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
     // NR = x - y W^T  (= -r);   G = 0 - NR Wt^T = r W
+    // the gradient block g = r W never goes to memory: the proximal step runs in GEMM-2's epilogue
     LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Y, k, w, ldw, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));
-    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.NR, d, ws.Wt, d, nullptr, 0, ws.G, k, (int)n, (int)k, (int)d, st));
-    LASSO_HIP_TRY(launch_generic_prox(zout, ldz, ws.Y, ws.G, (int)n, (int)k, lr_f, lam, coef, ws.dpart,
-                                      kGenGrid, st));
+    LASSO_HIP_TRY(launch_gemm_nt_prox(ws.NR, d, ws.Wt, d, zout, ldz, ws.Y, k, (int)n, (int)k, (int)d, lr_f, lam, coef,
+                                      ws.dpart, st));
     t_mom = t_next;
     if (tol > 0.0) {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, ws.delta);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, gemm_nt_prox_parts((int)n, (int)k),
+                         ws.delta);
       LASSO_HIP_TRY(hipGetLastError());
       LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -860,11 +863,11 @@ int run_generic(const float* x, int64_t ldx, const float* z_in, int64_t ldz_in,
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
     LASSO_HIP_TRY(launch_gemm_nt_sub(ws.Y, k, ws.Wc, k, x, ldx, ws.NR, d, (int)n, (int)d, (int)k, st));
-    LASSO_HIP_TRY(launch_gemm_nt_sub(ws.NR, d, ws.Wt, d, nullptr, 0, ws.G, k, (int)n, (int)k, (int)d, st));
-    LASSO_HIP_TRY(launch_generic_prox(z_out, ldz_out, ws.Y, ws.G, (int)n, (int)k, lr_f, lam, coef, ws.dpart,
-                                      kGenGrid, st));
+    LASSO_HIP_TRY(launch_gemm_nt_prox(ws.NR, d, ws.Wt, d, z_out, ldz_out, ws.Y, k, (int)n, (int)k, (int)d, lr_f, lam,
+                                      coef, ws.dpart, st));
     if (delta_dev) {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, kGenGrid, delta_dev + i);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, gemm_nt_prox_parts((int)n, (int)k),
+                         delta_dev + i);
       LASSO_HIP_TRY(hipGetLastError());
     }
     t_mom = t_next;
@@ -1147,7 +1150,7 @@ __global__ void step_from_lipschitz_kernel(const double* __restrict__ L, double 
 
 const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, int backtrack) {
   if (n <= 0 || d <= 0 || k <= 0) return "";
-  if (!fused_shape(d, k)) return "lasso::gemm_nt_kernel x2 + lasso::generic_prox_kernel (unfused)";
+  if (!fused_shape(d, k)) return "lasso::gemm_nt_kernel + lasso::gemm_nt_kernel<.., prox epilogue> (unfused)";
   if (dtype == LASSO_BF16) {
     int per_cu = 0;
     const int kpb = pad_k(k);
@@ -1223,8 +1226,8 @@ int lasso_fista_run(const void* x_dev, int64_t ldx, const void* z_in_dev, int64_
     return fail(LASSO_ERR_BAD_ARG, "leading dimension smaller than the row length");
   const int kp = pad_k(k);
   if (it0 + iters > maxiter) return fail(LASSO_ERR_BAD_ARG, "it0 + iters = %d > maxiter = %d", it0 + iters, maxiter);
-  if ((kernel_hint & ~LASSO_KERNEL_MASK) || ((kernel_hint & 0xF00) != LASSO_KERNEL_AUTO &&
-      (kernel_hint & 0xF00) != LASSO_KERNEL_TILE && (kernel_hint & 0xF00) != LASSO_KERNEL_SPLITK))
+  if ((kernel_hint & ~LASSO_KERNEL_MASK) || ((kernel_hint & 0x300) != LASSO_KERNEL_AUTO &&
+      (kernel_hint & 0x300) != LASSO_KERNEL_TILE && (kernel_hint & 0x300) != LASSO_KERNEL_SPLITK))
     return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", kernel_hint);
   // same carve as lasso_fista_prepare(maxiter): the momentum table it built is read here
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, false);
@@ -1278,7 +1281,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   stop_mode &= ~LASSO_KERNEL_MASK;
   if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
     return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
-  if ((hint & 0xF00) != LASSO_KERNEL_AUTO && (hint & 0xF00) != LASSO_KERNEL_TILE && (hint & 0xF00) != LASSO_KERNEL_SPLITK)
+  if ((hint & 0x300) != LASSO_KERNEL_AUTO && (hint & 0x300) != LASSO_KERNEL_TILE && (hint & 0x300) != LASSO_KERNEL_SPLITK)
     return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
@@ -1291,7 +1294,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                          maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
                          workspace_bytes, st);
   const int kp = pad_k(k);
-  if (half_any && (hint & 0xF00) != LASSO_KERNEL_TILE) {
+  if (half_any && (hint & 0x300) != LASSO_KERNEL_TILE) {
     // bf16 tensors: the persistent single-launch kernel when every 64-row tile has its own
     // resident workgroup (LASSO_KERNEL_TILE asks for the multi-launch kernels instead)
     bool ran = false;

@@ -41,6 +41,7 @@ struct FistaTileParams {
   // kernel's abort flag)
   const int* run_if;                     // nullable
   int part_stride;                       // partials[it * part_stride + part]
+  int variant;                           // split-k kernel: 0 = default, 1 = the register-gather form for every T (A/B knob)
 };
 constexpr int kStopRing = 64;
 constexpr int kSplitkMaxParts = 256;   // split-k kernel: groups x members never exceed the CU count
@@ -195,6 +196,11 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
                               const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
                               int kk, hipStream_t stream, int add = 0);
+// the same GEMM with the proximal step of the unfused FISTA path in its epilogue (gemm.hip)
+int gemm_nt_prox_parts(int m, int nn);
+hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int64_t ldb, float* Z, int64_t ldz,
+                               float* Y, int64_t ldy, int m, int nn, int kk, float lr, float lam, float coef,
+                               float* dpart, hipStream_t stream);
 hipError_t launch_cd_init(const float* z0, int64_t ldz0, float* Zt, int kp, int n, int k, int* active,
                           int* row_steps, float* S, hipStream_t stream);
 hipError_t launch_cd_rows(const CdParams& p, int kp, int cus, int* info, hipStream_t stream);

@@ -285,7 +285,10 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
 _STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
 _KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNEL_SPLITK,
            'splitk1': nat.KERNEL_SPLITK | 0x1000, 'splitk2': nat.KERNEL_SPLITK | 0x2000,
-           'splitk4': nat.KERNEL_SPLITK | 0x3000}
+           'splitk4': nat.KERNEL_SPLITK | 0x3000,
+           # A/B knobs: T = 2 / 4 with the register-gather exchange (the default streams the partials by LDS-DMA)
+           'splitk2g': nat.KERNEL_SPLITK | 0x400 | 0x2000, 'splitk4g': nat.KERNEL_SPLITK | 0x400 | 0x3000,
+           'splitk1s': nat.KERNEL_SPLITK | 0x800 | 0x1000}
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,

@@ -409,7 +409,10 @@ def test_g1_dictionary_drift_per_step(golden):
         Z = orc.sparse_encode(data, W, 0.5, algorithm='ista', lr=0.05)
         W = orc.update_dict(W.clone(), data, Z)
         traj.append(W.clone())
-    assert (traj[60] - T(g["D_fix"])).abs().max().item() <= 1e-6          # the oracle IS the golden run
+    # the oracle IS the golden run -- bitwise on the host that generated the fixture; on another CPU (other BLAS
+    # kernels, other summation order) the SAME torch code lands 1e-5 away after 60 steps (measured on the
+    # MI355X box's EPYC host): the EM map amplifies last-ulp differences for every implementation alike
+    assert (traj[60] - T(g["D_fix"])).abs().max().item() <= 1e-4
     # (a) local error of one HIP step from the oracle's state
     local = []
     for s in range(60):

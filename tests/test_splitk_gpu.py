@@ -33,7 +33,8 @@ def test_split_kernel_is_bitwise_the_tile_kernel(n, d, k, fast):
     for z0 in (torch.zeros(n, k, device="cuda"), warm):
         for iters in (1, 2, 9, 40):
             zt = ista(Xg, z0, Wg, 0.3, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel='tile')
-            for kern in ('splitk', 'splitk1', 'splitk2', 'splitk4'):   # cost-model choice, then T = 1, 2, 4 tiles per group
+            # cost-model choice, then T = 1, 2, 4 tiles per group (T >= 2: partials streamed by LDS-DMA; '..g': gathered in registers)
+            for kern in ('splitk', 'splitk1', 'splitk2', 'splitk4', 'splitk2g', 'splitk4g', 'splitk1s'):
                 zs = ista(Xg, z0, Wg, 0.3, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel=kern)
                 assert torch.equal(zt, zs), (kern, iters, (zt - zs).abs().max().item())
     ref = orc.fista(X, X.new_zeros(n, k), W, 0.3, fast=fast, lr=lr, maxiter=40, tol=0.0)

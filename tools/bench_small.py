@@ -20,13 +20,14 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 out = []
-for d, k in ((256, 1024), (256, 512), (200, 256)):
+SHAPES = ((256, 1024),) if "--k1024" in sys.argv else ((256, 1024), (256, 512), (200, 256))
+for d, k in SHAPES:
     for n in (16, 128, 256, 512, 768, 1024, 1536, 2048, 2560, 3072, 4096):
         X, W = recipe_xw(n, d, k)
         Xg, Wg = X.cuda(), W.cuda()
         z0 = torch.zeros(n, k, device="cuda")
         row = {"n": n, "d": d, "k": k}
-        for kern in ("tile", "splitk1", "splitk2", "splitk4", "auto"):
+        for kern in ("tile", "splitk1", "splitk1s", "splitk2", "splitk4", "splitk2g", "splitk4g", "auto"):
             ms = timed(lambda: ista(Xg, z0, Wg, 0.5, lr=0.05, maxiter=100, tol=0.0, kernel=kern))
             row[kern + "_us_per_iter"] = ms * 10.0
             row[kern + "_iters_per_s"] = 100 / ms * 1e3

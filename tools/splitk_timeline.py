@@ -13,7 +13,7 @@ from lasso_amd.linear.solvers import ista
 from recipes import recipe_xw
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 kern = sys.argv[2] if len(sys.argv) > 2 else 'splitk4'
-T = {'splitk1': 1, 'splitk2': 2, 'splitk4': 4}[kern]
+T = {'splitk1': 1, 'splitk2': 2, 'splitk4': 4, 'splitk2g': 2, 'splitk4g': 4, 'splitk1s': 1}[kern]
 X, W = recipe_xw(n, 256, 1024)
 Xg, Wg = X.cuda(), W.cuda()
 z0 = torch.zeros(n, 1024, device='cuda')
