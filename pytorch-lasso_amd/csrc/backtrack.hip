@@ -25,6 +25,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_grad_kernel(const BtParam
   lds_char* const pt = rings + NW * kRingBytesPerWave;
   lds_char* const rt = pt + kTileM * K * 4;
   lds_f32* const red = (lds_f32*)(rt + kTileM * D * 4);
+  if (p.skip && *p.skip != 0) return;
 
   TileCtx<K> c;
   c.init(p.Wp, p.Wtp, rings);
@@ -93,6 +94,7 @@ template <int K>
 __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtParams p, float lr,
                                                                     float lam, int force) {
   constexpr int NW = kFistaWaves;
+  if (p.skip && *p.skip != 0) return;
   if (!force && p.flags[0] != 0) return;   // an earlier trial of this iteration was accepted
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const rings = (lds_char*)smem;
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(256) void bt_decide_kernel(const float* __restrict_
                                                         float alpha, float half_over_lr, float lr, float lam,
                                                         int trial_index, int force,
                                                         int* __restrict__ flags, float* __restrict__ fvals,
-                                                        double* __restrict__ sums_out) {
+                                                        double* __restrict__ sums_out, const int* __restrict__ skip) {
+  if (skip && *skip != 0) return;
   if (!force && flags[0] != 0) return;
   __shared__ double sh[5][256];
   double acc[5] = {0, 0, 0, 0, 0};
@@ -239,9 +242,11 @@ __global__ __launch_bounds__(256) void bt_finish_recompute_kernel(float* __restr
                                                                   const float* __restrict__ G, int64_t total,
                                                                   float coef, const int* __restrict__ flags,
                                                                   const float* __restrict__ fvals,
-                                                                  float* __restrict__ dpart) {
+                                                                  float* __restrict__ dpart,
+                                                                  const int* __restrict__ skip) {
   __shared__ float sh[256];
   float acc = 0.0f;
+  if (skip && *skip != 0) return;
   if (flags[0] != 0) {
     const float lr = fvals[2], lam = fvals[3];
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -310,7 +315,7 @@ hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int tria
                             hipStream_t stream, double* sums_out) {
   hipLaunchKernelGGL(bt_decide_kernel, dim3(1), dim3(256), 0, stream, p.partials, p.ntiles,
                      (float)alpha, (float)(0.5 / lr), (float)lr, (float)(alpha * lr), trial_index, force, p.flags,
-                     p.fvals, sums_out);
+                     p.fvals, sums_out, p.skip);
   return hipGetLastError();
 }
 
@@ -374,9 +379,50 @@ hipError_t launch_generic_trial(const float* P, const float* G, float* Cand, int
 
 hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
                                       const int* flags, const float* fvals, float* dpart, int grid,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, const int* skip) {
   hipLaunchKernelGGL(bt_finish_recompute_kernel, dim3(grid), dim3(256), 0, stream, Z, Y, P, G, total, coef, flags,
-                     fvals, dpart);
+                     fvals, dpart, skip);
+  return hipGetLastError();
+}
+
+// End of outer iteration `it` of a solve enqueued without host waits (one block).  ctl: [0] 0 = running, 1 = the stop
+// rule fired, 2 = no trial of the pre-enqueued batch was accepted (the host continues from iteration ctl[1] on the
+// synchronous path: the state is untouched), [1] iterations completed, [2] last sum |z - z_next| (float bits).
+__global__ __launch_bounds__(256) void bt_iter_end_kernel(const float* __restrict__ dpart, int nparts,
+                                                          int* __restrict__ flags, const float* __restrict__ fvals,
+                                                          int* __restrict__ ctl, int it, float budget,
+                                                          int* __restrict__ trials, float* __restrict__ lrs,
+                                                          float* __restrict__ fs) {
+  if (ctl[0] != 0) return;
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  for (int t = threadIdx.x; t < nparts; t += 256) acc += dpart[t];     // the order of reduce_partials_kernel
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (flags[0] == 0) {
+      ctl[0] = 2;
+    } else {
+      const float delta = sh[0];
+      trials[it] = flags[2] + 1;
+      lrs[it] = fvals[2];
+      fs[it] = fvals[0];
+      ctl[1] = it + 1;
+      ctl[2] = __float_as_int(delta);
+      if (budget >= 0.0f && delta <= budget) ctl[0] = 1;                 // ista.py:93-95
+    }
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;             // the next iteration starts its search afresh
+  }
+}
+
+hipError_t launch_bt_iter_end(const float* dpart, int nparts, int* flags, const float* fvals, int* ctl, int it,
+                              float budget, int* trials, float* lrs, float* fs, hipStream_t stream) {
+  hipLaunchKernelGGL(bt_iter_end_kernel, dim3(1), dim3(256), 0, stream, dpart, nparts, flags, fvals, ctl, it, budget,
+                     trials, lrs, fs);
   return hipGetLastError();
 }
 

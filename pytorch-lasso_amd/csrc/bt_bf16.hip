@@ -35,6 +35,7 @@ __global__ __launch_bounds__(kThreads, 1) void bt16_grad_kernel(const BtParams p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const pt = (lds_char*)smem;       // [64][K] bf16; the r tile [64][256] reuses its start
   lds_f32* const red = (lds_f32*)(pt + kRows * K * 2);
+  if (p.skip && *p.skip != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const __bf16* X = (const __bf16*)p.Xh;
   const bf16x8* wq1 = (const bf16x8*)p.Wq1 + (int64_t)wid * (K / 32) * 2 * 64;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kThreads, 1) void bt16_grad_kernel(const BtParams p
 template <int K>
 __global__ __launch_bounds__(kThreads, 1) void bt16_trial_kernel(const BtParams p, float lr, float lam, int force) {
   constexpr int CPR = K / 8;
+  if (p.skip && *p.skip != 0) return;
   if (!force && p.flags[0] != 0) return;      // an earlier trial of this iteration was accepted
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const zt = (lds_char*)smem;

@@ -445,6 +445,8 @@ struct BtWorkspace {
   void* pgran;     // trial granules + |dz| granules
   int* pout;       // [4]
   int* ptrials; float* plrs; float* pfvals;   // [maxiter] each
+  int* rtrials; float* rlrs; float* rfs;      // [maxiter] each: record of a multi-launch solve enqueued without host waits
+  int* ctl;                                   // its control words (bt_iter_end_kernel)
   size_t bytes;
 };
 
@@ -482,6 +484,13 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
     w.ptrials = reinterpret_cast<int*>(take((size_t)cap * 4));
     w.plrs = take((size_t)cap * 4);
     w.pfvals = take((size_t)cap * 4);
+  }
+  {   // line search enqueued without host waits: the per-iteration record and the control words
+    const int cap = std::max(maxiter, 1);
+    w.rtrials = reinterpret_cast<int*>(take((size_t)cap * 4));
+    w.rlrs = take((size_t)cap * 4);
+    w.rfs = take((size_t)cap * 4);
+    w.ctl = reinterpret_cast<int*>(take(256));
   }
   w.bytes = off;
   return w;
@@ -562,7 +571,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   // (:93) -- are added over the ranks by the caller's callback; every rank then takes the same
   // decision from the same numbers.
   const bool half = dtype == LASSO_BF16;      // bf16 tensors: bt_bf16.hip kernels, 64-row tiles
-  BtWorkspace ws = carve_bt(workspace, n, k, kp, half);
+  BtWorkspace ws = carve_bt(workspace, n, k, kp, half, maxiter);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
@@ -600,6 +609,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   if (reduce && !recompute) return fail(LASSO_ERR_UNSUPPORTED, "row-sharded line search needs ldz == k");
   p.G = ws.G; p.C = recompute ? nullptr : ws.C; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
+  p.skip = nullptr;
   const float budget = (float)((double)(reduce ? n_global : n) * (double)k * tol);
   bool warned = false;
   double t_mom = 1.0;   // ista.py:78 (python int 1; same arithmetic in double)
@@ -607,6 +617,69 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   struct { int flags[4]; float fvals[4]; float delta; } host;
   int it = 0, prev_trials = kBtBatch - 1;
   float last = NAN;
+  // ---- the whole solve enqueued WITHOUT a host wait (one process, flat state): every outer iteration is the
+  // gradient, kBtBatch trial launches with the step sequence lr0 / eta^t (a trial behind the accepted one returns at
+  // once), the accept step and a one-block kernel that keeps the iteration's record and evaluates the stop rule on
+  // the device; once the rule fired -- or a search needed more than kBtBatch trials -- the remaining launches are
+  // no-ops (BtParams::skip).  ONE synchronisation at the end; only a search that ran out of trials is continued on
+  // the iteration-by-iteration path below, from the untouched state of the iteration that needed them.
+  if (!reduce && recompute && maxiter > 0) {
+    LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
+    LASSO_HIP_TRY(hipMemsetAsync(ws.ctl, 0, 4 * sizeof(int), st));
+    p.skip = ws.ctl;
+    double tm = 1.0;
+    for (int i = 0; i < maxiter; ++i) {
+      const double t_next = (1.0 + sqrt(1.0 + 4.0 * tm * tm)) / 2.0;                 // :98
+      const float coef = fast ? (float)((tm - 1.0) / t_next) : 0.0f;                 // :99
+      p.P = fast ? ws.Y : zout;
+      p.ldp = fast ? k : ldz;
+      if (half) LASSO_HIP_TRY(launch_bt16_grad(p, kp, grid, st));
+      else LASSO_HIP_TRY(launch_bt_grad(p, kp, grid, st));
+      double lr = lr0;
+      for (int b = 0; b < kBtBatch; ++b) {
+        if (half) {
+          LASSO_HIP_TRY(launch_bt16_trial(p, kp, grid, (float)lr, (float)(alpha * lr), 0, st));
+          LASSO_HIP_TRY(launch_bt_decide(p, alpha, lr, b, 0, st, nullptr));
+        } else {
+          LASSO_HIP_TRY(launch_bt_trial(p, kp, grid, alpha, lr, b, 0, st, nullptr));
+        }
+        lr = lr / eta;                                                                 // :47
+      }
+      LASSO_HIP_TRY(launch_bt_finish_recompute(zout, ws.Y, p.P, ws.G, n * k, coef, ws.flags, ws.fvals, ws.dpart,
+                                               kBtFinishGrid, st, ws.ctl));
+      LASSO_HIP_TRY(launch_bt_iter_end(ws.dpart, kBtFinishGrid, ws.flags, ws.fvals, ws.ctl, i,
+                                       tol > 0.0 ? budget : -1.0f, ws.rtrials, ws.rlrs, ws.rfs, st));
+      tm = t_next;
+    }
+    p.skip = nullptr;
+    int hctl[4] = {0, 0, 0, 0};
+    LASSO_HIP_TRY(hipMemcpyAsync(hctl, ws.ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    const int done = hctl[1];
+    if (done > 0) {
+      std::vector<int> ht(done);
+      std::vector<float> hl(done), hf(done);
+      LASSO_HIP_TRY(hipMemcpy(ht.data(), ws.rtrials, (size_t)done * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hl.data(), ws.rlrs, (size_t)done * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hf.data(), ws.rfs, (size_t)done * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < done; ++i) {
+        if (trials_out) trials_out[i] = ht[i];
+        if (accepted_lr_out) accepted_lr_out[i] = hl[i];
+        if (accepted_f_out) accepted_f_out[i] = hf[i];
+      }
+      prev_trials = ht[done - 1];
+      memcpy(&last, &hctl[2], sizeof(float));
+    }
+    it = done;
+    for (int i = 0; i < done; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+    if (hctl[0] != 2) {          // ran to maxiter, or the stop rule fired at iteration `done`
+      if (half) LASSO_HIP_TRY(launch_cvt_bf16(zout, k, zout_any, ldz_any, (int)n, (int)k, 0, st));
+      if (iters_out) *iters_out = it;
+      if (last_delta_out) *last_delta_out = last;
+      return LASSO_OK;
+    }
+    // a search ran out of pre-enqueued trials at iteration `it`: continue below, one iteration at a time
+  }
   for (; it < maxiter; ++it) {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;             // :98
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;                 // :99
@@ -724,6 +797,7 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
   LASSO_HIP_TRY(hipMemcpyAsync(ws.Y, Z, (size_t)n * k * 4, hipMemcpyDeviceToDevice, st));
   BtParams p;
   p.X = nullptr; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
+  p.skip = nullptr;
   p.Xh = x_any; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
   p.G = ws.G; p.C = nullptr; p.partials = ws.partials; p.flags = ws.flags; p.fvals = ws.fvals;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
@@ -902,6 +976,7 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
   }
   LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
   BtParams bp;                                             // only what bt_decide_kernel reads
+  bp.skip = nullptr;
   bp.partials = ws.part; bp.ntiles = kGenGrid; bp.flags = ws.flags; bp.fvals = ws.fvals;
   const float budget = (float)((double)(reduce ? n_global : n) * (double)k * tol);
   bool warned = false;

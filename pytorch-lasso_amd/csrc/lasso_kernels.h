@@ -92,6 +92,8 @@ struct BtParams {
   float* partials;                       // [5][ntiles]
   int* flags; float* fvals;
   int n, d, k, ntiles;
+  const int* skip;                       // nullable: *skip != 0 -> the launch is a no-op (a solve enqueued without host waits
+                                         // whose stop rule fired, or whose line search ran out of pre-enqueued trials)
   // bf16 variant (bt_bf16.hip): x in bf16, fragment-major bf16 copies of W, 64-row tiles
   const void* Xh; const void* Wq1; const void* Wq2;
 };
@@ -171,7 +173,11 @@ hipError_t launch_cvt_bf16(const void* src, int64_t ld_src, void* dst, int64_t l
                            hipStream_t stream);
 hipError_t launch_bt_finish_recompute(float* Z, float* Y, const float* P, const float* G, int64_t total, float coef,
                                       const int* flags, const float* fvals, float* dpart, int grid,
-                                      hipStream_t stream);
+                                      hipStream_t stream, const int* skip = nullptr);
+// end of an outer iteration of a line-search solve enqueued without host waits: sum |z - z_next|, the iteration's
+// record (trials, accepted step, F), the stop rule -- all on the device (backtrack.hip)
+hipError_t launch_bt_iter_end(const float* dpart, int nparts, int* flags, const float* fvals, int* ctl, int it,
+                              float budget, int* trials, float* lrs, float* fs, hipStream_t stream);
 // unfused line search (backtrack.hip): element-wise halves around launch_gemm_nt_sub
 hipError_t launch_sumsq_partials(const float* v, int64_t total, float* part, int grid, hipStream_t stream);
 hipError_t launch_generic_trial(const float* P, const float* G, float* Cand, int64_t total, float lr, float lam,
