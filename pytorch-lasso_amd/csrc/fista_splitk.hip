@@ -498,6 +498,380 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
   }
 }
 
+
+// =================================================================================================
+// Reduce-scatter form (K = 1024: C = 8 members = 8 waves = 8 column blocks of r; no in-kernel stop rule).
+// In the kernel above every member pulls ALL C partials of a tile (128 KiB per tile and compute unit), in two
+// dependent batches, before its GEMM-2 can start -- and a compute unit reads data another one has just written at
+// ~110 GB/s: >1 us per tile that nothing hides.  Here the C partials of a tile are summed ONCE:
+//   * member j reduces column block j (the 2 KiB blocks that wave j of every member produced), in the canonical
+//     left-to-right order, and publishes the reduced block (wave pair 2t, 2t+1 of the member takes tile slot t, one
+//     16-byte column half each: every wave has at most one such job per iteration, all jobs of an iteration run
+//     side by side);
+//   * every member then fetches the eight reduced blocks of a tile: 16 KiB instead of 128, two 16-byte loads per
+//     lane, issued a tile ahead (8 registers) -- the fetch of tile t+1 flies under GEMM-2 of tile t.
+// 36 KiB cross a compute unit's L2 port per tile instead of 128; the price is a second hop (flag2) per iteration,
+// paid once for all T tiles.  Same sums in the same order: bitwise the same code as every other kernel.
+template <int T>
+__global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_rs_kernel(const FistaTileParams p) {
+  const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
+  constexpr int K = 1024;
+  constexpr int C = K / kSlice;
+  constexpr int D = kFistaD;
+  constexpr int NW = kFistaWaves;
+  constexpr int YT_BYTES = kTileM * kSlice * 4;     // 8 KiB per tile slot
+  constexpr int RT_BYTES = kTileM * D * 4;          // 16 KiB
+  static_assert(C == NW && (T == 1 || T == 2 || T == 4), "geometry");
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int mem = idx % C;
+  const int grp = (idx / C) * 8 + xcd;
+  if (grp >= p.groups) return;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const yt = (lds_char*)smem;                 // [T] y slices
+  lds_char* const xt = yt + T * YT_BYTES;               // [T] -x in the GEMM-1 accumulator layout
+  lds_char* const rt = xt + T * RT_BYTES;               // [2] residual tiles
+  lds_f32* const red = (lds_f32*)(rt + 2 * RT_BYTES);   // [NW] delta sums, [NW+2] abort, [NW+3] one-XCD
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+
+  f32x4 b1[4][2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        b1[s][ss][cb] = *reinterpret_cast<const f32x4*>(p.Wp + (size_t)(32 * wid + 16 * cb + n) * K +
+                                                         kSlice * mem + 32 * s + 16 * ss + 4 * q);
+  f32x4 b2[D / 32][2];
+#pragma unroll
+  for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      b2[t][ss] = *reinterpret_cast<const f32x4*>(p.Wtp + (size_t)(kSlice * mem + 16 * wid + n) * D + 32 * t +
+                                                   16 * ss + 4 * q);
+
+  // exchange buffers: partials [parity][group][slot][member][wave][cb][lane] x 16 B, then the reduced blocks
+  // [parity][group][slot][block][cb][lane] x 16 B; flags1 [group][member][wave][slot], flags2 [group][member][cb][slot]
+  const unsigned part_bytes = (unsigned)(2 * p.groups * T * C * kPartBytes);
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, part_bytes + 2 * p.groups * T * kPartBytes, 0x00020000);
+  const unsigned my_part = (unsigned)((grp * T * C + mem) * kPartBytes + wid * 2048 + lane * 16);   // + slot * C * kPartBytes
+  const unsigned parity_stride = (unsigned)(p.groups * T * C * kPartBytes);
+  const unsigned rparity_stride = (unsigned)(p.groups * T * kPartBytes);
+  unsigned* const my_flag = p.xflags + ((size_t)(grp * C + mem) * NW + wid) * T;
+  const int col0 = kSlice * mem + 16 * wid;
+  // this wave's reduction job: tile slot jt, column half jcb of column block `mem`
+  const int jt = wid >> 1, jcb = wid & 1;
+  unsigned* const flags2 = p.xflags + (size_t)kSplitMaxParts * NW * 4 + 2 * (size_t)kSplitMaxParts;
+  unsigned* const my_flag2 = flags2 + ((size_t)(grp * C + mem) * 2 + jcb) * T + jt;
+
+  bool local;
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* const xid =
+        reinterpret_cast<unsigned long long*>(p.xflags + (size_t)kSplitMaxParts * NW * 4) + (size_t)grp * C;
+    if (wid == 0) {
+      if (lane == 0)
+        __hip_atomic_store(xid + mem, (1ull << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      bool ok, same;
+      do {
+        unsigned long long v = (1ull << 32) | xcc;
+        if (lane < C) v = __hip_atomic_load(xid + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = __all((unsigned)(v >> 32) == 1u);
+        same = __all((unsigned)v == xcc);
+        if (!ok) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((spins & 63) == 63 &&
+              __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            break;
+        }
+      } while (!ok && ++spins < kStopSpinLimit);
+      if (lane == 0) {
+        red[NW + 3] = (ok && same) ? 1.0f : 0.0f;
+        red[NW + 2] = ok ? 0.0f : 1.0f;
+        if (!ok) __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    local = red[NW + 3] != 0.0f;
+    if (red[NW + 2] != 0.0f) return;
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const __amdgpu_buffer_rsrc_t frsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.xflags, 0, (int)kSplitkFlagBytes, 0x00020000);
+  const unsigned my_flag_off = (unsigned)((((grp * C + mem) * NW + wid) * T) * 4);
+  const unsigned my_flag2_off = (unsigned)((kSplitMaxParts * NW * 4 + 2 * kSplitMaxParts + ((grp * C + mem) * 2 + jcb) * T + jt) * 4);
+  // bounded poll: `want` in every lane that takes part (lanes with `mine` false pass)
+  auto poll = [&](const unsigned* addr, bool mine, unsigned want, int limit) __attribute__((always_inline)) -> bool {
+    int spins = 0;
+    bool ok;
+    do {
+      unsigned v = want;
+      if (mine) v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = __all(v == want);
+      if (!ok) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63) == 63 && __hip_atomic_load(p.stop_out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          break;
+      }
+    } while (!ok && ++spins < limit);
+    if (!ok && lane == 0) {           // a peer is not resident: the whole grid gives up
+      __hip_atomic_store(p.stop_out + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      red[NW + 2] = 1.0f;
+    }
+    return ok;
+  };
+
+  unsigned epoch = 0;
+  bool aborted = false;
+  const int nparts = p.groups * C;
+  for (int round = 0; grp + p.groups * T * round < p.ntiles; ++round) {
+    int nt = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (grp + p.groups * (T * round + t) < p.ntiles) nt = t + 1;
+    f32x4 zreg[T];
+    static_for<T>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
+      const float* ysrc = p.y_in ? p.y_in : p.z_in;
+      const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = col0 + n;
+        const bool in = t < nt && (row0 + r) < p.n && cc < p.k;
+        zreg[t][rg] = (p.z_in && in) ? p.z_in[(int64_t)(row0 + r) * p.ldz_in + cc] : 0.0f;
+        const float yv = (ysrc && in) ? ysrc[(int64_t)(row0 + r) * ldy + cc] : 0.0f;
+        *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n)) = yv;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        f32x4 xn;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+          float v = 0.0f;
+          if (mem == 0 && t < nt && (row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+          xn[rg] = -v;
+        }
+        *(lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16) = xn;
+      }
+    });
+    if (tid == 0) red[NW + 2] = 0.0f;
+    LASSO_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+
+    for (int it = 0; it < p.iters; ++it) {
+      const float coef = p.coef[it];
+      ++epoch;
+      const unsigned par_off = (epoch & 1u) * parity_stride;
+      const unsigned rpar_off = part_bytes + (epoch & 1u) * rparity_stride + (unsigned)(grp * T * kPartBytes);
+
+      // ============ GEMM-1 of every tile: p_mem = y[:, slice] W[:, slice]^T (- x), published ====
+      SK_STAMP(0);
+      int pending = -1;
+      auto raise_flag = [&](int tp) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in the XCD's L2 / written through
+        if (lane == 0) {
+          if (local) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag_off + tp * 4, 0, 0);
+          else __hip_atomic_store(my_flag + tp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
+      static_for<T>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if (t < nt) {
+          f32x4 acc[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[cb] = *(const lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16);
+          const lds_char* const yrow = yt + t * YT_BYTES + n * (kSlice * 4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            f32x4 a[2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+              a[ss] = *(const lds_f32x4*)(yrow + (s >> 1) * 256 + (((8 * (s & 1) + 4 * ss + q) ^ n) << 4));
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                  acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b1[s][ss][cb][jj], acc[cb], 0, 0, 0);
+          }
+          SK_STAMP(1 + t);
+          if (pending >= 0) raise_flag(pending);
+          const unsigned dst = my_part + par_off + t * (C * kPartBytes);
+          if (local) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 0);
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[cb]), xrsrc, dst + cb * 1024, 0, 16);
+          }
+          pending = t;
+        }
+      });
+      if (pending >= 0) raise_flag(pending);
+      SK_STAMP(5);
+
+      // ============ reduce: this wave's job -- column half jcb of block `mem` of tile slot jt ====================
+      bool bad = false;
+      if (jt < nt) {
+        // wave `mem` of every member wrote the blocks (lane m polls member m's flag)
+        const unsigned* const f1 = p.xflags + ((size_t)(grp * C + (lane & (C - 1))) * NW + mem) * T + jt;
+        bad = !poll(f1, lane < C, epoch, kStopSpinLimit * 4);
+        if (!bad) {
+          const unsigned src = par_off + (unsigned)((grp * T + jt) * C * kPartBytes) + (unsigned)(mem * 2048 + jcb * 1024 + lane * 16);
+          f32x4 part[C];
+#pragma unroll
+          for (int m = 0; m < C; ++m)
+            part[m] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, src + m * kPartBytes, 0, 16));
+          f32x4 rs = part[0];
+#pragma unroll
+          for (int m = 1; m < C; ++m)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) rs[rg] = __fadd_rn(rs[rg], part[m][rg]);      // r = ((p_0 + p_1) + p_2) + ...
+          const unsigned dst = rpar_off + (unsigned)(jt * kPartBytes + mem * 2048 + jcb * 1024 + lane * 16);
+          if (local) __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(rs), xrsrc, dst, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(rs), xrsrc, dst, 0, 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            if (local) __builtin_amdgcn_raw_buffer_store_b32(epoch, frsrc, my_flag2_off, 0, 0);
+            else __hip_atomic_store(my_flag2, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      SK_STAMP(6);
+      // ============ the reduced blocks of every tile: block `wid` comes from member `wid` (lane = cb + 2 tile) =====
+      if (!bad) {
+        const unsigned* const f2 = flags2 + ((size_t)(grp * C + wid) * 2 + (lane & 1)) * T + (lane >> 1);
+        bad = !poll(f2, lane < 2 * nt, epoch, kStopSpinLimit * 4);
+      }
+      auto fetch_r = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
+        const unsigned src = rpar_off + (unsigned)(t * kPartBytes + wid * 2048 + lane * 16);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          rb[cb] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, src + cb * 1024, 0, 16));
+      };
+      f32x4 rnext[2];
+      if (!bad) fetch_r(0, rnext);
+
+      float dsum = 0.0f;
+      bool leave = false;
+      static_for<T>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if (t < nt && !leave) {
+          const f32x4 rsum[2] = {rnext[0], rnext[1]};
+          if (t + 1 < T && t + 1 < nt && !bad) fetch_r(t + 1, rnext);      // flies under this tile's GEMM-2
+          SK_STAMP(7 + 5 * t);
+          lds_char* const rbuf = rt + (t & 1) * RT_BYTES;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              *(lds_f32*)(rbuf + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = rsum[cb][rg];
+          LASSO_WAIT_LGKM0();
+          __builtin_amdgcn_s_barrier();                  // r tile complete
+          SK_STAMP(8 + 5 * t);
+          if (red[NW + 2] != 0.0f) {
+            aborted = true;
+            leave = true;
+          } else {
+            f32x4 g2 = {0.f, 0.f, 0.f, 0.f};
+            const lds_char* const rrow = rbuf + n * (D * 4);
+#pragma unroll
+            for (int tt = 0; tt < D / 32; ++tt) {
+              f32x4 a[2];
+#pragma unroll
+              for (int ss = 0; ss < 2; ++ss)
+                a[ss] = *(const lds_f32x4*)(rrow + (tt >> 1) * 256 + (((8 * (tt & 1) + 4 * ss + q) ^ n) << 4));
+#pragma unroll
+              for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                  g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ss][jj], b2[tt][ss][jj], g2, 0, 0, 0);
+            }
+            SK_STAMP(9 + 5 * t);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              lds_f32* const yp = (lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n));
+              const float zo = zreg[t][rg];
+              const float stp = __fmul_rn(lr_, g2[rg]);                         // lr * grad
+              const float zn = soft_threshold(__fsub_rn(*yp, stp), lam_);
+              dsum += __builtin_fabsf(__fsub_rn(zo, zn));                         // |z - z_next|
+              const float mom = __fmul_rn(coef, __fsub_rn(zn, zo));               // c (z_next - z)
+              *yp = __fadd_rn(zn, mom);
+              zreg[t][rg] = zn;
+            }
+          }
+        }
+      });
+      SK_STAMP(26);
+      if (leave) break;
+      dsum = wave_sum(dsum);
+      if (lane == 0) red[wid] = dsum;
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();                      // y slices complete; red[] complete
+      if (p.partials && tid == 0) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += red[w];
+        p.partials[((int64_t)it * p.part_stride) + (int64_t)round * nparts + grp * C + mem] = tsum;
+      }
+    }
+    if (aborted) break;
+
+    static_for<T>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = col0 + n;
+        if (t < nt && (row0 + r) < p.n && cc < p.k) {
+          p.z_out[(int64_t)(row0 + r) * p.ldz_out + cc] = zreg[t][rg];
+          if (p.y_out)
+            p.y_out[(int64_t)(row0 + r) * p.ldy_out + cc] =
+                *(const lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n));
+        }
+      }
+    });
+    __builtin_amdgcn_s_barrier();
+  }
+  if (p.partials && !aborted && tid < p.iters) {
+    const int total_rounds = p.part_stride / nparts;
+    int mine = 0;
+    while (grp + p.groups * T * mine < p.ntiles) ++mine;
+    for (int r = mine; r < total_rounds; ++r)
+      for (int it = tid; it < p.iters; it += kFistaThreads)
+        p.partials[(int64_t)it * p.part_stride + (int64_t)r * nparts + grp * C + mem] = 0.0f;
+  }
+}
+
+template <int T>
+static hipError_t launch_rs(const FistaTileParams& p, hipStream_t stream) {
+  constexpr int C = 8;
+  const size_t lds = lds_bytes(T);
+  const void* fn = reinterpret_cast<const void*>(&fista_splitk_rs_kernel<T>);
+  if (lds > 64 * 1024)
+    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  const int grid = (p.groups + 7) / 8 * 8 * C;
+  hipLaunchKernelGGL((fista_splitk_rs_kernel<T>), dim3(grid), dim3(kFistaThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
 template <int K, int T, bool STOP>
 static hipError_t launch_kts(const FistaTileParams& p, hipStream_t stream) {
   constexpr int C = K / kSlice;
@@ -512,6 +886,8 @@ static hipError_t launch_kts(const FistaTileParams& p, hipStream_t stream) {
 
 template <int K, int T>
 static hipError_t launch_kt(const FistaTileParams& p, hipStream_t stream) {
+  if constexpr (K == 1024)
+    if (!p.stop_on && ((T >= 2 && p.variant == 0) || p.variant == 2)) return launch_rs<T>(p, stream);   // reduce-scatter form
   return p.stop_on ? launch_kts<K, T, true>(p, stream) : launch_kts<K, T, false>(p, stream);
 }
 
@@ -537,7 +913,8 @@ int fista_splitk_members(int kpad) { return kpad / splitk::kSlice; }
 
 // payload bytes for `groups` groups working on `tiles` tiles at once
 size_t fista_splitk_exchange_bytes(int kpad, int groups, int tiles) {
-  return (size_t)2 * groups * tiles * (kpad / splitk::kSlice) * splitk::kPartBytes;
+  // partials of every member (two parities) + the reduced blocks of the reduce-scatter form
+  return (size_t)2 * groups * tiles * (kpad / splitk::kSlice) * splitk::kPartBytes + (size_t)2 * groups * tiles * splitk::kPartBytes;
 }
 
 hipError_t fista_splitk_occupancy(int kpad, int* blocks_per_cu) {

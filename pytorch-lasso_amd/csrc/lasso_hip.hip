@@ -283,7 +283,7 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 // split-k kernel with T tiles per group runs ceil(ntiles / (groups * T)) rounds of split_us[T].
 struct KernelCost { double tile_us, split_us[3]; };   // split_us: T = 1, 2, 4
 KernelCost kernel_cost(int kp) {
-  if (kp >= 1024) return {31.0, {5.9, 10.7, 20.0}};
+  if (kp >= 1024) return {31.0, {5.9, 10.4, 18.9}};      // T >= 2: the reduce-scatter form (fista_splitk_rs_kernel)
   if (kp >= 512) return {15.9, {5.45, 9.9, 19.4}};
   return {8.3, {5.2, 9.6, 18.9}};
 }
@@ -1239,7 +1239,8 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
   const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
   if (plan.split) {
     static thread_local char name[96];
-    snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
+    if (kp == 1024 && plan.tiles >= 2) snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_rs_kernel<%d>", plan.tiles);
+    else snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
     return name;
   }
   const TilePlan tp = plan_tiles(n, dpad);

@@ -48,7 +48,8 @@ constexpr int kSplitkMaxParts = 256;   // split-k kernel: groups x members never
 // split-k hand-off words (zeroed before every launch): [parts][waves][tile slots] epoch flags, then [parts] 8-byte XCC-id granules
 constexpr int kSplitkMaxTiles = 4;     // tiles a group works on at once
 constexpr size_t kSplitkFlagBytes =
-    (size_t)kSplitkMaxParts * kFistaWaves * kSplitkMaxTiles * 4 + (size_t)kSplitkMaxParts * 8;
+    (size_t)kSplitkMaxParts * kFistaWaves * kSplitkMaxTiles * 4 + (size_t)kSplitkMaxParts * 8 +
+    (size_t)kSplitkMaxParts * 2 * kSplitkMaxTiles * 4;     // + [parts][2][tile slots] flags of the reduced blocks
 // Bound of every in-kernel handshake spin (one poll = a few L2 round trips + s_sleep, roughly
 // a microsecond): ~0.1 s, far beyond any skew between co-resident workgroups.  Hitting it
 // means part of the grid is not resident (CUs held by another stream / process); the kernels

@@ -96,7 +96,7 @@ def test_auto_dispatch_names():
     from lasso_amd import _native as nat
     L = nat.lib()
     assert b"splitk" in L.lasso_fista_kernel_name(512, 256, 1024, nat.LASSO_F32, 0)
-    assert b"fista_splitk_kernel<1024, 2" in L.lasso_fista_kernel_name(1024, 256, 1024, nat.LASSO_F32, 0)
+    assert b"fista_splitk_rs_kernel<2>" in L.lasso_fista_kernel_name(1024, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(4096, 256, 1024, nat.LASSO_F32, 0)
     assert b"fista_tile_sp" in L.lasso_fista_kernel_name(512, 64, 256, nat.LASSO_F32, 0)     # tall tiles: no split
 
