@@ -77,6 +77,7 @@ typedef enum {
 #define LASSO_KERNEL_AUTO 0
 #define LASSO_KERNEL_TILE 0x100
 #define LASSO_KERNEL_SPLITK 0x200
+#define LASSO_KERNEL_UNFUSED 0x300   /* fixed-step fp32 solves: the general-GEMM path (state in HBM) also on the fused shapes */
 /* tuning knob: split-k with exactly T = 1, 2 or 4 tiles per workgroup group (default: by cost model) */
 #define LASSO_KERNEL_SPLITK_TILES(T) (0x200 | ((T) == 1 ? 0x1000 : (T) == 2 ? 0x2000 : 0x3000))
 /* tuning knob (A/B measurements): split-k with the register-gather exchange for every T (the default streams the

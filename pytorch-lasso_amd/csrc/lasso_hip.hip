@@ -1197,7 +1197,8 @@ static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
   if (kp < 0) return 0;
   if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16, maxiter).bytes;
   const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
-  return carve(nullptr, n, k, kp, maxiter, with_state).bytes;
+  // (LASSO_KERNEL_UNFUSED / the cost model may send a fused shape down the general-GEMM path: room for either)
+  return std::max(carve(nullptr, n, k, kp, maxiter, with_state).bytes, carve_generic(nullptr, n, d, k, false).bytes);
 }
 
 // region behind the solver's workspace that objective_out needs: the lasso_objective workspace,
@@ -1357,15 +1358,14 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   stop_mode &= ~LASSO_KERNEL_MASK;
   if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
     return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
-  if ((hint & 0x300) != LASSO_KERNEL_AUTO && (hint & 0x300) != LASSO_KERNEL_TILE && (hint & 0x300) != LASSO_KERNEL_SPLITK)
-    return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
+  const bool want_unfused = (hint & 0x300) == LASSO_KERNEL_UNFUSED;
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");
   if (!fused_shape(d, k) && backtrack)
     return solve_generic_backtracking(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
                                       maxiter, stop_rule ? tol : 0.0, eta_backtrack, iters_out, last_delta_out,
                                       trials_out, accepted_lr_out, accepted_f_out, workspace_dev, workspace_bytes, st);
-  if (!fused_shape(d, k))
+  if (!fused_shape(d, k) || (want_unfused && !backtrack && dtype == LASSO_F32 && !lr_dev && !async))
     return solve_generic(x, ldx, (const float*)w_dev, ldw, z0, ldz0, zout, ldz, n, d, k, alpha, lr, fast,
                          maxiter, stop_rule ? tol : 0.0, iters_out, last_delta_out, workspace_dev,
                          workspace_bytes, st);
