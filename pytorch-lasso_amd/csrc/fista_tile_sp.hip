@@ -460,6 +460,7 @@ hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int w
     switch (kpad) {
       case 256: return sp::occupancy_k<256, 16>(blocks_per_cu);
       case 512: return sp::occupancy_k<512, 16>(blocks_per_cu);
+      case 768: return sp::occupancy_k<768, 16>(blocks_per_cu);
       case 1024: return sp::occupancy_k<1024, 16>(blocks_per_cu);
     }
   } else if (dpad == 128) {
@@ -490,6 +491,7 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
     switch (kpad) {
       case 256: return sp::launch_k<256, 16>(p, grid, stream);
       case 512: return sp::launch_k<512, 16>(p, grid, stream);
+      case 768: return sp::launch_k<768, 16>(p, grid, stream);
       case 1024: return sp::launch_k<1024, 16>(p, grid, stream);
     }
   } else if (dpad == 128) {

@@ -284,10 +284,11 @@ int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = 
 struct KernelCost { double tile_us, split_us[3]; };   // split_us: T = 1, 2, 4
 KernelCost kernel_cost(int kp) {
   if (kp >= 1024) return {31.0, {5.9, 10.4, 18.9}};      // T >= 2: the reduce-scatter form (fista_splitk_rs_kernel)
+  if (kp >= 768) return {23.6, {1e9, 1e9, 1e9}};        // (768 atoms: tile kernel only -- 6 members do not split)
   if (kp >= 512) return {15.9, {5.45, 9.9, 19.4}};
   return {8.3, {5.2, 9.6, 18.9}};
 }
-struct KernelPlan { bool split; int groups, tiles; };
+struct KernelPlan { bool split; int groups, tiles; double us; };   // us: the model's microseconds per iteration
 
 int splitk_max_groups(int kp) {
   int per_cu = 0;
@@ -298,13 +299,14 @@ int splitk_max_groups(int kp) {
 }
 
 KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bits) {
-  KernelPlan plan = {false, 0, 1};
+  KernelPlan plan = {false, 0, 1, 0.0};
   const int hint = hint_bits & 0x300;
+  const int cus = std::max(device_cus(), 1);
+  const KernelCost cost = kernel_cost(kp);
+  plan.us = cost.tile_us * ((ntiles + cus - 1) / cus);
   if (dpad != kFistaD || hint == LASSO_KERNEL_TILE || ntiles <= 0) return plan;
   const int gmax = splitk_max_groups(kp);
   if (gmax <= 0) return plan;
-  const int cus = device_cus();
-  const KernelCost cost = kernel_cost(kp);
   // (5 % in favour of the tile kernel: it has no cross-workgroup dependencies)
   double best = hint == LASSO_KERNEL_SPLITK ? 1e30 : 0.95 * cost.tile_us * ((ntiles + cus - 1) / cus);
   const int forced = (hint_bits >> 12) & 3;           // LASSO_KERNEL_SPLITK_TILES(T): 1, 2, 3 -> T = 1, 2, 4
@@ -319,9 +321,23 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bit
     const double slot_us[5] = {0.0, cost.split_us[0], cost.split_us[1], 0.5 * (cost.split_us[1] + cost.split_us[2]),
                                cost.split_us[2]};
     const double us = cost.split_us[ti] * (rounds - 1) + slot_us[std::min(last_slots, 4)];
-    if (us < best) { best = us; plan.split = true; plan.groups = groups; plan.tiles = T; }
+    if (us < best) { best = us; plan.split = true; plan.groups = groups; plan.tiles = T; plan.us = us; }
   }
   return plan;
+}
+
+// Padded dictionary size of a fixed-step fp32 solve.  512 < k <= 768 has a 768-atom instantiation of the tile kernel
+// (a quarter less work than padding to 1024) -- used when the batch is large enough that the tile kernel at 768 beats
+// whatever the cost model picks at 1024 (small batches run the split-k kernel there, which needs a power of two of
+// 128-atom slices).  A function of the shape alone: the second halves of an asynchronous solve carve the same layout.
+int pad_k_solve(int64_t n, int64_t d, int64_t k) {
+  const int kp = pad_k(k);
+  if (kp != 1024 || k > 768 || n <= 0 || pad_d(d, 1024) != kFistaD) return kp;
+  const int ntiles = (int)((n + kTileM - 1) / kTileM);
+  const int cus = std::max(device_cus(), 1);
+  const KernelPlan at1024 = plan_kernel(1024, kFistaD, ntiles, false, LASSO_KERNEL_AUTO);
+  const double at768 = kernel_cost(768).tile_us * ((ntiles + cus - 1) / cus);
+  return at768 < at1024.us ? 768 : 1024;
 }
 
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
@@ -1236,7 +1252,7 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
     return backtrack ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
   }
   if (backtrack) return "lasso::bt_grad_kernel / bt_trial_kernel";
-  const int kp = pad_k(k), dpad = pad_d(d, kp);
+  const int kp = pad_k_solve(n, d, k), dpad = pad_d(d, kp);
   const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
   if (plan.split) {
     static thread_local char name[96];
@@ -1393,21 +1409,22 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                               stop_rule ? tol : 0.0, eta_backtrack,
                               iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
                               workspace_bytes, st);
-  Workspace ws = carve(workspace_dev, n, k, kp, maxiter, stop_rule);
+  const int kps = pad_k_solve(n, d, k);                  // (fp32 fixed step from here on: 768 atoms have their own tile kernel)
+  Workspace ws = carve(workspace_dev, n, k, kps, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
     return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   // one launch: pack W, momentum table, {lr, alpha*lr} from lambda_max (lr = LASSO_LR_AUTO), and the
   // zeroing of the in-kernel stop rule's granule ring and result words
   PrepareExtras px = {nullptr, 0, nullptr, 0, lip_dev, alpha, const_cast<float*>(lr_dev)};
-  const TilePlan tp0 = plan_tiles(n, pad_d(d, kp));
+  const TilePlan tp0 = plan_tiles(n, pad_d(d, kps));
   if (stop_rule && stop_mode == LASSO_STOP_GLOBAL) {
     px.zero_a = ws.gran; px.words_a = kStopRing * std::max(tp0.ntiles, kSplitMaxParts);
     px.zero_b = reinterpret_cast<unsigned long long*>(ws.stop_out); px.words_b = 2;
   }
-  if (int s = prepare_impl(ws, kp, (const float*)w_dev, ldw, d, k, maxiter, st, &px)) return s;
+  if (int s = prepare_impl(ws, kps, (const float*)w_dev, ldw, d, k, maxiter, st, &px)) return s;
 
   if (!stop_rule) {
-    if (int s = run_impl(ws, kp, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
+    if (int s = run_impl(ws, kps, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                          alpha, lr, fast, 0, maxiter, nullptr, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     if (iters_out) *iters_out = maxiter;
@@ -1431,13 +1448,13 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
       return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_SHARDED needs LASSO_SOLVE_ASYNC | LASSO_STOP_GLOBAL");
     if (maxiter > kChunkMax)
       return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: maxiter=%d > %d", maxiter, kChunkMax);
-    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     return LASSO_PENDING;
   }
   if (stop_mode == LASSO_STOP_GLOBAL) {
-    const TilePlan tp = plan_tiles(n, pad_d(d, kp));
+    const TilePlan tp = plan_tiles(n, pad_d(d, kps));
     const int ntiles = tp.ntiles;
     // The handshake needs every workgroup of the grid resident at once: one workgroup per CU
     // (LDS-bound), so the grid must not exceed what the occupancy query admits.  CUs held by
@@ -1445,9 +1462,9 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     // handshake times out, the kernel aborts as a whole without touching z_out, and the solve
     // is repeated on the chunked path below.
     // (the rule's granule fetch covers 256 tiles: four per lane of one wave)
-    if (ntiles <= std::min(fista_resident_workgroups(kp, pad_d(d, kp), tp.waves), 256)) {
+    if (ntiles <= std::min(fista_resident_workgroups(kps, pad_d(d, kps), tp.waves), 256)) {
       // (granule ring and stop_out were zeroed by the prepare launch)
-      if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
+      if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                            alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint, nullptr, lr_dev))
         return s;
       if (async) return LASSO_PENDING;     // the caller collects {iterations, last delta, abort flag} later
@@ -1471,7 +1488,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // repeats the solve synchronously, exactly like after an aborted handshake.  The E-step of an EM loop
   // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
   if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
-    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out);
@@ -1491,7 +1508,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     const int64_t nldz = final_chunk ? ldz : k;
     float* ny = ws.state[2 * flip + 1];
     // the aliasing copy above used state[2]; first chunk writes state[0]/[1] (flip = 0)
-    if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, nz, nldz, ny, k, n, d, k,
+    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, nz, nldz, ny, k, n, d, k,
                          alpha, lr, fast, done, c, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     LASSO_HIP_TRY(hipMemcpyAsync(hdelta.data(), ws.delta, c * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1503,7 +1520,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     }
     if (hit >= 0) {
       if (hit + 1 < c) {   // replay the chunk from its (intact) input state
-        if (int s = run_impl(ws, kp, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, zout, ldz, nullptr, 0,
+        if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, cur_y, cur_ldy, zout, ldz, nullptr, 0,
                              n, d, k, alpha, lr, fast, done, hit + 1, nullptr, st, -1.0f, hint, nullptr, lr_dev))
           return s;
       } else if (!final_chunk) {
@@ -1664,7 +1681,7 @@ int lasso_fista_solve_collect(int64_t n, int64_t d, int64_t k, int dtype, int ma
                               int32_t* out4_host, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || !(tol > 0.0) || !out4_host)
     return fail(LASSO_ERR_BAD_ARG, "no pending solve of this shape");
-  const int kp = pad_k(k);
+  const int kp = pad_k_solve(n, d, k);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, true);
   if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   LASSO_HIP_TRY(hipMemcpyAsync(out4_host, ws.stop_out, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1676,7 +1693,7 @@ float* lasso_fista_solve_deltas(int64_t n, int64_t d, int64_t k, int dtype, int 
   if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || maxiter > kChunkMax || !(tol > 0.0) ||
       !workspace_dev)
     return nullptr;
-  Workspace ws = carve(workspace_dev, n, k, pad_k(k), maxiter, true);
+  Workspace ws = carve(workspace_dev, n, k, pad_k_solve(n, d, k), maxiter, true);
   return workspace_bytes < ws.bytes ? nullptr : ws.delta;
 }
 
@@ -1685,7 +1702,7 @@ int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k,
   if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || n_global < n || maxiter <= 0 || maxiter > kChunkMax ||
       !(tol > 0.0))
     return fail(LASSO_ERR_BAD_ARG, "no pending sharded solve of this shape");
-  Workspace ws = carve(workspace_dev, n, k, pad_k(k), maxiter, true);
+  Workspace ws = carve(workspace_dev, n, k, pad_k_solve(n, d, k), maxiter, true);
   if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   const float budget = (float)((double)n_global * (double)k * tol);   // ista.py:64 on the whole batch
   hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums_dev ? sums_dev : ws.delta,
@@ -1700,7 +1717,7 @@ int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int max
                              size_t workspace_bytes, void* stream) {
   if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || maxiter <= 0 || !(tol > 0.0))
     return fail(LASSO_ERR_BAD_ARG, "no pending solve of this shape");
-  const int kp = pad_k(k);
+  const int kp = pad_k_solve(n, d, k);
   Workspace ws = carve(workspace_dev, n, k, kp, maxiter, true);
   if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   hipStream_t st = (hipStream_t)stream;

@@ -120,3 +120,32 @@ def test_chunked_stop_rule_through_multi_round_split_launches(n):
                            stop_mode='chunked', kernel=kern)
             assert info["iterations"] == tr.iterations, (kern, info, tr.iterations)
             assert abs(info["last_delta"] - tr.delta[-1]) <= 2e-6 * tr.delta[-1]
+
+
+@pytest.mark.parametrize("n,d,k", [(4096, 256, 768), (3500, 200, 700), (8192, 256, 640)])
+def test_768_atom_tile_kernel_is_bitwise_the_1024_atom_kernels(n, d, k):
+    """512 < k <= 768 on a large batch runs the 768-atom instantiation of the tile kernel (a quarter less work than
+    the padding to 1024); the same rows in a small batch run the split-k kernel padded to 1024.  The canonical
+    128-atom slice order makes a row's code independent of both (the padded slices add exact zeros)."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd import _native as nat
+    from oracle import lasso_oracle as orc
+    assert b"fista_tile_sp_kernel<768" in nat.lib().lasso_fista_kernel_name(n, d, k, nat.LASSO_F32, 0)
+    assert b"<768" not in nat.lib().lasso_fista_kernel_name(512, d, k, nat.LASSO_F32, 0)
+    X, W = _case(n, d, k, seed=n + k)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    for iters in (1, 25):
+        z = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=iters, tol=0.0)
+        zs = ista(Xg[:512], torch.zeros(512, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=iters, tol=0.0)
+        assert torch.equal(z[:512], zs), (iters, (z[:512] - zs).abs().max().item())
+    ref = orc.fista(X[:300], X.new_zeros(300, k), W, 0.3, lr=lr, maxiter=25, tol=0.0)
+    assert (z[:300].cpu() - ref).abs().max().item() <= 5e-5
+    # the stop rule (in-kernel at 4096 rows, chunked beyond) and lr='auto' on the 768-atom kernel
+    tr = orc.FistaTrace()
+    orc.fista(X, X.new_zeros(n, k), W, 0.3, lr=lr, maxiter=400, tol=1e-4, trace=tr)
+    _, info = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=400, tol=1e-4, return_info=True)
+    assert info["iterations"] == tr.iterations
+    za = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, maxiter=10)
+    zb = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=1.0 / orc.lipschitz_constant(W, "exact"), maxiter=10)
+    assert (za - zb).abs().max().item() <= 1e-4
