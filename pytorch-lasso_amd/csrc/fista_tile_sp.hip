@@ -449,6 +449,7 @@ hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int w
     if (dpad == 128) {
       switch (kpad) {
         case 256: return sp::occupancy_k<256, 16, 4>(blocks_per_cu);
+        case 384: return sp::occupancy_k<384, 16, 4>(blocks_per_cu);
         case 512: return sp::occupancy_k<512, 16, 4>(blocks_per_cu);
       }
     } else if (dpad == 64) {
@@ -466,6 +467,7 @@ hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int w
   } else if (dpad == 128) {
     switch (kpad) {
       case 256: return sp::occupancy_k<256, 32>(blocks_per_cu);
+      case 384: return sp::occupancy_k<384, 32>(blocks_per_cu);
       case 512: return sp::occupancy_k<512, 32>(blocks_per_cu);
     }
   } else if (dpad == 64) {
@@ -480,6 +482,7 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
     if (dpad == 128) {
       switch (kpad) {
         case 256: return sp::launch_k<256, 16, 4>(p, grid, stream);
+        case 384: return sp::launch_k<384, 16, 4>(p, grid, stream);
         case 512: return sp::launch_k<512, 16, 4>(p, grid, stream);
       }
     } else if (dpad == 64) {
@@ -497,6 +500,7 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
   } else if (dpad == 128) {
     switch (kpad) {
       case 256: return sp::launch_k<256, 32>(p, grid, stream);
+      case 384: return sp::launch_k<384, 32>(p, grid, stream);
       case 512: return sp::launch_k<512, 32>(p, grid, stream);
     }
   } else if (dpad == 64) {

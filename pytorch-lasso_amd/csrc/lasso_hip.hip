@@ -332,6 +332,8 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bit
 // 128-atom slices).  A function of the shape alone: the second halves of an asynchronous solve carve the same layout.
 int pad_k_solve(int64_t n, int64_t d, int64_t k) {
   const int kp = pad_k(k);
+  // 256 < k <= 384 with d <= 128: the 32 x 128 (16 x 128) tiles have a 384-atom instantiation; such shapes never split
+  if (kp == 512 && k <= 384 && d <= 128 && n > 0) return 384;
   if (kp != 1024 || k > 768 || n <= 0 || pad_d(d, 1024) != kFistaD) return kp;
   const int ntiles = (int)((n + kTileM - 1) / kTileM);
   const int cus = std::max(device_cus(), 1);

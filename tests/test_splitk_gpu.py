@@ -149,3 +149,28 @@ def test_768_atom_tile_kernel_is_bitwise_the_1024_atom_kernels(n, d, k):
     za = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, maxiter=10)
     zb = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=1.0 / orc.lipschitz_constant(W, "exact"), maxiter=10)
     assert (za - zb).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("n,d,k", [(4096, 100, 300), (700, 128, 384), (9000, 65, 257)])
+def test_384_atom_tile_kernels(n, d, k):
+    """256 < k <= 384 with d <= 128 runs the 384-atom instantiations of the 32 x 128 / 16 x 128 tile kernels (a quarter
+    less padding than 512): against the oracle, the stop rule, lr='auto'; rows independent of the batch they sit in."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd import _native as nat
+    from oracle import lasso_oracle as orc
+    assert b"fista_tile_sp_kernel<384" in nat.lib().lasso_fista_kernel_name(n, d, k, nat.LASSO_F32, 0)
+    X, W = _case(n, d, k, seed=n + k)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    z = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=25, tol=0.0)
+    ref = orc.fista(X[:400], X.new_zeros(min(n, 400), k), W, 0.3, lr=lr, maxiter=25, tol=0.0)
+    assert (z[:400].cpu() - ref).abs().max().item() <= 5e-5
+    zs = ista(Xg[:100], torch.zeros(100, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=25, tol=0.0)
+    assert torch.equal(z[:100], zs)
+    tr = orc.FistaTrace()
+    orc.fista(X, X.new_zeros(n, k), W, 0.3, lr=lr, maxiter=400, tol=1e-4, trace=tr)
+    _, info = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=400, tol=1e-4, return_info=True)
+    assert info["iterations"] == tr.iterations
+    za = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, maxiter=10)
+    zb = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=10)
+    assert (za - zb).abs().max().item() <= 1e-4
