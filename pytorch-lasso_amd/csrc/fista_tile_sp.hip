@@ -40,7 +40,7 @@ namespace sp {
 // per-wave work in a workgroup of half the height and half the LDS, two of which share a CU:
 // small batches of short rows (d <= 128) then spread over twice as many CUs.
 template <int K, int M, bool STOP, int NW = kFistaWaves>
-__global__ __launch_bounds__(64 * NW, 2) void fista_tile_sp_kernel(const FistaTileParams p) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_tile_sp_kernel(const FistaTileParams p) {
   // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
   const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
   constexpr int D = 512 * NW / M;
@@ -451,6 +451,8 @@ hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int w
         case 256: return sp::occupancy_k<256, 16, 4>(blocks_per_cu);
         case 384: return sp::occupancy_k<384, 16, 4>(blocks_per_cu);
         case 512: return sp::occupancy_k<512, 16, 4>(blocks_per_cu);
+        case 768: return sp::occupancy_k<768, 16, 4>(blocks_per_cu);
+        case 1024: return sp::occupancy_k<1024, 16, 4>(blocks_per_cu);
       }
     } else if (dpad == 64) {
       if (kpad == 256) return sp::occupancy_k<256, 32, 4>(blocks_per_cu);
@@ -484,6 +486,8 @@ hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, in
         case 256: return sp::launch_k<256, 16, 4>(p, grid, stream);
         case 384: return sp::launch_k<384, 16, 4>(p, grid, stream);
         case 512: return sp::launch_k<512, 16, 4>(p, grid, stream);
+        case 768: return sp::launch_k<768, 16, 4>(p, grid, stream);
+        case 1024: return sp::launch_k<1024, 16, 4>(p, grid, stream);
       }
     } else if (dpad == 64) {
       if (kpad == 256) return sp::launch_k<256, 32, 4>(p, grid, stream);

@@ -244,8 +244,13 @@ int fista_resident_workgroups(int kp, int dpad, int waves = kFistaWaves) {
 // its share -- 4-wave workgroups on half-height tiles, two per CU (the same waves per CU on twice
 // as many tiles; per CU the longest queue of rows is what counts).
 struct TilePlan { int waves, rows, ntiles; };
-TilePlan plan_tiles(int64_t n, int dpad) {
+TilePlan plan_tiles(int64_t n, int dpad, int kp = 0) {
   TilePlan t = {kFistaWaves, 4096 / dpad, 0};
+  if (kp > 512 && dpad == 128) {       // 128 columns with more than 512 atoms: the 32-row y tile does not fit -- 4 waves on 16 rows
+    t.waves = 4; t.rows = 16;
+    t.ntiles = (int)((n + 15) / 16);
+    return t;
+  }
   t.ntiles = (int)((n + t.rows - 1) / t.rows);
   if (dpad >= kFistaD || n <= 0) return t;
   const int cus = std::max(device_cus(), 1);
@@ -256,11 +261,20 @@ TilePlan plan_tiles(int64_t n, int dpad) {
   return t;
 }
 
+// (lasso_fista_solve may narrow the tile for the extent of one call: d <= 128 with more than 512 atoms on a batch that
+// fills the chip runs 4-wave workgroups on 16 x 128 tiles -- `NarrowTiles` below; thread-local like the error text)
+static thread_local int g_dpad_override = 0;
 int pad_d(int64_t d, int kp) {
+  if (g_dpad_override) return g_dpad_override;
   if (d <= 64 && kp <= 256) return 64;
   if (d <= 128 && kp <= 512) return 128;
   return kFistaD;
 }
+struct NarrowTiles {
+  explicit NarrowTiles(bool on) : on_(on) { if (on_) g_dpad_override = 128; }
+  ~NarrowTiles() { if (on_) g_dpad_override = 0; }
+  bool on_;
+};
 
 int check_common(int64_t n, int64_t d, int64_t k, int dtype, bool allow_large = false) {
   if (dtype != LASSO_F32)
@@ -326,20 +340,42 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bit
   return plan;
 }
 
-// Padded dictionary size of a fixed-step fp32 solve.  512 < k <= 768 has a 768-atom instantiation of the tile kernel
-// (a quarter less work than padding to 1024) -- used when the batch is large enough that the tile kernel at 768 beats
-// whatever the cost model picks at 1024 (small batches run the split-k kernel there, which needs a power of two of
-// 128-atom slices).  A function of the shape alone: the second halves of an asynchronous solve carve the same layout.
-int pad_k_solve(int64_t n, int64_t d, int64_t k) {
-  const int kp = pad_k(k);
-  // 256 < k <= 384 with d <= 128: the 32 x 128 (16 x 128) tiles have a 384-atom instantiation; such shapes never split
-  if (kp == 512 && k <= 384 && d <= 128 && n > 0) return 384;
-  if (kp != 1024 || k > 768 || n <= 0 || pad_d(d, 1024) != kFistaD) return kp;
+// Geometry of a fixed-step fp32 solve on the fused shapes: padded dictionary size and tile width.
+//   * 256 < k <= 384 with d <= 128: the 384-atom instantiations of the d <= 128 tile kernels;
+//   * 512 < k <= 768: the 768-atom instantiation of the tile kernel (a quarter less work than padding to 1024) where it
+//     beats what the cost model picks at 1024 (small batches run the split-k kernel there, which needs a power of two
+//     of 128-atom slices);
+//   * d <= 128 with more than 512 atoms: NARROW tiles -- 4-wave workgroups on 16 x 128 tiles instead of 8 waves on
+//     16 x 256 -- half the padded work per tile at nearly the same rate per wave (d=64, k=1024: 34 -> 60 TFLOP/s useful;
+//     d=128: 68 -> 119), again only where that beats the split-k kernel of a small batch.
+// Costs in microseconds per iteration and round of 256 tiles, measured on MI355X (round 3).  Every choice gives bitwise
+// the same code for a row (canonical 128-atom slices, exact-zero padding).  A function of the shape alone: the second
+// halves of an asynchronous solve carve the same workspace layout.
+struct SolveGeom { int kp; bool narrow; };
+SolveGeom solve_geometry(int64_t n, int64_t d, int64_t k) {
+  const int kp0 = pad_k(k);
+  if (kp0 == 512 && k <= 384 && d <= 128 && n > 0) return {384, false};
+  if (kp0 != 1024 || n <= 0) return {kp0, false};
   const int ntiles = (int)((n + kTileM - 1) / kTileM);
   const int cus = std::max(device_cus(), 1);
-  const KernelPlan at1024 = plan_kernel(1024, kFistaD, ntiles, false, LASSO_KERNEL_AUTO);
-  const double at768 = kernel_cost(768).tile_us * ((ntiles + cus - 1) / cus);
-  return at768 < at1024.us ? 768 : 1024;
+  const int rounds = (ntiles + cus - 1) / cus;
+  SolveGeom best = {1024, false};
+  double best_us = plan_kernel(1024, kFistaD, ntiles, false, LASSO_KERNEL_AUTO).us;
+  auto consider = [&](int kp, bool narrow, double us_per_round) {
+    if (us_per_round * rounds < best_us) { best_us = us_per_round * rounds; best = {kp, narrow}; }
+  };
+  if (k <= 768) consider(768, false, kernel_cost(768).tile_us);
+  if (d <= 128) {
+    consider(1024, true, 18.0);
+    if (k <= 768) consider(768, true, 13.7);
+  }
+  return best;
+}
+int pad_k_solve(int64_t n, int64_t d, int64_t k) { return solve_geometry(n, d, k).kp; }
+bool narrow_tiles(int64_t n, int64_t d, int64_t k, int kp, int hint_bits) {
+  if (d > 128 || kp <= 512 || n <= 0) return false;
+  if (hint_bits & 0x800) return true;                  // A/B knob
+  return solve_geometry(n, d, k).narrow;
 }
 
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
@@ -350,7 +386,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   if (used_split) *used_split = false;
   if (n == 0) return LASSO_OK;
   const int dpad = pad_d(d, kp);
-  const TilePlan tp = plan_tiles(n, dpad);
+  const TilePlan tp = plan_tiles(n, dpad, kp);
   const int ntiles = tp.ntiles;
   FistaTileParams p;
   p.X = x; p.ldx = ldx;
@@ -407,7 +443,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     }
   } else {
     // persistent over tiles: one 8-wave workgroup per CU (LDS bound), or two 4-wave ones
-    const int grid = std::min(ntiles, cus * (tp.waves == 4 ? 2 : 1));
+    const int grid = std::min(ntiles, cus * ((tp.waves == 4 && kp <= 512) ? 2 : 1));   // (4 waves, > 512 atoms: 104 KiB of LDS, one per CU)
     LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream, tp.waves));
   }
   if (delta && iters > 0) {
@@ -1254,7 +1290,9 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
     return backtrack ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
   }
   if (backtrack) return "lasso::bt_grad_kernel / bt_trial_kernel";
-  const int kp = pad_k_solve(n, d, k), dpad = pad_d(d, kp);
+  const SolveGeom geom = solve_geometry(n, d, k);
+  const NarrowTiles narrow(geom.narrow);
+  const int kp = geom.kp, dpad = pad_d(d, kp);
   const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
   if (plan.split) {
     static thread_local char name[96];
@@ -1262,7 +1300,7 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
     else snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
     return name;
   }
-  const TilePlan tp = plan_tiles(n, dpad);
+  const TilePlan tp = plan_tiles(n, dpad, kp);
   static thread_local char tname[96];
   snprintf(tname, sizeof(tname), "lasso::sp::fista_tile_sp_kernel<%d, %d, false, %d>", kp, tp.rows, tp.waves);
   return tname;
@@ -1412,13 +1450,14 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                               iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
                               workspace_bytes, st);
   const int kps = pad_k_solve(n, d, k);                  // (fp32 fixed step from here on: 768 atoms have their own tile kernel)
+  const NarrowTiles narrow(narrow_tiles(n, d, k, kps, hint));
   Workspace ws = carve(workspace_dev, n, k, kps, maxiter, stop_rule);
   if (workspace_bytes < ws.bytes)
     return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
   // one launch: pack W, momentum table, {lr, alpha*lr} from lambda_max (lr = LASSO_LR_AUTO), and the
   // zeroing of the in-kernel stop rule's granule ring and result words
   PrepareExtras px = {nullptr, 0, nullptr, 0, lip_dev, alpha, const_cast<float*>(lr_dev)};
-  const TilePlan tp0 = plan_tiles(n, pad_d(d, kps));
+  const TilePlan tp0 = plan_tiles(n, pad_d(d, kps), kps);
   if (stop_rule && stop_mode == LASSO_STOP_GLOBAL) {
     px.zero_a = ws.gran; px.words_a = kStopRing * std::max(tp0.ntiles, kSplitMaxParts);
     px.zero_b = reinterpret_cast<unsigned long long*>(ws.stop_out); px.words_b = 2;
@@ -1456,7 +1495,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return LASSO_PENDING;
   }
   if (stop_mode == LASSO_STOP_GLOBAL) {
-    const TilePlan tp = plan_tiles(n, pad_d(d, kps));
+    const TilePlan tp = plan_tiles(n, pad_d(d, kps), kps);
     const int ntiles = tp.ntiles;
     // The handshake needs every workgroup of the grid resident at once: one workgroup per CU
     // (LDS-bound), so the grid must not exceed what the occupancy query admits.  CUs held by

@@ -288,7 +288,7 @@ _KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNE
            'splitk4': nat.KERNEL_SPLITK | 0x3000,
            # A/B knobs: T = 2 / 4 with the register-gather exchange (the default streams the partials by LDS-DMA)
            'splitk2g': nat.KERNEL_SPLITK | 0x400 | 0x2000, 'splitk4g': nat.KERNEL_SPLITK | 0x400 | 0x3000,
-           'splitk1s': nat.KERNEL_SPLITK | 0x800 | 0x1000, 'unfused': 0x300}
+           'splitk1s': nat.KERNEL_SPLITK | 0x800 | 0x1000, 'unfused': 0x300, 'narrow': 0x800}
 
 
 def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_backtrack, verbose,

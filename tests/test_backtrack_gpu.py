@@ -371,5 +371,7 @@ def test_persistent_bf16_kernel_against_its_arithmetic_model(n, d, k, fast):
     zh, info = ista(Xb.cuda(), z0b.cuda(), Wb.cuda(), alpha, fast=fast, lr=1.0, maxiter=60, tol=2e-3, backtrack=True,
                     return_info=True)
     assert abs(info["iterations"] - minfo["iterations"]) <= 1, (info["iterations"], minfo["iterations"])
-    if info["iterations"] == minfo["iterations"]:
-        assert info["trials"] == minfo["trials"]
+    # (deep into a converging run F and Q of a trial agree to fp32 rounding, and a decision may fall either way: the
+    # first iterations, where they are apart, are compared)
+    m = min(8, info["iterations"], minfo["iterations"])
+    assert info["trials"][:m] == minfo["trials"][:m]

@@ -174,3 +174,33 @@ def test_384_atom_tile_kernels(n, d, k):
     za = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, maxiter=10)
     zb = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=10)
     assert (za - zb).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("n,d,k", [(4096, 64, 1024), (5000, 100, 1000), (8192, 128, 768), (4100, 33, 600)])
+def test_narrow_tiles_for_short_rows_and_large_dictionaries(n, d, k):
+    """d <= 128 with more than 512 atoms on a batch that fills the chip: 4-wave workgroups on 16 x 128 tiles instead of
+    8 waves on 16 x 256 (half the padded work; d=64, k=1024: 34 -> 60 TFLOP/s useful).  Bitwise the code of the wide
+    kernel and of the same rows in a small batch (split-k kernel), the oracle's code, the oracle's iteration count."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd import _native as nat
+    from oracle import lasso_oracle as orc
+    name = nat.lib().lasso_fista_kernel_name(n, d, k, nat.LASSO_F32, 0)
+    assert b"16, false, 4>" in name, name
+    X, W = _case(n, d, k, seed=n + k)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    z = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=25, tol=0.0)
+    zs = ista(Xg[:512], torch.zeros(512, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=25, tol=0.0)
+    assert torch.equal(z[:512], zs)
+    g = torch.Generator().manual_seed(5)
+    warm = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.1)).cuda()
+    zw = ista(Xg, warm, Wg, 0.3, fast=False, lr=lr, maxiter=9, tol=0.0)
+    assert torch.equal(zw[:300], ista(Xg[:300], warm[:300], Wg, 0.3, fast=False, lr=lr, maxiter=9, tol=0.0))
+    ref = orc.fista(X[:300], X.new_zeros(300, k), W, 0.3, lr=lr, maxiter=25, tol=0.0)
+    assert (z[:300].cpu() - ref).abs().max().item() <= 5e-5
+    tr = orc.FistaTrace()
+    orc.fista(X, X.new_zeros(n, k), W, 0.3, lr=lr, maxiter=400, tol=1e-4, trace=tr)
+    for mode in ('global', 'chunked'):
+        _, info = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=400, tol=1e-4, return_info=True,
+                       stop_mode=mode)
+        assert info["iterations"] == tr.iterations, (mode, info, tr.iterations)
