@@ -152,9 +152,29 @@ struct PrepareExtras {
   unsigned long long* zero_b; int words_b;      // nullable
   const double* lip; double alpha; float* lr_slot;   // nullable
 };
+// The momentum coefficients (t_i - 1) / t_{i+1} are a serial recurrence (a double sqrt and two divisions per step):
+// computed by one GPU thread, 100 of them took 17 us -- the whole prepare launch.  The first kCoefHead are the same
+// numbers for every solve: the host computes them once (same IEEE operations, same bits) and hands them over as a
+// launch argument; only a longer schedule continues on the device from t_kCoefHead.
+constexpr int kCoefHead = 256;
+struct CoefHead { float v[kCoefHead]; double t_next; };
+static const CoefHead& coef_head() {
+  static const CoefHead head = [] {
+    CoefHead h;
+    double t = 1.0;
+    for (int i = 0; i < kCoefHead; ++i) {
+      const double tn = (1.0 + sqrt(1.0 + 4.0 * (t * t))) / 2.0;
+      h.v[i] = (float)((t - 1.0) / tn);
+      t = tn;
+    }
+    h.t_next = t;
+    return h;
+  }();
+  return head;
+}
 __global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, int d, int k, int kp,
                                      float* __restrict__ wp, float* __restrict__ wtp, int dpad, float* __restrict__ coef,
-                                     float* __restrict__ zeros, int count, const PrepareExtras x) {
+                                     float* __restrict__ zeros, int count, const PrepareExtras x, const CoefHead head) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
@@ -172,6 +192,8 @@ __global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, i
   const int bid = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y, tid = ty * 32 + tx;
   for (int i = bid * 256 + tid; i < x.words_a; i += nb * 256) x.zero_a[i] = 0ull;
   for (int i = bid * 256 + tid; i < x.words_b; i += nb * 256) x.zero_b[i] = 0ull;
+  if (bid == nb - 1)
+    for (int i = tid; i < count && i < kCoefHead; i += 256) { coef[i] = head.v[i]; zeros[i] = 0.0f; }
   if (tid != 0) return;
   if (bid == 0 && x.lip) {
     const double lr = 1.0 / x.lip[0];
@@ -179,8 +201,8 @@ __global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, i
     x.lr_slot[1] = (float)(x.alpha * lr);
   }
   if (bid == nb - 1) {
-    double t = 1.0;
-    for (int i = 0; i < count; ++i) {
+    double t = head.t_next;
+    for (int i = kCoefHead; i < count; ++i) {
       const double tt = __dmul_rn(t, t);
       const double s = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(4.0, tt)));
       const double tn = __ddiv_rn(__dadd_rn(1.0, s), 2.0);
@@ -474,7 +496,7 @@ int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64
   PrepareExtras x = {nullptr, 0, nullptr, 0, nullptr, 0.0, nullptr};
   if (extras) x = *extras;
   hipLaunchKernelGGL(prepare_solve_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0, stream, w, ldw, (int)d, (int)k, kp,
-                     ws.wp, ws.wtp, dpad, ws.coef, ws.zeros, std::max(coef_cap, 1), x);
+                     ws.wp, ws.wtp, dpad, ws.coef, ws.zeros, std::max(coef_cap, 1), x, coef_head());
   LASSO_HIP_TRY(hipGetLastError());
   return LASSO_OK;
 }

@@ -328,6 +328,61 @@ __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __re
   if (threadIdx.x == 0) out[0] = sh[0] / tr;
 }
 
+// The same quotient in two launches that use the chip: kRayBlocks workgroups each reduce a contiguous chunk of <G, P>_F
+// and of the diagonal of P in a fixed order, one small block adds the partial sums in index order.  (The single block
+// above reads 1 MiB through one compute unit: 18 us at m = 256; these two launches take 5.)
+constexpr int kRayBlocks = 64;
+__global__ __launch_bounds__(256) void rayleigh_partial_kernel(const double* __restrict__ G, const double* __restrict__ P,
+                                                               int mp, double* __restrict__ part) {
+  __shared__ double sh[2][256];
+  const size_t total = (size_t)mp * mp;
+  const size_t chunk = (total + kRayBlocks - 1) / kRayBlocks;
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  double acc = 0.0, tr = 0.0;
+  for (size_t e0 = lo + threadIdx.x; e0 < hi; e0 += 8 * 256) {
+    double gv[8], pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t e = e0 + (size_t)256 * u < hi ? e0 + (size_t)256 * u : hi - 1;
+      gv[u] = G[e];
+      pv[u] = P[e];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t e = e0 + (size_t)256 * u;
+      if (e < hi) {
+        acc = fma(gv[u], pv[u], acc);
+        if (e / mp == e % mp) tr += pv[u];
+      }
+    }
+  }
+  sh[0][threadIdx.x] = acc;
+  sh[1][threadIdx.x] = tr;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+__global__ void rayleigh_finish_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  double num = 0.0, tr = 0.0;
+  for (int b = 0; b < kRayBlocks; ++b) { num += part[2 * b]; tr += part[2 * b + 1]; }
+  out[0] = num / tr;
+}
+// `part`: 2 kRayBlocks doubles of scratch (the split-partials region of the workspace is free by then)
+static void launch_rayleigh(const double* G, const double* P, int mp, double* out, double* part, hipStream_t stream) {
+  if (mp < 128) {            // small iterates: one block is the shorter path
+    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, P, mp, out);
+    return;
+  }
+  hipLaunchKernelGGL(rayleigh_partial_kernel, dim3(kRayBlocks), dim3(256), 0, stream, G, P, mp, part);
+  hipLaunchKernelGGL(rayleigh_finish_kernel, dim3(1), dim3(1), 0, stream, part, out);
+}
+
 }  // namespace
 
 // splits of a product with contraction length len: one 256-element span per workgroup up to
@@ -397,7 +452,7 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
       }
       src = dst;
     }
-    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, src, mp, out);
+    launch_rayleigh(G, src, mp, out, part, stream);
     return hipGetLastError();
   }
   for (int p = 0; p < squarings; ++p) {
@@ -406,7 +461,7 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
     if (ps > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, ps, mm, P[p & 1]);
     src = P[p & 1];
   }
-  hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, src, mp, out);
+  launch_rayleigh(G, src, mp, out, part, stream);
   return hipGetLastError();
 }
 
