@@ -224,6 +224,9 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
  *   N(0,1) vector keyed by (seed, atom).  degenerate_dev [k] (int32, device) is set to
  *   1 for those atoms; ndeg_out (HOST, nullable) receives their count and, when
  *   non-NULL, makes the call synchronise `stream`.
+ * lasso_dict_sweep_count: device address (inside the sweep's workspace) of that count, for callers that pass
+ *   ndeg_out = NULL and read it at their own synchronisation (4 bytes instead of a reduction over the k flags);
+ *   NULL for arguments lasso_dict_sweep would reject.
  * lasso_dict_fill_degenerate: deferred form of that replacement for drivers that want to
  *   draw directions only when an atom actually degenerated (the sweep never READS a
  *   replacement -- the degenerate atom leaves the model): call lasso_dict_sweep with
@@ -243,6 +246,7 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
                      const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
                      int32_t* degenerate_dev, int32_t* ndeg_out,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
+int32_t* lasso_dict_sweep_count(int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes);
 int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
                                const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
                                int64_t pool_ld, int positive, void* stream);

@@ -232,6 +232,44 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
   if (threadIdx.x == 0) delta[blockIdx.x] = sh[0];
 }
 
+// reduce_partials_kernel for `iters` rows and chunk_verdict_kernel behind it in ONE workgroup (the asynchronous
+// E-step of an EM loop: one launch less on the step's dependent chain).  Every delta[i] is the same sum in the
+// same order as reduce_partials_kernel's.
+struct ChunkVerdict { float budget; int* out; };
+__global__ __launch_bounds__(256) void reduce_verdict_kernel(const float* __restrict__ partials, int ntiles,
+                                                             float* __restrict__ delta, const float* __restrict__ alt,
+                                                             int alt_count, const int* __restrict__ alt_if, int iters,
+                                                             float budget, int* __restrict__ out) {
+  // One WAVE per row, rows w, w + 4, ...: lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
+  // (their strided sums), the first two levels of its tree are then this lane's (a0 + a2) + (a1 + a3), the last six
+  // the shuffles below -- no barrier per row.
+  __shared__ float sd[64];
+  if (alt && *alt_if != 0) { partials = alt; ntiles = alt_count; }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < iters; i += 4) {
+    const float* row = partials + (size_t)i * ntiles;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      for (int t = lane + 64 * h; t < ntiles; t += 256) a[h] += row[t];
+    float v = (a[0] + a[2]) + (a[1] + a[3]);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+    if (lane == 0) { delta[i] = v; sd[i] = v; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int hit = -1;
+    float last = sd[iters - 1];
+    for (int i = 0; i < iters; ++i)
+      if (sd[i] <= budget) { hit = i; last = sd[i]; break; }
+    out[0] = hit >= 0 ? hit + 1 : iters;
+    out[1] = __float_as_int(last);
+    out[2] = (hit >= 0 && hit + 1 < iters) ? 1 : 0;
+    out[3] = 0;
+  }
+}
+
 // the stop rule over one chunk's per-iteration deltas (ista.py:93-95): out = {iterations, last delta, redo, 0};
 // redo = the rule fired before the chunk's last iteration
 __global__ void chunk_verdict_kernel(const float* __restrict__ delta, int c, float budget, int* __restrict__ out) {
@@ -404,7 +442,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
              int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
              int fast, int it0, int iters, float* delta, hipStream_t stream, float stop_budget = -1.0f,
-             int hint = LASSO_KERNEL_AUTO, bool* used_split = nullptr, const float* lr_dev = nullptr) {
+             int hint = LASSO_KERNEL_AUTO, bool* used_split = nullptr, const float* lr_dev = nullptr,
+             const ChunkVerdict* verdict = nullptr) {
   if (used_split) *used_split = false;
   if (n == 0) return LASSO_OK;
   const int dpad = pad_d(d, kp);
@@ -469,7 +508,11 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream, tp.waves));
   }
   if (delta && iters > 0) {
-    if (plan.split)
+    if (verdict && iters <= 64)
+      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(256), 0, stream, plan.split ? split_rows : ws.partials,
+                         plan.split ? nparts : ntiles, delta, plan.split ? ws.partials : nullptr, plan.split ? ntiles : 0,
+                         plan.split ? ws.stop_out + 2 : nullptr, iters, verdict->budget, verdict->out);
+    else if (plan.split)
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, split_rows, nparts, delta,
                          ws.partials, ntiles, ws.stop_out + 2);
     else
@@ -1551,11 +1594,14 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // repeats the solve synchronously, exactly like after an aborted handshake.  The E-step of an EM loop
   // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
   if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
+    const ChunkVerdict cv{budget, ws.stop_out};
     if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
-                         alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
+                         alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev, &cv))
       return s;
-    hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out);
-    LASSO_HIP_TRY(hipGetLastError());
+    if (maxiter > 64 || n == 0) {
+      hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out);
+      LASSO_HIP_TRY(hipGetLastError());
+    }
     return LASSO_PENDING;
   }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
@@ -1954,7 +2000,7 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   float* dD = (float*)((char*)Dt + align_up((size_t)k * dp * 4));
   int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * dp * 4));
   float* D = (float*)d_dev;
-  LASSO_HIP_TRY(hipMemsetAsync(ndeg, 0, sizeof(int), st));
+  // (ndeg is written by degenerate_fixup_kernel on every path: no clearing launch in front)
   // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, zero padded to dp columns)
   if (dp != d) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
   LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st));
@@ -1975,6 +2021,18 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
     LASSO_HIP_TRY(hipStreamSynchronize(st));
   }
   return LASSO_OK;
+}
+
+// Device address of the sweep's count of degenerate atoms inside `workspace_dev` (valid once the sweep enqueued
+// with this workspace has run): a caller that does not want lasso_dict_sweep's host wait (ndeg_out = NULL) copies
+// these 4 bytes at its own synchronisation instead of reducing the k flags.
+int32_t* lasso_dict_sweep_count(int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes) {
+  if (!workspace_dev || d <= 0 || k <= 0 || d > kSweepMaxD || k > kSweepMaxK ||
+      workspace_bytes < lasso_dict_sweep_workspace_bytes(d, k))
+    return nullptr;
+  const int dp = (int)((d + 255) / 256 * 256);
+  char* base = (char*)workspace_dev;
+  return (int32_t*)(base + 2 * align_up((size_t)k * dp * 4) + align_up((size_t)kSweepBlock * dp * 4));
 }
 
 // ---- init='transpose': z0 = x W, sparse_encode.py:24-25 --------------------------------------

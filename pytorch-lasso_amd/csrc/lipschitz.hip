@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void syrk_f64_kernel(const TIn* __restrict__ A
 // diagonal are issued at once, the trace is reduced while they fly (two barriers, then shuffles), both operand
 // tiles go to LDS whole (132 KB at mp = 256) and the 64 fp64 MFMA steps run without a barrier in between.
 // NB = ceil(mp / 64): 16-byte column groups per thread and row.
+// (Round 3 tried one WAVE per 16 x 16 block with the operands loaded straight into the lanes' MFMA slots -- 256
+// workgroups, no LDS, no barrier, bitwise the same C: 8.2 us against this kernel's 7.4; the lane layout of the fp64
+// MFMA makes those loads 32-byte pieces, 2048 cache-line requests per wave.)
 template <int NB>
 __global__ __launch_bounds__(256) void square_f64_kernel(const double* __restrict__ A, int mp, double* __restrict__ C) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));

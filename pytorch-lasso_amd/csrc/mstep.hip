@@ -241,12 +241,12 @@ __device__ __forceinline__ float ordered_split_sum(const float* __restrict__ bas
 // per 32 x 32 tile (tr, tc), tc >= tr, of the upper triangle: coalesced reads, the transposed copy
 // through LDS.  (Tiles below the diagonal inside a diagonal 128-block are computed values too, but
 // bitwise equal to their mirror image -- the same products in the same order.)
-__global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __restrict__ part, int splits,
-                                                             int64_t split_stride, int64_t ldpart, int pc,
-                                                             float* __restrict__ C, int64_t ldc) {
+__device__ __forceinline__ void sum_splits_sym_body(int block, const float* __restrict__ part, int splits,
+                                                    int64_t split_stride, int64_t ldpart, int pc,
+                                                    float* __restrict__ C, int64_t ldc) {
   __shared__ float t[32][33];
   const int nt = (pc + 31) / 32;
-  int rem = blockIdx.x, tr = 0;
+  int rem = block, tr = 0;
   while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
   const int tc = tr + rem;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -281,6 +281,12 @@ __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __restrict__ part, int splits,
+                                                             int64_t split_stride, int64_t ldpart, int pc,
+                                                             float* __restrict__ C, int64_t ldc) {
+  sum_splits_sym_body(blockIdx.x, part, splits, split_stride, ldpart, pc, C, ldc);
+}
+
 // ---------------------------------------------------------------------------
 // Both M-step products in ONE launch on 256 x 256 blocks:  [A | B] = Z^T [Z | X].
 // At n = 65536 the 128 x 128 kernel above is HBM-bound, not MFMA-bound: Z (268 MB) does not stay
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __rest
 // samples = 4 + 8 LDS operand reads for 32 MFMAs; samples in chunks of 32, double-buffered LDS
 // (row stride 272 floats: conflict-free operand reads), next chunk's loads in registers.
 // Output: partial [split][k][k + d] (A's block (bi, bj) at columns 256 bj, B behind column k);
-// folded by sum_splits_sym_kernel (A, mirrored) and sum_splits_ld_kernel (B).
+// folded by sum_splits_ab_kernel (A mirrored like sum_splits_sym_kernel, B element by element).
 // ---------------------------------------------------------------------------
 constexpr int kG3B = 256, kG3S = 32, kG3Ld = 272;
 
@@ -381,14 +387,20 @@ __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict
         C[(int64_t)(64 * wr + 16 * mi + 4 * q + rg) * ldc + 128 * wc + 16 * nj + l15] = acc[mi][nj][rg];
 }
 
-// C[r][c] = sum_s part[s][r * ldpart + c]  (fixed order): the B part of gram_ab256_kernel's partials
-__global__ __launch_bounds__(256) void sum_splits_ld_kernel(const float* __restrict__ part, int splits,
-                                                            int64_t split_stride, int64_t ldpart, int rows, int cols,
-                                                            float* __restrict__ C, int64_t ldc) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)rows * cols) return;
-  const int64_t r = idx / cols, c = idx - r * cols;
-  C[r * ldc + c] = ordered_split_sum(part + r * ldpart + c, split_stride, splits);
+// Both folds of gram_ab256_kernel's partials in one launch: workgroups [0, nsym) are sum_splits_sym_kernel's on
+// A (k x k), the rest fold B (k x d, behind column k of the partials) element by element -- the same sums in
+// the same order, one launch less on the EM step's dependent chain.
+__global__ __launch_bounds__(256) void sum_splits_ab_kernel(const float* __restrict__ part, int splits,
+                                                            int64_t split_stride, int64_t ldpart, int k, int d, int nsym,
+                                                            float* __restrict__ A, float* __restrict__ B) {
+  if ((int)blockIdx.x < nsym) {
+    sum_splits_sym_body(blockIdx.x, part, splits, split_stride, ldpart, k, A, (int64_t)k);
+    return;
+  }
+  const int64_t idx = (int64_t)(blockIdx.x - nsym) * 256 + threadIdx.x;
+  if (idx >= (int64_t)k * d) return;
+  const int64_t r = idx / d, c = idx - r * d;
+  B[r * d + c] = ordered_split_sum(part + k + r * ldpart + c, split_stride, splits);
 }
 
 // C[r][c] = sum_s part[s][r][c]  (fixed order)
@@ -1126,10 +1138,9 @@ bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t 
   hipLaunchKernelGGL(gram_ab256_kernel, dim3(blocks, 1, sp), dim3(512), lds, stream, Z, ldz, k, X, ldx, d, n, scratch, rps);
   const int64_t stride = (int64_t)k * (k + d);
   const int nt = (k + 31) / 32;
-  hipLaunchKernelGGL(sum_splits_sym_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, scratch, sp, stride,
-                     (int64_t)(k + d), k, A, (int64_t)k);
-  hipLaunchKernelGGL(sum_splits_ld_kernel, dim3((unsigned)(((int64_t)k * d + 255) / 256)), dim3(256), 0, stream,
-                     scratch + k, sp, stride, (int64_t)(k + d), k, d, B, (int64_t)d);
+  const int nsym = nt * (nt + 1) / 2;
+  hipLaunchKernelGGL(sum_splits_ab_kernel, dim3(nsym + (unsigned)(((int64_t)k * d + 255) / 256)), dim3(256), 0, stream,
+                     scratch, sp, stride, (int64_t)(k + d), k, d, nsym, A, B);
   *err = hipGetLastError();
   return true;
 }

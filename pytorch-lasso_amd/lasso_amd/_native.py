@@ -90,6 +90,8 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_dict_sweep_count.restype = vp
+    lib.lasso_dict_sweep_count.argtypes = [i64, i64, vp, sz]
     lib.lasso_fista_solve_sharded.restype = i32
     lib.lasso_fista_solve_sharded.argtypes = [
         vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, i32, dbl, dbl, i32, i32, dbl, dbl,

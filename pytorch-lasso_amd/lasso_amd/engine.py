@@ -130,14 +130,19 @@ class HipEngine:
         L = self.lib
         with torch.cuda.device(self.device):
             ws = self._ws(L.lasso_dict_sweep_workspace_bytes(d, k), "sweep")
-            mask = torch.zeros(k, dtype=torch.int32, device=self.device)
+            mask = torch.empty(k, dtype=torch.int32, device=self.device)     # the sweep writes every flag
             nat.check(L.lasso_dict_sweep(
                 nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
                 int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), None, nat.ptr(ws), ws.numel(), self._stream()))
             if getattr(self, "_ndeg_host", None) is None:
                 self._ndeg_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             host = self._ndeg_host
-            host.copy_(mask.sum(dtype=torch.int32).reshape(1), non_blocking=True)
+            # the count the sweep's last kernel left in its workspace: 4 bytes to the host, no reduction launch
+            cptr = L.lasso_dict_sweep_count(d, k, nat.ptr(ws), ws.numel())
+            if not cptr:
+                raise nat.NativeError("lasso_dict_sweep_count: no count for d=%d k=%d" % (d, k))
+            off = int(cptr) - ws.data_ptr()
+            host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
 
@@ -221,14 +226,18 @@ class HipEngine:
         return gx, gw, gz0
 
     # -- objective ---------------------------------------------------------------
-    def objective_sums(self, X, Z, W, alpha):
-        """-> (loss_local 0-d float tensor, sums double[2] = {sum r^2, sum |z|}) on device."""
+    objective_loss_out = True      # objective_sums(..., loss_out=) exists (parallel.em_loop)
+
+    def objective_sums(self, X, Z, W, alpha, loss_out=None):
+        """-> (loss_local 0-d float tensor, sums double[2] = {sum r^2, sum |z|}) on device.
+        ``loss_out``: an optional 0-d fp32 device tensor (e.g. one slot of a loss history) the loss is
+        written to directly."""
         n, d = X.shape
         k = W.shape[1]
         L = self.lib
         with torch.cuda.device(self.device):
             ws = self._ws(L.lasso_objective_workspace_bytes(n, d, k), "obj")
-            loss = torch.empty((), dtype=torch.float32, device=self.device)
+            loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=self.device)
             sums = torch.empty(2, dtype=torch.float64, device=self.device)
             nat.check(L.lasso_objective(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0),
                                         nat.ptr(Z), Z.stride(0), n, d, k, nat.LASSO_F32, float(alpha),

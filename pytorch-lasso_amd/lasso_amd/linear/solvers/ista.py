@@ -27,9 +27,16 @@ def lazy_zeros(like, n, k):
     read-only zeros tensor.  The mark lives on this python object only -- views, clones and a
     caller's own broadcast tensors (``torch.full((1, 1), c).expand(n, k)``) never carry it and are
     read like any other z0 (sparse_encode.py:44-45)."""
-    z = like.new_zeros(1, 1).expand(n, k)
+    key = (like.device, like.dtype)
+    base = _ZERO_ELEMENT.get(key)
+    if base is None:         # one element per device and dtype, made once: an EM loop asks for this every step, and
+        base = _ZERO_ELEMENT[key] = like.new_zeros(1, 1)       # the fill launch sat on the step's dependent chain
+    z = base.expand(n, k)
     z._lasso_lazy_zeros = True
     return z
+
+
+_ZERO_ELEMENT = {}
 
 
 def _is_lazy_zeros(z0):

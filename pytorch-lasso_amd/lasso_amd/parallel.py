@@ -240,7 +240,8 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                 sharded = pending is not None
                 if stats is not None:
                     stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
-        loss_local, sums = engine.objective_sums(X, Z, weight, alpha)                     # :39
+        direct = world == 1 and getattr(engine, 'objective_loss_out', False)   # losses[i] written in place: no copy launch
+        loss_local, sums = engine.objective_sums(X, Z, weight, alpha, **(dict(loss_out=losses[i]) if direct else {}))  # :39
         A, B = engine.gram(Z, X, buf)
         if deferred is not None:
             mask, ndeg = deferred()
@@ -254,6 +255,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             # the in-kernel stop rule gave up (CUs held by other work): same rule, chunked
             Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
             loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
+            direct = False
             A, B = engine.gram(Z, X, buf)
         if world > 1:
             tail.copy_(sums)                 # the two objective sums ride in the Gram message
@@ -272,7 +274,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                     if stats is not None:
                         stats['replayed_steps'] = stats.get('replayed_steps', 0) + 1
             losses[i] = (0.5 * tail[0] + alpha * tail[1]) / n_total
-        else:
+        elif not direct:
             losses[i] = loss_local
         if persist:
             Z0 = Z                                                                        # :40-41
