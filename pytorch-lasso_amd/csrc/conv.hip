@@ -489,6 +489,8 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w
     bool done = false;
     if (hipError_t e = launch_conv_synth(Ym, w, x, r, g, cus, &done, stream); e != hipSuccess) return e;
     if (done) return hipSuccess;
+    if (hipError_t e = launch_conv_synth_few(Ym, w, x, r, g, cus, &done, stream); e != hipSuccess) return e;
+    if (done) return hipSuccess;
   }
   const int ckk = g.C * g.kh * g.kw;
   const int64_t M = (int64_t)g.N * g.Hz * g.Wz;

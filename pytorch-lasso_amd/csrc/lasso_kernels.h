@@ -237,6 +237,10 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w
 // an instantiated atom count); *done = false -> not covered
 hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
                              bool* done, hipStream_t stream);
+// conv_synth_few.hip: the same for C < 8 channels (columns = the taps, overlap-add in LDS); stride 1, K <= 128 a multiple
+// of 4, C kh kw <= 128
+hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
+                                 bool* done, hipStream_t stream);
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
                                  hipStream_t stream);
