@@ -114,6 +114,11 @@ def test_auto_step_and_stop_rule(golden):
     (2, 9, 100, 3, 3, 1, 1, 16, 16), (1, 16, 200, 3, 3, 1, 0, 7, 40), (2, 8, 32, 5, 5, 1, 2, 13, 19),
     (2, 16, 64, 5, 5, 1, 0, 9, 21), (1, 10, 128, 5, 5, 1, 4, 12, 17), (2, 8, 24, 7, 7, 1, 3, 14, 20),
     (1, 16, 64, 7, 7, 1, 0, 8, 25),
+    # C < 8, stride 1, K <= 128 a multiple of 4, <= 128 taps: the few-channel synthesis kernel (conv_synth_few.hip) --
+    # W in LDS (5 x 8, 8 x 8 column blocks x atom groups) and in registers, many bands per image with their halos,
+    # K % 16 != 0, a non-square kernel, asymmetric padding, more work items than workgroups
+    (3, 3, 128, 5, 5, 1, 2, 20, 24), (2, 1, 64, 7, 7, 1, 3, 13, 17), (2, 4, 20, 3, 3, 1, 1, 9, 11),
+    (1, 7, 100, 3, 5, 1, (0, 2), 8, 9), (600, 1, 16, 3, 3, 1, 1, 8, 8), (2, 3, 36, 5, 5, 1, 0, 6, 7),
     # same channel counts where it does not apply (stride 2, non-square kernel, C > 16): explicit path
     (2, 16, 32, 3, 3, 2, 1, 8, 9), (2, 8, 16, 3, 5, 1, 1, 9, 9), (1, 17, 8, 3, 3, 1, 1, 6, 6)])
 def test_shapes_match_oracle(N, C, K, kh, kw, stride, padding, Hz, Wz):

@@ -88,6 +88,27 @@ def test_update_dict_against_reference_outputs(golden):
         assert (V.cpu() - Vref).abs().max().item() <= 2e-4 * max(1.0, Vref.abs().max().item())
 
 
+def test_sweep_count_from_workspace(golden):
+    """sweep_begin reads the number of degenerate atoms from the sweep's workspace (lasso_dict_sweep_count) and
+    leaves the k flags un-cleared before the launch: count == flags.sum() == the atoms without codes, also when the
+    same engine (same cached workspace, stale flags) sweeps a second problem with a different count."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    g = golden("small_cases")
+    seen = []
+    for tag in "abcdab":
+        X, W, Z = T(g[tag + "_X"]).cuda(), T(g[tag + "_W"]).cuda(), T(g[tag + "_z_fista"]).cuda()
+        k, d = Z.shape[1], X.shape[1]
+        buf = torch.zeros(k * k + k * d, device="cuda")
+        A, B = eng.gram(Z, X, buf)
+        mask, ndeg = eng.sweep_begin(A, B, W.clone(), 1e-10, False)()
+        dead = int((Z.abs().sum(0) == 0).sum().item())
+        assert ndeg == int(mask.sum().item()) == dead, (tag, ndeg, dead)
+        assert set(mask.unique().tolist()) <= {0, 1}
+        seen.append(ndeg)
+    assert len(set(seen)) > 1 or seen[0] == 0        # (the fixtures include cases with and without dead atoms)
+
+
 def test_update_dict_positive_and_large():
     from lasso_amd.linear import update_dict
     orc = _orc()
