@@ -57,7 +57,25 @@ struct ProxEpilogue {
   float* dpart;                 // [gridDim.y * gridDim.x] per-block sums of |z - z_next|
 };
 
-template <int BM, int BN, bool VEC, bool EPI = false>
+// one LDS-DMA instruction: 64 lanes x 16 bytes from src + voff (per lane) to the 1 KiB at LDS address `lds_addr`
+// (lane-linear), no registers in between (see tile_device.hpp: dma_step)
+__device__ __forceinline__ void gemm_dma_piece(const float* src, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:0\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(src), "s"(lds_addr)
+      : "memory");
+}
+
+// DMA = true (kk % 32 == 0, 16-byte aligned operands, row offsets of a block below 2 GiB): the chunks go global -> LDS
+// by LDS-DMA -- each lane fetches the 16 bytes whose swizzled home is its lane-linear slot -- instead of through 8
+// registers and 8 ds_writes per thread and chunk; same LDS image, same fragment reads, bitwise the same product.
+template <int BM, int BN, bool VEC, bool EPI = false, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ B, int64_t ldb,
                                                          const float* __restrict__ C0, int64_t ldc0,
@@ -88,13 +106,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 #pragma unroll
     for (int h = 0; h < PB; ++h) *(f32x4*)(sb + buf * BN * 128 + swz_off(srow + 32 * h, sch)) = gb[h];
   };
-  fetch(0);
-  stash(0);
+  // DMA: per-lane byte offsets inside the block's rows (row clamped to the last valid one: its results are dropped)
+  unsigned va[PA], vb[PB];
+  const int wdma = __builtin_amdgcn_readfirstlane(w);
+  if constexpr (DMA) {
+#pragma unroll
+    for (int h = 0; h < PA; ++h) {
+      const int r = srow + 32 * h, c = sch ^ ((r >> 1) & 7);
+      va[h] = (unsigned)((int64_t)min(r, m - 1 - i0) * lda * 4 + c * 16);
+    }
+#pragma unroll
+    for (int h = 0; h < PB; ++h) {
+      const int r = srow + 32 * h, c = sch ^ ((r >> 1) & 7);
+      vb[h] = (unsigned)((int64_t)min(r, nn - 1 - j0) * ldb * 4 + c * 16);
+    }
+  }
+  auto dma = [&](int k0, int buf) {
+    const float* const abase = A + (int64_t)i0 * lda + k0;
+    const float* const bbase = B + (int64_t)j0 * ldb + k0;
+    const unsigned la = (unsigned)(uintptr_t)(sa + buf * BM * 128) + (unsigned)(8 * wdma) * 128u;
+    const unsigned lb = (unsigned)(uintptr_t)(sb + buf * BN * 128) + (unsigned)(8 * wdma) * 128u;
+#pragma unroll
+    for (int h = 0; h < PA; ++h) gemm_dma_piece(abase, va[h], la + 32 * 128 * h);
+#pragma unroll
+    for (int h = 0; h < PB; ++h) gemm_dma_piece(bbase, vb[h], lb + 32 * 128 * h);
+  };
+  if constexpr (DMA) {
+    dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's pieces are in LDS
+  } else {
+    fetch(0);
+    stash(0);
+  }
   __syncthreads();
   int buf = 0;
   for (int k0 = 0; k0 < kk; k0 += 32) {
     const bool more = k0 + 32 < kk;
-    if (more) fetch(k0 + 32);
+    if (more) {
+      if constexpr (DMA) dma(k0 + 32, buf ^ 1);
+      else fetch(k0 + 32);
+    }
     const char* const ta = sa + buf * BM * 128;
     const char* const tb = sb + buf * BN * 128;
 #pragma unroll
@@ -112,7 +163,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
           for (int nj = 0; nj < NJ; ++nj)
             acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[nj][j], acc[mi][nj], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
+    if constexpr (DMA) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+    } else {
+      if (more) stash(buf ^ 1);
+    }
     __syncthreads();
     buf ^= 1;
   }
@@ -170,6 +225,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
   }
 }
 
+// the LDS-DMA form's preconditions beyond VEC (16-byte aligned rows): whole 32-float chunks and 32-bit lane offsets
+#ifndef LASSO_GEMM_NODMA
+static bool gemm_dma_ok(int64_t lda, int64_t ldb, int kk, int bm, int bn) {
+  return kk % 32 == 0 && kk > 0 && lda * bm * 4 < ((int64_t)1 << 31) && ldb * bn * 4 < ((int64_t)1 << 31);
+}
+#else
+static bool gemm_dma_ok(int64_t, int64_t, int, int, int) { return false; }
+#endif
+
 template <int BM, int BN, bool VEC>
 hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
                        int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk, int add,
@@ -180,6 +244,17 @@ hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb,
         e != hipSuccess)
       return e;
   const dim3 grid((nn + BN - 1) / BN, (m + BM - 1) / BM);
+  if constexpr (VEC) {
+    if (gemm_dma_ok(lda, ldb, kk, BM, BN)) {
+      if (lds > 48 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, true, false, true>), lds);
+            e != hipSuccess)
+          return e;
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0,
+                         ldc0, C, ldc, m, nn, kk, add);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0, ldc0, C,
                      ldc, m, nn, kk, add);
   return hipGetLastError();
@@ -194,6 +269,17 @@ hipError_t launch_tile_prox(const float* A, int64_t lda, const float* B, int64_t
         e != hipSuccess)
       return e;
   const dim3 grid((nn + BN - 1) / BN, (m + BM - 1) / BM);
+  if constexpr (VEC) {
+    if (gemm_dma_ok(lda, ldb, kk, BM, BN)) {
+      if (lds > 48 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, true, true, true>), lds);
+            e != hipSuccess)
+          return e;
+      hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, true, true, true>), grid, dim3(256), lds, stream, A, lda, B, ldb,
+                         nullptr, 0, nullptr, 0, m, nn, kk, 0, ep);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC, true>), grid, dim3(256), lds, stream, A, lda, B, ldb, nullptr, 0,
                      nullptr, 0, m, nn, kk, 0, ep);
   return hipGetLastError();

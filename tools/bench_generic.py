@@ -4,6 +4,9 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
 import torch
+if '--lib' in sys.argv:
+    from lasso_amd import _native as _nat
+    _nat.use_library(os.path.abspath(sys.argv[sys.argv.index('--lib') + 1]))
 from lasso_amd.linear import sparse_encode
 from recipes import recipe_xw
 out = []
