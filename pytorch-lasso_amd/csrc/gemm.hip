@@ -287,14 +287,38 @@ hipError_t launch_tile_prox(const float* A, int64_t lda, const float* B, int64_t
 
 }  // namespace
 
-// blocks the fused GEMM-2 + prox launch uses for an [m x nn] result (= partial sums it writes)
-static void prox_blocks(int m, int nn, int* bm_out, int* bn_out) {
-  auto pad = [](int v, int b) { return (v + b - 1) / b * b; };
-  const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
-  const bool roomy = big_blocks >= 192;
-  *bm_out = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
-  *bn_out = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+static int gemm_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 1;
+  return cus;
 }
+
+// Block shape of an [m x nn] product (sides 128 or 64): the least modelled time on `cus` compute units --
+// blocks per CU (the padding of short sides is in the block count) x block area / (rate of the shape x a
+// co-residency factor): 128 x 128 blocks need the fewest LDS reads per MFMA but only pay off while every CU still
+// holds two workgroups at a time (one alone leaves its barriers uncovered); 784 output columns, for instance, are
+// 224 blocks of 128 x 128 on 256 CUs -- 416 of 128 x 64 run 8 % faster.  The accumulation order of an output
+// element does not depend on the shape: bitwise the same product either way.
+static void gemm_blocks(int m, int nn, int* bm_out, int* bn_out) {
+  const int cus = gemm_cus();
+  double best = 1e300;
+  int64_t best_blocks = 0;
+  for (int bm : {128, 64})
+    for (int bn : {128, 64}) {
+      const int64_t blocks = (int64_t)((m + bm - 1) / bm) * ((nn + bn - 1) / bn);
+      const int64_t per_cu = (blocks + cus - 1) / cus;
+      const double rate = (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64) ? 0.78 : 0.9;
+      const double t = (double)per_cu * bm * bn / (rate * (per_cu >= 2 ? 1.0 : 0.8));
+      if (t < best * (1.0 - 1e-9) || (t <= best * (1.0 + 1e-9) && blocks < best_blocks)) {
+        best = t; best_blocks = blocks; *bm_out = bm; *bn_out = bn;
+      }
+    }
+}
+
+// blocks the fused GEMM-2 + prox launch uses for an [m x nn] result (= partial sums it writes)
+static void prox_blocks(int m, int nn, int* bm_out, int* bn_out) { gemm_blocks(m, nn, bm_out, bn_out); }
 
 int gemm_nt_prox_parts(int m, int nn) {
   int bm, bn;
@@ -330,22 +354,12 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
   if (m <= 0 || nn <= 0) return hipSuccess;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
-  // Block shape: 128-wide sides once the problem still gives every CU a workgroup, except
-  // where a side is so short that 64-wide blocks waste less padding (m or nn just above a
-  // multiple of 128, or below 64).
-  auto pad = [](int v, int b) { return (v + b - 1) / b * b; };
-  const int64_t big_blocks = (int64_t)((m + 127) / 128) * ((nn + 127) / 128);
-  const bool roomy = big_blocks >= 192;
-  int bm = (roomy && m > 64 && pad(m, 128) <= pad(m, 64) + 32) ? 128 : 64;
-  int bn = (roomy && nn > 64 && pad(nn, 128) <= pad(nn, 64) + 32) ? 128 : 64;
+  int bm, bn;
+  gemm_blocks(m, nn, &bm, &bn);
   // Small products (U = B - A D^T of the M-step: 1024 x 256 outputs = 64 blocks of 64 x 64 on 256 CUs): 32-wide
-  // sides until every CU has a workgroup.  The accumulation order of an output element does not depend on the
-  // block shape, so the result is bitwise the same.
+  // sides until every CU has a workgroup.
   if (bm == 64 && bn == 64) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-      cus = 1;
+    const int cus = gemm_cus();
     auto blocks = [&](int a, int b) { return (int64_t)((m + a - 1) / a) * ((nn + b - 1) / b); };
     if (blocks(64, 64) < cus && m > 32) bm = 32;
     if (blocks(bm, 64) < cus && nn > 32) bn = 32;
