@@ -2,7 +2,8 @@
 """bench.py -- BASELINE's metric on MI355X: FISTA iterations/sec (+ time-to-tol) on
 n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em] [--scaling strong|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em|c3] [--scaling strong|weak]
+                    [--shape c4|c5] [--dtype bf16|f32] [--rows R] [--backend nccl|gloo] [--share-gpu]
 
 --workload fista (default): a "step" is one sparse_encode solve of --iters FISTA iterations
   (default 100, the count BASELINE.md's config-2 timing uses), inputs resident in HBM, tol=0.
@@ -18,6 +19,15 @@ n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU
   lr='auto', maxiter=10, tol=1e-5 + constrained least-squares M-step) on n=65536 rows sharded
   over the ranks, with the RCCL all-reduce of [Z^T Z | Z^T X | objective sums] per step;
   a "step" is one EM step; value = EM steps/s; the all-reduce time is reported separately.
+
+  --shape c5: the same loop at the shape of BASELINE config 5 (8 x 8 patches: d=64, k=256, alpha=0.1, synthetic
+  centred patches -- the Omniglot notebook is absent from the reference checkout); --rows sets the batch.
+--workload c3: BASELINE config 3, FISTA with the backtracking line search (ista.py:17-54), n=16384 d=256 k=1024,
+  lr0=1, 10 outer iterations, --dtype bf16 (default, config 3 as named) or f32 tensors; a "step" is one solve;
+  value = outer iterations/s; FLOPs as executed = (4 per outer iteration + 2 per trial) n d k.  N > 1: the rows
+  sharded, every F <= Q decision on sums all-reduced over the ranks (lasso_fista_solve_sharded).
+--backend gloo --share-gpu: every rank on cuda:0, collectives over gloo (host-staged) -- how the multi-rank
+  code paths of this file are executed on a ONE-GPU box (tests/test_bench_gpu.py); never a performance figure.
 
 With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this script spawns its N
 ranks itself through `python -m torch.distributed.run` on 127.0.0.1; under a launcher whose
@@ -145,7 +155,7 @@ class Ranks:
     """barrier + max-over-ranks timing, on RCCL ('nccl') or -- launcher self-test -- gloo."""
 
     def __init__(self, rank, world, device, backend):
-        self.rank, self.world, self.device, self.dist = rank, world, device, None
+        self.rank, self.world, self.device, self.dist, self.backend = rank, world, device, None, backend
         if world > 1:
             import torch.distributed as dist
             kw = {"device_id": device} if backend == "nccl" else {}
@@ -163,9 +173,16 @@ class Ranks:
         import torch
         if self.dist is None:
             return seconds
-        t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        t = torch.tensor([seconds], device=self.device if self.backend == "nccl" else "cpu", dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.item()
+
+    def sum_(self, t):
+        """in-place sum over the ranks of a device tensor (gloo: staged through the host)"""
+        if self.dist is not None:
+            from lasso_amd import parallel
+            parallel._all_reduce(t, None)
+        return t
 
     def close(self):
         if self.dist is not None:
@@ -228,6 +245,31 @@ def run_fista(args, ranks):
                              z=solve())
     main_mode = args.scaling if world > 1 else "strong"
     r = results[main_mode]
+    ttt = None
+    if not args.no_time_to_tol:
+        # time-to-tol with the reference's rule (ista.py:64,93: ONE sum over ALL rows of the batch, also when the rows
+        # are spread over the ranks): every rank runs the solve on its shard, the per-iteration sums of a chunk of <= 64
+        # iterations meet in one small all-reduce, every rank stops at the same iteration; time = max over the ranks
+        from lasso_amd import parallel
+        from lasso_amd.engine import HipEngine
+        eng = HipEngine(dev)
+        n_total = r["rows"] * world
+
+        def to_tol():
+            if world == 1:
+                return ista(r["Xg"], r["z0"], r["Wg"], ALPHA, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
+            return parallel.sharded_encode(eng, r["Xg"], r["Wg"], ALPHA, None, lr=lr, maxiter=2000, tol=1e-5,
+                                           n_global=n_total, return_info=True)
+        to_tol()
+        ranks.sync()
+        t1 = time.perf_counter()
+        _, info = to_tol()
+        torch.cuda.synchronize()
+        ttt = {"ms": 1e3 * ranks.max(time.perf_counter() - t1), "iterations": info["iterations"], "tol": 1e-5,
+               "rows_total": n_total, "rows_per_gpu": r["rows"],
+               "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), global over all ranks" if world > 1 else
+                       "sum|z-z_next| <= n*k*tol (ista.py:64,93), global (one rank holds the whole batch)",
+               "reference_iterations": 263 if n_total == N_ROWS else None}
     out = None
     if rank == 0:
         def line(mode):
@@ -287,18 +329,8 @@ def run_fista(args, ranks):
                                        "ms_per_step": 1e3 * el / args.steps, "repeats": "median of 3 timed regions",
                                        "kernel": kernel_name(rows_s)}
             out["strong_scaling_shards_on_one_gpu"] = shards
-        if not args.no_time_to_tol:
-            # time-to-tol of THIS rank's shard with the reference's global rule on the shard
-            Xg, Wg, z0 = r["Xg"], r["Wg"], r["z0"]
-            ista(Xg, z0, Wg, ALPHA, lr=lr, maxiter=2000, tol=1e-5)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, info = ista(Xg, z0, Wg, ALPHA, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
-            torch.cuda.synchronize()
-            out["time_to_tol"] = {"ms": 1e3 * (time.perf_counter() - t1),
-                                  "iterations": info["iterations"], "tol": 1e-5, "rows": r["rows"],
-                                  "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), exact global over the "
-                                          "rows of rank 0"}
+        if ttt is not None:
+            out["time_to_tol"] = ttt
         if not args.no_extras and world == 1:
             # SURVEY 8d's other figures for this configuration, each with its own timed region
             Xg, Wg, z0 = r["Xg"], r["Wg"], r["z0"]
@@ -338,8 +370,7 @@ def run_fista(args, ranks):
         from lasso_amd.engine import HipEngine
         q = results["strong"]
         _, sums = HipEngine(dev).objective_sums(q["Xg"], q["z"], q["Wg"], ALPHA)
-        if ranks.dist is not None:
-            ranks.dist.all_reduce(sums)
+        ranks.sum_(sums)
         obj = ((0.5 * sums[0] + ALPHA * sums[1]) / N_ROWS).item()
         if rank == 0:
             out["objective_after_100"] = obj
@@ -351,22 +382,30 @@ def run_fista(args, ranks):
     return out
 
 
+EM_SHAPES = {
+    # name: (config, d, k, alpha, default rows)
+    "c4": ("BASELINE config 4", D, K, ALPHA, N_EM),
+    "c5": ("BASELINE config 5 shape (8x8 patches; synthetic centred patches stand in for Omniglot)", 64, 256, 0.1, N_EM),
+}
+
+
 def run_em(args, ranks):
-    """BASELINE config 4: one EM step = E-step (FISTA, reference defaults) + objective + Gram +
-    all-reduce + atom sweep on n=65536 rows sharded over the ranks."""
+    """BASELINE config 4 (or config 5's shape): one EM step = E-step (FISTA, reference defaults) + objective +
+    Gram + all-reduce + atom sweep on the rows sharded over the ranks (dict_learning.py:23-53)."""
     import torch
     from lasso_amd.engine import HipEngine
     from lasso_amd import parallel
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from recipes import recipe_c4_init
+    from recipes import recipe_c4_init, recipe_c5
     rank, world, dev = ranks.rank, ranks.world, ranks.device
-    if N_EM % world:
-        raise SystemExit("bench.py: %d rows do not split over %d ranks" % (N_EM, world))
-    rows = N_EM // world
-    X_all, _ = recipe(N_EM)
+    cfg, d, k, alpha, n_default = EM_SHAPES[args.shape]
+    n_all = args.rows or n_default
+    if n_all % world:
+        raise SystemExit("bench.py: %d rows do not split over %d ranks" % (n_all, world))
+    rows = n_all // world
+    X_all = recipe(n_all)[0] if args.shape == "c4" else recipe_c5(n_all)
     Xg = X_all[rank * rows:(rank + 1) * rows].to(dev)
     eng = HipEngine(dev)
-    state = {"D": recipe_c4_init().to(dev)}
+    state = {"D": recipe_c4_init(d, k).to(dev)}
     comm_ms = []
     real_all_reduce = parallel._all_reduce
 
@@ -377,47 +416,133 @@ def run_em(args, ranks):
         e0.record()
         real_all_reduce(t, group)
         e1.record()
-        comm_ms.append((e0, e1))
+        comm_ms.append((e0, e1, t.numel() * t.element_size()))
         return t
     parallel._all_reduce = timed_all_reduce
+    eng.em_stats = {}
 
     def em(steps):
-        state["D"], state["loss"] = parallel.em_loop(eng, Xg, state["D"], ALPHA, constrained=True, steps=steps,
+        state["D"], state["loss"] = parallel.em_loop(eng, Xg, state["D"], alpha, constrained=True, steps=steps,
                                                      solver_kwargs=dict(algorithm="ista"))
-    if args.warmup:
-        em(args.warmup)
-    ranks.sync()
-    del comm_ms[:]
-    t0 = time.perf_counter()
-    em(args.steps)                     # exactly K EM steps between the two barriers
-    ranks.sync()
-    elapsed = ranks.max(time.perf_counter() - t0)
+    try:
+        if args.warmup:
+            em(args.warmup)
+        ranks.sync()
+        del comm_ms[:]
+        eng.em_stats.clear()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0 = time.perf_counter()
+        ev[0].record()
+        em(args.steps)                     # exactly K EM steps between the two barriers
+        ev[1].record()
+        ranks.sync()
+        elapsed = ranks.max(time.perf_counter() - t0)
+    finally:
+        parallel._all_reduce = real_all_reduce
     out = None
     if rank == 0:
-        ar = sorted(a.elapsed_time(b) for a, b in comm_ms[-args.steps:]) if comm_ms else []
+        ar = sorted(a.elapsed_time(b) for a, b, _ in comm_ms[-args.steps:]) if comm_ms else []
         # E-step flops dominate: 10 iterations x 4 n d k per rank, + Gram 2nk^2 + 2nkd + objective 2ndk
-        flop = (10 * 4.0 + 2.0 + 2.0) * rows * D * K + 2.0 * rows * K * K
+        flop = (10 * 4.0 + 2.0 + 2.0) * rows * d * k + 2.0 * rows * k * k
         ms = 1e3 * elapsed / args.steps
+        dev_ms = ev[0].elapsed_time(ev[1]) / args.steps
         out = {
-            "metric": "dict_learning_em_steps_per_sec (n=65536 d=256 k=1024 fp32, constrained, defaults)",
+            "metric": "dict_learning_em_steps_per_sec (n=%d d=%d k=%d fp32, constrained, defaults)" % (n_all, d, k),
             "value": args.steps / elapsed, "unit": "EM steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: dict_learning EM step, n=65536 d=256 k=1024, FISTA E-step "
-                                   "(lr='auto', maxiter=10, tol=1e-5) + constrained M-step",
-                       "rows_per_gpu": rows, "rows_total": N_EM,
+            "config": {"workload": "%s: dict_learning EM step, n=%d d=%d k=%d alpha=%g, FISTA E-step "
+                                   "(lr='auto', maxiter=10, tol=1e-5) + constrained M-step" % (cfg, n_all, d, k, alpha),
+                       "rows_per_gpu": rows, "rows_total": n_all,
                        "parallelism": "row-sharded x%d, one all-reduce of [A|B|sums] per step" % world},
             "all_reduce_ms": {"median": ar[len(ar) // 2] if ar else 0.0, "max": ar[-1] if ar else 0.0,
-                              "bytes": 4 * (K * K + K * D + 2 + 10), "note": "device time of the one RCCL all-reduce "
+                              "bytes": 4 * (k * k + k * d + 2 + 10),
+                              "bytes_sent": sorted({nb for _, _, nb in comm_ms}),
+                              "per_step": len(comm_ms) / float(args.steps),
+                              "note": "device time of the one RCCL all-reduce "
                               "per EM step -- [A | B | objective sums | the E-step's 10 stop-rule sums] -- (0 at N=1: "
                               "no collective)"},
-            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel": "whole EM step (E-step kernel dominates)",
-                         "flop_per_launch": flop, "per": "GPU (rank 0)"},
+            "roofline": {"bound": "mfma", "achieved": flop / (dev_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "kernel": "whole EM step (E-step kernel dominates; the Lipschitz squarings "
+                                                    "and the atom sweep are latency chains)",
+                         "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": dev_ms,
+                         "avg_launch_note": "HIP events around the K timed EM steps / K"},
+            "em_path": dict(eng.em_stats),
             "objective_last_step": float(state["loss"][-1]),
         }
+    return out
+
+
+C3_ROWS, C3_OUTER = 16384, 10
+C3_TRIALS = [5, 3, 5, 4, 4, 4, 4, 3, 5, 5]          # the reference's fp32 trace (tests/golden/g3_c3_trace.npz)
+C3_OBJ = {"f32": (64.142166, 1e-5), "bf16": (64.151779, 2e-3)}   # reference objective, rtol
+PEAK_BF16_MFMA_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def run_c3(args, ranks):
+    """BASELINE config 3: FISTA with the backtracking line search (ista.py:17-54), n=16384 d=256 k=1024, lr0 = 1,
+    10 outer iterations, bf16 (or fp32) tensors; a step = one solve."""
+    import torch
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd import parallel
+    from lasso_amd.engine import HipEngine
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    n_all = args.rows or C3_ROWS
+    if n_all % world:
+        raise SystemExit("bench.py: %d rows do not split over %d ranks" % (n_all, world))
+    rows = n_all // world
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    X_all, W = recipe(n_all)
+    Xg, Wg = X_all[rank * rows:(rank + 1) * rows].to(dev).to(dt), W.to(dev).to(dt)
+    z0 = torch.zeros(rows, K, device=dev, dtype=dt)
+    eng = HipEngine(dev)
+    kw = dict(lr=1.0, maxiter=C3_OUTER, tol=0.0, backtrack=True)
+
+    def solve(info=False):
+        if world == 1:
+            return ista(Xg, z0, Wg, ALPHA, return_info=info, **kw)
+        return parallel.sharded_encode(eng, Xg, Wg, ALPHA, z0, n_global=n_all, return_info=info, **kw)
+    elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
+    z, info = solve(True)
+    _, sums = eng.objective_sums(Xg.float(), z.float(), Wg.float(), ALPHA)
+    ranks.sum_(sums)
+    obj = ((0.5 * sums[0] + ALPHA * sums[1]) / n_all).item()
+    if rank != 0:
+        return None
+    trials = list(info["trials"])
+    flop = (4.0 * len(trials) + 2.0 * sum(trials)) * rows * D * K          # as executed, this rank
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    achieved = flop / (kern_ms[0] * 1e-3) / 1e12
+    from lasso_amd import _native as nat
+    name = nat.lib().lasso_fista_kernel_name(rows, D, K, nat.LASSO_BF16 if args.dtype == "bf16" else nat.LASSO_F32, 1)
+    out = {
+        "metric": "fista_backtracking_outer_iterations_per_sec (n=%d d=256 k=1024 %s, lr0=1, eta=1.5)" % (n_all, args.dtype),
+        "value": args.steps * len(trials) / elapsed, "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: FISTA with backtracking line search, n=%d d=256 k=1024 %s tensors, "
+                               "lr0=1.0, %d outer iterations; step = one solve" % (n_all, args.dtype, C3_OUTER) +
+                               ("" if n_all == C3_ROWS else " (NOT the 16384-row batch of config 3)"),
+                   "rows_per_gpu": rows, "rows_total": n_all,
+                   "parallelism": "row-sharded x%d%s" % (world, ", every F<=Q decision on all-reduced sums" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": name.decode() if name else None,
+                     "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
+                     "flop_note": "(4 per outer iteration + 2 per trial) n d k as executed: %d outer iterations, "
+                                  "%d trials" % (len(trials), sum(trials)),
+                     "avg_launch_note": "HIP events around the K timed solves / K"},
+        "trials": trials, "reference_trials_fp32": C3_TRIALS,
+        "objective": obj, "objective_reference": C3_OBJ[args.dtype][0],
+    }
+    if n_all == C3_ROWS:
+        ref, rtol = C3_OBJ[args.dtype]
+        bad = abs(obj - ref) > rtol * ref or (args.dtype == "f32" and trials != C3_TRIALS)
+        if bad:
+            print(json.dumps(out))
+            raise SystemExit("bench.py: config 3 (%s) ended at objective %.6f, trials %s -- reference %.6f (rtol %g), "
+                             "fp32 trace %s: the timed solve is wrong" % (args.dtype, obj, trials, ref, rtol, C3_TRIALS))
     return out
 
 
@@ -434,32 +559,46 @@ def run_launcher_selftest(args, ranks):
             "config": {"workload": "launcher self-test (no kernel)"}}
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)    # 0.32 s timed at the headline shape
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100, help="FISTA iterations per step (solve)")
-    ap.add_argument("--workload", choices=["fista", "em", "launcher-selftest"], default="fista")
+    ap.add_argument("--workload", choices=["fista", "em", "c3", "launcher-selftest"], default="fista")
+    ap.add_argument("--shape", choices=sorted(EM_SHAPES), default="c4", help="em workload: config 4 or config 5's shape")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="c3 workload: tensor dtype")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collectives: nccl (= RCCL, the product) or gloo (host-staged; tests on a one-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank on cuda:0 (needs --backend gloo): executes the multi-rank code paths on ONE GPU")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="which figure is `value` at N > 1 (both are measured and reported)")
-    ap.add_argument("--rows", type=int, default=N_ROWS,
-                    help="fista workload: total rows of the batch (default 4096 = BASELINE config 2; e.g. 512 = "
-                         "the shard one rank of an 8-GPU strong-scaling run works on)")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="total rows of the batch (default: fista 4096 = BASELINE config 2 -- e.g. 512 = the shard one "
+                         "rank of an 8-GPU strong-scaling run works on --, em 65536, c3 16384)")
     ap.add_argument("--no-shards", action="store_true", help="skip the per-shard timings of the N=1 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ISTA / Lipschitz / lr='auto' / sustained legs")
     ap.add_argument("--no-time-to-tol", action="store_true")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = parser().parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL wants one GPU per rank)")
+    if args.workload == "fista" and args.rows is None:
+        args.rows = N_ROWS
 
     selftest = args.workload == "launcher-selftest"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not selftest:
             import torch
             have = torch.cuda.device_count()
-            if have < args.gpus:
+            if have < args.gpus and not (args.share_gpu and have >= 1):
                 raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible -- one process per GPU, "
                                  "ranks cannot share a device" % (args.gpus, have))
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -470,11 +609,15 @@ def main():
         ranks = Ranks(rank, world, torch.device("cpu"), "gloo")
         out = run_launcher_selftest(args, ranks)
     else:
-        if torch.cuda.device_count() <= local_rank:
+        gpu = 0 if args.share_gpu else local_rank
+        if torch.cuda.device_count() <= gpu:
             raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        ranks = Ranks(rank, world, torch.device("cuda", local_rank), "nccl")
-        out = run_em(args, ranks) if args.workload == "em" else run_fista(args, ranks)
+        torch.cuda.set_device(gpu)
+        ranks = Ranks(rank, world, torch.device("cuda", gpu), args.backend)
+        out = {"em": run_em, "c3": run_c3, "fista": run_fista}[args.workload](args, ranks)
+        if out is not None and world > 1:
+            out["backend"] = args.backend + (" (all ranks share cuda:0: a code-path run, not a performance figure)"
+                                             if args.share_gpu else " (RCCL over xGMI)" if args.backend == "nccl" else "")
     ranks.close()
     if rank == 0:
         print(json.dumps(out))

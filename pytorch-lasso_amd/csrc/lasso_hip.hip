@@ -434,7 +434,8 @@ SolveGeom solve_geometry(int64_t n, int64_t d, int64_t k) {
 int pad_k_solve(int64_t n, int64_t d, int64_t k) { return solve_geometry(n, d, k).kp; }
 bool narrow_tiles(int64_t n, int64_t d, int64_t k, int kp, int hint_bits) {
   if (d > 128 || kp <= 512 || n <= 0) return false;
-  if (hint_bits & 0x800) return true;                  // A/B knob
+  if ((hint_bits & 0x800) && (hint_bits & 0x300) == LASSO_KERNEL_AUTO) return true;   // A/B knob "narrow": 0x800 ALONE
+  if ((hint_bits & 0x300) == LASSO_KERNEL_SPLITK) return false;   // (with LASSO_KERNEL_SPLITK 0x800 is the exchange variant)
   return solve_geometry(n, d, k).narrow;
 }
 
@@ -469,7 +470,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   p.stop_out = ws.stop_out;
   p.xch = nullptr; p.xflags = nullptr; p.groups = 0;
   p.run_if = nullptr; p.part_stride = ntiles;
-  p.variant = (hint & 0x400) ? 1 : (hint & 0x800) ? 2 : 0;       // A/B knobs: register gather for every T / streamed for every T
+  // A/B knobs of the split-k kernel (only together with LASSO_KERNEL_SPLITK; 0x800 alone is the "narrow tiles" knob)
+  p.variant = (hint & 0x300) != LASSO_KERNEL_SPLITK ? 0 : (hint & 0x400) ? 1 : (hint & 0x800) ? 2 : 0;
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   // in-place launches keep the tile kernel: a split-k launch that gives up is redone from its
@@ -742,12 +744,20 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   // the device; once the rule fired -- or a search needed more than kBtBatch trials -- the remaining launches are
   // no-ops (BtParams::skip).  ONE synchronisation at the end; only a search that ran out of trials is continued on
   // the iteration-by-iteration path below, from the untouched state of the iteration that needed them.
-  if (!reduce && recompute && maxiter > 0) {
+  // The solve is enqueued in WINDOWS of kBtWindow outer iterations (all `maxiter` iterations at once meant
+  // ~19 launches per remaining iteration of empty work after the rule fired -- maxiter = 1000 stopping at 20: ~19k
+  // no-op launches); the control words are read between windows, and after a search that ran out of pre-enqueued
+  // trials -- ONE iteration on the synchronous path below -- the next window is enqueued asynchronously again.
+  const bool can_async = !reduce && recompute;
+  constexpr int kBtWindow = 16;
+  while (it < maxiter) {
+  if (can_async) {
+    const int win0 = it, wlen = std::min(kBtWindow, maxiter - it);
     LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
     LASSO_HIP_TRY(hipMemsetAsync(ws.ctl, 0, 4 * sizeof(int), st));
     p.skip = ws.ctl;
-    double tm = 1.0;
-    for (int i = 0; i < maxiter; ++i) {
+    double tm = t_mom;
+    for (int i = win0; i < win0 + wlen; ++i) {
       const double t_next = (1.0 + sqrt(1.0 + 4.0 * tm * tm)) / 2.0;                 // :98
       const float coef = fast ? (float)((tm - 1.0) / t_next) : 0.0f;                 // :99
       p.P = fast ? ws.Y : zout;
@@ -774,32 +784,29 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     int hctl[4] = {0, 0, 0, 0};
     LASSO_HIP_TRY(hipMemcpyAsync(hctl, ws.ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
-    const int done = hctl[1];
-    if (done > 0) {
-      std::vector<int> ht(done);
-      std::vector<float> hl(done), hf(done);
-      LASSO_HIP_TRY(hipMemcpy(ht.data(), ws.rtrials, (size_t)done * 4, hipMemcpyDeviceToHost));
-      LASSO_HIP_TRY(hipMemcpy(hl.data(), ws.rlrs, (size_t)done * 4, hipMemcpyDeviceToHost));
-      LASSO_HIP_TRY(hipMemcpy(hf.data(), ws.rfs, (size_t)done * 4, hipMemcpyDeviceToHost));
-      for (int i = 0; i < done; ++i) {
-        if (trials_out) trials_out[i] = ht[i];
-        if (accepted_lr_out) accepted_lr_out[i] = hl[i];
-        if (accepted_f_out) accepted_f_out[i] = hf[i];
+    const int done = hctl[1] > 0 ? hctl[1] : win0;      // (ctl[1] = iterations completed, absolute; 0: none in this window)
+    if (done > win0) {
+      const int cnt = done - win0;
+      std::vector<int> ht(cnt);
+      std::vector<float> hl(cnt), hf(cnt);
+      LASSO_HIP_TRY(hipMemcpy(ht.data(), ws.rtrials + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hl.data(), ws.rlrs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hf.data(), ws.rfs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; ++i) {
+        if (trials_out) trials_out[win0 + i] = ht[i];
+        if (accepted_lr_out) accepted_lr_out[win0 + i] = hl[i];
+        if (accepted_f_out) accepted_f_out[win0 + i] = hf[i];
       }
-      prev_trials = ht[done - 1];
+      prev_trials = ht[cnt - 1];
       memcpy(&last, &hctl[2], sizeof(float));
+      for (int i = win0; i < done; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
     }
     it = done;
-    for (int i = 0; i < done; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
-    if (hctl[0] != 2) {          // ran to maxiter, or the stop rule fired at iteration `done`
-      if (half) LASSO_HIP_TRY(launch_cvt_bf16(zout, k, zout_any, ldz_any, (int)n, (int)k, 0, st));
-      if (iters_out) *iters_out = it;
-      if (last_delta_out) *last_delta_out = last;
-      return LASSO_OK;
-    }
-    // a search ran out of pre-enqueued trials at iteration `it`: continue below, one iteration at a time
+    if (hctl[0] == 1) break;     // the stop rule fired at iteration `done` (:93-95)
+    if (hctl[0] != 2) continue;  // the window ran through: next window
+    // a search ran out of pre-enqueued trials at iteration `it`: that iteration below, from its untouched state
   }
-  for (; it < maxiter; ++it) {
+  {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;             // :98
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;                 // :99
     p.P = fast ? ws.Y : zout;
@@ -884,7 +891,9 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     if (accepted_f_out) accepted_f_out[it] = host.fvals[0];        // F(z_next) of the accepted trial (:28)
     last = host.delta;
     t_mom = t_next;
-    if (tol > 0.0 && host.delta <= budget) { ++it; break; }                            // :93-95
+    ++it;
+    if (tol > 0.0 && host.delta <= budget) break;                                      // :93-95
+  }
   }
   if (half) LASSO_HIP_TRY(launch_cvt_bf16(zout, k, zout_any, ldz_any, (int)n, (int)k, 0, st));
   if (iters_out) *iters_out = it;
@@ -1316,8 +1325,15 @@ static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
   if (kp < 0) return 0;
   if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16, maxiter).bytes;
   const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
+  // Every padded dictionary size solve_geometry() / the kernel hints can pick for this shape: a SMALLER kp means more
+  // split-k groups, i.e. a LARGER exchange region (carve(384) needs ~2.2 MiB more than carve(512)), so the size is the
+  // maximum over the candidates, not the size at pad_k(k) (an exactly-sized workspace failed at
+  // d=64, k=300 and for most n at d <= 32).
+  size_t bytes = carve(nullptr, n, k, kp, maxiter, with_state).bytes;
+  if (kp == 512 && k <= 384 && d <= 128) bytes = std::max(bytes, carve(nullptr, n, k, 384, maxiter, with_state).bytes);
+  if (kp == 1024 && k <= 768) bytes = std::max(bytes, carve(nullptr, n, k, 768, maxiter, with_state).bytes);
   // (LASSO_KERNEL_UNFUSED / the cost model may send a fused shape down the general-GEMM path: room for either)
-  return std::max(carve(nullptr, n, k, kp, maxiter, with_state).bytes, carve_generic(nullptr, n, d, k, false).bytes);
+  return std::max(bytes, carve_generic(nullptr, n, d, k, false).bytes);
 }
 
 // region behind the solver's workspace that objective_out needs: the lasso_objective workspace,
@@ -1479,6 +1495,11 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   stop_mode &= ~LASSO_KERNEL_MASK;
   if (stop_mode != LASSO_STOP_GLOBAL && stop_mode != LASSO_STOP_NONE && stop_mode != LASSO_STOP_GLOBAL_CHUNKED)
     return fail(LASSO_ERR_BAD_ARG, "stop_mode %d", stop_mode);
+  // defined hints: AUTO (optionally | 0x800 = narrow tiles), TILE, UNFUSED, SPLITK with its T / exchange knobs
+  if (((hint & 0x300) != LASSO_KERNEL_SPLITK && (hint & 0x3400)) ||
+      ((hint & 0x300) != LASSO_KERNEL_SPLITK && (hint & 0x300) != LASSO_KERNEL_AUTO && (hint & 0x800)) ||
+      ((hint & 0x400) && (hint & 0x800)))
+    return fail(LASSO_ERR_BAD_ARG, "kernel hint 0x%x", hint);
   const bool want_unfused = (hint & 0x300) == LASSO_KERNEL_UNFUSED;
   const bool stop_rule = tol > 0.0 && stop_mode != LASSO_STOP_NONE;
   if (!workspace_dev) return fail(LASSO_ERR_WORKSPACE, "workspace is null");

@@ -48,22 +48,30 @@ class HipEngine:
         sharded form (line search, maxiter > 64, shapes beyond the fused kernels, ...): the caller then
         takes the synchronous sharded path."""
         from .linear.solvers import ista
-        kw = dict(solver_kwargs)
-        kw.pop('n_global', None)
-        d, k = W.shape
-        plain = (kw.pop('algorithm', 'ista') == 'ista' and kw.pop('init', None) is None and not kw.get('verbose')
-                 and not kw.get('backtrack') and not kw.get('return_info') and X.dtype == torch.float32
-                 and X.is_cuda and W.is_cuda and (z0 is None or z0.is_cuda) and d <= 256 and k <= 1024
-                 and X.shape[0] > 0 and kw.get('stop_mode', 'global') == 'global')
-        maxiter, tol = kw.get('maxiter', 10), kw.get('tol', 1e-5)
-        if not plain or not (0 < maxiter <= 64):
+        if not self.sharded_async_ok(X, W, **solver_kwargs) or not (z0 is None or z0.is_cuda) or X.shape[0] == 0:
             return None
+        kw = dict(solver_kwargs)
+        for name in ('n_global', 'algorithm', 'init'):
+            kw.pop(name, None)
+        tol = kw.get('tol', 1e-5)
         if z0 is None:
             from .linear.solvers.ista import lazy_zeros
             z0 = lazy_zeros(X, X.shape[0], W.shape[1])
         if not tol > 0:
             return ista(X, z0, W, alpha, begin=True, **kw)          # no rule: nothing to agree on
         return ista(X, z0, W, alpha, begin=True, shard=True, **kw)
+
+    def sharded_async_ok(self, X, W, **solver_kwargs):
+        """Whether encode_begin_sharded has a form for these arguments.  Depends on the solver's keyword
+        arguments, d, k, the dtype and the device only -- NOT on this rank's row count -- so that every rank of
+        an EM loop reaches the same answer (parallel.em_loop sums the answers over the ranks all the same)."""
+        kw = solver_kwargs
+        d, k = W.shape
+        maxiter = kw.get('maxiter', 10)
+        return bool(kw.get('algorithm', 'ista') == 'ista' and kw.get('init', None) is None and not kw.get('verbose')
+                    and not kw.get('backtrack') and not kw.get('return_info') and X.dtype == torch.float32
+                    and X.is_cuda and W.is_cuda and d <= 256 and k <= 1024
+                    and kw.get('stop_mode', 'global') == 'global' and 0 < maxiter <= 64)
 
     def encode_begin(self, X, W, alpha, z0, **solver_kwargs):
         """sparse_encode that does not wait for the stop rule's outcome: returns (Z, pending);

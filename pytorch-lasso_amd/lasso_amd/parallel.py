@@ -148,30 +148,59 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
         z, info = engine.encode_sharded_backtrack(X, W, alpha, z0, lr, fast, maxiter, tol, eta, int(n_global),
                                                   reduce_host)
         return (z, info) if return_info else z
-    if return_info:
-        raise NotImplementedError("sharded E-step: return_info needs backtrack=True")
+    def result(z, iterations, last):
+        return (z, dict(iterations=iterations, last_delta=last)) if return_info else z
+
+    def run(z, y, it0, c, want_delta):
+        if n == 0:      # a rank without rows: nothing to launch, zero sums -- but the SAME collectives as its peers
+            return z, y, (X.new_zeros(c, dtype=torch.float32) if want_delta else None)
+        return engine.fista_run(X, W, z, y, alpha, lr, fast, it0, c, want_delta)
+
     if not tol > 0:
-        z, _, _ = engine.fista_run(X, W, z0, None, alpha, lr, fast, 0, maxiter, False)
-        return z
+        z, _, _ = run(z0, None, 0, maxiter, False)
+        return result(z, maxiter, float('nan'))
     if n_global is None:          # (the EM driver passes the row count of the whole batch)
         n_glob = torch.tensor([float(n)], dtype=torch.float64, device=X.device)
         _all_reduce(n_glob, group)
         n_global = n_glob.item()
+    # ista.py:64,93 on the rows of ALL ranks: sum_i |z - z_next| <= n_global * k * tol, compared in fp32
     budget = torch.tensor(float(n_global) * k * tol, dtype=torch.float32).item()
     chunk, done = 64, 0
     z, y = z0, None
+    last = float('nan')
     while done < maxiter:
         c = min(chunk, maxiter - done)
-        z2, y2, delta = engine.fista_run(X, W, z, y, alpha, lr, fast, done, c, True)
-        _all_reduce(delta, group)
-        hits = (delta <= budget).nonzero()
-        if hits.numel():
-            i = int(hits[0])
-            if i + 1 < c:
-                z2, _, _ = engine.fista_run(X, W, z, y, alpha, lr, fast, done, i + 1, False)
-            return z2
-        z, y, done = z2, y2, done + c
-    return z
+        z2, y2, delta = run(z, y, done, c, True)
+        _all_reduce(delta, group)           # ONE small all-reduce per chunk of <= 64 iterations, not per iteration
+        hdelta = delta.tolist()             # the chunk's one host read; every rank sees the same summed vector
+        hit = next((i for i, v in enumerate(hdelta) if v <= budget), -1)
+        if hit >= 0:
+            if hit + 1 < c:                 # replay the chunk from its intact input state up to the stopping iteration
+                z2, _, _ = run(z, y, done, hit + 1, False)
+            return result(z2, done + hit + 1, hdelta[hit])
+        z, y, done, last = z2, y2, done + c, hdelta[-1]
+    return result(z, done, last)
+
+
+class _EmptyShardPending:
+    """The asynchronous sharded E-step of a rank that holds NO rows: zero stop-rule sums in the message, and
+    the verdict every rank reads -- 'the rule fired before the last iteration' (chunk_verdict_kernel's third
+    word) -- taken from the summed vector with the same fp32 comparison."""
+
+    def __init__(self, ndelta, k, tol, device):
+        self.deltas = torch.zeros(ndelta, dtype=torch.float32, device=device)
+        self._k, self._tol, self._reduced, self._n_global = k, tol, None, 0
+        self.iterations, self.last_delta = None, None
+
+    def judge(self, reduced, n_global):
+        self._reduced, self._n_global = reduced, n_global
+
+    def __call__(self):
+        budget = torch.tensor(float(self._n_global) * self._k * self._tol, dtype=torch.float32).item()
+        h = self._reduced.tolist()
+        hit = next((i for i, v in enumerate(h) if v <= budget), -1)
+        self.iterations, self.last_delta = (hit + 1 if hit >= 0 else len(h)), h[hit]
+        return not (hit >= 0 and hit + 1 < len(h))
 
 
 def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-2, steps=60,
@@ -182,9 +211,15 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     world, rank = _world(group)
     n_local, d = X.shape
     k = weight.shape[1]
-    n_glob = torch.tensor([float(n_local)], dtype=torch.float64, device=X.device)
+    # Which form the E-step takes must not depend on anything rank-local (a rank on another path would issue
+    # other collectives than its peers: hang or corruption), so "this rank cannot take the asynchronous sharded
+    # form" is summed over the ranks next to the row count, once, before the loop.
+    can_async = (world > 1 and hasattr(engine, 'encode_begin_sharded') and hasattr(engine, 'sweep_begin')
+                 and getattr(engine, 'sharded_async_ok', lambda *a, **kw: True)(X, weight, **solver_kwargs))
+    n_glob = torch.tensor([float(n_local), 0.0 if can_async else 1.0], dtype=torch.float64, device=X.device)
     _all_reduce(n_glob, group)
-    n_total = n_glob.item()
+    n_total = n_glob[0].item()
+    every_rank_async = n_glob[1].item() == 0
     losses = torch.zeros(steps, device=X.device)
     # One GPU: the step is enqueued without waiting on it -- the stop rule's outcome and the
     # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
@@ -195,7 +230,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     # objective, Gram product, ONE all-reduce, the rule judged on the device from the summed vector -- and
     # the one host wait per step behind all of it.  (RCCL reduces on the stream; gloo, used when ranks
     # share a GPU in tests, stages the message through the host -- that copy is then the wait.)
-    shard_async = world > 1 and hasattr(engine, 'encode_begin_sharded') and hasattr(engine, 'sweep_begin')
+    shard_async = world > 1 and every_rank_async
     ndelta = int(solver_kwargs.get('maxiter', 10)) if shard_async else 0
     if not 0 < ndelta <= 64:
         ndelta = 0
@@ -220,29 +255,45 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         if world > 1:
             _broadcast(cand, group)                              # ... and uses rank 0's directions
         engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
-        if Zprev is not None:
+        if Zprev is not None and Zprev.shape[0] > 0:
             engine.zero_columns(Zprev, mask)                                              # :98
 
     def encode_sync():
         return sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
+
+    tol = float(solver_kwargs.get('tol', 1e-5))
+
+    def local_stats(Z, **kw):
+        """(loss, {sum r^2, sum |z|}, A, B) of this rank's rows; a rank without rows contributes zeros"""
+        if n_local == 0 and world > 1:
+            buf[:k * k + k * d].zero_()
+            return (torch.zeros((), device=X.device), torch.zeros(2, dtype=torch.float64, device=X.device),
+                    buf[:k * k].view(k, k), buf[k * k:k * k + k * d].view(k, d))
+        loss_local, sums = engine.objective_sums(X, Z, weight, alpha, **kw)               # :39
+        A, B = engine.gram(Z, X, buf)
+        return loss_local, sums, A, B
 
     i, Zlast = 0, None
     while i < steps:
         pending, sharded = None, False
         if overlap:
             Z, pending = engine.encode_begin(X, weight, alpha, Z0, **solver_kwargs)       # :38
+        elif not ndelta:
+            Z = encode_sync()
         else:
-            began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs) if ndelta else None
-            if began is None:
-                Z = encode_sync()
+            if n_local == 0:
+                Z = Z0 if Z0 is not None else X.new_zeros(0, k)
+                pending = _EmptyShardPending(ndelta, k, tol, X.device) if tol > 0 else None
             else:
+                began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs)
+                if began is None:       # sharded_async_ok() said yes on every rank: this is a bug, not a fallback
+                    raise RuntimeError("encode_begin_sharded refused arguments sharded_async_ok accepted")
                 Z, pending = began
-                sharded = pending is not None
-                if stats is not None:
-                    stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
+            sharded = pending is not None
+            if stats is not None:
+                stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
         direct = world == 1 and getattr(engine, 'objective_loss_out', False)   # losses[i] written in place: no copy launch
-        loss_local, sums = engine.objective_sums(X, Z, weight, alpha, **(dict(loss_out=losses[i]) if direct else {}))  # :39
-        A, B = engine.gram(Z, X, buf)
+        loss_local, sums, A, B = local_stats(Z, **(dict(loss_out=losses[i]) if direct else {}))
         if deferred is not None:
             mask, ndeg = deferred()
             deferred = None
@@ -254,9 +305,8 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         if pending is not None and not sharded and not pending():
             # the in-kernel stop rule gave up (CUs held by other work): same rule, chunked
             Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
-            loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
+            loss_local, sums, A, B = local_stats(Z)
             direct = False
-            A, B = engine.gram(Z, X, buf)
         if world > 1:
             tail.copy_(sums)                 # the two objective sums ride in the Gram message
             if sharded:
@@ -267,8 +317,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                 if not pending():            # the step's host wait; every rank reads the same verdict
                     # the rule fired before the last iteration (rare in an EM loop): exact rule, chunked replay
                     Z = encode_sync()
-                    loss_local, sums = engine.objective_sums(X, Z, weight, alpha)
-                    A, B = engine.gram(Z, X, buf)
+                    loss_local, sums, A, B = local_stats(Z)
                     tail.copy_(sums)
                     _all_reduce(buf, group)
                     if stats is not None:
@@ -284,7 +333,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                 Zlast = Z
             else:
                 mask = constrained_mstep(engine, A, B, weight, group=group)
-                if mask is not None:
+                if mask is not None and Z.shape[0] > 0:
                     engine.zero_columns(Z, mask)                                          # :98
         else:
             weight = engine.ridge(A, B, lambd * n_total, check=True)                      # :46-47

@@ -375,3 +375,39 @@ def test_persistent_bf16_kernel_against_its_arithmetic_model(n, d, k, fast):
     # first iterations, where they are apart, are compared)
     m = min(8, info["iterations"], minfo["iterations"])
     assert info["trials"][:m] == minfo["trials"][:m]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_windows_of_the_enqueued_line_search(dtype):
+    """The line search is enqueued in windows of 16 outer iterations without host waits (csrc/lasso_hip.hip
+    solve_backtracking).  (a) a stop rule that fires inside the third window: the oracle's iteration count and
+    trace, nothing enqueued beyond that window; (b) searches that need MORE trials than a window pre-enqueues (lr0 = 30:
+    ~14 trials each) take one synchronous iteration each and the windows resume -- the oracle's trace again."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    g = torch.Generator().manual_seed(5)
+    W = torch.nn.functional.normalize(torch.randn(48, 160, generator=g), dim=0).to(dtype)
+    X = torch.randn(300, 48, generator=g).to(dtype)
+    z0 = torch.zeros(300, 160, dtype=dtype)
+    Xr, Wr, z0r = X.float(), W.float(), z0.float()          # the oracle in fp32 on the same (bf16-representable) data
+    kw = dict(kernel="tile") if dtype == torch.bfloat16 else {}     # bf16: the multi-launch kernels (this driver)
+    tr = orc.FistaTrace()
+    orc.fista(Xr, z0r, Wr, 0.3, lr=1.0, maxiter=1000, tol=3e-4, backtrack=True, trace=tr)
+    assert 32 < tr.iterations < 200
+    _, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, lr=1.0, maxiter=1000, tol=3e-4, backtrack=True,
+                   return_info=True, **kw)
+    if dtype == torch.float32:
+        assert info["iterations"] == tr.iterations and info["trials"] == list(tr.trials)
+    else:           # bf16 gradients move the late iterations a little: the count may differ by a few
+        assert abs(info["iterations"] - tr.iterations) <= max(3, tr.iterations // 10)
+    tr = orc.FistaTrace()
+    ref = orc.fista(Xr, z0r, Wr, 0.3, lr=30.0, maxiter=20, tol=0.0, backtrack=True, trace=tr)
+    assert min(tr.trials) > 8
+    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, lr=30.0, maxiter=20, tol=0.0, backtrack=True,
+                     return_info=True, **kw)
+    assert info["iterations"] == 20
+    if dtype == torch.float32:
+        assert info["trials"] == list(tr.trials)
+        assert (got.cpu() - ref).abs().max().item() <= 5e-5
+    else:
+        assert sum(abs(a - b) for a, b in zip(info["trials"], tr.trials)) <= 2

@@ -49,3 +49,25 @@ def test_gpus_2_on_a_one_gpu_box_fails_loudly():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "only 1 GPU" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_argument_parsing_of_the_workloads():
+    """every workload / shape / dtype / backend the driver (or a test) may ask for parses; nonsense does not"""
+    sys.path.insert(0, ROOT)
+    import bench
+    ap = bench.parser()
+    a = ap.parse_args([])
+    assert (a.gpus, a.workload, a.shape, a.dtype, a.backend, a.share_gpu, a.rows) == (1, "fista", "c4", "bf16", "nccl", False, None)
+    a = ap.parse_args("--gpus 8 --steps 7 --warmup 2 --workload c3 --dtype f32".split())
+    assert (a.gpus, a.steps, a.warmup, a.workload, a.dtype) == (8, 7, 2, "c3", "f32")
+    a = ap.parse_args("--workload em --shape c5 --rows 8192 --backend gloo --share-gpu".split())
+    assert (a.workload, a.shape, a.rows, a.backend, a.share_gpu) == ("em", "c5", 8192, "gloo", True)
+    for bad in (["--workload", "c9"], ["--shape", "c2"], ["--dtype", "fp8"], ["--backend", "mpi"]):
+        with pytest.raises(SystemExit):
+            ap.parse_args(bad)
+    assert bench.EM_SHAPES["c5"][1:4] == (64, 256, 0.1) and bench.EM_SHAPES["c4"][1:3] == (256, 1024)
+
+
+def test_share_gpu_needs_gloo():
+    r = _run(["--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "--share-gpu needs --backend gloo" in r.stderr

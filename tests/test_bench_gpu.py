@@ -1,0 +1,84 @@
+"""bench.py's MULTI-RANK code paths executed on the one GPU of the test box: two ranks sharing cuda:0, collectives
+over gloo (`--backend gloo --share-gpu`).  RCCL wants one GPU per rank, so the driver's 8-GPU run is the first time
+the nccl backend carries these lines -- everything else of the N > 1 path (sharding, the all-reduced objective, the
+global stop rule of the time-to-tol leg, the one M-step message per EM step, the all-reduced line-search decisions)
+runs here.  Figures of such a run are code-path evidence, never performance."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _bench(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+SHARED = ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1"]
+
+
+def test_two_rank_fista_line_and_global_time_to_tol():
+    out = _bench(SHARED + ["--workload", "fista", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["rows_per_gpu"] == 2048 and out["config"]["rows_total"] == 4096
+    assert out["weak_scaling"]["rows_per_gpu"] == 4096 and out["weak_scaling"]["value"] > 0
+    # the all-reduced objective of the sharded 4096-row batch after 100 iterations
+    assert abs(out["objective_after_100"] - 63.609337) <= 2e-6 * 63.609337
+    # iterations-to-tol under the reference's rule on ALL rows (ista.py:64,93): 263 at any number of ranks
+    t = out["time_to_tol"]
+    assert t["iterations"] == 263 and "global over all ranks" in t["rule"] and t["rows_total"] == 4096
+    assert out["roofline"]["frac"] > 0 and "gloo" in out["backend"]
+
+
+def test_two_rank_em_line_has_one_message_per_step():
+    out = _bench(SHARED + ["--workload", "em"])
+    assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 32768
+    ar = out["all_reduce_ms"]
+    assert ar["bytes"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
+    assert ar["bytes_sent"] == [ar["bytes"]] and ar["per_step"] == 1.0       # ONE collective per EM step, that size
+    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
+    # the first EM steps of config 4 on the whole batch: losses[2] of the reference's run (tests/golden/g4_c4_em.npz)
+    import numpy as np
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "g4_c4_em.npz"))["c_losses_auto"]
+    assert abs(out["objective_last_step"] - float(ref[2])) <= 2e-4
+
+
+def test_two_rank_em_line_at_the_shape_of_config_5():
+    out = _bench(SHARED + ["--workload", "em", "--shape", "c5", "--rows", "16384"])
+    assert out["config"]["rows_per_gpu"] == 8192 and "d=64 k=256" in out["metric"]
+    assert out["all_reduce_ms"]["bytes_sent"] == [4 * (256 * 256 + 256 * 64 + 12)]
+    assert out["em_path"].get("overlapped_steps") == 2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_two_rank_line_search_line(dtype):
+    out = _bench(SHARED + ["--workload", "c3", "--dtype", dtype])
+    assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 8192 and out["dtype"] == dtype
+    assert len(out["trials"]) == 10
+    if dtype == "f32":      # every F <= Q decision on sums over both ranks: the reference's trace on the whole batch
+        assert out["trials"] == [5, 3, 5, 4, 4, 4, 4, 3, 5, 5]
+        assert abs(out["objective"] - 64.142166) <= 1e-5 * 64.142166
+    else:
+        assert abs(out["objective"] - 64.151779) <= 2e-3 * 64.151779
+
+
+def test_one_rank_lines_of_configs_3_and_5():
+    for dtype in ("bf16", "f32"):
+        out = _bench(["--workload", "c3", "--dtype", dtype, "--steps", "3", "--warmup", "1"])
+        assert out["n_gpus"] == 1 and out["roofline"]["peak"] == (2500.0 if dtype == "bf16" else 157.3)
+        assert out["roofline"]["flop_per_launch"] == (4 * 10 + 2 * sum(out["trials"])) * 16384 * 256 * 1024
+        assert 0 < out["roofline"]["frac"] < 1
+    out = _bench(["--workload", "em", "--shape", "c5", "--steps", "5", "--warmup", "2"])
+    assert out["n_gpus"] == 1 and out["all_reduce_ms"]["per_step"] == 0.0

@@ -398,3 +398,23 @@ def test_workspace_cache_is_bounded():
     finally:
         nat._WS_MAX_ENTRIES = old
         nat.release_workspaces()
+
+
+@pytest.mark.parametrize("n,d,k", [(4096, 64, 300), (64, 16, 300), (3000, 32, 350), (6000, 64, 384), (2500, 200, 700),
+                                   (100, 100, 640)])
+@pytest.mark.parametrize("tol", [0.0, 1e-4])
+def test_exactly_sized_workspace_fits_every_geometry(n, d, k, tol):
+    """lasso_fista_workspace_bytes must cover whichever padded dictionary size solve_geometry() picks (384 / 768
+    atoms carve a LARGER split-k exchange region than 512 / 1024): a workspace of exactly that size -- what a fresh
+    process allocates -- is accepted (LASSO_ERR_WORKSPACE at d=64, k=300), and the code is the oracle's."""
+    from lasso_amd import _native as nat
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    g = torch.Generator().manual_seed(n + d + k)
+    W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+    X = torch.randn(n, d, generator=g)
+    nat.release_workspaces()                       # the next solve allocates exactly lasso_fista_workspace_bytes
+    z = ista(X.cuda(), torch.zeros(n, k, device="cuda"), W.cuda(), 0.4, lr=0.2, maxiter=12, tol=tol)
+    nat.release_workspaces()
+    zr = orc.fista(X, torch.zeros(n, k), W, 0.4, lr=0.2, maxiter=12, tol=tol)
+    assert (z.cpu() - zr).abs().max().item() <= 5e-5

@@ -82,6 +82,12 @@ def _worker(rank, world, port, tmp):
         D, losses = dict_learning_sharded(X[lo:hi], 40, alpha=0.3, steps=4, init_weight=D0,
                                           engine=Eng(), constrained=kw["constrained"], **skw)
         out[tag + "_D"], out[tag + "_l"] = D.numpy(), losses.numpy()
+        # the same with ALL rows on rank 0 and none on rank 1: the empty rank issues the same collectives
+        torch.manual_seed(1)
+        elo, ehi = (0, 100) if rank == 0 else (100, 100)
+        D, losses = dict_learning_sharded(X[elo:ehi], 40, alpha=0.3, steps=4, init_weight=D0,
+                                          engine=Eng(), constrained=kw["constrained"], **skw)
+        out["e" + tag + "_D"], out["e" + tag + "_l"] = D.numpy(), losses.numpy()
     np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -103,6 +109,10 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert np.array_equal(r0[tag + "_l"], r1[tag + "_l"])
         assert np.abs(r0[tag + "_l"] - lref.numpy()).max() < 2e-5, tag
         assert np.abs(r0[tag + "_D"] - Dref.numpy()).max() < 2e-4, tag
+        assert np.array_equal(r0["e" + tag + "_D"], r1["e" + tag + "_D"]), tag      # rank 1 held no rows
+        assert np.array_equal(r0["e" + tag + "_l"], r1["e" + tag + "_l"]), tag
+        assert np.abs(r0["e" + tag + "_l"] - lref.numpy()).max() < 2e-5, tag
+        assert np.abs(r0["e" + tag + "_D"] - Dref.numpy()).max() < 2e-4, tag
 
 
 def _bt_worker(rank, world, port, tmp):
@@ -117,7 +127,10 @@ def _bt_worker(rank, world, port, tmp):
     lo, hi = (0, 37) if rank == 0 else (37, 100)
     z, info = sharded_encode(Eng(), X[lo:hi], D0, 0.3, None, lr=1.5, maxiter=12, tol=0.0, backtrack=True,
                              eta_backtrack=1.5, return_info=True)
-    np.savez(os.path.join(tmp, "bt%d.npz" % rank), z=z.numpy(), trials=np.array(info["trials"]))
+    # fixed step, the reference's stop rule on the rows of BOTH ranks (ista.py:64,93): iterations-to-tol
+    zt, it = sharded_encode(Eng(), X[lo:hi], D0, 0.3, None, lr=0.1, maxiter=300, tol=1e-4, return_info=True)
+    np.savez(os.path.join(tmp, "bt%d.npz" % rank), z=z.numpy(), trials=np.array(info["trials"]),
+             zt=zt.numpy(), it=np.array(it["iterations"]), last=np.array(it["last_delta"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,3 +148,8 @@ def test_two_rank_line_search_equals_the_whole_batch(tmp_path):
     assert list(r0["trials"]) == list(r1["trials"]) == list(tr.trials)
     assert max(tr.trials) > 1                                   # the search did backtrack
     assert np.abs(np.concatenate([r0["z"], r1["z"]]) - zo.numpy()).max() <= 1e-5
+    tr = orc.FistaTrace()
+    zt = orc.fista(X, torch.zeros(100, 40), D0, alpha=0.3, lr=0.1, maxiter=300, tol=1e-4, trace=tr)
+    assert int(r0["it"]) == int(r1["it"]) == tr.iterations and 64 < tr.iterations < 300     # several chunks + a replay
+    assert float(r0["last"]) == float(r1["last"]) and float(r0["last"]) <= 100 * 40 * 1e-4
+    assert np.abs(np.concatenate([r0["zt"], r1["zt"]]) - zt.numpy()).max() <= 1e-5

@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from margins import record_margins
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,6 +52,17 @@ def _worker(rank, world, port, tmp):
                                            engine=eng, **kw)
         out[tag + "_D"], out[tag + "_l"] = Dl.cpu().numpy(), losses.cpu().numpy()
         out[tag + "_stats"] = np.array([eng.em_stats.get("overlapped_steps", 0), eng.em_stats.get("replayed_steps", 0)])
+    # a rank WITHOUT rows (rank 1) takes the same path and issues the same collectives as its peer: the asynchronous
+    # form ("auto"), its replay ("tol_short") and the synchronous chunked form ("tol")
+    lo, hi = (0, N) if rank == 0 else (N, N)
+    for tag in ("auto", "tol_short", "tol"):
+        torch.manual_seed(1)
+        eng = HipEngine()
+        eng.em_stats = {}
+        Dl, losses = dict_learning_sharded(X[lo:hi], K, alpha=0.3, steps=3, init_weight=D0, engine=eng, **CASES[tag])
+        out["empty_" + tag + "_D"], out["empty_" + tag + "_l"] = Dl.cpu().numpy(), losses.cpu().numpy()
+        out["empty_" + tag + "_stats"] = np.array([eng.em_stats.get("overlapped_steps", 0),
+                                                   eng.em_stats.get("replayed_steps", 0)])
     np.savez(os.path.join(tmp, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -57,6 +70,8 @@ def _worker(rank, world, port, tmp):
 
 def test_two_ranks_on_the_hip_engine(tmp_path):
     from lasso_amd.linear import dict_learning
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lasso_oracle as orc
     port = 31500 + (os.getpid() % 2000)
     mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
@@ -68,6 +83,7 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
         assert np.array_equal(r0[tag + "_stats"], r1[tag + "_stats"]), tag
         assert (int(r0[tag + "_stats"][0]) >= 4) == (tag != "tol"), (tag, r0[tag + "_stats"])
     assert int(r0["tol_short_stats"][1]) >= 1 and int(r0["auto_stats"][1]) == 0
+    margins = {}
     for tag, kw in CASES.items():
         # both ranks hold the same replicated dictionary and the same global objective, bit for bit
         assert np.array_equal(r0[tag + "_D"], r1[tag + "_D"]), tag
@@ -77,6 +93,18 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
                                    device="cuda", **kw)
         assert np.abs(r0[tag + "_l"] - lref.cpu().numpy()).max() <= 1e-4, tag
         assert np.abs(r0[tag + "_D"] - Dref.cpu().numpy()).max() <= 1e-4, tag
+        # ... and directly against the oracle (the reference's arithmetic on the whole batch, CPU)
+        torch.manual_seed(1)
+        Do, lo_ = orc.dict_learning(X, K, alpha=0.3, steps=4, init_weight=D0, **kw)
+        margins[tag] = (float(np.abs(r0[tag + "_l"] - lo_.numpy()).max()), float(np.abs(r0[tag + "_D"] - Do.numpy()).max()))
+        assert margins[tag][0] <= 1e-4 and margins[tag][1] <= 3e-4, (tag, margins[tag])
+        if "empty_" + tag + "_D" in r0.files:      # rank 1 without rows: the whole batch on rank 0, same collectives
+            assert np.array_equal(r0["empty_" + tag + "_D"], r1["empty_" + tag + "_D"]), tag
+            assert np.array_equal(r0["empty_" + tag + "_l"], r1["empty_" + tag + "_l"]), tag
+            assert np.array_equal(r0["empty_" + tag + "_stats"], r1["empty_" + tag + "_stats"]), tag
+            assert (int(r0["empty_" + tag + "_stats"][0]) >= 3) == (tag != "tol"), tag
+            assert np.abs(r0["empty_" + tag + "_l"] - lo_.numpy()[:3]).max() <= 1e-4, tag
+    record_margins("two_ranks_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
 
 
 # ---- row-sharded line search (ista.py:23-52 on two ranks) -------------------------------------
