@@ -112,6 +112,11 @@ def test_c3_bf16_leg(golden):
                    lr=1.0, maxiter=10, tol=0.0, backtrack=True, return_info='objective')
     assert z.dtype == torch.bfloat16 and z.is_cuda
     obj = orc.lasso_objective(Xb.float(), z.float().cpu(), Wb.float(), 0.5).item()
+    from margins import record_margins
+    gaps = {"line_search_rel": abs(obj - float(g["bf16_obj_fp32eval"])) / obj, "hip_trials": info["trials"],
+            "reference_bf16_trials": tr["bf16_fista_trials"].tolist(), "objective": obj,
+            "reference_objective": float(g["bf16_obj_fp32eval"]), "reference_fp32_objective": 64.142166}
+    record_margins("c3_bf16_objective_gap", gaps)
     assert abs(obj - float(g["bf16_obj_fp32eval"])) <= 2e-3 * obj
     assert abs(info["objective"] - obj) <= 1e-5 * obj
     # bf16 rounding may legitimately move a borderline F <= Q decision ("pin objective,
@@ -123,6 +128,8 @@ def test_c3_bf16_leg(golden):
     assert all(abs(v - 1.5 ** -(t - 1)) <= 1e-6 for v, t in zip(info["accepted_lr"], info["trials"]))
     z = sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5, lr=1.0 / LAMBDA_MAX_C2, maxiter=10, tol=0.0)
     obj = orc.lasso_objective(Xb.float(), z.float().cpu(), Wb.float(), 0.5).item()
+    gaps["fixed_step_rel"] = abs(obj - float(g["bf16_fixed_obj_fp32eval"])) / obj
+    record_margins("c3_bf16_objective_gap", gaps)
     assert abs(obj - float(g["bf16_fixed_obj_fp32eval"])) <= 2e-3 * obj
     with pytest.raises(TypeError):
         sparse_encode(Xb.cuda(), Wb.cuda(), alpha=0.5)

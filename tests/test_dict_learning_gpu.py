@@ -7,7 +7,15 @@ import torch
 
 from recipes import recipe_xw, recipe_c4_init, recipe_c5, LAMBDA_MAX_C2, LAMBDA_MAX_C4
 
+from margins import record_margins
+
 pytestmark = pytest.mark.gpu
+
+# Elementwise bars of the free-running EM fixtures, each <= 3x the deviation MEASURED on MI355X (round 4:
+# profiles/r04/parity_margins.json); the first values are round 3's, kept until the measurement is in
+G1_D_ATOL, G1_Z_ATOL = 1e-3, 2e-3
+G5_LOSS_ATOL, G5_D_ATOL = 1e-4, 5e-3
+G4_LOSS_ATOL, G4_D_ATOL, G4_RIDGE_LOSS_ATOL = 2e-4, 2e-3, 5e-4
 
 
 def T(a):
@@ -175,11 +183,16 @@ def test_g1_readme_dict_learning(golden):
     _ = torch.randn(100, 10)
     D, losses = dict_learning(data, 50, alpha=0.5, algorithm='ista', lr=0.05, progbar=False)
     assert D.device.type == "cpu" and losses.shape == (60,)
-    assert (losses - T(g["losses_fix"])).abs().max().item() <= 1e-5
-    assert (D - T(g["D_fix"])).abs().max().item() <= 1e-3
+    m = {"losses_fix": (losses - T(g["losses_fix"])).abs().max().item(), "D_fix": (D - T(g["D_fix"])).abs().max().item()}
     z = sparse_encode(data, D, alpha=0.2, algorithm='ista', lr=0.05)
+    m["z_fix"] = (z - T(g["z_fix"])).abs().max().item()
+    record_margins("g1_readme_vs_reference", m)
+    # bars = <= 3x what profiles/r04/parity_margins.json records (60 EM steps amplify last-ulp differences: the
+    # per-step test below pins every single step to 2e-5)
+    assert m["losses_fix"] <= 1e-5
+    assert m["D_fix"] <= G1_D_ATOL
     assert z.device.type == "cpu"
-    assert (z - T(g["z_fix"])).abs().max().item() <= 2e-3
+    assert m["z_fix"] <= G1_Z_ATOL
     # lr='auto' path (native Lipschitz) against the reference's lr='auto' run
     torch.manual_seed(0)
     _ = torch.randn(100, 10)
@@ -207,8 +220,10 @@ def test_g5_patches(golden):
     X = recipe_c5(8192, reseed=False)
     D, losses = dict_learning(X.cuda(), 256, alpha=0.1, steps=10, algorithm='ista', progbar=False,
                               device='cuda', init_weight=T(g["D0"]))
-    assert (losses.cpu() - T(g["losses"])).abs().max().item() <= 1e-4     # SURVEY 8d G5 tolerance
-    assert (D.cpu() - T(g["D"])).abs().max().item() <= 5e-3
+    m = {"losses": (losses.cpu() - T(g["losses"])).abs().max().item(), "D": (D.cpu() - T(g["D"])).abs().max().item()}
+    record_margins("g5_patches_vs_reference", m)
+    assert m["losses"] <= G5_LOSS_ATOL     # (SURVEY 8d G5 tolerance: 1e-4)
+    assert m["D"] <= G5_D_ATOL
 
 
 def test_g4_c4_em_steps(golden):
@@ -223,12 +238,16 @@ def test_g4_c4_em_steps(golden):
     D, losses = dict_learning(Xg, 1024, alpha=0.5, steps=3, algorithm='ista', progbar=False,
                               device='cuda', init_weight=D0)
     ref = T(g["c_losses_auto"])
+    m = {"losses": (losses.cpu() - ref).abs().max().item(),
+         "D_cols": (D[:, :32].cpu() - T(g["c_D_cols_auto"])).abs().max().item()}
     assert abs(losses[0].item() - 59.917267) <= 1e-4
-    assert (losses.cpu() - ref).abs().max().item() <= 2e-4
-    assert (D[:, :32].cpu() - T(g["c_D_cols_auto"])).abs().max().item() <= 2e-3
+    assert m["losses"] <= G4_LOSS_ATOL
+    assert m["D_cols"] <= G4_D_ATOL
     Dr, lr_ = dict_learning(Xg, 1024, alpha=0.5, constrained=False, steps=3, algorithm='ista',
                             progbar=False, device='cuda', init_weight=D0)
-    assert (lr_.cpu() - T(g["r_losses_auto"])).abs().max().item() <= 5e-4
+    m["ridge_losses"] = (lr_.cpu() - T(g["r_losses_auto"])).abs().max().item()
+    record_margins("g4_c4_vs_reference", m)
+    assert m["ridge_losses"] <= G4_RIDGE_LOSS_ATOL
 
 
 def test_sharded_driver_world1_equals_single_gpu(golden):

@@ -11,6 +11,7 @@ from recipes import recipe_xw, LAMBDA_MAX_C2
 pytestmark = pytest.mark.gpu
 
 Z_ATOL = 5e-5
+Z_ATOL_263 = 2e-4        # set from the measured margin below (profiles/r04/parity_margins.json)
 OBJ_RTOL = 1e-6
 
 
@@ -115,17 +116,26 @@ def test_c2_trajectory_against_golden(golden):
     X, W = recipe_xw(4096)
     Xg, Wg = X.cuda(), W.cuda()
     lr = 1.0 / LAMBDA_MAX_C2
+    from margins import record_margins
+    achieved = {}
     for M, obj_ref, st in zip(g["Ms"], g["objective"], g["stats"]):
         M = int(M)
         if M > 263:
             continue
         z = sparse_encode(Xg, Wg, alpha=0.5, lr=lr, maxiter=M, tol=0.0).cpu()
         obj = orc.lasso_objective(X, z, W, 0.5).item()
-        assert abs(obj - obj_ref) <= OBJ_RTOL * obj_ref, (M, obj, obj_ref)
         blk = torch.from_numpy(g["z_block_M%d" % M])
-        tol_z = Z_ATOL if M <= 100 else 2e-4
-        assert (z[:64, :64] - blk).abs().max().item() <= tol_z, M
-        assert (z[::64, ::16] - torch.from_numpy(g["z_strided_M%d" % M])).abs().max().item() <= tol_z
+        dz_blk = (z[:64, :64] - blk).abs().max().item()
+        dz_str = (z[::64, ::16] - torch.from_numpy(g["z_strided_M%d" % M])).abs().max().item()
+        achieved["M%d" % M] = {"max_dz": max(dz_blk, dz_str), "rel_dobjective": abs(obj - obj_ref) / obj_ref,
+                               "max_abs_z": float(blk.abs().max())}
+        record_margins("c2_fista_vs_reference", achieved)
+        assert abs(obj - obj_ref) <= OBJ_RTOL * obj_ref, (M, obj, obj_ref)
+        # north_star's fp32 bar is 5e-5 (Z_ATOL) -- held through M = 100; at M = 263 (the reference's stopping
+        # iteration) 263 momentum steps have amplified the last-ulp differences between MKL's and the MFMA's
+        # summation orders: the bar there is 3x what profiles/r04/parity_margins.json records
+        tol_z = Z_ATOL if M <= 100 else Z_ATOL_263
+        assert dz_blk <= tol_z and dz_str <= tol_z, (M, dz_blk, dz_str)
         assert abs(z.double().abs().sum().item() - st[1]) <= 1e-5 * st[1]
     z = sparse_encode(Xg, Wg, alpha=0.5, fast=False, lr=lr, maxiter=100, tol=0.0).cpu()
     assert (z[:64, :64] - torch.from_numpy(g["ista_z_block_M100"])).abs().max().item() <= Z_ATOL
@@ -140,7 +150,7 @@ def test_c2_iterations_to_tol(golden):
     assert info["iterations"] == 263, info                            # FISTA 263
     obj = orc.lasso_objective(X, z.cpu(), W, 0.5).item()
     assert abs(obj - float(g["tol_fista_obj"])) <= OBJ_RTOL * obj
-    assert (z.cpu()[:64, :64] - torch.from_numpy(g["z_block_M263"])).abs().max().item() <= 2e-4
+    assert (z.cpu()[:64, :64] - torch.from_numpy(g["z_block_M263"])).abs().max().item() <= Z_ATOL_263
     # the objective_out of the C ABI (HIP lasso_loss of the returned code) says the same
     _, info_o = ista(X.cuda(), torch.zeros(4096, 1024, device="cuda"), W.cuda(), 0.5,
                      lr=1.0 / LAMBDA_MAX_C2, maxiter=2000, tol=1e-5, return_info='objective')
@@ -413,8 +423,9 @@ def test_exactly_sized_workspace_fits_every_geometry(n, d, k, tol):
     g = torch.Generator().manual_seed(n + d + k)
     W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
     X = torch.randn(n, d, generator=g)
+    lr = 0.9 / ((k / d) * (1.0 + (d / k) ** 0.5) ** 2)      # below 1 / lambda_max of a random normalised dictionary
     nat.release_workspaces()                       # the next solve allocates exactly lasso_fista_workspace_bytes
-    z = ista(X.cuda(), torch.zeros(n, k, device="cuda"), W.cuda(), 0.4, lr=0.2, maxiter=12, tol=tol)
+    z = ista(X.cuda(), torch.zeros(n, k, device="cuda"), W.cuda(), 0.4, lr=lr, maxiter=12, tol=tol)
     nat.release_workspaces()
-    zr = orc.fista(X, torch.zeros(n, k), W, 0.4, lr=0.2, maxiter=12, tol=tol)
+    zr = orc.fista(X, torch.zeros(n, k), W, 0.4, lr=lr, maxiter=12, tol=tol)
     assert (z.cpu() - zr).abs().max().item() <= 5e-5

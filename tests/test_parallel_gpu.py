@@ -97,7 +97,7 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
         torch.manual_seed(1)
         Do, lo_ = orc.dict_learning(X, K, alpha=0.3, steps=4, init_weight=D0, **kw)
         margins[tag] = (float(np.abs(r0[tag + "_l"] - lo_.numpy()).max()), float(np.abs(r0[tag + "_D"] - Do.numpy()).max()))
-        assert margins[tag][0] <= 1e-4 and margins[tag][1] <= 3e-4, (tag, margins[tag])
+        assert margins[tag][0] <= 1e-5 and margins[tag][1] <= 2e-5, (tag, margins[tag])   # measured: <= 3e-6 / 4e-6 (profiles/r04)
         if "empty_" + tag + "_D" in r0.files:      # rank 1 without rows: the whole batch on rank 0, same collectives
             assert np.array_equal(r0["empty_" + tag + "_D"], r1["empty_" + tag + "_D"]), tag
             assert np.array_equal(r0["empty_" + tag + "_l"], r1["empty_" + tag + "_l"]), tag
