@@ -655,7 +655,7 @@ int solve_bf16_persistent(const void* x_dev, int64_t ldx, const void* w_dev, int
   p.budget = tol > 0.0 ? (float)((double)n * (double)k * tol) : -1.0f;
   p.coef = ws.pcoef;
   p.gran = ws.pgran;
-  p.dgran = reinterpret_cast<unsigned long long*>((char*)ws.pgran + (size_t)8 * ntiles * 32);
+  p.dgran = reinterpret_cast<unsigned long long*>((char*)ws.pgran + bt16_persist_trial_granule_bytes(ntiles));
   p.out = ws.pout;
   p.trials = ws.ptrials; p.lrs = ws.plrs; p.fvals = ws.pfvals;
   LASSO_HIP_TRY(launch_bt16_persist(p, kp, st));

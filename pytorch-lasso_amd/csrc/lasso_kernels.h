@@ -117,6 +117,7 @@ struct Bt16PersistParams {
   int* trials; float* lrs; float* fvals; // [maxiter] device trace of the line search (nullable)
 };
 size_t bt16_persist_granule_bytes(int ntiles);
+size_t bt16_persist_trial_granule_bytes(int ntiles);   // the |dz| granules of the stop rule follow the trial granules
 hipError_t bt16_persist_occupancy(int kpad, int* per_cu);
 hipError_t launch_bt16_persist(const Bt16PersistParams& p, int kpad, hipStream_t stream);
 
