@@ -44,7 +44,7 @@
 #define LASSO_BT16_G2RING 4   // GEMM-2 of the gradient: W fragment ring depth in steps
 #endif
 #ifndef LASSO_BT16_ACCEPT_BATCH
-#define LASSO_BT16_ACCEPT_BATCH 8   // passes of the accept step whose loads are in flight together
+#define LASSO_BT16_ACCEPT_BATCH 4   // passes of the accept step per register set (two sets: 2 x this many passes in flight)
 #endif
 // timing-only ablations of the trial batch (results invalid): -DLASSO_BT16_ABL_NOMFMA / _NOCAND / _NOBAR
 #ifdef LASSO_BT16_ABL_NOMFMA
@@ -59,9 +59,6 @@
 #endif
 #ifndef LASSO_BT16_LEAD
 #define LASSO_BT16_LEAD 8      // candidate operations in front of the first MFMA of the step behind a pass barrier
-#endif
-#ifndef LASSO_BT16_SCALAR
-#define LASSO_BT16_SCALAR 0    // candidate arithmetic of the trial batch: 1 = plain fp32 VALU operations, 0 = packed (v_pk_*_f32)
 #endif
 #ifndef LASSO_BT16_SCHED
 #define LASSO_BT16_SCHED 0     // how a trial step's MFMAs and candidate arithmetic are scheduled (see `step`)
@@ -101,6 +98,7 @@ constexpr int kMaxTrials = 1000;     // ista.py:17 (maxiter=1000)
 constexpr int kPass = 64;            // atoms per trial pass
 constexpr int kStageBytes = kRows * kPass * 2;       // 8 KiB
 constexpr int TB = 5;                // trials of the line search computed per batch (one cross-workgroup decision each)
+constexpr int kCandOps = 28;         // plain VALU operations of one thread's candidate (4 elements x 7 stages)
 constexpr int kSlotBytes = 32 * kPass * 2;           // a staging tile of the line search: [32 rows][64 atoms] bf16
 // staging tile of (trial t, pass parity): trials 0-2 double-buffered, 3-4 single (8 tiles = the 32 KiB scratch)
 __host__ __device__ constexpr int slot_of(int t, int par) { return t < 3 ? 2 * t + par : 3 + t; }
@@ -143,6 +141,31 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
   return x;
+}
+
+// the same on the ALU path (DPP row shifts + four readlanes, like wave_sum): a fixed order, no LDS round trips --
+// the line search's decision sums 4 TB + 1 values per wave this way
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr_f64(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double x) {
+  x += dpp_row_shr_f64<0x111>(x);
+  x += dpp_row_shr_f64<0x112>(x);
+  x += dpp_row_shr_f64<0x114>(x);
+  x += dpp_row_shr_f64<0x118>(x);        // lane 15 of every 16-lane row holds the row's total
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  double r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * i + 15);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * i + 15);
+    r[i] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // byte offset of 16-byte chunk c8 (0..7) of row `row` in a staging tile (128 B per row)
@@ -209,6 +232,8 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
   __bf16* const Zg = (__bf16*)p.Z;
   __bf16* const Gg = (__bf16*)p.G;             // [ntiles * 64][K] bf16, row stride K
   const __bf16* const Z0g = (const __bf16*)p.Z0;
+  // r0 of this wave's 64 x 32 block in GEMM-1's accumulator layout: [tile][wave][rb][cb][lane] f32x4 (16-byte, coalesced)
+  f32x4* const R0g = (f32x4*)p.R0 + ((int64_t)blockIdx.x * kWaves + wid) * 8 * 64 + lane;
   const bool zvec = (p.ldz & 7) == 0 && (((uintptr_t)p.Z) & 15) == 0 && (p.k & 7) == 0;
   const bool z0vec = Z0g && (p.ldz0 & 7) == 0 && (((uintptr_t)p.Z0) & 15) == 0 && (p.k & 7) == 0;
   const bool erow_ok = (row0 + erow) < p.n;
@@ -275,10 +300,14 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
   const __bf16* const grow = Gg + (int64_t)(row0 + erow) * K + 8 * ec8;   // + kPass * j
   auto load_g8 = [&](int j) { return *reinterpret_cast<const u32x4*>(grow + kPass * j); };
 
-  // ---- x in GEMM-1's accumulator layout (4 rows per packed entry), resident ------------------
-  u32x2 Xr[4][2];
+  // ---- x in GEMM-1's accumulator layout (4 rows per packed entry) -> workspace -------------------
+  // (16 registers for the whole solve were what the compiler spilled first once the line search held five
+  // accumulator sets: 21 scratch loads in front of every residual.  Now it is fetched where it is used, 4 x 16
+  // bytes per lane, issued ahead of the GEMM whose residual needs it.)
+  u32x4* const XrG = (u32x4*)p.XR + ((int64_t)blockIdx.x * kWaves + wid) * 4 * 64 + lane;     // [rb] stride 64
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
+  for (int rb = 0; rb < 4; ++rb) {
+    u32x2 xr2[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       float v[4];
@@ -287,8 +316,10 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         const int r = row0 + 16 * rb + 4 * q + rg, cc = 32 * wid + 16 * cb + cl;
         v[rg] = (r < p.n && cc < p.d) ? (float)Xg[(int64_t)r * p.ldx + cc] : 0.0f;
       }
-      Xr[rb][cb] = pack4(v);
+      xr2[cb] = pack4(v);
     }
+    XrG[rb * 64] = (u32x4){xr2[0][0], xr2[0][1], xr2[1][0], xr2[1][1]};
+  }
   // ---- y_0 = z_0 (ista.py:76-78) -> the p tile -------------------------------------------------
 #pragma unroll 1
   for (int j = 0; j < NP; ++j) {
@@ -298,17 +329,15 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
   }
   __syncthreads();
 
-  // residual of an accumulator set: acc <- acc - x, returns this lane's sum r^2
-  auto residual = [&](f32x4 (&acc)[4][2]) {
+  // residual of an accumulator set: acc <- acc - x (xq: this lane's x of the four row blocks), returns its sum r^2
+  auto residual = [&](f32x4 (&acc)[4][2], const u32x4 (&xq)[4]) {
     float rss = 0.0f;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         float xv[4];
-        u32x2 xr = Xr[rb][cb];
-        asm volatile("" : "+v"(xr));             // unpack here, not hoisted out of the solve (see unpack8_here)
-        unpack4(xr, xv);
+        unpack4((u32x2){xq[rb][2 * cb], xq[rb][2 * cb + 1]}, xv);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const float res = acc[rb][cb][rg] - xv[rg];
@@ -336,9 +365,18 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 xq[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) xq[rb] = XrG[rb * 64];
       gemm1_bf16_deep<K>(pt, w1rsrc, lane16, lane, acc);
       BT16_STAMP(11);
-      rss0 = residual(acc);
+      rss0 = residual(acc, xq);
+      if (p.backtrack) {                           // r0 in the accumulator layout, for the line search's sum dz g
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) R0g[(rb * 2 + cb) * 64] = acc[rb][cb];
+      }
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -484,22 +522,33 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         u32x4 ga[TB], gb[TB];
         bool ok = true;
         int spins = 0;
+        // poll ONE granule per workgroup (the last trial's second one: 16 bytes) until it carries this epoch, then
+        // fetch all 2 TB and check every tag -- the granules of a batch leave together, a straggler among them
+        // (a store overtaken by a later one) only repeats the fetch.  Polling all of them moved 40 KiB per workgroup
+        // and round through the fabric while the late workgroups were still computing.
         for (;;) {
-          bool all = true;
+          const u32x4 last = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 32 * (TB - 1) + 16, 0, 16);
+          bool all = last[0] == e;
+          if (__all(all)) {
 #pragma unroll
-          for (int t = 0; t < TB; ++t) {
-            ga[t] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 32 * t, 0, 16);
-            gb[t] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 32 * t + 16, 0, 16);
+            for (int t = 0; t < TB; ++t) {
+              ga[t] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 32 * t, 0, 16);
+              gb[t] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off + 32 * t + 16, 0, 16);
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) all = all && ga[t][0] == e && gb[t][0] == e;
+            if (__all(all)) break;
           }
-#pragma unroll
-          for (int t = 0; t < TB; ++t) all = all && ga[t][0] == e && gb[t][0] == e;
-          if (all) break;
           if (++spins >= kStopSpinLimit ||
               ((spins & 63) == 63 && __hip_atomic_load(p.out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             ok = false;
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) {
+#pragma unroll
+          for (int t = 0; t < TB; ++t) { ga[t] = (u32x4){0u, 0u, 0u, 0u}; gb[t] = (u32x4){0u, 0u, 0u, 0u}; }
         }
         const bool mine = tid < p.ntiles;
         ok = __all(ok);
@@ -513,7 +562,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         }
         sv[4 * TB] = (double)__uint_as_float(gb[0][2]);       // sum r0^2
 #pragma unroll
-        for (int jj = 0; jj < NV; ++jj) sv[jj] = wave_sum_f64(mine ? sv[jj] : 0.0);
+        for (int jj = 0; jj < NV; ++jj) sv[jj] = wave_sum_f64_dpp(mine ? sv[jj] : 0.0);
         if (lane == 0) {
 #pragma unroll
           for (int jj = 0; jj < NV; ++jj) dpart[NV * wid + jj] = sv[jj];
@@ -559,10 +608,10 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 
     // the TB trials with steps (lrs[t], lams[t]) on this tile, sums published as epoch e
     auto run_batch = [&](const float (&lrs)[TB], const float (&lams)[TB], unsigned e) {
-      float l1[TB], rss1[TB];
-      f32x2 dzg2[TB], dz22[TB];
+      float l1[TB], rss1[TB], dzg[TB];
+      f32x2 dz22[TB];
 #pragma unroll
-      for (int t = 0; t < TB; ++t) { l1[t] = 0.f; rss1[t] = 0.f; dzg2[t] = (f32x2){0.f, 0.f}; dz22[t] = (f32x2){0.f, 0.f}; }
+      for (int t = 0; t < TB; ++t) { l1[t] = 0.f; rss1[t] = 0.f; dzg[t] = 0.f; dz22[t] = (f32x2){0.f, 0.f}; }
       BT16_STAMP(2);
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
@@ -592,39 +641,21 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         // one packed pair (elements 2 e2, 2 e2 + 1) of trial TG's candidate for the pass whose p, g are in pv, gv
         auto cand_pair = [&](auto tg_c, int e2, float (&zn)[4]) __attribute__((always_inline)) {
           constexpr int TG = decltype(tg_c)::value;
-#if LASSO_BT16_SCALAR
-          // plain (single-lane-pair) fp32 VALU operations: on gfx950 a packed v_pk_add/mul/fma_f32 beside MFMAs costs
-          // several times two plain operations (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); this
-          // translation unit is built with -fno-slp-vectorize so that the compiler does not re-pack them
+          // plain fp32 VALU operations (this translation unit is built with -fno-slp-vectorize: a packed
+          // v_pk_*_f32 re-formed by the SLP vectoriser costs 2.6 plain operations on gfx950)
 #pragma unroll
           for (int e = 2 * e2; e < 2 * e2 + 2; ++e) {
             const float pe = pv[e], ge = gv[e];
 #ifdef LASSO_BT16_ABL_NOCAND
-            const float ze = pe;
+            const float ze = pe; (void)ge;
 #else
-            const float ze = bf16_round(soft_threshold(__fsub_rn(pe, __fmul_rn(lrs[TG], ge)), lams[TG]));   // ista.py:40
+            const float ze = soft_threshold(fmaf(-lrs[TG], ge, pe), lams[TG]);    // ista.py:40 (rounded to bf16 by pack4)
 #endif
             const float de = __fsub_rn(ze, pe);                                                            // :31
             l1[TG] += __builtin_fabsf(ze);
-            dzg2[TG][e & 1] = fmaf(de, ge, dzg2[TG][e & 1]);         // (sums: one rounding per term instead of two)
             dz22[TG][e & 1] = fmaf(de, de, dz22[TG][e & 1]);
             zn[e] = ze;
           }
-#else
-          const f32x2 lr2 = {lrs[TG], lrs[TG]};
-          const f32x2 p2 = {pv[2 * e2], pv[2 * e2 + 1]}, g2v = {gv[2 * e2], gv[2 * e2 + 1]};
-#ifdef LASSO_BT16_ABL_NOCAND
-          const f32x2 z2 = p2; (void)lr2;
-#else
-          const f32x2 v2 = p2 - lr2 * g2v;                                                          // ista.py:40
-          const f32x2 z2 = {bf16_round(soft_threshold(v2[0], lams[TG])), bf16_round(soft_threshold(v2[1], lams[TG]))};
-#endif
-          const f32x2 d2 = z2 - p2;                                                                 // :31
-          l1[TG] += __builtin_fabsf(z2[0]) + __builtin_fabsf(z2[1]);
-          dzg2[TG] = dzg2[TG] + d2 * g2v;
-          dz22[TG] = dz22[TG] + d2 * d2;
-          zn[2 * e2] = z2[0]; zn[2 * e2 + 1] = z2[1];
-#endif
         };
         auto load_a = [&](int slot, bf16x8 (&a)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -648,41 +679,47 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
                         __attribute__((always_inline)) {
           constexpr int TM = decltype(tm_c)::value, PAR = decltype(par_c)::value, TG = decltype(tg_c)::value,
                         NXT = decltype(nxt_c)::value, LEAD = decltype(lead_c)::value;
-          float cm[4], cv[4], cz[4], cd[4];
+          float cm[4], cv[4];
           u32x2 packed = {0u, 0u};
-          // operation `op` (0..39) of the candidate: stage op / 4 on element op % 4
+          // operation `op` (0 .. kCandOps - 1) of the candidate: stage op / 4 on element op % 4.  Per element 6.5 plain
+          // fp32 VALU operations (round 4 started at 11: p - lr g is ONE fma -- the candidate is rounded to bf16
+          // right after, the reference's own bf16 run rounds each of its three ATen results --, and sum dz g is not
+          // formed here at all: with g = r0 W it equals sum r0 (r1 - r0), which the MFMA role evaluates on the two
+          // residuals it holds anyway -- see the residuals below).  VALU and bf16 MFMAs share a SIMD almost
+          // exclusively on gfx950 (tools/ubench/mix.hip: {1 MFMA + 5 v_fma} x 2 waves = 28.3 ns against 16.9 + 17.8
+          // apart; a v_pk_fma_f32 costs 2.6 plain ones), so every operation saved here is time saved.
           auto cand_op = [&](auto op_c) __attribute__((always_inline)) {
             constexpr int op = decltype(op_c)::value, stg = op >> 2, e = op & 3;
 #ifndef LASSO_BT16_ABL_NOCAND
-            if constexpr (TG >= 0 && op < 40) {
+            if constexpr (TG >= 0 && op < kCandOps) {
               constexpr int T_ = TG >= 0 ? TG : 0;
-              if constexpr (stg == 0) cm[e] = __fmul_rn(lrs[T_], gv[e]);
-              else if constexpr (stg == 1) cv[e] = __fsub_rn(pv[e], cm[e]);                       // ista.py:40
-              else if constexpr (stg == 2) cm[e] = __builtin_amdgcn_fmed3f(cv[e], -lams[T_], lams[T_]);
-              else if constexpr (stg == 3) cv[e] = __fsub_rn(cv[e], cm[e]);                       // soft threshold
-              else if constexpr (stg == 4) {                                                      // bf16 rounding: pairs
+              if constexpr (stg == 0) cv[e] = fmaf(-lrs[T_], gv[e], pv[e]);                       // ista.py:40
+              else if constexpr (stg == 1) cm[e] = __builtin_amdgcn_fmed3f(cv[e], -lams[T_], lams[T_]);
+              else if constexpr (stg == 2) cv[e] = __fsub_rn(cv[e], cm[e]);                       // soft threshold
+              else if constexpr (stg == 3) {                                                      // -> bf16 (MFMA operand): pairs
                 if constexpr ((e & 1) == 0) {
                   const float vv[4] = {cv[e], cv[e + 1], 0.f, 0.f};
                   const u32x2 pk = pack4(vv);
                   packed[e >> 1] = pk[0];
                 }
               }
-              else if constexpr (stg == 5) cz[e] = __uint_as_float((e & 1) ? (packed[e >> 1] & 0xffff0000u) : (packed[e >> 1] << 16));
-              else if constexpr (stg == 6) cd[e] = __fsub_rn(cz[e], pv[e]);                       // :31
-              else if constexpr (stg == 7) l1[T_] += __builtin_fabsf(cz[e]);
-              else if constexpr (stg == 8) dzg2[T_][e & 1] = fmaf(cd[e], gv[e], dzg2[T_][e & 1]);
-              else dz22[T_][e & 1] = fmaf(cd[e], cd[e], dz22[T_][e & 1]);
+              // the element sums of ista.py:30-35 take the candidate BEFORE its bf16 rounding (no unpack: one
+              // operation per element less); the rounding errors are unbiased and <= 2^-9 |z| each -- ~1e-6 of a
+              // sum over a batch, below the fp32 accumulation error of the sums themselves
+              else if constexpr (stg == 4) cm[e] = __fsub_rn(cv[e], pv[e]);                       // dz, :31
+              else if constexpr (stg == 5) l1[T_] += __builtin_fabsf(cv[e]);
+              else dz22[T_][e & 1] = fmaf(cm[e], cm[e], dz22[T_][e & 1]);
             }
 #endif
           };
           if constexpr (NXT >= 0) load_a(NXT, an);
           __builtin_amdgcn_sched_barrier(0);
-          constexpr int PER = (40 - LEAD + 7) / 8;       // operations per group behind the lead
+          constexpr int PER = (kCandOps - LEAD + 7) / 8;  // operations per group behind the lead
           static_for<LEAD>([&](auto o_c) { cand_op(o_c); });
           static_for<8>([&](auto g_c) {
             constexpr int g = decltype(g_c)::value;
             static_for<PER>([&](auto o_c) { cand_op(integral_constant<int, LEAD + PER * g + decltype(o_c)::value>{}); });
-            if constexpr (TG >= 0 && g == 5)             // the candidate is complete from stage 5 on (op 24)
+            if constexpr (TG >= 0 && g == 4)             // the candidate is complete once stage 3 is through (op 15)
               *(lds_u32x2*)(st + slot_of(TG >= 0 ? TG : 0, PAR ^ 1) * kSlotBytes + stW4) = packed;
             {
               constexpr int u = g >> 2, rb = (g >> 1) & 1, cb = g & 1;
@@ -716,7 +753,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           load_a(6, aA);                           // (j; trial 3)
           unpack4(*(const lds_u32x2*)(ph + ((PAR ^ 1) ? ptO4 : ptE4) + 256 * ((j + 1) >> 1)), pv);
           unpack4(gq[PAR ^ 1], gv);
-          gq[PAR ^ 1] = load_g4(min(j + 3, NP - 1));
+          if (j + 3 < NP) gq[PAR ^ 1] = load_g4(j + 3);      // (no load that nobody waits for: a barrier's vmcnt(0) would)
           step(integral_constant<int, 3>{}, par_c, integral_constant<int, 0>{}, integral_constant<int, 7>{}, integral_constant<int, LASSO_BT16_LEAD>{}, aA, aB);
           step(integral_constant<int, 4>{}, par_c, integral_constant<int, 1>{}, integral_constant<int, slot_of(0, PAR)>{}, Z0c, aB, aA);
           BT16_PASS_BARRIER();                     // the single-buffered tiles (trials 3, 4) are consumed
@@ -730,6 +767,14 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           pass(2 * j2 + 1, integral_constant<int, 1>{});
         }
         pass(NP - 2, integral_constant<int, 0>{});
+        f32x4 r0frag[2][2];                        // r0 of this half's rows (the gradient phase wrote it), for the residuals
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) r0frag[rb][cb] = R0g[((2 * h + rb) * 2 + cb) * 64];
+        u32x4 xqh[2];                              // ... and x of these rows
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) xqh[rb] = XrG[(2 * h + rb) * 64];
         __syncthreads();
         {                                          // last pass (parity 1): MFMAs only
           constexpr integral_constant<int, 1> P1{};
@@ -742,21 +787,23 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           step(integral_constant<int, 1>{}, P1, NONE, integral_constant<int, slot_of(2, 1)>{}, Z0c, aB, aA);
           step(integral_constant<int, 2>{}, P1, NONE, NONE, Z0c, aA, aB);
         }
-        // residuals of the half: r1 = acc - x, this lane's sum r1^2 per trial
+        // residuals of the half: r1 = acc - x, this lane's sum r1^2 per trial -- and sum dz g, evaluated as
+        // sum r0 (r1 - r0): g = r0 W, so <g, dz> = <r0, dz W^T> = <r0, r1 - r0> (the gradient phase left r0 in the
+        // workspace in this very layout; fp32)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb) {
-            u32x2 xr = h ? Xr[2 + rb][cb] : Xr[rb][cb];
-            asm volatile("" : "+v"(xr));           // unpack here, not hoisted out of the solve (see unpack8_here)
             float xv[4];
-            unpack4(xr, xv);
+            unpack4((u32x2){xqh[rb][2 * cb], xqh[rb][2 * cb + 1]}, xv);
+            const f32x4 r0v = r0frag[rb][cb];
 #pragma unroll
             for (int t = 0; t < TB; ++t)
 #pragma unroll
               for (int rg = 0; rg < 4; ++rg) {
                 const float res = acc[t][rb][cb][rg] - xv[rg];
                 rss1[t] = fmaf(res, res, rss1[t]);
+                dzg[t] = fmaf(r0v[rg], res - r0v[rg], dzg[t]);
               }
           }
         if (h == 0) BT16_STAMP(3);
@@ -765,7 +812,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       __syncthreads();                             // every wave is done with the staging tiles: red[] may be written
 #pragma unroll
       for (int t = 0; t < TB; ++t) {
-        const float s0 = wave_sum(rss1[t]), s1 = wave_sum(l1[t]), s2 = wave_sum(dzg2[t][0] + dzg2[t][1]),
+        const float s0 = wave_sum(rss1[t]), s1 = wave_sum(l1[t]), s2 = wave_sum(dzg[t]),
                     s3 = wave_sum(dz22[t][0] + dz22[t][1]);
         if (lane == 0) {
           red[64 + (4 * t) * kWaves + wid] = s0;
@@ -794,6 +841,38 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     // ================================ step size (ista.py:86-90) =============================
     float lr_acc = (float)p.lr0, lam_acc = (float)(p.alpha * p.lr0), f_acc = __builtin_nanf("");
     int t_acc = 0;
+    // accept step, AB passes at a time with ALL their g and z loads in flight together (kept packed: 8 registers per
+    // pass): the phase is a chain of memory round trips (four passes per trip took 14.8 us at K = 1024).  Round 4:
+    // two register sets -- a batch's loads fly under the previous batch's arithmetic, and the first batch's are
+    // issued BEFORE the line search's decision is awaited (they do not depend on it).
+    constexpr int AB = NP < LASSO_BT16_ACCEPT_BATCH ? NP : LASSO_BT16_ACCEPT_BATCH;
+    static_assert(NP % AB == 0, "accept batch must divide the passes");
+    u32x4 gA[AB], zA[AB], gB[AB], zB[AB];
+    auto accept_load = [&](int jb, u32x4 (&gq)[AB], u32x4 (&zq)[AB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < AB; ++u) gq[u] = load_g8(jb + u);
+#pragma unroll
+      for (int u = 0; u < AB; ++u) zq[u] = it == 0 ? load_z8p(Z0g, p.ldz0, z0vec, jb + u) : load_z8p(Zg, p.ldz, zvec, jb + u);
+    };
+    auto accept_compute = [&](int jb, const u32x4 (&gq)[AB], const u32x4 (&zq)[AB], float& dsum) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < AB; ++u) {
+        const int j = jb + u;
+        float pv[8], gv[8], zn[8], yn[8], zo1[8];
+        lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
+        unpack8(*pp, pv);
+        unpack8(gq[u], gv);
+        unpack8(zq[u], zo1);
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          zn[e8] = bf16_round(soft_threshold(fmaf(-lr_acc, gv[e8], pv[e8]), lam_acc));   // the trial's candidate, ista.py:40
+          dsum += __builtin_fabsf(__fsub_rn(zo1[e8], zn[e8]));                        // :93
+          yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo1[e8])));    // :99-100
+        }
+        store_z8(j, zn);                                                              // :102
+        *pp = pack8(yn);                                                              // next point, in place
+      }
+    };
     if (p.backtrack) {
       // batch b holds the trials s0 .. s0 + TB - 1 with the steps lr0 / eta^s (in double like the reference's
       // python floats, ista.py:47)
@@ -806,6 +885,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           lr_d = lr_d / p.eta;
         }
         run_batch(lrs, lams, ++epoch);
+        accept_load(0, gA, zA);                    // (independent of the decision awaited next)
         BT16_STAMP(4);
         float fv = 0.f;
         const int nvalid = min(TB, kMaxTrials - s0);
@@ -832,33 +912,14 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     // ================================ accept: z+, |z - z+|, momentum (ista.py:93-102) ========
     BT16_STAMP(9);
     float dsum = 0.0f;
-    // AB passes at a time, ALL their g and z loads in flight together (kept packed: 8 registers per pass): the
-    // phase is a chain of memory round trips, and with four passes per trip it took 14.8 us at K = 1024
-    constexpr int AB = NP < LASSO_BT16_ACCEPT_BATCH ? NP : LASSO_BT16_ACCEPT_BATCH;
-    static_assert(NP % AB == 0, "accept batch must divide the passes");
+    if (!p.backtrack) accept_load(0, gA, zA);
 #pragma unroll 1
-    for (int jb = 0; jb < NP; jb += AB) {
-      u32x4 gq[AB], zq[AB];
-#pragma unroll
-      for (int u = 0; u < AB; ++u) gq[u] = load_g8(jb + u);
-#pragma unroll
-      for (int u = 0; u < AB; ++u) zq[u] = it == 0 ? load_z8p(Z0g, p.ldz0, z0vec, jb + u) : load_z8p(Zg, p.ldz, zvec, jb + u);
-#pragma unroll
-      for (int u = 0; u < AB; ++u) {
-        const int j = jb + u;
-        float pv[8], gv[8], zn[8], yn[8], zo1[8];
-        lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
-        unpack8(*pp, pv);
-        unpack8(gq[u], gv);
-        unpack8(zq[u], zo1);
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
-          dsum += __builtin_fabsf(__fsub_rn(zo1[e8], zn[e8]));                        // :93
-          yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo1[e8])));    // :99-100
-        }
-        store_z8(j, zn);                                                              // :102
-        *pp = pack8(yn);                                                              // next point, in place
+    for (int jb = 0; jb < NP; jb += 2 * AB) {
+      if (jb + AB < NP) accept_load(jb + AB, gB, zB);        // the next batch's round trip under this batch's arithmetic
+      accept_compute(jb, gA, zA, dsum);
+      if (jb + AB < NP) {
+        if (jb + 2 * AB < NP) accept_load(jb + 2 * AB, gA, zA);
+        accept_compute(jb + AB, gB, zB, dsum);
       }
     }
     iterations = it + 1;
