@@ -561,8 +561,6 @@ struct BtWorkspace {
   float* Zf;       // bf16 tensors: fp32 working copy of z
   // persistent bf16 solve (bt16_persist.hip)
   void* pG;        // [ntiles64 * 64][kp] bf16 gradient
-  void* pR0;       // [ntiles64][64][256] f32 residual at the current point
-  void* pXr;       // [ntiles64][8][4][64] x 16 B: x in the accumulator layout
   void* pZ0;       // [n][k] bf16 copy of z0 when it aliases z_out (a fall-back needs it intact)
   float* pcoef;    // [maxiter] momentum coefficients (+ [maxiter] zeros)
   void* pgran;     // trial granules + |dz| granules
@@ -595,13 +593,11 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
   w.C = take((size_t)n * k * 4);
   w.Y = take((size_t)n * k * 4);
   w.Zf = half ? take((size_t)n * k * 4) : nullptr;      // (wp / wtp hold the two bf16 packs then)
-  w.pG = w.pR0 = w.pXr = w.pZ0 = w.pgran = nullptr; w.pcoef = nullptr; w.pout = nullptr; w.ptrials = nullptr; w.plrs = w.pfvals = nullptr;
+  w.pG = w.pZ0 = w.pgran = nullptr; w.pcoef = nullptr; w.pout = nullptr; w.ptrials = nullptr; w.plrs = w.pfvals = nullptr;
   if (half) {
     const int64_t nt64 = (n + 63) / 64;
     const int cap = std::max(maxiter, 1);
     w.pG = take((size_t)nt64 * 64 * kp * 2);
-    w.pR0 = take((size_t)nt64 * 64 * kFistaD * 4);
-    w.pXr = take((size_t)nt64 * 8 * 4 * 64 * 16);
     w.pZ0 = take((size_t)n * k * 2);
     w.pcoef = take((size_t)cap * 4 * 2);
     w.pgran = take(bt16_persist_granule_bytes((int)std::max<int64_t>(nt64, 1)));
@@ -652,14 +648,14 @@ int solve_bf16_persistent(const void* x_dev, int64_t ldx, const void* w_dev, int
   LASSO_HIP_TRY(hipMemsetAsync(ws.pout, 0, 16, st));
   Bt16PersistParams p;
   p.X = x_dev; p.ldx = ldx; p.Wq1 = ws.wp; p.Wq2 = ws.wtp;
-  p.Z0 = z0; p.ldz0 = ldz0; p.Z = z_out_dev; p.ldz = ldz; p.G = ws.pG; p.R0 = ws.pR0; p.XR = ws.pXr;
+  p.Z0 = z0; p.ldz0 = ldz0; p.Z = z_out_dev; p.ldz = ldz; p.G = ws.pG;
   p.n = (int)n; p.d = (int)d; p.k = (int)k; p.ntiles = ntiles;
   p.maxiter = maxiter; p.fast = fast; p.backtrack = backtrack;
   p.alpha = alpha; p.lr0 = lr; p.eta = eta;
   p.budget = tol > 0.0 ? (float)((double)n * (double)k * tol) : -1.0f;
   p.coef = ws.pcoef;
   p.gran = ws.pgran;
-  p.dgran = reinterpret_cast<unsigned long long*>((char*)ws.pgran + bt16_persist_trial_granule_bytes(ntiles));
+  p.dgran = reinterpret_cast<unsigned long long*>((char*)ws.pgran + (size_t)8 * ntiles * 32);
   p.out = ws.pout;
   p.trials = ws.ptrials; p.lrs = ws.plrs; p.fvals = ws.pfvals;
   LASSO_HIP_TRY(launch_bt16_persist(p, kp, st));

@@ -106,8 +106,6 @@ struct Bt16PersistParams {
   const void* Z0; int64_t ldz0;          // bf16 [n][k] initial code, nullable -> zeros
   void* Z; int64_t ldz;                  // bf16 [n][k]: the iterate z, updated in place; the result
   void* G;                               // bf16 [ntiles * 64][Kpad] workspace: the gradient at the current point
-  void* XR;                              // u32x4 [ntiles][8][4][64] workspace: x in GEMM-1's accumulator layout (packed bf16)
-  void* R0;                              // f32 [ntiles][64][256] workspace: the residual at the current point (line search)
   int n, d, k, ntiles;
   int maxiter, fast, backtrack;
   double alpha, lr0, eta;
@@ -119,7 +117,6 @@ struct Bt16PersistParams {
   int* trials; float* lrs; float* fvals; // [maxiter] device trace of the line search (nullable)
 };
 size_t bt16_persist_granule_bytes(int ntiles);
-size_t bt16_persist_trial_granule_bytes(int ntiles);   // the |dz| granules of the stop rule follow the trial granules
 hipError_t bt16_persist_occupancy(int kpad, int* per_cu);
 hipError_t launch_bt16_persist(const Bt16PersistParams& p, int kpad, hipStream_t stream);
 

@@ -28,8 +28,8 @@ buf = (C.c_uint64 * (1024 * 16))()
 assert lib.lasso_debug_bt16_stamps(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16)[:256].astype(np.float64) / 100.0   # 100 MHz -> us
 t -= t[:, 0].min()
-names = ['iter start', 'gradient done', 'batch start', 'batch: half 0 done', 'decide begin', 'decide end',
-         'batch: half 1 done', 'batch published', '(unused)', 'accept start', 'accept end']
+names = ['iter start', 'gradient done', 'trial1 start', 'trial1 issue', 'trial1 decide begin', 'trial1 decide end',
+         'trial1 passes end', 'trial1 published', 'trial2 start', 'accept start', 'accept end']
 print('%-22s %8s %8s %8s   (absolute, us from the first workgroup entering the iteration)' % ('stamp', 'min', 'median', 'max'))
 for i, nme in enumerate(names):
     print('%-22s %8.2f %8.2f %8.2f' % (nme, t[:, i].min(), np.median(t[:, i]), t[:, i].max()))
@@ -43,13 +43,14 @@ phase(0, 11, '  GEMM-1')
 phase(11, 12, '  residual -> LDS, barrier')
 phase(12, 13, '  GEMM-2 up to the last g stores')
 phase(13, 1, '  last g stores + barrier')
-phase(1, 2, 'sum r0^2, barrier')
-phase(2, 3, 'batch of 5 trials: rows 0-31')
-phase(3, 6, 'batch of 5 trials: rows 32-63')
-phase(6, 7, 'batch: reduce + publish')
-phase(4, 5, 'decision (sweep of all granules)')
-phase(5, 9, 'decision -> accept')
+phase(2, 3, 'trial1: passes before the sweep loads')
+phase(3, 4, 'trial1: double pass after issue')
+phase(4, 5, 'trial1: decide (verdict of trial0)')
+phase(5, 6, 'trial1: remaining passes')
+phase(6, 7, 'trial1: publish')
+phase(7, 8, 'trial1 end -> trial2 start')
 phase(9, 10, 'accept')
-phase(0, 10, 'whole outer iteration')
 late = np.argsort(-t[:, 7])[:8]
-print('latest publishers (workgroup, XCD = wg % 8):', [(int(w), int(w) % 8) for w in late])
+print('latest publishers of trial1 (workgroup, XCD = wg % 8):', [(int(w), int(w) % 8) for w in late])
+xcd = np.array([t[np.arange(256) % 8 == x, 6].mean() - t[np.arange(256) % 8 == x, 5].mean() for x in range(8)])
+print('mean "remaining passes" per XCD:', np.round(xcd, 2))
