@@ -162,6 +162,146 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trial_kernel(const BtPara
   LASSO_WAIT_VMCNT(0);
 }
 
+// Several trials of one outer iteration in ONE launch (round 4).  Every trial t of an iteration uses the same point p,
+// the same gradient g0 and the step lr0 / eta^t (ista.py:38-47): the single-trial kernel above re-read p and g of
+// every tile for every trial (134 MB per trial at config 3, a burst of ~27 us in front of 61 us of GEMM) and cost a
+// launch plus a decision launch each.  Here a workgroup keeps p and g of its tile in REGISTERS (8 + 8 16-byte pieces
+// per thread), and per trial forms the candidate tile in LDS from them, runs GEMM-1 on it and writes the trial's four
+// tile sums to `partsM[t]`; bt_decide_multi_kernel then takes the first trial with F <= Q.  Needs 16-byte-aligned
+// flat p / g (k % 4 == 0; the driver falls back to the single-trial launches otherwise) and the recomputing accept
+// step (no candidate goes to memory).
+template <int K>
+__global__ __launch_bounds__(kFistaThreads, 2) void bt_trials_kernel(const BtParams p, const BtSteps s, int ntrials,
+                                                                     float* __restrict__ partsM) {
+  constexpr int NW = kFistaWaves;
+  constexpr int ITER = kTileM * (K / 4) / kFistaThreads;
+  if (p.skip && *p.skip != 0) return;
+  if (p.flags[0] != 0) return;             // a trial of an earlier batch of this iteration was accepted
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const rings = (lds_char*)smem;
+  lds_char* const zt = rings + NW * kRingBytesPerWave;
+  lds_f32* const red = (lds_f32*)(zt + kTileM * K * 4);
+
+  TileCtx<K> c;
+  c.init(p.Wp, p.Wp, rings);
+  const int tid = threadIdx.x;
+  const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+  dma_step(c.w1, c.voff1, c.ring);
+  dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+    f32x4 pa[ITER], ga[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {       // all 2 ITER pieces in flight together: one memory round trip per tile
+      const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
+      const int64_t rr = min(row0 + r, p.n - 1);
+      const int cl = min(cc, p.k - 4);
+      pa[i] = *reinterpret_cast<const f32x4*>(p.P + rr * p.ldp + cl);
+      ga[i] = *reinterpret_cast<const f32x4*>(p.G + rr * (int64_t)p.k + cl);
+    }
+    f32x4 negx[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
+        float v = 0.0f;
+        if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+        negx[cb][rg] = -v;
+      }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {       // rows / columns beyond the matrix read clamped addresses: zero them
+      const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
+      if (!((row0 + r) < p.n && cc < p.k)) { pa[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; ga[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+#pragma unroll 1
+    for (int t = 0; t < ntrials; ++t) {
+      const float lr = s.lr[t], lam = s.lam[t];
+      float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
+        f32x4 zn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          zn[e] = soft_threshold(__fsub_rn(pa[i][e], __fmul_rn(lr, ga[i][e])), lam);     // ista.py:40
+          const float dz = __fsub_rn(zn[e], pa[i][e]);                                    // :31
+          l1 += __builtin_fabsf(zn[e]);
+          dzg = __fadd_rn(dzg, __fmul_rn(dz, ga[i][e]));
+          dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
+        }
+        *(lds_f32x4*)(zt + tile_chunk_off<K>(r, cc)) = zn;
+      }
+      f32x4 acc[2] = {negx[0], negx[1]};
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      gemm1_stream_sp<K>(c, zt, acc, c.w1, c.w1 + 32, c.voff1);
+      float rss = 0.0f;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rss = fmaf(acc[cb][rg], acc[cb][rg], rss);
+      rss = wave_sum(rss); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
+      if (lane == 0) { red[4 * wid] = rss; red[4 * wid + 1] = l1; red[4 * wid + 2] = dzg; red[4 * wid + 3] = dz2; }
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      if (tid < 4) {
+        float a = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += red[4 * w + tid];
+        partsM[((int64_t)t * 4 + tid) * p.ntiles + tile] = a;
+      }
+      __builtin_amdgcn_s_barrier();        // zt / red reuse by the next trial
+    }
+  }
+  LASSO_WAIT_VMCNT(0);
+}
+
+// The decisions of a batch of trials, in trial order, by one block: the sums and the comparison of bt_decide_kernel
+// (same per-thread strides, same tree, same fp32 operation order) for t = 0 .. ntrials - 1; the first trial with
+// F <= Q is the accepted one.  partials: [0][tile] = sum r0^2 of the gradient kernel.
+__global__ __launch_bounds__(256) void bt_decide_multi_kernel(const float* __restrict__ partials,
+                                                              const float* __restrict__ partsM, int ntiles,
+                                                              float alpha, const BtSteps s, int ntrials,
+                                                              int first_index, int* __restrict__ flags,
+                                                              float* __restrict__ fvals, const int* __restrict__ skip) {
+  if (skip && *skip != 0) return;
+  if (flags[0] != 0) return;
+  __shared__ double sh[5][256];
+  for (int t = 0; t < ntrials; ++t) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int tl = threadIdx.x; tl < ntiles; tl += 256) {
+      acc[0] += partials[tl];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[1 + q] += partsM[((size_t)t * 4 + q) * ntiles + tl];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + st];
+      __syncthreads();
+    }
+    const float rss0 = (float)sh[0][0], rss1 = (float)sh[1][0], l1 = (float)sh[2][0];
+    const float dzg = (float)sh[3][0], dz2 = (float)sh[4][0];
+    const float f0 = __fmul_rn(0.5f, rss0);                                        // ista.py:23
+    const float al1 = __fmul_rn(alpha, l1);
+    const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                         // :28
+    const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(s.hol[t], dz2)), al1);  // :32-35
+    const bool ok = F <= Q;                                                        // :45 (every thread: same values)
+    __syncthreads();                                                               // sh[] is rewritten by the next trial
+    if (threadIdx.x == 0) {
+      fvals[0] = F; fvals[1] = Q;
+      flags[1] = first_index + t + 1;
+      if (ok) { flags[0] = 1; flags[2] = first_index + t; fvals[2] = s.lr[t]; fvals[3] = s.lam[t]; }
+    }
+    if (ok) return;
+  }
+}
+
 // One block.  partials layout: [0][t] rss0, [1][t] rss1, [2][t] l1, [3][t] dz.g0, [4][t] dz^2.
 // flags: [0] accepted, [1] trials evaluated so far this iteration, [2] index of accepted trial.
 // fvals: [0] F, [1] Q of the last evaluated trial (diagnostics), [2] accepted lr, [3] its alpha*lr
@@ -309,6 +449,31 @@ hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, 
   }
   if (e != hipSuccess) return e;
   return launch_bt_decide(p, alpha, lr, trial_index, force, stream, sums_out);
+}
+
+template <int K>
+static hipError_t launch_trials_k(const BtParams& p, const BtSteps& s, int ntrials, float* partsM, int grid,
+                                  hipStream_t stream) {
+  const size_t lds = (size_t)kFistaWaves * kRingBytesPerWave + (size_t)kTileM * K * 4 + 256;
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_trials_kernel<K>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(bt_trials_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p, s, ntrials, partsM);
+  return hipGetLastError();
+}
+
+// `ntrials` <= kBtMultiMax trials with the steps of `s` (trial indices first_index ..), then their decisions
+hipError_t launch_bt_trials(const BtParams& p, int kpad, int grid, double alpha, const BtSteps& s, int ntrials,
+                            int first_index, float* partsM, hipStream_t stream) {
+  hipError_t e;
+  switch (kpad) {
+    case 256: e = launch_trials_k<256>(p, s, ntrials, partsM, grid, stream); break;
+    case 512: e = launch_trials_k<512>(p, s, ntrials, partsM, grid, stream); break;
+    case 1024: e = launch_trials_k<1024>(p, s, ntrials, partsM, grid, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bt_decide_multi_kernel, dim3(1), dim3(256), 0, stream, p.partials, partsM, p.ntiles, (float)alpha, s,
+                     ntrials, first_index, p.flags, p.fvals, p.skip);
+  return hipGetLastError();
 }
 
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,

@@ -556,6 +556,7 @@ constexpr int kBtMaxTrials = 1000;   // ista.py:17 (maxiter=1000)
 
 struct BtWorkspace {
   float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
+  float* partsM;   // [kBtMultiMax][4][ntiles] tile sums of the trials of a multi-trial launch (fp32 tensors)
   double* sums;    // [kBtMaxTrials][5] per-trial sums of a row-sharded solve
   float* G; float* C; float* Y;
   float* Zf;       // bf16 tensors: fp32 working copy of z
@@ -584,6 +585,7 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
   w.wp = take((size_t)kFistaD * kp * 4);
   w.wtp = take((size_t)kp * kFistaD * 4);
   w.partials = take((size_t)5 * std::max<int64_t>(ntiles, 1) * 4);
+  w.partsM = take((size_t)kBtMultiMax * 4 * std::max<int64_t>(ntiles, 1) * 4);
   w.dpart = take((size_t)kBtFinishGrid * 4);
   w.delta = take(256);
   w.flags = reinterpret_cast<int*>(take(256));
@@ -686,7 +688,8 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
                        int dtype, double alpha, double lr0, int fast, int maxiter, double tol, double eta,
                        int32_t* iters_out, float* last_delta_out, int32_t* trials_out, float* accepted_lr_out,
                        float* accepted_f_out, void* workspace, size_t ws_bytes, hipStream_t st,
-                       lasso_allreduce_fn reduce = nullptr, void* reduce_ctx = nullptr, int64_t n_global = 0) {
+                       lasso_allreduce_fn reduce = nullptr, void* reduce_ctx = nullptr, int64_t n_global = 0,
+                       int bt_hint = 0 /* 1: single-trial launches also for fp32 tensors (A/B) */) {
   // reduce != nullptr: this process holds a row shard.  The sums behind the two global decisions
   // of an iteration -- F <= Q of every trial (ista.py:23,28,32-35) and sum |z_next - z| <= n k tol
   // (:93) -- are added over the ranks by the caller's callback; every rank then takes the same
@@ -750,6 +753,10 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   // trials -- ONE iteration on the synchronous path below -- the next window is enqueued asynchronously again.
   const bool can_async = !reduce && recompute;
   constexpr int kBtWindow = 16;
+  constexpr int kBtFirst = 5;          // trials of the first multi-trial launch of an iteration
+  // multi-trial launches (bt_trials_kernel): fp32 tensors, flat 16-byte-aligned point and gradient
+  const bool multi = !half && can_async && (k & 3) == 0 && k >= 4 && (((uintptr_t)zout) & 15) == 0 &&
+                     (((uintptr_t)ws.Y) & 15) == 0 && (((uintptr_t)ws.G) & 15) == 0 && !(bt_hint & 1);
   while (it < maxiter) {
   if (can_async) {
     const int win0 = it, wlen = std::min(kBtWindow, maxiter - it);
@@ -765,6 +772,19 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       if (half) LASSO_HIP_TRY(launch_bt16_grad(p, kp, grid, st));
       else LASSO_HIP_TRY(launch_bt_grad(p, kp, grid, st));
       double lr = lr0;
+      if (multi) {
+        // fp32 tensors: the kBtBatch pre-enqueued trials as TWO launches -- trials 0 .. kBtFirst-1 (p and g of a tile
+        // read once, in registers for all of them) and the rest (a no-op once a trial of the first launch passed)
+        for (int b0 = 0; b0 < kBtBatch; b0 += kBtFirst) {
+          BtSteps steps;
+          const int nb = std::min(kBtFirst, kBtBatch - b0);
+          for (int b = 0; b < nb; ++b) {
+            steps.lr[b] = (float)lr; steps.lam[b] = (float)(alpha * lr); steps.hol[b] = (float)(0.5 / lr);
+            lr = lr / eta;                                                             // :47
+          }
+          LASSO_HIP_TRY(launch_bt_trials(p, kp, grid, alpha, steps, nb, b0, ws.partsM, st));
+        }
+      } else
       for (int b = 0; b < kBtBatch; ++b) {
         if (half) {
           LASSO_HIP_TRY(launch_bt16_trial(p, kp, grid, (float)lr, (float)(alpha * lr), 0, st));
@@ -1534,7 +1554,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                               half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,
                               stop_rule ? tol : 0.0, eta_backtrack,
                               iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                              workspace_bytes, st);
+                              workspace_bytes, st, nullptr, nullptr, 0, (hint & 0x300) == LASSO_KERNEL_TILE ? 1 : 0);
   const int kps = pad_k_solve(n, d, k);                  // (fp32 fixed step from here on: 768 atoms have their own tile kernel)
   const NarrowTiles narrow(narrow_tiles(n, d, k, kps, hint));
   Workspace ws = carve(workspace_dev, n, k, kps, maxiter, stop_rule);

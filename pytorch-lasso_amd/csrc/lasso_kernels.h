@@ -161,6 +161,11 @@ hipError_t launch_objective_generic(const float* X, int64_t ldx, const float* W,
                                     hipStream_t stream);
 
 hipError_t launch_bt_grad(const BtParams& p, int kpad, int grid, hipStream_t stream);
+// several trials of one outer iteration in one launch (backtrack.hip bt_trials_kernel): their steps, by value
+constexpr int kBtMultiMax = 8;
+struct BtSteps { float lr[kBtMultiMax]; float lam[kBtMultiMax]; float hol[kBtMultiMax]; };   // step, alpha * step, 0.5 / step
+hipError_t launch_bt_trials(const BtParams& p, int kpad, int grid, double alpha, const BtSteps& s, int ntrials,
+                            int first_index, float* partsM /* [kBtMultiMax][4][ntiles] */, hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
                            int trial_index, int force, hipStream_t stream, double* sums_out = nullptr);
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,

@@ -97,12 +97,15 @@ def test_auto_step_and_stop_rule(golden):
         # (1e-6-level difference).  How much that matters after up to 200 momentum steps
         # depends on the problem (the bound is a LOWER bound of L, so 1/bound sits at the edge
         # of stability): measure the oracle's own sensitivity to a 2e-6 change of the step.
+        assert abs(info["iterations"] - rinfo["iterations"]) <= 1, (tag, info, rinfo)
+        err = (got.cpu() - ref).abs().max().item()
+        if err <= 2e-4:
+            continue            # (the two extra 200-iteration oracle runs below only where they are needed: 60 s of CPU)
         L = orc.conv_lipschitz_bound(w, pd).item()
         sens = max((orc.conv_fista(x, z0, w, alpha, stride=st, padding=pd, maxiter=200, tol=1e-4,
                                    lr=float(np.float32(1.0 / (L * (1 + rel))))) - ref).abs().max().item()
                    for rel in (2e-6, -2e-6))
-        assert abs(info["iterations"] - rinfo["iterations"]) <= 1, (tag, info, rinfo)
-        assert (got.cpu() - ref).abs().max().item() <= 2e-4 + 3 * sens, (tag, info, rinfo, sens)
+        assert err <= 2e-4 + 3 * sens, (tag, info, rinfo, sens)
 
 
 @pytest.mark.parametrize("N,C,K,kh,kw,stride,padding,Hz,Wz", [

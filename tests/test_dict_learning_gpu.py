@@ -11,11 +11,12 @@ from margins import record_margins
 
 pytestmark = pytest.mark.gpu
 
-# Elementwise bars of the free-running EM fixtures, each <= 3x the deviation MEASURED on MI355X (round 4:
-# profiles/r04/parity_margins.json); the first values are round 3's, kept until the measurement is in
-G1_D_ATOL, G1_Z_ATOL = 1e-3, 2e-3
-G5_LOSS_ATOL, G5_D_ATOL = 1e-4, 5e-3
-G4_LOSS_ATOL, G4_D_ATOL, G4_RIDGE_LOSS_ATOL = 2e-4, 2e-3, 5e-4
+# Elementwise bars of the free-running EM fixtures, each ~5x the deviation MEASURED on MI355X in round 4
+# (profiles/r04/parity_margins.json; round 3's bars were 7x .. 4000x): G1 (60 steps) D 3.1e-5, z 3.5e-5; G5 (10 steps)
+# losses 6e-8 (one ulp), D 1.1e-6; G4 (3 steps at n = 65536) losses 3.8e-6 (one ulp of 60), D 5.8e-7, ridge losses 7.6e-6
+G1_D_ATOL, G1_Z_ATOL = 1.5e-4, 1.5e-4
+G5_LOSS_ATOL, G5_D_ATOL = 1e-6, 1e-5
+G4_LOSS_ATOL, G4_D_ATOL, G4_RIDGE_LOSS_ATOL = 2e-5, 5e-6, 4e-5
 
 
 def T(a):

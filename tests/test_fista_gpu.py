@@ -11,7 +11,7 @@ from recipes import recipe_xw, LAMBDA_MAX_C2
 pytestmark = pytest.mark.gpu
 
 Z_ATOL = 5e-5
-Z_ATOL_263 = 2e-4        # set from the measured margin below (profiles/r04/parity_margins.json)
+Z_ATOL_263 = 1.5e-5      # M = 263: measured 3.5e-6 on MI355X (profiles/r04/parity_margins.json); north_star's bar is 5e-5
 OBJ_RTOL = 1e-6
 
 
@@ -131,10 +131,10 @@ def test_c2_trajectory_against_golden(golden):
                                "max_abs_z": float(blk.abs().max())}
         record_margins("c2_fista_vs_reference", achieved)
         assert abs(obj - obj_ref) <= OBJ_RTOL * obj_ref, (M, obj, obj_ref)
-        # north_star's fp32 bar is 5e-5 (Z_ATOL) -- held through M = 100; at M = 263 (the reference's stopping
-        # iteration) 263 momentum steps have amplified the last-ulp differences between MKL's and the MFMA's
-        # summation orders: the bar there is 3x what profiles/r04/parity_margins.json records
-        tol_z = Z_ATOL if M <= 100 else Z_ATOL_263
+        # north_star's fp32 bar is 5e-5 (Z_ATOL); measured (profiles/r04/parity_margins.json): 1.3e-7 at M = 1,
+        # 2.4e-6 at M = 100, 3.5e-6 at M = 263 (the reference's stopping iteration) -- the bar of the long runs is
+        # ~4x that, the short runs keep 5e-5 / 10
+        tol_z = Z_ATOL / 10 if M <= 100 else Z_ATOL_263
         assert dz_blk <= tol_z and dz_str <= tol_z, (M, dz_blk, dz_str)
         assert abs(z.double().abs().sum().item() - st[1]) <= 1e-5 * st[1]
     z = sparse_encode(Xg, Wg, alpha=0.5, fast=False, lr=lr, maxiter=100, tol=0.0).cpu()

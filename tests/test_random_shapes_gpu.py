@@ -46,7 +46,7 @@ def test_stop_rule_random_shapes():
     """iterations-to-tolerance equal to the oracle's (exact global rule, in-kernel or chunked)."""
     from lasso_amd.linear.solvers import ista
     from oracle import lasso_oracle as orc
-    for i, (n, d, k) in enumerate(_shapes(10, 202, 256, 1024, nmax=6000)):
+    for i, (n, d, k) in enumerate(_shapes(7, 202, 256, 1024, nmax=4000)):      # (the oracle's 300 iterations on the CPU set the time)
         X, W = _problem(n, d, k, 50 + i)
         lr = 1.0 / max(orc.lipschitz_constant(W, "exact"), 1e-3)
         z0 = torch.zeros(n, k)
