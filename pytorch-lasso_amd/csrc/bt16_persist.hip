@@ -502,10 +502,11 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb) b[par][u][cb] = wfrag1((2 * par + u) * 2 + cb);
       u32x4 gq[2] = {load_g8(0), load_g8(1)};   // g of the next two passes (bf16, 16 B each)
-      // two elements of a candidate and their share of the three element sums -- PLAIN fp32 VALU operations: on
-      // gfx950 a packed v_pk_mul/add/fma_f32 takes 2.6 x a plain operation (tools/ubench/mix.hip: 4.6 ns against
-      // 1.78 ns per wave instruction and SIMD), so the packed form of rounds 2-3 cost more than it saved; this file is
-      // built with -fno-slp-vectorize so that the compiler does not re-pack them.  The two sums accumulate by fma.
+      // two elements of a candidate and their share of the three element sums -- PLAIN fp32 VALU operations: beside
+      // MFMAs a packed v_pk_mul/add/fma_f32 costs more than the two plain operations it replaces on gfx950
+      // (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured here: 1.047 -> 1.011 ms per config-3 solve
+      // with the packed form of rounds 2-3 replaced); this file is built with -fno-slp-vectorize so that the compiler
+      // does not re-pack them.  The two sums accumulate by fma.
       auto cand2 = [&](const float (&pv)[8], const float (&gv)[8], float (&zn)[8], int e2) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 2 * e2; e < 2 * e2 + 2; ++e) {

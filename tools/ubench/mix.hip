@@ -13,8 +13,11 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, long long* cy
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x + e); b[e] = (__bf16)(float)(threadIdx.x * 3 + e); }
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   float v[8];
+  f32x2 vp[4];
   for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.001f + i;
+  for (int i = 0; i < 4; ++i) vp[i] = (f32x2){threadIdx.x * 0.002f + i, threadIdx.x * 0.003f - i};
   const float c0 = out[0], c1 = out[1];
   __syncthreads();
   const long long t0 = clock64();
@@ -33,10 +36,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, long long* cy
           else if ((q & 3) == 2) v[i] = __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
           else v[i] = c1 + __builtin_fabsf(v[i]);
         } else {
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          f32x2 t = {v[i], v[(i + 1) & 7]};
-          t = __builtin_elementwise_fma(t, (f32x2){c0, c0}, (f32x2){c1, c1});
-          v[i] = t[0]; v[(i + 1) & 7] = t[1];
+          vp[i & 3] = __builtin_elementwise_fma(vp[i & 3], (f32x2){c0, c0}, (f32x2){c1, c1});   // register pairs: no moves
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, long long* cy
   }
   const long long t1 = clock64();
   float s = 0.f;
-  for (int i = 0; i < 8; ++i) s += v[i] + acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 8; ++i) s += v[i] + vp[i & 3][i >> 2 & 1] + acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[2 + blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
