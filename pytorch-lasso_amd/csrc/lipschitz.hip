@@ -236,50 +236,99 @@ __global__ __launch_bounds__(256) void gram_span_f64_kernel(const float* __restr
   for (int rg = 0; rg < 4; ++rg) Cz[(size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15] = acc[rg];
 }
 
+// wave-wide sum of doubles on the ALU path (DPP row shifts + four readlanes): a fixed order, no LDS round trips
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr_f64(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double x) {
+  x += dpp_row_shr_f64<0x111>(x);
+  x += dpp_row_shr_f64<0x112>(x);
+  x += dpp_row_shr_f64<0x114>(x);
+  x += dpp_row_shr_f64<0x118>(x);        // lane 15 of every 16-lane row holds the row's total
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  double r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * i + 15);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * i + 15);
+    r[i] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // ALL squarings of a small iterate (m = mp <= 64: dictionaries with d or k <= 64, e.g. 8 x 8 patches) in ONE
-// launch of one workgroup: the iterate lives in LDS (two 64 x 65 buffers), wave w owns the 16 x 16 output block
-// (w / nb, w % nb), per squaring {trace by the tree of square_f64_kernel, 16 fp64 MFMA steps on operands scaled
-// as they are read, one barrier}.  The same arithmetic per squaring as the per-launch kernels -- bitwise the same
-// iterate -- for 0.7 us instead of a 7 us launch each.
-__global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __restrict__ G, int mp, int squarings,
+// launch of one workgroup: the iterate lives in LDS (two MP x (MP + 2) buffers), one wave per 16 x 16 block of the
+// UPPER triangle (the iterate is symmetric: the strictly lower blocks are written as mirror images -- 10 of 16 blocks
+// at MP = 64), per squaring {all 2 x MP/4 operand reads of the block issued together, MP/4 fp64 MFMA steps, the block
+// scaled by 1 / tr(P)^2, the diagonal waves' share of the NEW trace by DPP sums, ONE barrier}.  Round 3's form read two
+// operands per MFMA step in a rolled loop (one LDS round trip per step), scaled both operands, and spent three
+// barriers on the trace tree of the per-launch kernels: 3.3 us per squaring; this one: see DESIGN.md 3.3.
+// P_{i+1} = P_i P_i^T / tr(P_i)^2 as before; the sums inside a squaring are taken in another (fixed) order.
+template <int MP>
+__global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __restrict__ G, int squarings,
                                                                 double* __restrict__ Pout) {
-  constexpr int RS = 65;
-  __shared__ double buf[2][64 * RS];
-  __shared__ double sh[256];
+  constexpr int RS = MP + 2, NBK = MP / 16, NBLK = NBK * (NBK + 1) / 2;   // (row pitch = 4 banks mod 64: the operand reads and the mirror writes are conflict-free)
+  __shared__ double buf[2][MP * RS];
+  __shared__ double trp[2][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nb = mp / 16, bi = w / nb, bj = w % nb;            // waves >= nb * nb idle in the MFMA part
   const int l15 = lane & 15, q = lane >> 4;
-  for (int e = tid; e < mp * mp; e += 1024) buf[0][(e / mp) * RS + e % mp] = G[e];
+  // block (bi <= bj) of wave w < NBLK: row-major walk of the upper triangle
+  int bi = 0, bj = 0;
+  {
+    int rem = w;
+    for (int r = 0; r < NBK; ++r) {
+      const int cnt = NBK - r;
+      if (rem < cnt) { bi = r; bj = r + rem; break; }
+      rem -= cnt;
+    }
+  }
+  for (int e = tid; e < MP * MP; e += 1024) buf[0][(e / MP) * RS + e % MP] = G[e];
+  if (tid < 8) trp[tid >> 2][tid & 3] = 0.0;
+  __syncthreads();
+  if (w < NBK) {                              // tr(G): wave w adds rows 16 w .. 16 w + 15 of the diagonal
+    const double d = lane < 16 ? buf[0][(16 * w + lane) * RS + 16 * w + lane] : 0.0;
+    const double t = wave_sum_f64_dpp(d);
+    if (lane == 0) trp[0][w] = t;
+  }
   __syncthreads();
   int cur = 0;
+#pragma unroll 1
   for (int p = 0; p < squarings; ++p) {
     const double* const src = buf[cur];
     double* const dst = buf[cur ^ 1];
-    if (tid < 256) sh[tid] = tid < mp ? src[tid * RS + tid] : 0.0;
-    __syncthreads();
-    if (tid < 128) sh[tid] += sh[tid + 128];
-    __syncthreads();
-    if (tid < 64) {
-      double v = sh[tid] + sh[tid + 64];
-#pragma unroll
-      for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
-      if (tid == 0) sh[0] = v;
-    }
-    __syncthreads();
-    const double inv = 1.0 / sh[0];
-    if (w < nb * nb) {
-      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double tr = ((trp[cur][0] + trp[cur][1]) + trp[cur][2]) + trp[cur][3];
+    const double inv = 1.0 / tr, inv2 = inv * inv;
+    if (w < NBLK) {
+      double a[MP / 4], b[MP / 4];
       const double* const pa = src + (16 * bi + l15) * RS + q;
       const double* const pb = src + (16 * bj + l15) * RS + q;
-      for (int ks = 0; ks < mp / 4; ++ks)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks] * inv, pb[4 * ks] * inv, acc, 0, 0, 0);
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) dst[(16 * bi + q + 4 * rg) * RS + 16 * bj + l15] = acc[rg];
+      for (int ks = 0; ks < MP / 4; ++ks) { a[ks] = pa[4 * ks]; b[ks] = pb[4 * ks]; }
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < MP / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+      double dg = 0.0;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const double v = acc[rg] * inv2;
+        const int r = q + 4 * rg;                                  // row inside the block; column = l15
+        dst[(16 * bi + r) * RS + 16 * bj + l15] = v;
+        if (bi != bj) dst[(16 * bj + l15) * RS + 16 * bi + r] = v;   // mirror image
+        else if (r == l15) dg = v;
+      }
+      if (bi == bj) {
+        const double t = wave_sum_f64_dpp(dg);
+        if (lane == 0) trp[cur ^ 1][bi] = t;
+      }
     }
     __syncthreads();
     cur ^= 1;
   }
-  for (int e = tid; e < mp * mp; e += 1024) Pout[e] = buf[cur][(e / mp) * RS + e % mp];
+  for (int e = tid; e < MP * MP; e += 1024) Pout[e] = buf[cur][(e / MP) * RS + e % MP];
 }
 
 // C[e] = sum_z part[z][e]  (fixed order)
@@ -434,7 +483,8 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G);
   const double* src = G;
   if (mp <= 64 && squarings > 0) {         // small iterate: every squaring in one launch of one workgroup
-    hipLaunchKernelGGL(square_chain_f64_kernel, dim3(1), dim3(1024), 0, stream, G, mp, squarings, P[0]);
+    if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);
+    else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);
     hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, P[0], mp, out);
     return hipGetLastError();
   }
