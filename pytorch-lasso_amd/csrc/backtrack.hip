@@ -258,47 +258,50 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_trials_kernel(const BtPar
   LASSO_WAIT_VMCNT(0);
 }
 
-// The decisions of a batch of trials, in trial order, by one block: the sums and the comparison of bt_decide_kernel
-// (same per-thread strides, same tree, same fp32 operation order) for t = 0 .. ntrials - 1; the first trial with
-// F <= Q is the accepted one.  partials: [0][tile] = sum r0^2 of the gradient kernel.
-__global__ __launch_bounds__(256) void bt_decide_multi_kernel(const float* __restrict__ partials,
-                                                              const float* __restrict__ partsM, int ntiles,
-                                                              float alpha, const BtSteps s, int ntrials,
-                                                              int first_index, int* __restrict__ flags,
-                                                              float* __restrict__ fvals, const int* __restrict__ skip) {
+// The decisions of a batch of trials by one block: 128 threads per trial add that trial's five sums (double, fixed
+// strides and tree -- the single-trial decision's sums in another grouping), then thread 0 walks the trials in order
+// with the fp32 operation order of bt_decide_kernel; the first trial with F <= Q is the accepted one.  (As a loop over
+// the trials with one block-wide reduction each this launch took 13 us for five trials; the trials' sums are independent.)
+// partials: [0][tile] = sum r0^2 of the gradient kernel.
+__global__ __launch_bounds__(1024) void bt_decide_multi_kernel(const float* __restrict__ partials,
+                                                               const float* __restrict__ partsM, int ntiles,
+                                                               float alpha, const BtSteps s, int ntrials,
+                                                               int first_index, int* __restrict__ flags,
+                                                               float* __restrict__ fvals, const int* __restrict__ skip) {
   if (skip && *skip != 0) return;
   if (flags[0] != 0) return;
-  __shared__ double sh[5][256];
-  for (int t = 0; t < ntrials; ++t) {
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (int tl = threadIdx.x; tl < ntiles; tl += 256) {
+  __shared__ double sh[kBtMultiMax][5][128];
+  const int t = threadIdx.x >> 7, l = threadIdx.x & 127;
+  double acc[5] = {0, 0, 0, 0, 0};
+  if (t < ntrials)
+    for (int tl = l; tl < ntiles; tl += 128) {
       acc[0] += partials[tl];
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[1 + q] += partsM[((size_t)t * 4 + q) * ntiles + tl];
     }
 #pragma unroll
-    for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = acc[q];
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st)
+  for (int q = 0; q < 5; ++q) sh[t][q][l] = acc[q];
+  __syncthreads();
+  for (int st = 64; st > 0; st >>= 1) {
+    if (l < st)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + st];
-      __syncthreads();
-    }
-    const float rss0 = (float)sh[0][0], rss1 = (float)sh[1][0], l1 = (float)sh[2][0];
-    const float dzg = (float)sh[3][0], dz2 = (float)sh[4][0];
+      for (int q = 0; q < 5; ++q) sh[t][q][l] += sh[t][q][l + st];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  for (int u = 0; u < ntrials; ++u) {
+    const float rss0 = (float)sh[u][0][0], rss1 = (float)sh[u][1][0], l1 = (float)sh[u][2][0];
+    const float dzg = (float)sh[u][3][0], dz2 = (float)sh[u][4][0];
     const float f0 = __fmul_rn(0.5f, rss0);                                        // ista.py:23
     const float al1 = __fmul_rn(alpha, l1);
     const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                         // :28
-    const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(s.hol[t], dz2)), al1);  // :32-35
-    const bool ok = F <= Q;                                                        // :45 (every thread: same values)
-    __syncthreads();                                                               // sh[] is rewritten by the next trial
-    if (threadIdx.x == 0) {
-      fvals[0] = F; fvals[1] = Q;
-      flags[1] = first_index + t + 1;
-      if (ok) { flags[0] = 1; flags[2] = first_index + t; fvals[2] = s.lr[t]; fvals[3] = s.lam[t]; }
+    const float Q = __fadd_rn(__fadd_rn(__fadd_rn(f0, dzg), __fmul_rn(s.hol[u], dz2)), al1);  // :32-35
+    fvals[0] = F; fvals[1] = Q;
+    flags[1] = first_index + u + 1;
+    if (F <= Q) {                                                                  // :45
+      flags[0] = 1; flags[2] = first_index + u; fvals[2] = s.lr[u]; fvals[3] = s.lam[u];
+      return;
     }
-    if (ok) return;
   }
 }
 
@@ -471,7 +474,7 @@ hipError_t launch_bt_trials(const BtParams& p, int kpad, int grid, double alpha,
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bt_decide_multi_kernel, dim3(1), dim3(256), 0, stream, p.partials, partsM, p.ntiles, (float)alpha, s,
+  hipLaunchKernelGGL(bt_decide_multi_kernel, dim3(1), dim3(1024), 0, stream, p.partials, partsM, p.ntiles, (float)alpha, s,
                      ntrials, first_index, p.flags, p.fvals, p.skip);
   return hipGetLastError();
 }

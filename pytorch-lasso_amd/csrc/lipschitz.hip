@@ -301,6 +301,11 @@ __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __
     const double* const src = buf[cur];
     double* const dst = buf[cur ^ 1];
     const double tr = ((trp[cur][0] + trp[cur][1]) + trp[cur][2]) + trp[cur][3];
+    // tr(P_p) = sum mu_i^2 / (sum mu_i)^2 of the previous iterate's eigenvalues: 1 - tr is twice the weight of
+    // everything beside the dominant eigenvector.  Below 1e-15 the iterate IS the rank-one projector to fp64 precision
+    // and further squarings reproduce it: stop (every thread reads the same tr; dictionaries with a healthy gap get
+    // there after 10-13 of the 20 squarings; a multiple top eigenvalue never does and runs them all).
+    if (p > 0 && 1.0 - tr < 1e-15) break;
     const double inv = 1.0 / tr, inv2 = inv * inv;
     if (w < NBLK) {
       double a[MP / 4], b[MP / 4];
