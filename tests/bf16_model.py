@@ -45,7 +45,7 @@ def solve(x, z0, weight, alpha, lr0, maxiter, tol=0.0, fast=True, backtrack=True
         coef = _f32((t_mom - 1.0) / t_next) if fast else 0.0
         p = y
         r0 = p @ wf.T - xf                                            # GEMM-1, fp32 accumulation; residual()
-        rss0 = _f32(r0.double().pow(2).sum().item())
+        rss0 = _f32((r0 * r0).sum(dtype=torch.float64).item())        # (fp32 terms, double accumulation: no 16M-element fp64 temporaries)
         g = bf(bf(r0) @ wf)                                           # residual tile and g are stored as bf16
         lr_acc, lam_acc, t_acc = _f32(lr0), _f32(alpha * lr0), 0
         if backtrack:
@@ -54,11 +54,11 @@ def solve(x, z0, weight, alpha, lr0, maxiter, tol=0.0, fast=True, backtrack=True
                 lr_s, lam_s, hol = _f32(lr_d), _f32(alpha * lr_d), _f32(0.5 / lr_d)
                 zc = bf(_shrink(p - lr_s * g, lam_s))                 # candidates(): bf16_round(soft_threshold(v, lam))
                 d = zc - p
-                l1 = _f32(zc.double().abs().sum().item())
-                dzg = _f32((d * g).double().sum().item())
-                dz2 = _f32((d * d).double().sum().item())
+                l1 = _f32(zc.abs().sum(dtype=torch.float64).item())
+                dzg = _f32((d * g).sum(dtype=torch.float64).item())
+                dz2 = _f32((d * d).sum(dtype=torch.float64).item())
                 r1 = zc @ wf.T - xf
-                rss1 = _f32(r1.double().pow(2).sum().item())
+                rss1 = _f32((r1 * r1).sum(dtype=torch.float64).item())
                 f0 = _f32(np.float32(0.5) * np.float32(rss0))                                   # decide(): ista.py:23
                 al1 = _f32(np.float32(alpha_f) * np.float32(l1))
                 F = _f32(np.float32(_f32(np.float32(0.5) * np.float32(rss1))) + np.float32(al1))  # :28
@@ -73,7 +73,7 @@ def solve(x, z0, weight, alpha, lr0, maxiter, tol=0.0, fast=True, backtrack=True
         trials.append(t_acc + 1)
         lrs.append(lr_acc)
         zn = bf(_shrink(p - lr_acc * g, lam_acc))                     # accept: ista.py:40 with the accepted step
-        last = _f32((z - zn).double().abs().sum().item())             # :93
+        last = _f32((z - zn).abs().sum(dtype=torch.float64).item())   # :93
         y = bf(zn + coef * (zn - z))                                  # :99-100, the next point (bf16 tile)
         z = zn                                                        # :102
         t_mom = t_next

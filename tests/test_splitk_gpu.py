@@ -77,7 +77,7 @@ def test_split_kernel_in_kernel_stop_rule(n):
     Xg, Wg = X.cuda(), W.cuda()
     z0 = torch.zeros(n, 1024, device="cuda")
     lr = 1.0 / LAMBDA_MAX_C2
-    for fast, tol in ((True, 1e-4), (False, 3e-4), (True, 1e-5)):
+    for fast, tol in ((True, 1e-4), (False, 3e-4), (True, 1e-5))[:3 if n <= 1024 else 2]:   # (the 263-iteration CPU run: small batches only)
         tr = orc.FistaTrace()
         orc.fista(X, X.new_zeros(n, 1024), W, 0.5, fast=fast, lr=lr, maxiter=1000, tol=tol, trace=tr)
         zs, info_s = ista(Xg, z0, Wg, 0.5, fast=fast, lr=lr, maxiter=1000, tol=tol, return_info=True,
@@ -122,7 +122,7 @@ def test_chunked_stop_rule_through_multi_round_split_launches(n):
             assert abs(info["last_delta"] - tr.delta[-1]) <= 2e-6 * tr.delta[-1]
 
 
-@pytest.mark.parametrize("n,d,k", [(4096, 256, 768), (3500, 200, 700), (8192, 256, 640)])
+@pytest.mark.parametrize("n,d,k", [(4096, 256, 768), (3500, 200, 700), (4608, 256, 640)])
 def test_768_atom_tile_kernel_is_bitwise_the_1024_atom_kernels(n, d, k):
     """512 < k <= 768 on a large batch runs the 768-atom instantiation of the tile kernel (a quarter less work than
     the padding to 1024); the same rows in a small batch run the split-k kernel padded to 1024.  The canonical
@@ -176,7 +176,7 @@ def test_384_atom_tile_kernels(n, d, k):
     assert (za - zb).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("n,d,k", [(4096, 64, 1024), (5000, 100, 1000), (8192, 128, 768), (4100, 33, 600)])
+@pytest.mark.parametrize("n,d,k", [(4096, 64, 1024), (5000, 100, 1000), (4352, 128, 768), (4100, 33, 600)])
 def test_narrow_tiles_for_short_rows_and_large_dictionaries(n, d, k):
     """d <= 128 with more than 512 atoms on a batch that fills the chip: 4-wave workgroups on 16 x 128 tiles instead of
     8 waves on 16 x 256 (half the padded work; d=64, k=1024: 34 -> 60 TFLOP/s useful).  Bitwise the code of the wide
