@@ -215,11 +215,38 @@ __global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, i
 
 // delta[i] = sum_t partials[i][t], fixed summation order (deterministic).  `alt` (nullable):
 // the rows of the stand-by launch, taken instead when *alt_if != 0 (the split-k kernel gave up).
-__global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles,
-                                       float* __restrict__ delta, const float* __restrict__ alt = nullptr,
-                                       int alt_count = 0, const int* __restrict__ alt_if = nullptr) {
+// `base` (nullable): rows that are always added in front -- a ragged batch whose full rounds ran on the tile kernel
+// and whose tail ran on the split-k kernel (PartialSets below).
+struct PartialSets {
+  const float* src; int n, stride;            // the launch's own partial sums, row i at src + i * stride
+  const float* alt; int alt_n, alt_stride;    // stand-by rows, nullable
+  const int* alt_if;
+  const float* base; int base_n, base_stride; // nullable
+};
+__global__ void reduce_partial_sets_kernel(const PartialSets ps, float* __restrict__ delta) {
   __shared__ float sh[256];
-  if (alt && *alt_if != 0) { partials = alt; ntiles = alt_count; }
+  const float* partials = ps.src;
+  int ntiles = ps.n, stride = ps.stride;
+  if (ps.alt && *ps.alt_if != 0) { partials = ps.alt; ntiles = ps.alt_n; stride = ps.alt_stride; }
+  float acc = 0.0f;
+  if (ps.base) {
+    const float* brow = ps.base + (size_t)blockIdx.x * ps.base_stride;
+    for (int t = threadIdx.x; t < ps.base_n; t += 256) acc += brow[t];
+  }
+  const float* row = partials + (size_t)blockIdx.x * stride;
+  for (int t = threadIdx.x; t < ntiles; t += 256) acc += row[t];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) delta[blockIdx.x] = sh[0];
+}
+
+// the plain form: delta[i] = sum of row i of a dense [rows][ntiles] array (line search, unfused path)
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles, float* __restrict__ delta) {
+  __shared__ float sh[256];
   const float* row = partials + (size_t)blockIdx.x * ntiles;
   float acc = 0.0f;
   for (int t = threadIdx.x; t < ntiles; t += 256) acc += row[t];
@@ -232,23 +259,29 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
   if (threadIdx.x == 0) delta[blockIdx.x] = sh[0];
 }
 
-// reduce_partials_kernel for `iters` rows and chunk_verdict_kernel behind it in ONE workgroup (the asynchronous
+// reduce_partial_sets_kernel for `iters` rows and chunk_verdict_kernel behind it in ONE workgroup (the asynchronous
 // E-step of an EM loop: one launch less on the step's dependent chain).  Every delta[i] is the same sum in the
 // same order as reduce_partials_kernel's.
 struct ChunkVerdict { float budget; int* out; };
-__global__ __launch_bounds__(256) void reduce_verdict_kernel(const float* __restrict__ partials, int ntiles,
-                                                             float* __restrict__ delta, const float* __restrict__ alt,
-                                                             int alt_count, const int* __restrict__ alt_if, int iters,
+__global__ __launch_bounds__(256) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
                                                              float budget, int* __restrict__ out) {
   // One WAVE per row, rows w, w + 4, ...: lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
   // (their strided sums), the first two levels of its tree are then this lane's (a0 + a2) + (a1 + a3), the last six
   // the shuffles below -- no barrier per row.
   __shared__ float sd[64];
-  if (alt && *alt_if != 0) { partials = alt; ntiles = alt_count; }
+  const float* partials = ps.src;
+  int ntiles = ps.n, stride = ps.stride;
+  if (ps.alt && *ps.alt_if != 0) { partials = ps.alt; ntiles = ps.alt_n; stride = ps.alt_stride; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = w; i < iters; i += 4) {
-    const float* row = partials + (size_t)i * ntiles;
+    const float* row = partials + (size_t)i * stride;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ps.base) {
+      const float* brow = ps.base + (size_t)i * ps.base_stride;
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        for (int t = lane + 64 * h; t < ps.base_n; t += 256) a[h] += brow[t];
+    }
 #pragma unroll
     for (int h = 0; h < 4; ++h)
       for (int t = lane + 64 * h; t < ntiles; t += 256) a[h] += row[t];
@@ -439,6 +472,23 @@ bool narrow_tiles(int64_t n, int64_t d, int64_t k, int kp, int hint_bits) {
   return solve_geometry(n, d, k).narrow;
 }
 
+// Tiles of a ragged batch's last, partly filled round that go to the split-k kernel (0: none); see run_impl.
+// `whole`: what plan_kernel() chose for the whole batch (tile kernel alone, or split-k alone); the hybrid must beat it.
+int ragged_tail(int kp, int dpad, int ntiles, int waves, int hint, const KernelPlan& whole, KernelPlan* tail_plan) {
+  const int cus = std::max(device_cus(), 1);
+  const int rounds = (ntiles + cus - 1) / cus;
+  if (rounds < 2 || dpad != kFistaD || waves != kFistaWaves || (hint & 0x300) != LASSO_KERNEL_AUTO) return 0;
+  const int t = ntiles - (rounds - 1) * cus;
+  if (t >= cus) return 0;
+  const KernelPlan sp = plan_kernel(kp, dpad, t, false, LASSO_KERNEL_SPLITK);
+  const double tile_us = kernel_cost(kp).tile_us;
+  if (!sp.split) return 0;
+  const double hybrid_us = (rounds - 1) * tile_us + sp.us;
+  if (hybrid_us >= 0.95 * rounds * tile_us || (whole.split && hybrid_us >= whole.us)) return 0;
+  if (tail_plan) *tail_plan = sp;
+  return t;
+}
+
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
              int64_t ldz_in, const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out,
              float* y_out, int64_t ldy_out, int64_t n, int64_t d, int64_t k, double alpha, double lr,
@@ -478,48 +528,74 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   // inputs, which must still be there
   const bool in_place = (z_in && z_in == z_out) || (y_in && y_in == y_out) || (y_in && y_in == z_out) ||
                         (z_in && y_out && z_in == y_out);
-  const KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, in_place ? LASSO_KERNEL_TILE : hint);
-  int nparts = ntiles;
+  KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, in_place ? LASSO_KERNEL_TILE : hint);
   float* const split_rows = ws.partials + (size_t)kChunkMax * ntiles;    // behind the tile kernel's rows
-  if (plan.split) {
+  // ---- ragged batches (round 4): the tile kernel runs ceil(ntiles / #CUs) rounds, so 257 tiles cost what 512 do.
+  // The LAST, partly filled round goes to the split-k kernel instead when the cost model says so: the full rounds on
+  // the tile kernel (rows [0, n_main)), then the tail's tiles on the split-k kernel (its own launch on the same
+  // stream; rows are independent and a row's code is bitwise the same from either kernel).  n = 5000 at k = 1024:
+  // 63 -> 42 us per iteration.
+  KernelPlan tplan = {false, 0, 1, 0.0};
+  const int tail = (in_place || p.stop_on) ? 0 : ragged_tail(kp, dpad, ntiles, tp.waves, hint, plan, &tplan);
+  if (tail) plan.split = false;                  // (the hybrid beats the split-k kernel on the whole batch as well)
+  // the split-k kernel on the tiles of `q` (+ its stand-by): returns the partial sums per row of that launch
+  auto launch_split = [&](FistaTileParams q, const KernelPlan& pl, float* standby_partials, int* nparts_out) -> int {
     // cross-workgroup hand-offs: epoch tags and the abort flag start from zero in every launch
-    p.xch = ws.xch; p.xflags = ws.xflags; p.groups = plan.groups;
+    q.xch = ws.xch; q.xflags = ws.xflags; q.groups = pl.groups;
     const int members = fista_splitk_members(kp);
-    const int rounds = (ntiles + plan.groups * plan.tiles - 1) / (plan.groups * plan.tiles);
-    nparts = rounds * plan.groups * members;          // one partial per workgroup and round
-    p.part_stride = nparts;
-    if (p.partials) p.partials = split_rows;
+    const int rounds = (q.ntiles + pl.groups * pl.tiles - 1) / (pl.groups * pl.tiles);
+    const int np = rounds * pl.groups * members;      // one partial per workgroup and round
+    *nparts_out = np;
+    q.part_stride = np;
+    if (q.partials) q.partials = split_rows;
     LASSO_HIP_TRY(hipMemsetAsync(ws.xflags, 0, kSplitkFlagBytes, stream));
-    if (!p.stop_on) LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, stream));   // (the stop-rule caller zeroed it)
-    LASSO_HIP_TRY(launch_fista_splitk(p, kp, plan.tiles, stream));
+    if (!q.stop_on) LASSO_HIP_TRY(hipMemsetAsync(ws.stop_out, 0, 16, stream));   // (the stop-rule caller zeroed it)
+    LASSO_HIP_TRY(launch_fista_splitk(q, kp, pl.tiles, stream));
     if (used_split) *used_split = true;
-    if (!p.stop_on) {
+    if (!q.stop_on) {
       // No host synchronisation on this path, so the stand-by is enqueued right behind: the tile
       // kernel, which returns at once unless the split-k kernel raised its abort flag (a peer
       // workgroup was not resident) -- then it redoes the launch from the untouched inputs.
       // (With the stop rule on, the caller reads the flag at its synchronisation instead.)
-      FistaTileParams f = p;
+      FistaTileParams f = q;
       f.run_if = ws.stop_out + 2;
       f.part_stride = ntiles;
-      if (f.partials) f.partials = ws.partials;
-      LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(ntiles, cus), stream, tp.waves));
+      if (f.partials) f.partials = standby_partials;
+      LASSO_HIP_TRY(launch_fista_tile_sp(f, kp, dpad, std::min(q.ntiles, cus), stream, tp.waves));
     }
+    return LASSO_OK;
+  };
+  int nparts = ntiles;
+  const int main_tiles = ntiles - tail;
+  if (plan.split) {
+    if (int st = launch_split(p, plan, ws.partials, &nparts)) return st;
   } else {
     // persistent over tiles: one 8-wave workgroup per CU (LDS bound), or two 4-wave ones
-    const int grid = std::min(ntiles, cus * ((tp.waves == 4 && kp <= 512) ? 2 : 1));   // (4 waves, > 512 atoms: 104 KiB of LDS, one per CU)
-    LASSO_HIP_TRY(launch_fista_tile_sp(p, kp, dpad, grid, stream, tp.waves));
+    FistaTileParams pm = p;
+    if (tail) { pm.n = main_tiles * kTileM; pm.ntiles = main_tiles; }
+    const int grid = std::min(main_tiles, cus * ((tp.waves == 4 && kp <= 512) ? 2 : 1));   // (4 waves, > 512 atoms: 104 KiB of LDS, one per CU)
+    LASSO_HIP_TRY(launch_fista_tile_sp(pm, kp, dpad, grid, stream, tp.waves));
+    if (tail) {
+      const int64_t r0 = (int64_t)main_tiles * kTileM;
+      FistaTileParams q = p;
+      q.X = p.X + r0 * p.ldx;
+      if (p.z_in) q.z_in = p.z_in + r0 * p.ldz_in;
+      if (p.y_in) q.y_in = p.y_in + r0 * p.ldy_in;
+      q.z_out = p.z_out + r0 * p.ldz_out;
+      if (p.y_out) q.y_out = p.y_out + r0 * p.ldy_out;
+      q.n = (int)(n - r0); q.ntiles = tail;
+      if (int st = launch_split(q, tplan, ws.partials + main_tiles, &nparts)) return st;
+    }
   }
   if (delta && iters > 0) {
+    PartialSets ps = {ws.partials, ntiles, ntiles, nullptr, 0, 0, nullptr, nullptr, 0, 0};
+    if (plan.split) ps = {split_rows, nparts, nparts, ws.partials, ntiles, ntiles, ws.stop_out + 2, nullptr, 0, 0};
+    else if (tail) ps = {split_rows, nparts, nparts, ws.partials + main_tiles, tail, ntiles, ws.stop_out + 2,
+                         ws.partials, main_tiles, ntiles};
     if (verdict && iters <= 64)
-      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(256), 0, stream, plan.split ? split_rows : ws.partials,
-                         plan.split ? nparts : ntiles, delta, plan.split ? ws.partials : nullptr, plan.split ? ntiles : 0,
-                         plan.split ? ws.stop_out + 2 : nullptr, iters, verdict->budget, verdict->out);
-    else if (plan.split)
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, split_rows, nparts, delta,
-                         ws.partials, ntiles, ws.stop_out + 2);
+      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(256), 0, stream, ps, delta, iters, verdict->budget, verdict->out);
     else
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(iters), dim3(256), 0, stream, ws.partials, ntiles, delta,
-                         nullptr, 0, nullptr);
+      hipLaunchKernelGGL(reduce_partial_sets_kernel, dim3(iters), dim3(256), 0, stream, ps, delta);
     LASSO_HIP_TRY(hipGetLastError());
   }
   return LASSO_OK;
@@ -1395,14 +1471,20 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
   const NarrowTiles narrow(geom.narrow);
   const int kp = geom.kp, dpad = pad_d(d, kp);
   const KernelPlan plan = plan_kernel(kp, dpad, (int)((n + kTileM - 1) / kTileM), false, LASSO_KERNEL_AUTO);
-  if (plan.split) {
+  const TilePlan tp = plan_tiles(n, dpad, kp);
+  KernelPlan tplan = {false, 0, 1, 0.0};
+  const int tail = ragged_tail(kp, dpad, tp.ntiles, tp.waves, LASSO_KERNEL_AUTO, plan, &tplan);
+  if (plan.split && !tail) {
     static thread_local char name[96];
     if (kp == 1024 && plan.tiles >= 2) snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_rs_kernel<%d>", plan.tiles);
     else snprintf(name, sizeof(name), "lasso::splitk::fista_splitk_kernel<%d, %d, false>", kp, plan.tiles);
     return name;
   }
-  const TilePlan tp = plan_tiles(n, dpad, kp);
-  static thread_local char tname[96];
+  static thread_local char tname[160];
+  if (tail)
+    snprintf(tname, sizeof(tname), "lasso::sp::fista_tile_sp_kernel<%d, %d, false, %d> + the last %d tiles on the split-k kernel (T = %d)",
+             kp, tp.rows, tp.waves, tail, tplan.tiles);
+  else
   snprintf(tname, sizeof(tname), "lasso::sp::fista_tile_sp_kernel<%d, %d, false, %d>", kp, tp.rows, tp.waves);
   return tname;
 }

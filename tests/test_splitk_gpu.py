@@ -206,3 +206,39 @@ def test_narrow_tiles_for_short_rows_and_large_dictionaries(n, d, k):
         _, info = ista(Xg, torch.zeros(n, k, device="cuda"), Wg, 0.3, lr=lr, maxiter=400, tol=1e-4, return_info=True,
                        stop_mode=mode)
         assert info["iterations"] == tr.iterations, (mode, info, tr.iterations)
+
+
+@pytest.mark.parametrize("n,k", [(4100, 1024), (5000, 1024), (6200, 1024), (8200, 1024), (4500, 512), (9000, 300)])
+def test_ragged_batches_run_their_last_round_on_the_split_kernel(n, k):
+    """More tiles than CUs, the last round partly filled: the full rounds run on the tile kernel, the tail's tiles on
+    the split-k kernel (lasso_hip.hip run_impl).  Codes bitwise those of the tile kernel alone -- cold and warm start,
+    FISTA and ISTA --; the per-iteration sums of |z - z_next| (tile rows + split-k rows) agree with it to fp32 rounding,
+    through both reduction kernels; chained chunks (y state in and out) stay bitwise; the stop rule's iteration count
+    is the tile kernel's."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd.engine import HipEngine
+    from lasso_amd import _native as nat
+    name = nat.lib().lasso_fista_kernel_name(n, 256, k, nat.LASSO_F32, 0)
+    assert b"split-k" in name or b"splitk" in name          # (tiny tails: the cost model may give the whole batch to split-k)
+    assert b"split-k" not in nat.lib().lasso_fista_kernel_name(8192, 256, k, nat.LASSO_F32, 0)      # whole rounds: tile kernel only
+    X, W = _case(n, 256, k, seed=n + k)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 0.9 / ((k / 256) * (1.0 + (256 / k) ** 0.5) ** 2)
+    z0 = torch.zeros(n, k, device="cuda")
+    g = torch.Generator().manual_seed(7)
+    warm = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.1)).cuda()
+    for fast, start, iters in ((True, z0, 12), (False, warm, 5)):
+        za = ista(Xg, start, Wg, 0.4, fast=fast, lr=lr, maxiter=iters, tol=0.0)
+        zt = ista(Xg, start, Wg, 0.4, fast=fast, lr=lr, maxiter=iters, tol=0.0, kernel='tile')
+        assert torch.equal(za, zt), (fast, (za - zt).abs().max().item())
+    eng = HipEngine()
+    z1, y1, d1 = eng.fista_run(Xg, Wg, None, None, 0.4, lr, True, 0, 6, True)
+    z2, y2, d2 = eng.fista_run(Xg, Wg, z1, y1, 0.4, lr, True, 6, 5, True)
+    t1, u1, e1 = eng.fista_run(Xg, Wg, None, None, 0.4, lr, True, 0, 6, True, kernel=nat.KERNEL_TILE)
+    t2, u2, e2 = eng.fista_run(Xg, Wg, t1, u1, 0.4, lr, True, 6, 5, True, kernel=nat.KERNEL_TILE)
+    assert torch.equal(z2, t2) and torch.equal(y2, u2)
+    assert (torch.cat([d1, d2]) / torch.cat([e1, e2]) - 1).abs().max().item() <= 2e-6
+    _, ia = ista(Xg, z0, Wg, 0.4, lr=lr, maxiter=300, tol=2e-4, return_info=True)
+    _, it = ista(Xg, z0, Wg, 0.4, lr=lr, maxiter=300, tol=2e-4, return_info=True, kernel='tile')
+    assert ia["iterations"] == it["iterations"] and 5 < ia["iterations"] < 300
+    assert abs(ia["last_delta"] - it["last_delta"]) <= 2e-6 * it["last_delta"]
