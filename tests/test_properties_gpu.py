@@ -141,3 +141,35 @@ def test_stop_rule_survives_a_busy_gpu():
     # the chunked mode on its own (what the fall-back runs)
     z, info = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=2000, tol=1e-5, return_info=True, stop_mode='chunked')
     assert info["iterations"] == 263 and torch.equal(z, z_ref)
+
+
+def test_ragged_batch_tail_survives_a_busy_gpu():
+    """A ragged batch runs its last round on the split-k kernel (run_impl).  When that kernel's workgroups are not all
+    resident (a second stream holds CUs) it gives up and the stand-by tile launch redoes the TAIL rows from the
+    untouched inputs -- codes, per-iteration sums and the stop rule's count as on a quiet GPU."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd.engine import HipEngine
+    n = 4096 + 600
+    X, W = recipe_xw(n)
+    Xg, Wg = X.cuda(), W.cuda()
+    z0 = torch.zeros(n, 1024, device="cuda")
+    lr = 1.0 / LAMBDA_MAX_C2
+    eng = HipEngine()
+    z_ref = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=30, tol=0.0, kernel='tile')
+    _, _, d_ref = eng.fista_run(Xg, Wg, None, None, 0.5, lr, True, 0, 30, True)
+    _, info_ref = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=400, tol=1e-4, return_info=True, kernel='tile')
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    b = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 4 * trial):
+                a = torch.mm(a, b) * 1e-2
+        z = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=30, tol=0.0)
+        _, _, d = eng.fista_run(Xg, Wg, None, None, 0.5, lr, True, 0, 30, True)
+        _, info = ista(Xg, z0, Wg, 0.5, lr=lr, maxiter=400, tol=1e-4, return_info=True)
+        torch.cuda.synchronize()
+        assert torch.equal(z, z_ref), trial
+        assert (d / d_ref - 1).abs().max().item() <= 2e-6, trial
+        assert info["iterations"] == info_ref["iterations"], (trial, info, info_ref)
