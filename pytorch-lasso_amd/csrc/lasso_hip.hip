@@ -1619,6 +1619,34 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     // resident workgroup (LASSO_KERNEL_TILE asks for the multi-launch kernels instead)
     bool ran = false;
     const void* z0_fb = z0_dev;
+    int per_cu = 0;
+    const int64_t cap = bt16_persist_occupancy(kp, &per_cu) == hipSuccess ? (int64_t)per_cu * device_cus() * 64 : 0;
+    if (!backtrack && !stop_rule && cap > 0 && n > cap) {
+      // Fixed step without the stop rule: rows are independent, so a batch beyond the persistent kernel's capacity
+      // (one resident workgroup per 64-row tile: 16384 rows) is a sequence of launches over row blocks of that size
+      // instead of the multi-launch kernels (2.7x slower per row).  With the stop rule or the line search the
+      // decisions need sums over ALL rows at once -- those keep the multi-launch path.
+      const char* xb = (const char*)x_dev; const char* zb = (const char*)z0_dev; char* ob = (char*)z_out_dev;
+      bool all = true;
+      int64_t r0 = 0;
+      for (; r0 < n; r0 += cap) {
+        const int64_t nb = std::min(cap, n - r0);
+        bool ran_b = false;
+        const void* fb = nullptr;
+        const int sb = solve_bf16_persistent(xb + r0 * ldx * 2, ldx, w_dev, ldw, zb ? zb + r0 * ldz0 * 2 : nullptr, ldz0,
+                                             ob + r0 * ldz * 2, ldz, nb, d, k, kp, alpha, lr, fast, maxiter, 0.0, 0,
+                                             eta_backtrack, nullptr, nullptr, nullptr, nullptr, nullptr, workspace_dev,
+                                             workspace_bytes, st, &ran_b, &fb);
+        if (sb != LASSO_OK) return sb;
+        if (!ran_b) { all = false; break; }       // a block gave up (busy GPU): the multi-launch path redoes everything
+      }
+      if (all) {
+        if (iters_out) *iters_out = maxiter;
+        return LASSO_OK;
+      }
+      if (z0_dev && z0_dev == z_out_dev && r0 > 0)
+        return fail(LASSO_ERR_HIP, "in-place bf16 solve interrupted after %lld rows", (long long)r0);
+    } else {
     const int s = solve_bf16_persistent(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr,
                                         fast, maxiter, stop_rule ? tol : 0.0, backtrack, eta_backtrack, iters_out,
                                         last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
@@ -1626,6 +1654,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     if (ran || (s != LASSO_OK && s != LASSO_WARN_LINESEARCH)) return s;
     z0_dev = z0_fb;
     if (z0_fb != z0) ldz0 = k;
+    }
   }
   if (half_any && !backtrack)
     return solve_fixed_bf16(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, kp, alpha, lr, fast,

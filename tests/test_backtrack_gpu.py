@@ -420,3 +420,24 @@ def test_windows_of_the_enqueued_line_search(dtype):
         assert (got.cpu() - ref).abs().max().item() <= 5e-5
     else:
         assert sum(abs(a - b) for a, b in zip(info["trials"], tr.trials)) <= 2
+
+
+def test_bf16_fixed_step_beyond_the_persistent_kernels_capacity():
+    """Fixed step, no stop rule, bf16 tensors, more rows than the single-launch kernel holds resident (64 x #CUs): the
+    batch runs as row blocks of that size on the SAME kernel (rows are independent) -- the codes are bitwise those of
+    the rows solved block by block, in place too, and the objective is the fp32 kernels' to the bf16 bar."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    n = 16384 + 4000
+    X, W = recipe_xw(n)
+    Xb, Wb = X.bfloat16().cuda(), W.bfloat16().cuda()
+    z0 = torch.zeros(n, 1024, dtype=torch.bfloat16, device="cuda")
+    lr = 1.0 / LAMBDA_MAX_C2
+    z = ista(Xb, z0, Wb, 0.5, lr=lr, maxiter=8, tol=0.0)
+    za = ista(Xb[:16384], z0[:16384], Wb, 0.5, lr=lr, maxiter=8, tol=0.0)
+    zb = ista(Xb[16384:], z0[16384:], Wb, 0.5, lr=lr, maxiter=8, tol=0.0)
+    assert torch.equal(z[:16384], za) and torch.equal(z[16384:], zb)
+    zf = ista(Xb.float(), z0.float(), Wb.float(), 0.5, lr=lr, maxiter=8, tol=0.0)
+    ob = orc.lasso_objective(Xb.float().cpu(), z.float().cpu(), Wb.float().cpu(), 0.5).item()
+    of = orc.lasso_objective(Xb.float().cpu(), zf.cpu(), Wb.float().cpu(), 0.5).item()
+    assert abs(ob - of) <= 1e-3 * of, (ob, of)
