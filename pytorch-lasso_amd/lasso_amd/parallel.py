@@ -179,6 +179,19 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
                 z2, _, _ = run(z, y, done, hit + 1, False)
             return result(z2, done + hit + 1, hdelta[hit])
         z, y, done, last = z2, y2, done + c, hdelta[-1]
+        # scheduling only (the stop decision stays exact; every rank holds the same summed vector, so every rank sizes
+        # the next chunk alike): iterations left from the geometric decay over this chunk, approached with short chunks
+        # so that little is speculated past the stopping iteration -- the heuristic of lasso_fista_solve's chunked path
+        chunk = 64
+        if c >= 8 and budget > 0:
+            h = c // 2
+            hi, lo = max(hdelta[:h]), max(hdelta[h:])
+            if lo > budget and hi > lo:
+                left = math.log(lo / budget) / (math.log(hi / lo) / h)
+                if left < 128:
+                    chunk = max(8, min(int(left) - 6, 64))
+            elif lo <= 4 * budget:
+                chunk = 8
     return result(z, done, last)
 
 
