@@ -433,6 +433,23 @@ KernelPlan plan_kernel(int kp, int dpad, int ntiles, bool lockstep, int hint_bit
   return plan;
 }
 
+// Tiles of a ragged batch's last, partly filled round that go to the split-k kernel (0: none); see run_impl.
+// `whole`: what plan_kernel() chose for the whole batch (tile kernel alone, or split-k alone); the hybrid must beat it.
+int ragged_tail(int kp, int dpad, int ntiles, int waves, int hint, const KernelPlan& whole, KernelPlan* tail_plan) {
+  const int cus = std::max(device_cus(), 1);
+  const int rounds = (ntiles + cus - 1) / cus;
+  if (rounds < 2 || dpad != kFistaD || waves != kFistaWaves || (hint & 0x300) != LASSO_KERNEL_AUTO) return 0;
+  const int t = ntiles - (rounds - 1) * cus;
+  if (t >= cus) return 0;
+  const KernelPlan sp = plan_kernel(kp, dpad, t, false, LASSO_KERNEL_SPLITK);
+  const double tile_us = kernel_cost(kp).tile_us;
+  if (!sp.split) return 0;
+  const double hybrid_us = (rounds - 1) * tile_us + sp.us;
+  if (hybrid_us >= 0.95 * rounds * tile_us || (whole.split && hybrid_us >= whole.us)) return 0;
+  if (tail_plan) *tail_plan = sp;
+  return t;
+}
+
 // Geometry of a fixed-step fp32 solve on the fused shapes: padded dictionary size and tile width.
 //   * 256 < k <= 384 with d <= 128: the 384-atom instantiations of the d <= 128 tile kernels;
 //   * 512 < k <= 768: the 768-atom instantiation of the tile kernel (a quarter less work than padding to 1024) where it
@@ -453,7 +470,13 @@ SolveGeom solve_geometry(int64_t n, int64_t d, int64_t k) {
   const int cus = std::max(device_cus(), 1);
   const int rounds = (ntiles + cus - 1) / cus;
   SolveGeom best = {1024, false};
-  double best_us = plan_kernel(1024, kFistaD, ntiles, false, LASSO_KERNEL_AUTO).us;
+  const KernelPlan whole = plan_kernel(1024, kFistaD, ntiles, false, LASSO_KERNEL_AUTO);
+  double best_us = whole.us;
+  {   // a ragged batch at 1024 atoms: full rounds on the tile kernel + the tail on the split-k kernel (run_impl)
+    KernelPlan tp = {false, 0, 1, 0.0};
+    if (ragged_tail(1024, kFistaD, ntiles, kFistaWaves, LASSO_KERNEL_AUTO, whole, &tp))
+      best_us = (rounds - 1) * kernel_cost(1024).tile_us + tp.us;
+  }
   auto consider = [&](int kp, bool narrow, double us_per_round) {
     if (us_per_round * rounds < best_us) { best_us = us_per_round * rounds; best = {kp, narrow}; }
   };
@@ -470,23 +493,6 @@ bool narrow_tiles(int64_t n, int64_t d, int64_t k, int kp, int hint_bits) {
   if ((hint_bits & 0x800) && (hint_bits & 0x300) == LASSO_KERNEL_AUTO) return true;   // A/B knob "narrow": 0x800 ALONE
   if ((hint_bits & 0x300) == LASSO_KERNEL_SPLITK) return false;   // (with LASSO_KERNEL_SPLITK 0x800 is the exchange variant)
   return solve_geometry(n, d, k).narrow;
-}
-
-// Tiles of a ragged batch's last, partly filled round that go to the split-k kernel (0: none); see run_impl.
-// `whole`: what plan_kernel() chose for the whole batch (tile kernel alone, or split-k alone); the hybrid must beat it.
-int ragged_tail(int kp, int dpad, int ntiles, int waves, int hint, const KernelPlan& whole, KernelPlan* tail_plan) {
-  const int cus = std::max(device_cus(), 1);
-  const int rounds = (ntiles + cus - 1) / cus;
-  if (rounds < 2 || dpad != kFistaD || waves != kFistaWaves || (hint & 0x300) != LASSO_KERNEL_AUTO) return 0;
-  const int t = ntiles - (rounds - 1) * cus;
-  if (t >= cus) return 0;
-  const KernelPlan sp = plan_kernel(kp, dpad, t, false, LASSO_KERNEL_SPLITK);
-  const double tile_us = kernel_cost(kp).tile_us;
-  if (!sp.split) return 0;
-  const double hybrid_us = (rounds - 1) * tile_us + sp.us;
-  if (hybrid_us >= 0.95 * rounds * tile_us || (whole.split && hybrid_us >= whole.us)) return 0;
-  if (tail_plan) *tail_plan = sp;
-  return t;
 }
 
 int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const float* z_in,
