@@ -2160,11 +2160,16 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   float* D = (float*)d_dev;
   // (ndeg is written by degenerate_fixup_kernel on every path: no clearing launch in front)
   // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, zero padded to dp columns)
-  if (dp != d) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
+  // The single-launch sweep (dp == 256) reads its old atoms from D itself, never reads the padding of U, and its
+  // last launch writes the new dictionary: no transposed copies, no clearing of U (four launches off the chain).
+  const bool direct = dp == 256 && k % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)D & 15) == 0;
+  if (dp != d && !direct) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
   LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st));
   // Dt[j][dd] = D[dd][j]  (zero padded to dp features)
-  LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
+  if (!direct) LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
   SweepParams p;
+  p.Dsrc = direct ? D : nullptr; p.ldd = ldd;
+  p.Dout = direct ? D : nullptr; p.ldo = ldd;
   p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
@@ -2173,7 +2178,7 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   void* const extra = dp == 256 ? (void*)((char*)ndeg + 256) : nullptr;
   LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
   // D[dd][j] = Dt[j][dd]
-  LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
+  if (!direct) LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
   if (ndeg_out) {
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));

@@ -73,6 +73,10 @@ struct SweepParams {
   const float* A; int64_t lda;           // [k][k]   Z^T Z
   float* U; int64_t ldu;                 // [k][dp]  B - A D^T, updated in place
   float* Dt;                             // [k][dp]  atoms as rows (in/out)
+  const float* Dsrc; int64_t ldd;        // nullable: the dictionary itself, [d][k] -- the single-launch sweep then reads
+                                         //   its old atoms from here (no transposed copy), 16-byte aligned, ldd, k % 4 == 0
+  float* Dout; int64_t ldo;              // nullable: [d][k] the new dictionary, written by the last launch (repair of
+                                         //   the degenerate atoms + transposition in one)
   float* dD;                             // [kSweepBlock][dp] scratch
   int dp;                                // d rounded up to a multiple of 256 (<= kSweepMaxD)
   const float* pool; int pool_rows;      // [pool_rows][pool_ld] replacement directions (nullable)

@@ -431,6 +431,23 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
   const float r3 = __int_as_float(__builtin_amdgcn_readlane(v, 63));
   return (r0 + r1) + (r2 + r3);
 }
+// The same sum, same order, with the row totals combined by row_bcast:15 / row_bcast:31 (lane 63 ends up with
+// (r2 + r3) + (r0 + r1)): two DPP adds and one readlane in place of four readlanes and three adds.
+__device__ __forceinline__ float wave_sum_dpp_bcast(float x) {
+  int v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = __float_as_int(x);
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  // (as assembly: the rows the mask leaves out keep x, which the builtin can only express with a zero-filled
+  // temporary and a separate add; the s_nop are the VALU-write -> DPP-read wait states hipcc does not see in here)
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
 
 // counter-based standard normal (splitmix-style hash + Box-Muller); used only when the
 // caller supplies no replacement pool for degenerate atoms
@@ -608,12 +625,39 @@ __device__ __forceinline__ void sp_mma(f32x4 (&acc)[2][4], const float* __restri
   }
 }
 
+// The sweeper's U rows of the current block in LDS, "quad interleaved": the four rows 4 Q .. 4 Q + 3 at
+// one column are one 16-byte word -- the accumulator of a v_mfma_f32_4x4x1 (register = row of the quad,
+// lane = column) and of the block-level 16x16x4 products (register = row 4 q + rg) alike.
+__device__ __forceinline__ int sp_ub(int row, int col) { return (((row >> 2) * 256 + col) << 2) + (row & 3); }
+
+// One group of a block's product: the 8 delta rows 8 g .. 8 g + 7 (k-steps 2 g, 2 g + 1 of sp_mma, same order)
+template <int NT, typename BLoad>
+__device__ __forceinline__ void sp_mma_group(f32x4 (&acc)[2][NT], const float* __restrict__ sAn, BLoad&& bload, int g,
+                                             int l15, int q) {
+  float b[2][NT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[s][nt] = bload(4 * (2 * g + s) + q, nt);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int ks = 2 * g + s;
+    const float a0 = sAn[l15 * kSpLdA + 4 * ks + q], a1 = sAn[(16 + l15) * kSpLdA + 4 * ks + q];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[s][nt], acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[s][nt], acc[1][nt], 0, 0, 0);
+    }
+  }
+}
+
 struct SweepPersist {
   float* DtN;          // [k][256] new atoms
   float* dDg;          // [nblk * 32][256] published deltas
   float* Uw;           // [nblk * 32][256] worker results
-  int* flags;          // [0] blocks published, [1] abort, [8 + r] rows of block r handed over
+  int* flags;          // [0] groups of 8 deltas published, [1] abort, [8 + r] rows of block r handed over
   int solo;            // 1: one workgroup, no workers
+  int wg_stride;       // worker i is workgroup i * wg_stride (8: every worker on the sweeper's XCD)
   const int* run_if;   // nullable: run only if *run_if != 0 (the stand-by launch)
 };
 constexpr int kSpSelf = 1;      // newest deltas the sweeper applies itself
@@ -628,8 +672,8 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
   const int nblk = (p.k + JB - 1) / JB;
   int* const f_pub = x.flags, * const f_abort = x.flags + 1, * const f_rows = x.flags + 8;
   const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(x.dDg, 0, nblk * JB * DP * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(x.DtN, 0, nblk * JB * DP * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(x.Uw, 0, nblk * JB * DP * 4, 0x00020000);
-  __shared__ int sh_ok;
   // negated A[rb rows][cb columns] -> sAn (zero beyond k)
   // (every load below is unconditional on a clamped address, the mask applied to the value: a
   // load under a lane mask gets its own s_waitcnt and the batch degenerates into a chain of latencies)
@@ -650,8 +694,11 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
 
   if (blockIdx.x > 0) {
     // ---------------- worker: rows of block r ------------------------------------------------
-    const int r = blockIdx.x + kSpSelf;
+    if (blockIdx.x % x.wg_stride) return;
+    const int r = blockIdx.x / x.wg_stride + kSpSelf;
     float* const sAn = smem;                                 // [2][32][34]
+    __shared__ int sh_dead;
+    if (tid == 0) sh_dead = 0;
     f32x4 acc[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -661,32 +708,34 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
         for (int rg = 0; rg < 4; ++rg) {
           const int row = JB * r + 16 * mt + 4 * q + rg;
           const float v = p.U[(int64_t)min(row, kl) * p.ldu + 64 * w + 16 * nt + l15];
-          acc[mt][nt][rg] = row < p.k ? v : 0.0f;
+          acc[mt][nt][rg] = (row < p.k && 64 * w + 16 * nt + l15 < p.d) ? v : 0.0f;   // (the padding is never read)
         }
     load_an(sAn, r, 0, tid, 256);
+    // The deltas arrive in groups of 8 atoms (flags[0] counts the groups): the worker of the block next in
+    // line has consumed three quarters of the newest block's deltas when its last group is published.
+    // Every wave follows the flag itself; the block of A for b + 1 is fetched while the groups of b arrive.
+    bool alive = true;
     for (int b = 0; b <= r - kSpSelf - 1; ++b) {
-      float* const cur = sAn + (b & 1) * JB * kSpLdA;
-      if (w == 0) {
+      __syncthreads();                                       // sAn[b & 1] staged, sAn[(b + 1) & 1] free
+      if (sh_dead) return;
+      const float* const cur = sAn + (b & 1) * JB * kSpLdA;
+      if (b + 1 <= r - kSpSelf - 1) load_an(sAn + ((b + 1) & 1) * JB * kSpLdA, r, b + 1, tid, 256);
+      for (int g = 0; g < 4 && alive; ++g) {
         bool ok = true;
-        if (lane == 0) ok = spin_until(f_pub, b + 1, f_abort);
-        ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-        if (lane == 0) sh_ok = ok;
-      } else if (b + 1 <= r - kSpSelf - 1) {
-        load_an(sAn + ((b + 1) & 1) * JB * kSpLdA, r, b + 1, tid - 64, 192);   // next block of A meanwhile
+        if (lane == 0) ok = spin_until(f_pub, 4 * b + g + 1, f_abort);
+        alive = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        if (alive) sp_mma_group<4>(acc, cur, dd_global(b), g, l15, q);
       }
-      __syncthreads();
-      if (!sh_ok) return;
-      sp_mma(acc, cur, dd_global(b), l15, q);
-      __syncthreads();                                       // sAn / sh_ok reuse
+      if (!alive) sh_dead = 1;
     }
+    __syncthreads();
+    if (sh_dead) return;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][rg]), ursrc,
-              (unsigned)(((JB * r + 16 * mt + 4 * q + rg) * DP + 64 * w + 16 * nt + l15) * 4), 0, 16);
+      for (int nt = 0; nt < 4; ++nt)                         // quad-interleaved, as the sweeper's LDS tile (sp_ub)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), ursrc,
+            (unsigned)((JB * r * DP + sp_ub(16 * mt + 4 * q, 64 * w + 16 * nt + l15)) * 4), 0, 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // written through
     __syncthreads();
     if (tid == 0) __hip_atomic_store(f_rows + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -701,7 +750,8 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
   // deltas of block b - 1 until wave 1 has published them, then the old atoms of block b + 1
   float* const dDl = sAp + 4 * JB * kSpLdA;                  // [2][32][272]
   float* const Ub = dDl + 2 * JB * kSpLdB;                   // [32][272]       U rows of the block
-  __shared__ volatile int pub_done;                          // blocks whose deltas wave 1 has copied out of dDl
+  __shared__ volatile int a_staged;                          // blocks whose A blocks wave 1 has staged
+  __shared__ volatile int chain_prog;                        // atoms whose deltas the chain has written to dDl
   __shared__ volatile int rows_taken;                        // blocks whose Ub rows wave 0 holds in registers
   __shared__ int sh_abort;
   // (loads first, LDS stores after: one memory latency per staging step, not one per loop trip)
@@ -725,42 +775,80 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       const int e = t0 + i * nt, a = e >> 5, c = e & 31;
       if (e < JB * JB) {
         sA[par * JB * JB + e] = ra[i];
+        sAp[(2 * par + 1) * JB * kSpLdA + a * kSpLdA + c] = -ra[i];          // -A[b][b]: A operand of the chain's MFMAs
 #pragma unroll
         for (int h = 0; h < kSpSelf; ++h) sAp[(2 * par + h) * JB * kSpLdA + a * kSpLdA + c] = rp[h][i];
       }
     }
   };
+  // (nt == 128: thread t0 < 64 stages columns 0 .. 127, the others columns 128 .. 255 -- of every row)
   auto stage_rows = [&](int nb, bool from_worker, int t0, auto nt_c) {
     constexpr int nt = decltype(nt_c)::value, kPer = (JB * DP / 4 + nt - 1) / nt;
     f32x4 rv[kPer];
+    auto unit = [&](int i) {                                 // index of the i-th 16-byte unit of this thread
+      if constexpr (nt == 128) {
+        const int u = (t0 & 63) + 64 * i;                    // 0 .. 1023 inside the half
+        return from_worker ? ((u >> 7) * 256 + 128 * (t0 >> 6) + (u & 127)) : ((u >> 5) * 64 + 32 * (t0 >> 6) + (u & 31));
+      } else {
+        return t0 + i * nt;
+      }
+    };
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      const int e = min(t0 + i * nt, JB * DP / 4 - 1), a = e >> 6, c4 = (e & 63) * 4;
-      if (from_worker) {                                     // (wave-uniform)
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ursrc, (unsigned)(((JB * nb + a) * DP + c4) * 4), 0, 16);
+      const int e = min(unit(i), JB * DP / 4 - 1), a = e >> 6, c4 = (e & 63) * 4;
+      if (from_worker) {                                     // (wave-uniform) already quad-interleaved
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ursrc, (unsigned)((JB * nb * DP + 4 * e) * 4), 0, 16);
         rv[i] = __builtin_bit_cast(f32x4, t);
       } else {
         rv[i] = *(const f32x4*)(p.U + (int64_t)min(JB * nb + a, kl) * p.ldu + c4);
-        if (JB * nb + a >= p.k) rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          if (JB * nb + a >= p.k || c4 + f >= p.d) rv[i][f] = 0.0f;
       }
     }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      const int e = t0 + i * nt, a = e >> 6, c4 = (e & 63) * 4;
-      if (e < JB * DP / 4) *(f32x4*)(Ub + a * kSpLdB + c4) = rv[i];
+      const int e = unit(i), a = e >> 6, c4 = (e & 63) * 4;
+      if (e < JB * DP / 4) {
+        if (from_worker) {
+          *(f32x4*)(Ub + 4 * e) = rv[i];
+        } else {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) Ub[sp_ub(a, c4 + f)] = rv[i][f];
+        }
+      }
     }
   };
   auto stage_old = [&](int nb, int t0, auto nt_c, bool wait_pub) {
     constexpr int nt = decltype(nt_c)::value, kPer = JB * DP / 4 / nt;
     f32x4 rv[kPer];
+    if (p.Dsrc) {
+      // from D[d][k]: a unit is four atoms of one feature (16 bytes of a row of D).  Neighbouring lanes take
+      // neighbouring FEATURES (rows of D: the loads are not coalesced, 16 of 128 bytes per row and instruction, the
+      // other seven units of the row come from the cache) so that the four LDS stores of a unit are conflict-free --
+      // with neighbouring atoms in neighbouring lanes they are 8-way conflicts, and the chain next door feels them
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int u = t0 + i * nt, c = u & 255, j = JB * nb + 4 * (u >> 8);
+        rv[i] = *(const f32x4*)(p.Dsrc + (int64_t)min(c, p.d - 1) * p.ldd + min(j, p.k - 4));
+        if (c >= p.d || j >= p.k) rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      float* const dst = dDl + (nb & 1) * JB * kSpLdB;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int u = t0 + i * nt, c = u & 255, a4 = 4 * (u >> 8);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dst[(a4 + f) * kSpLdB + c] = rv[i][f];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       const int e = t0 + i * nt, a = e >> 6, c4 = (e & 63) * 4;
       rv[i] = *(const f32x4*)(p.Dt + (int64_t)min(JB * nb + a, kl) * DP + c4);
       if (JB * nb + a >= p.k) rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (wait_pub)
-      while (pub_done < nb - 1) __builtin_amdgcn_s_sleep(1); // wave 1 has copied the deltas of block nb - 2 + 1 out
+    (void)wait_pub;   // (the deltas this overwrites were published while their chain ran, before the loop-top barrier)
     float* const dst = dDl + (nb & 1) * JB * kSpLdB;
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
@@ -768,7 +856,7 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       *(f32x4*)(dst + a * kSpLdB + c4) = rv[i];
     }
   };
-  if (tid == 0) { rows_taken = 0; sh_abort = 0; pub_done = 0; }
+  if (tid == 0) { rows_taken = 0; sh_abort = 0; chain_prog = 0; a_staged = 0; }
   using I64 = std::integral_constant<int, 64>;
   using I128 = std::integral_constant<int, 128>;
   using I256 = std::integral_constant<int, 256>;
@@ -801,10 +889,8 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            acc[mt][nt][rg] = Ub[(16 * mt + 4 * q + rg) * kSpLdB + 64 * w + 16 * nt + l15];
+        for (int nt = 0; nt < 4; ++nt)     // rows 16 mt + 4 q + (0..3): one quad of the interleaved tile
+          acc[mt][nt] = *(const f32x4*)(Ub + sp_ub(16 * mt + 4 * q, 64 * w + 16 * nt + l15));
       if (solo) {
         float* const sAn = sAp + (2 * (par ^ 1)) * JB * kSpLdA;   // free until block b + 1 is staged
         for (int bb = 0; bb <= b - kSpSelf - 1; ++bb) {
@@ -815,19 +901,14 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
         }
         __syncthreads();
       }
-      if (kSpSelf >= 2 && b >= 2)
-        sp_mma(acc, sAp + (2 * par + 1) * JB * kSpLdA,
-               [&](int kk, int nt) { return dDl[(par * JB + kk) * kSpLdB + 64 * w + 16 * nt + l15]; }, l15, q);
-      sp_mma(acc, sAp + (2 * par) * JB * kSpLdA,
-             [&](int kk, int nt) { return dDl[((par ^ 1) * JB + kk) * kSpLdB + 64 * w + 16 * nt + l15]; }, l15, q);
-      __syncthreads();                                       // all reads of Ub / dDl[par] done
+      const auto dd_lds = [&](int kk, int nt) { return dDl[((par ^ 1) * JB + kk) * kSpLdB + 64 * w + 16 * nt + l15]; };
+      if (solo) sp_mma(acc, sAp + (2 * par) * JB * kSpLdA, dd_lds, l15, q);
+      else sp_mma_group<4>(acc, sAp + (2 * par) * JB * kSpLdA, dd_lds, 3, l15, q);   // (waves 2-3 did groups 0 .. 2)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            Ub[(16 * mt + 4 * q + rg) * kSpLdB + 64 * w + 16 * nt + l15] = acc[mt][nt][rg];
+          *(f32x4*)(Ub + sp_ub(16 * mt + 4 * q, 64 * w + 16 * nt + l15)) = acc[mt][nt];
       __syncthreads();
     }
     if (w == 0) {
@@ -836,52 +917,84 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       const int j0 = JB * b, nb_at = min(JB, p.k - j0), fo = 4 * lane;
       const float* const cA = sA + par * JB * JB;
       float* const dOut = dDl + par * JB * kSpLdB;
-      f32x2 u[JB][2];
+      // lane l holds columns 4 l .. 4 l + 3 of all 32 rows: u[Q][c] = rows 4 Q .. 4 Q + 3 at column 4 l + c
+      const float* const cAn = sAp + (2 * par + 1) * JB * kSpLdA + (lane & 3);
+      f32x4 u[JB / 4][4];
 #pragma unroll
-      for (int a = 0; a < JB; ++a) {
-        const f32x4 t = *(const f32x4*)(Ub + a * kSpLdB + fo);
-        u[a][0] = (f32x2){t[0], t[1]};
-        u[a][1] = (f32x2){t[2], t[3]};
-      }
+      for (int Q = 0; Q < JB / 4; ++Q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[Q][c] = *(const f32x4*)(Ub + sp_ub(4 * Q, fo + c));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps hipcc from sinking the loads past the flag)
       rows_taken = b + 1;
       unsigned degmask = 0;
+      // The rank-one updates of the later rows, u_b -= A[b][a] delta_a, run on the matrix pipe beside the
+      // reduction chain: one v_mfma_f32_4x4x1 (16 blocks: rows of a quad x 4 lanes' columns, k = 1 -- a plain
+      // fused multiply-add per element) updates a quad of rows at 64 columns; its A operand is the quad's
+      // -A[a][4 Q + (lane & 3)], the same for every block.  Rows <= a of the quad that holds atom a are
+      // dead by then, whatever lands in them.  The LDS operands of atom a + 1 are fetched before atom a
+      // writes its delta (hipcc cannot move a load across that store): no LDS latency on the chain.
+      float cqn[JB / 4], caan;
+      f32x4 dcn;
+      auto fetch = [&](auto a_c) {
+        constexpr int a = decltype(a_c)::value;
+#pragma unroll
+        for (int Q = (a + 1) / 4; Q < JB / 4; ++Q) cqn[Q] = cAn[a * kSpLdA + 4 * Q];
+        caan = cA[a * JB + a];
+        dcn = *(const f32x4*)(dOut + a * kSpLdB + fo);        // the old atom; its delta goes back here
+      };
+      fetch(std::integral_constant<int, 0>{});
       auto chain = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;       // all 32 atoms exist: no per-atom branch
         static_for<JB>([&](auto a_c) {
-          constexpr int a = decltype(a_c)::value;
-          float cf[JB];
+          constexpr int a = decltype(a_c)::value, Q0 = a / 4, r0 = a % 4, Qs = (a + 1) / 4;
+          float cq[JB / 4];
 #pragma unroll
-          for (int b4 = 0; b4 < JB / 4; ++b4) {
-            const f32x4 t4 = *(const f32x4*)(cA + a * JB + 4 * b4);
-            cf[4 * b4] = t4[0]; cf[4 * b4 + 1] = t4[1]; cf[4 * b4 + 2] = t4[2]; cf[4 * b4 + 3] = t4[3];
-          }
-          const f32x4 dc4 = *(const f32x4*)(dOut + a * kSpLdB + fo);      // the old atom; its delta goes back here
+          for (int Q = Qs; Q < JB / 4; ++Q) cq[Q] = cqn[Q];
+          const float caa = caan;
+          const f32x4 dc4 = dcn;
+          if constexpr (a + 1 < JB) fetch(std::integral_constant<int, a + 1>{});
           float v[4], ss = 0.0f;
 #pragma unroll
           for (int f = 0; f < 4; ++f) {
-            v[f] = fmaxf(fmaf(cf[a], dc4[f], u[a][f >> 1][f & 1]), lo);   // u_j = U_j + A_jj d_j   (:85-88)
+            v[f] = fmaxf(fmaf(caa, dc4[f], u[Q0][f][r0]), lo);            // u_j = U_j + A_jj d_j   (:85-88)
             ss = fmaf(v[f], v[f], ss);
           }
+#ifndef LASSO_ABL_NORED      // (timing ablations: results invalid)
+#ifdef LASSO_SWEEP_RED_READLANE
           ss = wave_sum_dpp(ss);
+#else
+          ss = wave_sum_dpp_bcast(ss);
+#endif
+#endif
           const bool deg = ss < eps2;
+#ifdef LASSO_ABL_NORSQ
+          const float inv = deg ? 0.0f : ss * 0.001f;
+#else
           const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
+#endif
           f32x4 dnew, delta;
 #pragma unroll
           for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dc4[f]; }
           if (!FULL && a >= nb_at) delta = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (FULL || a < nb_at) {
-            *(f32x4*)(x.DtN + (int64_t)(j0 + a) * DP + fo) = dnew;
+#ifndef LASSO_ABL_NOSTORE
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dnew), nrsrc, (unsigned)(fo * 4),
+                                                   (unsigned)((j0 + a) * DP * 4), 0);
+#endif
             degmask |= (deg ? 1u : 0u) << a;
           }
           *(f32x4*)(dOut + a * kSpLdB + fo) = delta;
-          const f32x2 d01 = {delta[0], delta[1]}, d23 = {delta[2], delta[3]};
+          if constexpr (a % 8 == 7) chain_prog = j0 + a + 1;   // (LDS keeps a wave's writes in order: no wait)
+#ifdef LASSO_ABL_NOUPD
+          constexpr int Qe = Qs + 1 < JB / 4 ? Qs + 1 : JB / 4;     // only the quad of the next atom
+#else
+          constexpr int Qe = JB / 4;
+#endif
 #pragma unroll
-          for (int bb = a + 1; bb < JB; ++bb) {                // v_pk_fma_f32: two features per instruction
-            const f32x2 nc = {-cf[bb], -cf[bb]};
-            u[bb][0] = __builtin_elementwise_fma(nc, d01, u[bb][0]);
-            u[bb][1] = __builtin_elementwise_fma(nc, d23, u[bb][1]);
-          }
+          for (int Q = Qs; Q < Qe; ++Q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              u[Q][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(cq[Q], delta[c], u[Q][c], 0, 0, 0);
         });
       };
       if (nb_at == JB) chain(std::true_type{});
@@ -889,26 +1002,34 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       if (lane < nb_at) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);
       SP_STAMP(2);
     } else if (w == 1) {
-      // ---- wave 1: publish the deltas of block b - 1, then stage the A blocks of block b + 1 ------
+      // ---- wave 1: stage the A blocks of block b + 1, then publish the deltas of THIS block behind the chain,
+      // eight atoms at a time (LDS -> global, written through, drained, then the group count)
       const int nb = b + 1;
       SP_STAMP(4);
-      if (b >= 1) {
-        const float* const src = dDl + (par ^ 1) * JB * kSpLdB;
-#pragma unroll 8
-        for (int e = (tdyn & 63); e < JB * DP / 4; e += 64) {
-          const int a = e >> 6, c4 = (e & 63) * 4;
+      if (b > 0) {       // the last group of block b - 1: its stores were issued before the loop-top barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!solo && lane == 0) __hip_atomic_store(f_pub, 4 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (nb < nblk) {
+        stage_a(nb, par ^ 1, tdyn & 63, I64{});
+        a_staged = nb;                                       // (behind the tile's writes: LDS keeps a wave's order)
+      }
+      SP_STAMP(6);
+      const float* const src = dDl + par * JB * kSpLdB;
+      for (int g = 0; g < 4; ++g) {
+        while (chain_prog < JB * b + 8 * (g + 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int a = 8 * g + i, c4 = (tdyn & 63) * 4;
           const f32x4 v = *(const f32x4*)(src + a * kSpLdB + c4);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drsrc,
-                                                 (unsigned)(((JB * (b - 1) + a) * DP + c4) * 4), 0, 16);
+                                                 (unsigned)(((JB * b + a) * DP + c4) * 4), 0, 16);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads are done: the buffer may be refilled
-        pub_done = b;
+        if (g == 3) break;   // (nobody in this workgroup waits for these stores: drained and flagged in the next trip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // written through
-        if (!solo && lane == 0) __hip_atomic_store(f_pub, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!solo && lane == 0) __hip_atomic_store(f_pub, 4 * b + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       SP_STAMP(5);
-      if (nb < nblk) stage_a(nb, par ^ 1, tdyn & 63, I64{});
-      SP_STAMP(6);
     } else {
       // ---- waves 2-3: old atoms and U rows of block b + 1 ---------------------------------------
       const int ht = tdyn - 128, nb = b + 1;
@@ -926,6 +1047,31 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
         if (!ok) sh_abort = 1;
         else stage_rows(nb, from_worker, ht, I128{});
         if (w == 2) SP_STAMP(9);
+        if (ok && !solo) {
+          // U_{b+1} -= A[b+1][b] dD_b for the first 24 atoms of THIS block, behind the chain (the half of the
+          // columns this wave has just staged); the last 8 atoms' share is what is left at the loop top
+          const int h = w - 2;
+          f32x4 acc2[2][8];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              acc2[mt][nt] = *(const f32x4*)(Ub + sp_ub(16 * mt + 4 * q, 128 * h + 16 * nt + l15));
+          while (a_staged < nb) __builtin_amdgcn_s_sleep(1);
+          for (int g = 0; g < 3; ++g) {
+            while (chain_prog < JB * b + 8 * (g + 1)) __builtin_amdgcn_s_sleep(1);
+            sp_mma_group<8>(acc2, sAp + (2 * (par ^ 1)) * JB * kSpLdA,
+                            [&](int kk, int nt) { return dDl[(par * JB + kk) * kSpLdB + 128 * h + 16 * nt + l15]; },
+                            g, l15, q);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              *(f32x4*)(Ub + sp_ub(16 * mt + 4 * q, 128 * h + 16 * nt + l15)) = acc2[mt][nt];
+          if (w == 2) SP_STAMP(10);
+        }
       }
     }
   }
@@ -984,6 +1130,69 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
     __syncthreads();
     for (int dd = threadIdx.x; dd < p.dp; dd += 256) p.Dt[(int64_t)j * p.dp + dd] = direction(i, j, dd) * inv;
   }
+}
+
+// Last launch of the single-launch sweep: workgroup g takes the 32 new atoms of block g (rows of DtN), replaces the
+// degenerate ones among them exactly as degenerate_fixup_kernel does (the i-th degenerate atom in atom order takes
+// pool row i; same reduction order for its norm), and writes them as columns of the dictionary: repair and
+// transposition in one launch.  Workgroup 0 also leaves the count of degenerate atoms.
+__global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams p) {
+  constexpr int JB = kSweepBlock;
+  __shared__ float tile[JB][257];
+  __shared__ int s_before[256], s_total[256], s_list[JB];
+  __shared__ float sh[256];
+  __shared__ int s_n, s_first;
+  const int tid = threadIdx.x, j0 = JB * blockIdx.x, nb_at = min(JB, p.k - j0);
+  const int per = (p.k + 255) / 256;
+  const int lo = min(tid * per, p.k), hi = min(lo + per, p.k);
+  int before = 0, total = 0;
+  for (int j = lo; j < hi; ++j) {
+    const int f = p.degenerate[j] != 0;
+    total += f;
+    before += (j < j0) ? f : 0;
+  }
+  s_before[tid] = before; s_total[tid] = total;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i, a = e >> 6, c4 = (e & 63) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a < nb_at) v = *(const f32x4*)(p.Dt + (int64_t)(j0 + a) * 256 + c4);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) tile[a][c4 + f] = v[f];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int b = 0, t = 0;
+    for (int i = 0; i < 256; ++i) { b += s_before[i]; t += s_total[i]; }
+    if (blockIdx.x == 0) p.ndeg_in_out[0] = t;
+    int n = 0;
+    if (t)
+      for (int a = 0; a < nb_at; ++a)
+        if (p.degenerate[j0 + a]) s_list[n++] = a;
+    s_n = n; s_first = b;
+  }
+  __syncthreads();
+  for (int i = 0; i < s_n; ++i) {
+    const int a = s_list[i], j = j0 + a, idx = s_first + i;
+    float g = 0.0f;
+    if (tid < p.d) {
+      if (p.pool && p.pool_rows > 0) g = p.pool[(int64_t)min(idx, p.pool_rows - 1) * p.pool_ld + tid];
+      else g = counter_normal(p.seed, (unsigned)j, (unsigned)tid);
+      if (p.positive) g = fmaxf(g, 0.0f);
+    }
+    sh[tid] = fmaf(g, g, 0.0f);
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) sh[tid] += sh[tid + s];
+      __syncthreads();
+    }
+    const float inv = 1.0f / sqrtf(sh[0]);
+    tile[a][tid] = g * inv;
+    __syncthreads();
+  }
+  const int a = tid & 31;
+  if (a < nb_at)
+    for (int c = tid >> 5; c < p.d; c += 8) p.Dout[(int64_t)c * p.ldo + j0 + a] = tile[a][c];
 }
 
 // Deferred form of the replacement (multi-GPU driver): the sweep never reads a replacement
@@ -1258,7 +1467,13 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_persist_kernel), lds);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(x.flags, 0, 4096, stream)) != hipSuccess) return e;
-  const int grid = x.solo ? 1 : nblk - kSpSelf;
+  // Workgroups go round the 8 XCDs in launch order: worker i is workgroup 8 i, on the sweeper's XCD -- deltas and
+  // rows change hands through that XCD's L2.  The workgroups in between return at once.
+#ifndef LASSO_SWEEP_WG_STRIDE
+#define LASSO_SWEEP_WG_STRIDE 8
+#endif
+  x.wg_stride = LASSO_SWEEP_WG_STRIDE;
+  const int grid = x.solo ? 1 : (nblk - kSpSelf - 1) * x.wg_stride + 1;
   hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(256), lds, stream, p, x);
   if (!x.solo) {            // stand-by: runs only if the grid gave up (a workgroup was not resident)
     SweepPersist y = x;
@@ -1280,7 +1495,8 @@ hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* per
     if ((e = sweep_persistent(p, persist_extra, dt_out, stream)) != hipSuccess) return e;
     SweepParams f = p;
     f.Dt = *dt_out;
-    hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, f);
+    if (p.Dout) hipLaunchKernelGGL(fixup_transpose_kernel, dim3((p.k + kSweepBlock - 1) / kSweepBlock), dim3(256), 0, stream, f);
+    else hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, f);
     return hipGetLastError();
   }
   switch (p.dp) {

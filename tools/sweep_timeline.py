@@ -8,7 +8,7 @@ for p in (ROOT, os.path.join(ROOT, 'pytorch-lasso_amd'), os.path.join(ROOT, 'tes
     sys.path.insert(0, p)
 import torch
 from lasso_amd import _native as nat
-nat.use_library(os.path.join(ROOT, 'variants', 'liblasso_sweep_t.so'))
+nat.use_library(sys.argv[sys.argv.index('--lib') + 1] if '--lib' in sys.argv else os.path.join(ROOT, 'variants', 'liblasso_sweep_t.so'))
 from lasso_amd.engine import HipEngine
 eng = HipEngine()
 k, d, n = 1024, 256, 4096
@@ -28,7 +28,7 @@ nblk = (k + 31) // 32; rows = nblk * 32 * 256
 f = ws.view(torch.uint8)
 t = f[off_ex + 3 * rows * 4 + 1024: off_ex + 3 * rows * 4 + 1024 + nblk * 128].view(torch.int64).view(nblk, 16).cpu()
 t0 = int(t[0, 0])
-names = {0: "top", 1: "chain0", 2: "chain1", 4: "h_start", 5: "h_pub", 6: "h_stageA", 7: "h_taken", 8: "h_worker", 9: "h_rows"}
+names = {0: "top", 1: "chain0", 2: "chain1", 4: "h_start", 5: "h_pub", 6: "h_stageA", 7: "h_taken", 8: "h_worker", 9: "h_rows", 10: "h_prog"}
 for b in list(range(0, 6)) + [16, 30, 31]:
     print(b, " ".join("%s=%.2f" % (names[i], (int(t[b, i]) - t0) / 100.0) for i in names if int(t[b, i]) != 0))
 print("total us", (int(t[nblk - 1, 2]) - t0) / 100.0)
