@@ -114,6 +114,13 @@ const char* lasso_hip_last_error(void);
 /* Number of compute units of the current HIP device (0 and LASSO_ERR_HIP if none). */
 int lasso_hip_device_cus(int* cus_out);
 
+/* Test hook.  The atom sweep (lasso_dict_sweep) and the Lipschitz squarings (lasso_lipschitz, LASSO_LR_AUTO) are
+ * single launches of co-operating workgroups, each followed by a stand-by launch that redoes the work in ONE
+ * workgroup when the grid could not get all its workgroups resident (and returns at once otherwise).  on != 0 makes
+ * the library enqueue the stand-by form alone, so that a test can hold it against the co-operative one bit for bit
+ * without having to saturate the GPU.  Returns the previous setting.  Process-wide; not for production use. */
+int lasso_debug_force_standby(int on);
+
 /* ---- FISTA / ISTA solve: replaces lasso/linear/solvers/ista.py:57-104 ------------
  *   min_z 0.5*||z W^T - x||^2 + alpha*||z||_1,  fixed step `lr`.
  *   z0_dev == NULL means zero initialisation (sparse_encode.py:22-23).

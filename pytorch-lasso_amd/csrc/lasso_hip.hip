@@ -1412,6 +1412,12 @@ const char* lasso_hip_status_string(int status) {
 
 const char* lasso_hip_last_error(void) { return g_err; }
 
+int lasso_debug_force_standby(int on) {
+  const int prev = lasso::g_force_standby;
+  lasso::g_force_standby = on ? 1 : 0;
+  return prev;
+}
+
 int lasso_hip_device_cus(int* cus_out) {
   const int c = device_cus();
   if (cus_out) *cus_out = c;

@@ -55,6 +55,9 @@ constexpr size_t kSplitkFlagBytes =
 // means part of the grid is not resident (CUs held by another stream / process); the kernels
 // then abort as a whole and the host repeats the solve on a path without handshakes.
 constexpr int kStopSpinLimit = 1 << 17;
+// lasso_debug_force_standby (lasso_hip.h): the co-operative launches of the sweep and the Lipschitz squarings are
+// skipped, their one-workgroup stand-by forms run alone
+extern int g_force_standby;
 
 // lasso_loss tile kernel (objective.hip)
 struct ObjectiveParams {

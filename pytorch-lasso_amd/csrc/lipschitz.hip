@@ -17,6 +17,7 @@
 #include "lasso_kernels.h"
 
 namespace lasso {
+int g_force_standby = 0;
 namespace {
 
 constexpr int kLipTile = 32;   // output tile per workgroup (256 threads, 2x2 per thread)
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __
 
 // C[e] = sum_z part[z][e]  (fixed order)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const double* __restrict__ part, int splits, int64_t mm,
-                                                            double* __restrict__ C) {
+                                                            double* __restrict__ C, int* __restrict__ zero4 = nullptr) {
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;    // flags of the launch behind this one
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= mm) return;
   double v = part[e];
@@ -458,6 +460,182 @@ static void launch_rayleigh(const double* G, const double* P, int mp, double* ou
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Every squaring of a 64 < mp <= 256 iterate AND the Rayleigh quotient in ONE launch (round 4).  The chain of 20
+// square_f64_kernel launches + 2 for the quotient cost 7.4 us per squaring (a launch each, whether it squares or --
+// once the iterate has converged -- only copies) on a chip that needs 1 us for the arithmetic.  Here the (mp / 32)^2
+// workgroups keep their tile, meet at a barrier in global memory after each squaring (tiles written through,
+// drained, one relaxed atomic per workgroup; loads past the caches), ALL leave the loop at the first squaring whose
+// input already is the rank-one projector (same test, same trace, so the same iterate reaches the quotient as in the
+// multi-launch form, where the remaining squarings only copy), and then each reduces its chunk of <G, P> and tr P --
+// the chunks and orders of rayleigh_partial_kernel / rayleigh_finish_kernel; the workgroup that arrives last adds
+// the partial sums in index order.  Arithmetic per tile is square_f64_kernel's: bitwise the same lambda.
+// All workgroups must be resident (64 at mp = 256): every wait is bounded; on a timeout the grid raises flags[1]
+// and leaves, and a stand-by launch of the same kernel (one workgroup, every tile itself) redoes the computation
+// from G -- it returns at once otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+struct LipPersist {
+  const double* G; double* P0; double* P1; double* part; double* out;
+  int* flags;          // [0] barrier arrivals, [1] abort, [2] quotient arrivals
+  int mp, squarings, solo;
+  const int* run_if;   // nullable: run only if *run_if != 0
+};
+
+__device__ __forceinline__ bool lip_spin_until(const int* flag, int want, int* abort_flag) {
+  for (int spins = 0; spins < kStopSpinLimit; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void square_persist_f64_kernel(const LipPersist x) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  if (x.run_if && *x.run_if == 0) return;
+  extern __shared__ __attribute__((aligned(16))) double sq_smem[];
+  const int mp = x.mp, RS = mp + 1;
+  double* const sa = sq_smem;                 // [32][RS]
+  double* const sb = sq_smem + 32 * RS;       // [32][RS]
+  double* const sh = sq_smem + 64 * RS;       // [256]
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;
+  const int side = mp / 32, tiles = side * side, nwg = x.solo ? 1 : (int)gridDim.x;
+  const unsigned bytes = (unsigned)((size_t)mp * mp * sizeof(double));
+  // device-coherent accesses (sc1): what another workgroup wrote in this launch is read past L1 / L2
+  auto ld2 = [](const __amdgpu_buffer_rsrc_t r, size_t idx) {
+    return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(idx * 8), 0, 16));
+  };
+  auto ld1 = [](const __amdgpu_buffer_rsrc_t r, size_t idx) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)(idx * 8), 0, 16));
+  };
+  auto st1 = [](const __amdgpu_buffer_rsrc_t r, size_t idx, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (unsigned)(idx * 8), 0, 16);
+  };
+  const double* src = x.G;
+  for (int p = 0; p < x.squarings; ++p) {
+    double* const dst = (p & 1) ? x.P1 : x.P0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes, 0x00020000);
+    bool converged = false;
+    for (int t = blockIdx.x; t < tiles; t += nwg) {
+      const int i0 = (t / side) * 32, j0 = (t % side) * 32;
+      f64x2 ra[4][NB], rb[4][NB];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int r = ty + 8 * a, tt = min(2 * (tx + 32 * b), mp - 2);
+          ra[a][b] = ld2(rs, (size_t)(i0 + r) * mp + tt);
+          rb[a][b] = ld2(rs, (size_t)(j0 + r) * mp + tt);
+        }
+      // tr A: the tree of square_f64_kernel
+      sh[tid] = tid < mp ? ld1(rs, (size_t)tid * mp + tid) : 0.0;
+      __syncthreads();
+      if (tid < 128) sh[tid] += sh[tid + 128];
+      __syncthreads();
+      if (tid < 64) {
+        double v = sh[tid] + sh[tid + 64];
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+        if (tid == 0) sh[0] = v;
+      }
+      __syncthreads();
+      const double tr = sh[0];
+      if (p > 0 && 1.0 - tr < 1e-15) { converged = true; break; }   // (the same for every tile and workgroup)
+      const double inv = 1.0 / tr;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int r = ty + 8 * a, tt = 2 * (tx + 32 * b);
+          if (tt < mp) {
+            sa[r * RS + tt] = ra[a][b][0] * inv; sa[r * RS + tt + 1] = ra[a][b][1] * inv;
+            sb[r * RS + tt] = rb[a][b][0] * inv; sb[r * RS + tt + 1] = rb[a][b][1] * inv;
+          }
+        }
+      __syncthreads();
+      const int iw = 16 * (w >> 1), jw = 16 * (w & 1);
+      const int l15 = lane & 15, q = lane >> 4;
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      const double* const pa = sa + (iw + l15) * RS + q;
+      const double* const pb = sb + (jw + l15) * RS + q;
+      for (int c = 0; c < mp / 32; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[32 * c + 4 * ks], pb[32 * c + 4 * ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) st1(rd, (size_t)(i0 + iw + q + 4 * rg) * mp + j0 + jw + l15, acc[rg]);
+      __syncthreads();                                      // (solo: the next tile reuses the LDS tiles)
+    }
+    if (converged) break;
+    src = dst;
+    // every tile of this squaring written before any workgroup reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!x.solo) {
+      if (tid == 0) {
+        __hip_atomic_fetch_add(x.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_ok = lip_spin_until(x.flags, nwg * (p + 1), x.flags + 1);
+      }
+      __syncthreads();
+      if (!sh_ok) return;
+    }
+  }
+  // ---- <G, P> / tr P: chunk c as rayleigh_partial_kernel's workgroup c ----
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(x.part, 0, 2 * kRayBlocks * 8, 0x00020000);
+    double* const r0 = sq_smem, * const r1 = sq_smem + 256;
+    const size_t total = (size_t)mp * mp;
+    const size_t chunk = (total + kRayBlocks - 1) / kRayBlocks;
+    for (int c = blockIdx.x; c < kRayBlocks; c += nwg) {
+      const size_t lo = (size_t)c * chunk, hi = lo + chunk < total ? lo + chunk : total;
+      double acc = 0.0, tr = 0.0;
+      for (size_t e0 = lo + tid; e0 < hi; e0 += 8 * 256) {
+        double gv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const size_t e = e0 + (size_t)256 * u < hi ? e0 + (size_t)256 * u : hi - 1;
+          gv[u] = x.G[e];
+          pv[u] = ld1(rs, e);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const size_t e = e0 + (size_t)256 * u;
+          if (e < hi) {
+            acc = fma(gv[u], pv[u], acc);
+            if (e / mp == e % mp) tr += pv[u];
+          }
+        }
+      }
+      __syncthreads();
+      r0[tid] = acc;
+      r1[tid] = tr;
+      __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) { r0[tid] += r0[tid + s2]; r1[tid] += r1[tid + s2]; }
+        __syncthreads();
+      }
+      if (tid == 0) { st1(rp, 2 * c, r0[0]); st1(rp, 2 * c + 1, r1[0]); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const bool last = x.solo || __hip_atomic_fetch_add(x.flags + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+      if (last) {
+        double num = 0.0, tr = 0.0;
+        for (int b = 0; b < kRayBlocks; ++b) { num += ld1(rp, 2 * b); tr += ld1(rp, 2 * b + 1); }
+        x.out[0] = num / tr;
+      }
+    }
+  }
+}
+
 // splits of a product with contraction length len: one 256-element span per workgroup up to
 // kLipMaxSplits, several spans per workgroup beyond that
 static void lip_splits(int len, int* splits, int* spans_per_split) {
@@ -501,8 +679,36 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
     hipLaunchKernelGGL((syrk_f64_kernel<float, false>), dim3(mp / kLipTile, mp / kLipTile, gs), dim3(256), 0, stream,
                        W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
   }
-  if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G);
+  int* const pflags = reinterpret_cast<int*>(out + 16);
+  const bool persist = mp > 64 && mp <= 256 && squarings > 0 && gs > 1;     // (gs > 1: the fold launch clears the flags)
+  if (gs > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, gs, mm, G,
+                                 persist ? pflags : (int*)nullptr);
   const double* src = G;
+#ifndef LASSO_LIP_MULTI_LAUNCH
+  if (persist) {
+    const size_t lds = (size_t)(64 * (mp + 1) + 256) * sizeof(double);
+    const int nb = (mp + 63) / 64;
+    const void* fn = nb == 2 ? (const void*)&square_persist_f64_kernel<2> : nb == 3 ? (const void*)&square_persist_f64_kernel<3>
+                             : (const void*)&square_persist_f64_kernel<4>;
+    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+    LipPersist x;
+    x.G = G; x.P0 = P[0]; x.P1 = P[1]; x.part = part; x.out = out; x.flags = pflags;
+    x.mp = mp; x.squarings = squarings; x.solo = 0; x.run_if = nullptr;
+    LipPersist y = x;
+    y.solo = 1; y.run_if = pflags + 1;
+    int tiles = (mp / kLipTile) * (mp / kLipTile);
+    if (g_force_standby) { x.solo = 1; tiles = 1; }        // (test hook: the one-workgroup form as the first launch)
+    switch (nb) {
+      case 2: hipLaunchKernelGGL(square_persist_f64_kernel<2>, dim3(tiles), dim3(256), lds, stream, x);
+              hipLaunchKernelGGL(square_persist_f64_kernel<2>, dim3(1), dim3(256), lds, stream, y); break;
+      case 3: hipLaunchKernelGGL(square_persist_f64_kernel<3>, dim3(tiles), dim3(256), lds, stream, x);
+              hipLaunchKernelGGL(square_persist_f64_kernel<3>, dim3(1), dim3(256), lds, stream, y); break;
+      default: hipLaunchKernelGGL(square_persist_f64_kernel<4>, dim3(tiles), dim3(256), lds, stream, x);
+               hipLaunchKernelGGL(square_persist_f64_kernel<4>, dim3(1), dim3(256), lds, stream, y); break;
+    }
+    return hipGetLastError();
+  }
+#endif
   if (mp <= 64 && squarings > 0) {         // small iterate: every squaring in one launch of one workgroup
     if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);
     else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);

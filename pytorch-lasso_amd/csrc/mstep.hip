@@ -1459,9 +1459,7 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
   x.Uw = x.dDg + rows;
   x.flags = (int*)(x.Uw + rows);
   x.solo = nblk <= kSpSelf + 1;
-#ifdef LASSO_SWEEP_FORCE_SOLO   // debugging aid
-  x.solo = 1;
-#endif
+  if (g_force_standby) x.solo = 1;   // (test hook, lasso_debug_force_standby)
   x.run_if = nullptr;
   const size_t lds = (size_t)(2 * kSweepBlock * kSweepBlock + 4 * kSweepBlock * kSpLdA + 3 * kSweepBlock * kSpLdB) * 4;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_persist_kernel), lds);

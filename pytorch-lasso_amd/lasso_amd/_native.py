@@ -56,6 +56,8 @@ def _declare(lib):
     lib.lasso_hip_status_string.argtypes = [i32]
     lib.lasso_hip_last_error.restype = C.c_char_p
     lib.lasso_hip_device_cus.argtypes = [C.POINTER(i32)]
+    lib.lasso_debug_force_standby.restype = i32
+    lib.lasso_debug_force_standby.argtypes = [i32]
     lib.lasso_fista_workspace_bytes.restype = sz
     lib.lasso_fista_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, dbl, i32, i32]
     lib.lasso_fista_kernel_name.restype = C.c_char_p

@@ -471,3 +471,49 @@ def test_g1_dictionary_drift_per_step(golden):
         assert (losses.cpu() - T(g["losses_fix"])[:s]).abs().max().item() <= 1e-5
     assert drift[1] <= 1e-5 and drift[2] <= 2e-5 and drift[5] <= 5e-5, drift
     assert drift[10] <= 1e-4 and drift[20] <= 3e-4 and drift[60] <= 1e-3, drift
+
+
+def test_standby_forms_of_the_cooperative_launches():
+    """The atom sweep and the Lipschitz squarings are single launches of co-operating workgroups with a one-workgroup
+    stand-by behind them (run when the grid could not get resident).  lasso_debug_force_standby enqueues the stand-by
+    form alone: the same dictionary, flags and lambda_max, bit for bit -- also with degenerate atoms (pool rows), a
+    partly filled last block of atoms, d < 256 (padding never read) and a dictionary that is a view (ld > k)."""
+    from lasso_amd import _native as nat
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    lib = nat.lib()
+    cases = []
+    for (n, d, k, seed, dead) in [(4096, 256, 1024, 0, 0), (2048, 64, 256, 1, 3), (1024, 100, 300, 2, 2), (1024, 256, 96, 3, 0)]:
+        g = torch.Generator().manual_seed(seed)
+        Z = torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)
+        if dead:
+            Z[:, torch.randperm(k, generator=g)[:dead]] = 0
+        X = torch.randn(n, d, generator=g)
+        D = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
+        pool = torch.randn(max(dead, 1), d, generator=g)
+        cases.append((Z.cuda(), X.cuda(), D.cuda(), pool.cuda(), dead))
+
+    def run():
+        out = []
+        for Z, X, D, pool, dead in cases:
+            d, k = D.shape
+            A, B = eng.gram(Z, X, torch.empty(k * k + k * d, device="cuda"))
+            wide = torch.zeros(d, k + 8, device="cuda")            # ld = k + 8
+            Dv = wide[:, :k]
+            Dv.copy_(D)
+            mask, ndeg = eng.sweep(A, B, Dv, pool, 1e-10, False)
+            assert ndeg == dead
+            out.append((Dv.clone(), mask.clone(), eng.lipschitz(Dv.contiguous()), eng.lipschitz(D)))
+        torch.cuda.synchronize()
+        return out
+
+    ref = run()
+    assert lib.lasso_debug_force_standby(1) == 0
+    try:
+        alone = run()
+    finally:
+        assert lib.lasso_debug_force_standby(0) == 1
+    for (Dr, mr, l1r, l2r), (Ds, ms, l1s, l2s) in zip(ref, alone):
+        assert torch.equal(Dr, Ds) and torch.equal(mr, ms)
+        assert float(l1r) == float(l1s) and float(l2r) == float(l2s)
+        assert (Dr.norm(dim=0) - 1).abs().max().item() <= 1e-5
