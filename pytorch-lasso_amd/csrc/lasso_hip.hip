@@ -263,9 +263,9 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 // E-step of an EM loop: one launch less on the step's dependent chain).  Every delta[i] is the same sum in the
 // same order as reduce_partials_kernel's.
 struct ChunkVerdict { float budget; int* out; };
-__global__ __launch_bounds__(256) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
-                                                             float budget, int* __restrict__ out) {
-  // One WAVE per row, rows w, w + 4, ...: lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
+__global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
+                                                              float budget, int* __restrict__ out) {
+  // One WAVE per row, rows w, w + 16, ... (16 waves: the 10 rows of an EM step's chunk in one pass): lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
   // (their strided sums), the first two levels of its tree are then this lane's (a0 + a2) + (a1 + a3), the last six
   // the shuffles below -- no barrier per row.
   __shared__ float sd[64];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void reduce_verdict_kernel(const PartialSets p
   int ntiles = ps.n, stride = ps.stride;
   if (ps.alt && *ps.alt_if != 0) { partials = ps.alt; ntiles = ps.alt_n; stride = ps.alt_stride; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = w; i < iters; i += 4) {
+  for (int i = w; i < iters; i += 16) {
     const float* row = partials + (size_t)i * stride;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (ps.base) {
@@ -599,7 +599,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     else if (tail) ps = {split_rows, nparts, nparts, ws.partials + main_tiles, tail, ntiles, ws.stop_out + 2,
                          ws.partials, main_tiles, ntiles};
     if (verdict && iters <= 64)
-      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(256), 0, stream, ps, delta, iters, verdict->budget, verdict->out);
+      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(1024), 0, stream, ps, delta, iters, verdict->budget, verdict->out);
     else
       hipLaunchKernelGGL(reduce_partial_sets_kernel, dim3(iters), dim3(256), 0, stream, ps, delta);
     LASSO_HIP_TRY(hipGetLastError());

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams 
 constexpr int kSpLdB = 272;     // row stride of the [32][256] LDS tiles: MFMA B-operand reads conflict-free
 constexpr int kSpLdA = 34;      // row stride of the negated off-diagonal A blocks (MFMA A operand)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bool spin_until(const int* flag, int want, int* abort_flag) {
@@ -913,19 +914,13 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
     }
     if (w == 0) {
       SP_STAMP(1);
-      // ---- the chain of block b (as sweep_block_kernel<.., 1, 4>), rows and old atoms in registers
-      const int j0 = JB * b, nb_at = min(JB, p.k - j0), fo = 4 * lane;
+      // ---- the chain of block b: rows and old atoms in registers.  Lane l holds columns F l .. F l + F - 1 of
+      // all 32 rows (F = 4; 2 or 1 when d <= 128 / 64: the columns beyond are zero and stay zero, nobody has to
+      // carry them through the chain): u[Q][c] = rows 4 Q .. 4 Q + 3 at column F l + c
+      const int j0 = JB * b, nb_at = min(JB, p.k - j0);
       const float* const cA = sA + par * JB * JB;
       float* const dOut = dDl + par * JB * kSpLdB;
-      // lane l holds columns 4 l .. 4 l + 3 of all 32 rows: u[Q][c] = rows 4 Q .. 4 Q + 3 at column 4 l + c
       const float* const cAn = sAp + (2 * par + 1) * JB * kSpLdA + (lane & 3);
-      f32x4 u[JB / 4][4];
-#pragma unroll
-      for (int Q = 0; Q < JB / 4; ++Q)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) u[Q][c] = *(const f32x4*)(Ub + sp_ub(4 * Q, fo + c));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps hipcc from sinking the loads past the flag)
-      rows_taken = b + 1;
       unsigned degmask = 0;
       // The rank-one updates of the later rows, u_b -= A[b][a] delta_a, run on the matrix pipe beside the
       // reduction chain: one v_mfma_f32_4x4x1 (16 blocks: rows of a quad x 4 lanes' columns, k = 1 -- a plain
@@ -933,72 +928,107 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       // -A[a][4 Q + (lane & 3)], the same for every block.  Rows <= a of the quad that holds atom a are
       // dead by then, whatever lands in them.  The LDS operands of atom a + 1 are fetched before atom a
       // writes its delta (hipcc cannot move a load across that store): no LDS latency on the chain.
-      float cqn[JB / 4], caan;
-      f32x4 dcn;
-      auto fetch = [&](auto a_c) {
-        constexpr int a = decltype(a_c)::value;
+      auto chain_wave = [&](auto f_c) {
+        constexpr int F = decltype(f_c)::value;
+        const int fo = F * lane;
+        auto ldF = [](const float* ptr, float (&v)[F]) {
+          if constexpr (F == 4) { const f32x4 t = *(const f32x4*)ptr; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+          else if constexpr (F == 2) { const f32x2 t = *(const f32x2*)ptr; v[0] = t[0]; v[1] = t[1]; }
+          else v[0] = *ptr;
+        };
+        auto stF = [](float* ptr, const float (&v)[F]) {
+          if constexpr (F == 4) *(f32x4*)ptr = (f32x4){v[0], v[1], v[2], v[3]};
+          else if constexpr (F == 2) *(f32x2*)ptr = (f32x2){v[0], v[1]};
+          else *ptr = v[0];
+        };
+        f32x4 u[JB / 4][F];
 #pragma unroll
-        for (int Q = (a + 1) / 4; Q < JB / 4; ++Q) cqn[Q] = cAn[a * kSpLdA + 4 * Q];
-        caan = cA[a * JB + a];
-        dcn = *(const f32x4*)(dOut + a * kSpLdB + fo);        // the old atom; its delta goes back here
-      };
-      fetch(std::integral_constant<int, 0>{});
-      auto chain = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;       // all 32 atoms exist: no per-atom branch
-        static_for<JB>([&](auto a_c) {
-          constexpr int a = decltype(a_c)::value, Q0 = a / 4, r0 = a % 4, Qs = (a + 1) / 4;
-          float cq[JB / 4];
+        for (int Q = 0; Q < JB / 4; ++Q)
 #pragma unroll
-          for (int Q = Qs; Q < JB / 4; ++Q) cq[Q] = cqn[Q];
-          const float caa = caan;
-          const f32x4 dc4 = dcn;
-          if constexpr (a + 1 < JB) fetch(std::integral_constant<int, a + 1>{});
-          float v[4], ss = 0.0f;
+          for (int c = 0; c < F; ++c) u[Q][c] = *(const f32x4*)(Ub + sp_ub(4 * Q, fo + c));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (also keeps hipcc from sinking the loads past the flag)
+        rows_taken = b + 1;
+        float cqn[JB / 4], caan, dcn[F];
+        auto fetch = [&](auto a_c) {
+          constexpr int a = decltype(a_c)::value;
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            v[f] = fmaxf(fmaf(caa, dc4[f], u[Q0][f][r0]), lo);            // u_j = U_j + A_jj d_j   (:85-88)
-            ss = fmaf(v[f], v[f], ss);
-          }
+          for (int Q = (a + 1) / 4; Q < JB / 4; ++Q) cqn[Q] = cAn[a * kSpLdA + 4 * Q];
+          caan = cA[a * JB + a];
+          ldF(dOut + a * kSpLdB + fo, dcn);                  // the old atom; its delta goes back here
+        };
+        fetch(std::integral_constant<int, 0>{});
+        auto chain = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;     // all 32 atoms exist: no per-atom branch
+          static_for<JB>([&](auto a_c) {
+            constexpr int a = decltype(a_c)::value, Q0 = a / 4, r0 = a % 4, Qs = (a + 1) / 4;
+            float cq[JB / 4];
+#pragma unroll
+            for (int Q = Qs; Q < JB / 4; ++Q) cq[Q] = cqn[Q];
+            const float caa = caan;
+            float dc[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) dc[f] = dcn[f];
+            if constexpr (a + 1 < JB) fetch(std::integral_constant<int, a + 1>{});
+            float v[F], ss = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              v[f] = fmaxf(fmaf(caa, dc[f], u[Q0][f][r0]), lo);            // u_j = U_j + A_jj d_j   (:85-88)
+              ss = fmaf(v[f], v[f], ss);
+            }
 #ifndef LASSO_ABL_NORED      // (timing ablations: results invalid)
 #ifdef LASSO_SWEEP_RED_READLANE
-          ss = wave_sum_dpp(ss);
+            ss = wave_sum_dpp(ss);
 #else
-          ss = wave_sum_dpp_bcast(ss);
+            ss = wave_sum_dpp_bcast(ss);
 #endif
 #endif
-          const bool deg = ss < eps2;
+            const bool deg = ss < eps2;
 #ifdef LASSO_ABL_NORSQ
-          const float inv = deg ? 0.0f : ss * 0.001f;
+            const float inv = deg ? 0.0f : ss * 0.001f;
 #else
-          const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
+            const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
 #endif
-          f32x4 dnew, delta;
+            float dnew[F], delta[F];
 #pragma unroll
-          for (int f = 0; f < 4; ++f) { dnew[f] = v[f] * inv; delta[f] = dnew[f] - dc4[f]; }
-          if (!FULL && a >= nb_at) delta = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (FULL || a < nb_at) {
+            for (int f = 0; f < F; ++f) {
+              dnew[f] = v[f] * inv;
+              delta[f] = (!FULL && a >= nb_at) ? 0.0f : dnew[f] - dc[f];
+            }
+            if (FULL || a < nb_at) {
 #ifndef LASSO_ABL_NOSTORE
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dnew), nrsrc, (unsigned)(fo * 4),
-                                                   (unsigned)((j0 + a) * DP * 4), 0);
+              const unsigned so = (unsigned)((j0 + a) * DP * 4);
+              if constexpr (F == 4)
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(dnew[0]), __float_as_uint(dnew[1]),
+                                                               __float_as_uint(dnew[2]), __float_as_uint(dnew[3])},
+                                                       nrsrc, (unsigned)(fo * 4), so, 0);
+              else if constexpr (F == 2)
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(dnew[0]), __float_as_uint(dnew[1])},
+                                                      nrsrc, (unsigned)(fo * 4), so, 0);
+              else
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnew[0]), nrsrc, (unsigned)(fo * 4), so, 0);
 #endif
-            degmask |= (deg ? 1u : 0u) << a;
-          }
-          *(f32x4*)(dOut + a * kSpLdB + fo) = delta;
-          if constexpr (a % 8 == 7) chain_prog = j0 + a + 1;   // (LDS keeps a wave's writes in order: no wait)
+              degmask |= (deg ? 1u : 0u) << a;
+            }
+            stF(dOut + a * kSpLdB + fo, delta);
+            if constexpr (a % 8 == 7) chain_prog = j0 + a + 1;   // (LDS keeps a wave's writes in order: no wait)
 #ifdef LASSO_ABL_NOUPD
-          constexpr int Qe = Qs + 1 < JB / 4 ? Qs + 1 : JB / 4;     // only the quad of the next atom
+            constexpr int Qe = Qs + 1 < JB / 4 ? Qs + 1 : JB / 4;     // only the quad of the next atom
 #else
-          constexpr int Qe = JB / 4;
+            constexpr int Qe = JB / 4;
 #endif
 #pragma unroll
-          for (int Q = Qs; Q < Qe; ++Q)
+            for (int Q = Qs; Q < Qe; ++Q)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-              u[Q][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(cq[Q], delta[c], u[Q][c], 0, 0, 0);
-        });
+              for (int c = 0; c < F; ++c)
+                u[Q][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(cq[Q], delta[c], u[Q][c], 0, 0, 0);
+          });
+        };
+        if (nb_at == JB) chain(std::true_type{});
+        else chain(std::false_type{});
       };
-      if (nb_at == JB) chain(std::true_type{});
-      else chain(std::false_type{});
+      if (p.d <= 64) chain_wave(std::integral_constant<int, 1>{});
+      else if (p.d <= 128) chain_wave(std::integral_constant<int, 2>{});
+      else chain_wave(std::integral_constant<int, 4>{});
       if (lane < nb_at) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);
       SP_STAMP(2);
     } else if (w == 1) {
@@ -1075,6 +1105,340 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small dictionaries (d <= 64, k <= 256: the 8 x 8 patches of BASELINE config 5): the whole sweep in ONE workgroup
+// with every U row in LDS (k x 64 floats) -- no workers, no hand-offs through memory, no stand-by, no repair launch.
+// Wave 0 runs the chain of block b (one column per lane; the in-block rank-one updates on v_mfma_f32_4x4x1 as in
+// sweep_persist_kernel).  Waves 1-3 own the 32-row blocks r = 1, 2, ... round robin and keep them up to date behind
+// the chain: while the chain of block b runs they apply the finished deltas of block b - 1 to every row block
+// r > b (U_r -= A[r][b-1] dD_{b-1}, 64 v_mfma_f32_16x16x4 per product, the A operands straight from global memory,
+// fetched one product ahead) and the first 24 deltas of block b to row block b + 1 as the chain publishes them; the
+// last 8 are applied by all four waves at the loop top.  They also stage the next block's old atoms and A[b][b] and
+// write the previous block's new atoms into the dictionary (in place: those columns were read a block earlier).
+// Per row block the updates arrive in the order of the other forms of the sweep (blocks ascending, atoms ascending
+// in groups of four on the MFMA) and the chain is sweep_persist_kernel's: bitwise the same dictionary.
+// Degenerate atoms are repaired at the end as degenerate_fixup_kernel does (same reduction order).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSsLdD = 80;      // row stride of the [32][64] delta tiles: MFMA B-operand reads conflict-free
+constexpr int kSsMaxBlk = 8;    // k <= 256
+__device__ __forceinline__ int ss_ub(int row, int col) { return (((row >> 2) * 64 + col) << 2) + (row & 3); }
+
+__global__ __launch_bounds__(256) void sweep_small_kernel(const SweepParams p) {
+  constexpr int JB = kSweepBlock;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nblk = (p.k + JB - 1) / JB, kl = p.k - 1;
+  float* const Ur = smem;                                   // [nblk][8][64][4]  U rows, quad interleaved per block
+  float* const sA = Ur + nblk * JB * 64;                    // [2][32][32]       A[b][b]
+  float* const sAn = sA + 2 * JB * JB;                      // [2][32][34]      -A[b][b]
+  float* const dD = sAn + 2 * JB * kSpLdA;                  // [2][32][80]       deltas of block b
+  float* const oldA = dD + 2 * JB * kSsLdD;                 // [2][32][64]       old atoms of block b
+  __shared__ volatile int chain_prog;
+  __shared__ float sh[256];
+  __shared__ int s_idx[JB * kSsMaxBlk], s_deg[JB * kSsMaxBlk];
+  __shared__ int s_count;
+  const float lo = p.positive ? 0.0f : -INFINITY;
+  const float eps2 = p.eps * p.eps;
+  using I1 = std::integral_constant<int, 1>;
+  using I4 = std::integral_constant<int, 4>;
+
+  // -A[r][bb] operands of one product for this lane: rows 32 r + l15 (+16), columns 32 bb + 4 ks + q.  Through a
+  // buffer descriptor: one multiply per product, the column block as a scalar offset, rows >= k read as zero (beyond
+  // the descriptor); bb < r, so the 32 columns always exist.  (With 64-bit address arithmetic per element, requesting
+  // the operands cost a helper wave more issue time than the products they feed.)
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((int64_t)p.k * p.lda * 4), 0x00020000);
+  auto load_a = [&](int r, int bb, float (&a0)[8], float (&a1)[8]) {
+    const unsigned v0 = (unsigned)(((JB * r + l15) * (int)p.lda + q) * 4), v1 = v0 + (unsigned)(16 * (int)p.lda * 4);
+    const unsigned so = (unsigned)(JB * bb * 4);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      a0[ks] = -__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, v0, so + 16 * ks, 0));
+      a1[ks] = -__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, v1, so + 16 * ks, 0));
+    }
+  };
+  // U_r (columns 16 nt0 .. of NT 16-column tiles) += (-A[r][bb]) dD_bb over the k-steps KS0 .. KS0 + NKS - 1
+  auto product = [&](float* ur, const float* dd, const float (&a0)[8], const float (&a1)[8], int ks0, int nt0,
+                     auto nt_c, auto nks_c) {
+    constexpr int NT = decltype(nt_c)::value, NKS = decltype(nks_c)::value;
+    f32x4 acc[2][NT];
+    float bv[NKS][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[s2][nt] = dd[(4 * (ks0 + s2) + q) * kSsLdD + 16 * (nt0 + nt) + l15];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = *(const f32x4*)(ur + ss_ub(16 * mt + 4 * q, 16 * (nt0 + nt) + l15));
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) {
+      float x0 = a0[0], x1 = a1[0];                         // a0[ks0 + s2] without a dynamically indexed register array
+#pragma unroll
+      for (int i = 1; i < 8; ++i) { x0 = (ks0 + s2 == i) ? a0[i] : x0; x1 = (ks0 + s2 == i) ? a1[i] : x1; }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, bv[s2][nt], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bv[s2][nt], acc[1][nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *(f32x4*)(ur + ss_ub(16 * mt + 4 * q, 16 * (nt0 + nt) + l15)) = acc[mt][nt];
+  };
+  using K2 = std::integral_constant<int, 2>;
+  using K8 = std::integral_constant<int, 8>;
+  auto owner = [](int r) { return 1 + r % 3; };             // the helper wave that keeps row block r up to date
+
+  // ---- everything in: U rows (columns >= d and rows >= k are zero), block 0's old atoms and A[0][0]
+  for (int e0 = tid; e0 < nblk * JB * 16; e0 += 8 * 256) {
+    f32x4 rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = min(e0 + 256 * i, nblk * JB * 16 - 1), row = e >> 4, c4 = (e & 15) * 4;
+      rv[i] = *(const f32x4*)(p.U + (int64_t)min(row, kl) * p.ldu + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = e0 + 256 * i, row = e >> 4, c4 = (e & 15) * 4;
+      if (e < nblk * JB * 16) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          Ur[(row >> 5) * JB * 64 + ss_ub(row & 31, c4 + f)] = (row < p.k && c4 + f < p.d) ? rv[i][f] : 0.0f;
+      }
+    }
+  }
+  {
+    float rv[4];                                            // A[0][0] and its negation
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, a = e >> 5, c = e & 31;
+      const float v = p.A[(int64_t)min(a, kl) * p.lda + min(c, kl)];
+      rv[i] = (a >= p.k || c >= p.k) ? 0.0f : v;
+    }
+    f32x4 ro[2];                                            // columns 0 .. 31 of D -> rows of oldA[0] (zero padded)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, c = u & 63, jj = 4 * (u >> 6);
+      ro[i] = *(const f32x4*)(p.Dsrc + (int64_t)min(c, p.d - 1) * p.ldd + min(jj, p.k - 4));
+      if (c >= p.d || jj >= p.k) ro[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, a = e >> 5, c = e & 31;
+      sA[e] = rv[i];
+      sAn[a * kSpLdA + c] = -rv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, c = u & 63;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) oldA[(4 * (u >> 6) + f) * 64 + c] = ro[i][f];
+    }
+  }
+  if (tid == 0) chain_prog = 0;
+  // operands of this wave's products at the current block: pa* of U_r -= A[r][b-1] dD_{b-1} for its row blocks
+  // r = r0, r0 + 3, r0 + 6 > b; pf* of the chain-following U_{b+1} -= A[b+1][b] dD_b.  They are requested one block
+  // ahead (na*, nf*): no product waits for memory.
+  float pa0[3][8], pa1[3][8], pf0[8], pf1[8], na0[3][8], na1[3][8], nf0[8], nf1[8];
+  if (w > 0 && 1 < nblk && owner(1) == w) load_a(1, 0, pf0, pf1);
+  float top_a[4] = {0.f, 0.f, 0.f, 0.f};
+  // new atoms go straight to the dictionary (lane = feature; the columns of block b were read a block ago)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.Dout, 0, (int)((int64_t)p.d * p.ldo * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Dsrc), 0, (int)((int64_t)p.d * p.ldd * 4), 0x00020000);
+  const unsigned ovoff = lane < p.d ? (unsigned)((int64_t)lane * p.ldo * 4) : 0xFFFFFF00u;   // (beyond the buffer: dropped)
+#ifdef LASSO_SWEEP_TIMING
+  long long* const tlog = (long long*)p.dD;                 // [nblk + 1][8] wall_clock64 stamps (debug builds)
+#define SS_STAMP(slot) do { if (lane == 0) tlog[b * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SS_STAMP(slot) do {} while (0)
+#endif
+  for (int b = 0; b < nblk; ++b) {
+    const int par = b & 1;
+    __syncthreads();                                        // helpers done with block b - 1's work; block b staged
+    if (w == 0) SS_STAMP(0);
+    if (b > 0) {                                            // the last 8 deltas of block b - 1 -> rows of block b
+      float a0[8] = {}, a1[8] = {};                         // (its A operands were fetched a block ago: no memory wait here)
+      a0[6] = top_a[0]; a0[7] = top_a[1]; a1[6] = top_a[2]; a1[7] = top_a[3];
+      product(Ur + b * JB * 64, dD + (par ^ 1) * JB * kSsLdD, a0, a1, 6, w, I1{}, K2{});
+      __syncthreads();
+    }
+    if (b + 1 < nblk) {                                     // -A[b+1][b] at k-steps 6, 7 for the next loop top
+      const unsigned v0 = (unsigned)(((JB * (b + 1) + l15) * (int)p.lda + q) * 4), so = (unsigned)((JB * b + 24) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        top_a[i] = -__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, v0 + (i >> 1) * 16 * (int)p.lda * 4,
+                                                                           so + 16 * (i & 1), 0));
+    }
+    if (w == 0) {
+      SS_STAMP(1);
+      // ---- the chain of block b (sweep_persist_kernel's, one column per lane)
+      const int j0 = JB * b, nb_at = min(JB, p.k - j0);
+      const float* const cA = sA + par * JB * JB;
+      const float* const cAn = sAn + par * JB * kSpLdA + (lane & 3);
+      const float* const ub = Ur + b * JB * 64;
+      const float* const oa = oldA + par * JB * 64;
+      float* const dOut = dD + par * JB * kSsLdD;
+      f32x4 u[JB / 4];
+#pragma unroll
+      for (int Q = 0; Q < JB / 4; ++Q) u[Q] = *(const f32x4*)(ub + ss_ub(4 * Q, lane));
+      unsigned degmask = 0;
+      float cqn[JB / 4], caan, dcn;
+      auto fetch = [&](auto a_c) {
+        constexpr int a = decltype(a_c)::value;
+#pragma unroll
+        for (int Q = (a + 1) / 4; Q < JB / 4; ++Q) cqn[Q] = cAn[a * kSpLdA + 4 * Q];
+        caan = cA[a * JB + a];
+        dcn = oa[a * 64 + lane];
+      };
+      fetch(std::integral_constant<int, 0>{});
+      auto chain = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;        // all 32 atoms exist: no per-atom branch
+      static_for<JB>([&](auto a_c) {
+        constexpr int a = decltype(a_c)::value, Q0 = a / 4, r0 = a % 4, Qs = (a + 1) / 4;
+        float cq[JB / 4];
+#pragma unroll
+        for (int Q = Qs; Q < JB / 4; ++Q) cq[Q] = cqn[Q];
+        const float caa = caan, dc = dcn;
+        if constexpr (a + 1 < JB) fetch(std::integral_constant<int, a + 1>{});
+        const float v = fmaxf(fmaf(caa, dc, u[Q0][r0]), lo);              // u_j = U_j + A_jj d_j   (:85-88)
+        float ss = fmaf(v, v, 0.0f);
+        ss = wave_sum_dpp_bcast(ss);
+        const bool deg = ss < eps2;
+        const float inv = deg ? 0.0f : __builtin_amdgcn_rsqf(ss);
+        const float dnew = v * inv;
+        const float delta = (FULL || a < nb_at) ? dnew - dc : 0.0f;
+        if (FULL || a < nb_at) {
+          degmask |= (deg ? 1u : 0u) << a;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnew), orsrc, ovoff, (unsigned)((j0 + a) * 4), 0);
+        }
+        dOut[a * kSsLdD + lane] = delta;
+        if constexpr (a % 8 == 7) chain_prog = j0 + a + 1;                 // (LDS keeps a wave's writes in order)
+#pragma unroll
+        for (int Q = Qs; Q < JB / 4; ++Q) u[Q] = __builtin_amdgcn_mfma_f32_4x4x1f32(cq[Q], delta, u[Q], 0, 0, 0);
+      });
+      };
+      if (nb_at == JB) chain(std::true_type{});
+      else chain(std::false_type{});
+      SS_STAMP(2);
+      if (lane < JB) s_deg[j0 + lane] = lane < nb_at ? (int)((degmask >> lane) & 1u) : 0;
+      if (lane < nb_at) p.degenerate[j0 + lane] = (int)((degmask >> lane) & 1u);
+    } else {
+      // ---- waves 1-3: this wave's row blocks, then the staging for block b + 1.  Order of the memory traffic: the
+      // staging loads and the next block's A operands are requested first, the products run on operands requested
+      // a block ago, the staged values go to LDS last.
+      const float* const ddp = dD + (par ^ 1) * JB * kSsLdD;              // deltas of block b - 1 (complete)
+      const float* const ddc = dD + par * JB * kSsLdD;                    // deltas of block b (being written)
+      const int nb = b + 1;
+      float sd[16];
+      f32x4 so[8];
+      // (the wave that follows the chain this block -- the owner of row block nb -- stages nothing)
+      const bool st_diag = nb < nblk && w == owner(nb + 1), st_old = nb < nblk && w == owner(nb + 2);
+      if (st_diag) {                                                      // A[nb][nb]
+        // (rows beyond k read as zero through the descriptor; columns beyond k are masked: lane & 31 is the column)
+        const unsigned v0 = (unsigned)((((JB * nb + (lane >> 5)) * (int)p.lda) + JB * nb + (lane & 31)) * 4);
+        const bool colok = JB * nb + (lane & 31) < p.k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, v0 + (unsigned)(2 * i * (int)p.lda * 4), 0, 0));   // (the row in the CHECKED part of the offset)
+          sd[i] = colok ? v : 0.0f;
+        }
+      }
+      if (st_old) {                                                       // old atoms of block nb (feature = lane)
+        const unsigned v0 = (unsigned)((lane * (int)p.ldd + JB * nb) * 4);    // (features >= d: beyond the descriptor, zero)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          so[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srsrc, v0, 16 * i, 0));
+          if (JB * nb + 4 * i >= p.k) so[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      int r1 = b + 2;                                                     // the next block's products
+      while (r1 < nblk && owner(r1) != w) ++r1;
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2)
+        if (r1 + 3 * s2 < nblk) load_a(r1 + 3 * s2, b, na0[s2], na1[s2]);
+      const bool follows_next = b + 2 < nblk && owner(b + 2) == w;
+      if (follows_next) load_a(b + 2, b + 1, nf0, nf1);
+      SS_STAMP(2 + w);
+      int r0 = b + 1;
+      while (r0 < nblk && owner(r0) != w) ++r0;
+      if (b > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+          if (r0 + 3 * s2 < nblk) product(Ur + (r0 + 3 * s2) * JB * 64, ddp, pa0[s2], pa1[s2], 0, 0, I4{}, K8{});
+      }
+      if (nb < nblk && owner(nb) == w) {
+        for (int g = 0; g < 3; ++g) {
+          while (chain_prog < JB * b + 8 * (g + 1)) __builtin_amdgcn_s_sleep(1);
+          product(Ur + nb * JB * 64, ddc, pf0, pf1, 2 * g, 0, I4{}, K2{});
+        }
+      }
+      if (st_diag) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = lane + 64 * i, a = e >> 5, c = e & 31;
+          sA[(nb & 1) * JB * JB + e] = sd[i];
+          sAn[(nb & 1) * JB * kSpLdA + a * kSpLdA + c] = -sd[i];
+        }
+      }
+      if (st_old) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) oldA[((nb & 1) * JB + 4 * i + f) * 64 + lane] = so[i][f];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { pa0[s2][i] = na0[s2][i]; pa1[s2][i] = na1[s2][i]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { pf0[i] = nf0[i]; pf1[i] = nf1[i]; }
+      if (w == 1) SS_STAMP(6);                              // this wave's work done
+      if (w == 2) SS_STAMP(7);
+    }
+  }
+#ifdef LASSO_SWEEP_TIMING
+  { const int b = nblk; if (w == 0) SS_STAMP(0); }
+#endif
+  // ---- degenerate atoms (rare), as degenerate_fixup_kernel: the i-th in atom order takes pool row i
+  __syncthreads();
+  const int ndeg = __syncthreads_count(tid < p.k && s_deg[tid] != 0);     // (k <= 256 threads: one flag each)
+  if (tid == 0) {
+    int c = 0;
+    if (ndeg)                                               // rare: the ordered list, serially
+      for (int jj = 0; jj < p.k; ++jj)
+        if (s_deg[jj]) s_idx[c++] = jj;
+    s_count = c;
+    p.ndeg_in_out[0] = c;
+  }
+  __syncthreads();
+  if (s_count) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = 0; i < s_count; ++i) {
+    const int jj = s_idx[i];
+    float g = 0.0f;
+    if (tid < p.d) {
+      if (p.pool && p.pool_rows > 0) g = p.pool[(int64_t)min(i, p.pool_rows - 1) * p.pool_ld + tid];
+      else g = counter_normal(p.seed, (unsigned)jj, (unsigned)tid);
+      if (p.positive) g = fmaxf(g, 0.0f);
+    }
+    sh[tid] = fmaf(g, g, 0.0f);
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (tid < s2) sh[tid] += sh[tid + s2];
+      __syncthreads();
+    }
+    const float inv = 1.0f / sqrtf(sh[0]);
+    if (tid < p.d) p.Dout[(int64_t)tid * p.ldo + jj] = g * inv;
+    __syncthreads();
+  }
+}
+size_t sweep_small_lds(int k) {
+  const int nblk = (k + kSweepBlock - 1) / kSweepBlock;
+  return (size_t)(nblk * kSweepBlock * 64 + 2 * kSweepBlock * kSweepBlock + 2 * kSweepBlock * kSpLdA +
+                  2 * kSweepBlock * kSsLdD + 2 * kSweepBlock * 64) * 4;
 }
 
 // Replacement directions for the degenerate atoms, in atom order: the i-th degenerate atom
@@ -1489,6 +1853,14 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* persist_extra, float** dt_out) {
   hipError_t e;
   if (dt_out) *dt_out = p.Dt;
+#ifndef LASSO_SWEEP_NO_SMALL
+  if (p.d <= 64 && p.k <= kSweepBlock * kSsMaxBlk && p.Dsrc && p.Dout) {     // the one-workgroup sweep, nothing else
+    const size_t lds = sweep_small_lds(p.k);
+    if ((e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_small_kernel), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(sweep_small_kernel, dim3(1), dim3(256), lds, stream, p);
+    return hipGetLastError();
+  }
+#endif
   if (p.dp == 256 && persist_extra && dt_out) {
     if ((e = sweep_persistent(p, persist_extra, dt_out, stream)) != hipSuccess) return e;
     SweepParams f = p;

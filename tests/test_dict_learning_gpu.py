@@ -517,3 +517,33 @@ def test_standby_forms_of_the_cooperative_launches():
         assert torch.equal(Dr, Ds) and torch.equal(mr, ms)
         assert float(l1r) == float(l1s) and float(l2r) == float(l2s)
         assert (Dr.norm(dim=0) - 1).abs().max().item() <= 1e-5
+
+
+def test_small_dictionaries_sweep_in_one_workgroup():
+    """d <= 64, k <= 256 (BASELINE config 5's shape) runs the sweep as ONE workgroup with every U row in LDS
+    (sweep_small_kernel); a dictionary the library cannot read in place (a view with an odd leading dimension) takes
+    the general single-launch sweep with its worker workgroups and transposed copies instead.  Both are the same
+    sequence of operations per atom: the same dictionary and flags, bit for bit -- full and partly filled last blocks
+    of atoms, d < 64, degenerate atoms (pool rows in atom order), `positive`."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    for (n, d, k, seed, dead, positive) in [(2048, 64, 256, 1, 0, False), (2048, 64, 256, 2, 3, False),
+                                            (1024, 48, 200, 3, 2, True), (512, 64, 32, 4, 0, False),
+                                            (512, 20, 64, 5, 1, False), (1024, 64, 160, 6, 0, False)]:
+        g = torch.Generator().manual_seed(seed)
+        Z = torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)
+        if dead:
+            Z[:, torch.randperm(k, generator=g)[:dead]] = 0
+        X = torch.randn(n, d, generator=g)
+        D = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+        pool = torch.randn(max(dead, 1), d, generator=g).cuda()
+        A, B = eng.gram(Z.cuda(), X.cuda(), torch.empty(k * k + k * d, device="cuda"))
+        D1 = D.clone()
+        m1, n1 = eng.sweep(A, B, D1, pool, 1e-10, positive)
+        odd = torch.zeros(d, k + 1, device="cuda")
+        D2 = odd[:, :k]
+        D2.copy_(D)
+        m2, n2 = eng.sweep(A, B, D2, pool, 1e-10, positive)
+        assert n1 == n2 == dead, (d, k, n1, n2)
+        assert torch.equal(m1, m2) and torch.equal(D1, D2), (d, k)
+        assert (D1.norm(dim=0) - 1).abs().max().item() <= 1e-5

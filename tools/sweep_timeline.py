@@ -12,6 +12,8 @@ nat.use_library(sys.argv[sys.argv.index('--lib') + 1] if '--lib' in sys.argv els
 from lasso_amd.engine import HipEngine
 eng = HipEngine()
 k, d, n = 1024, 256, 4096
+if '--shape' in sys.argv:
+    k, d = [int(v) for v in sys.argv[sys.argv.index('--shape') + 1].split('x')]
 g = torch.Generator().manual_seed(k)
 Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.3)).cuda()
 X = torch.randn(n, d, generator=g).cuda()
@@ -29,6 +31,6 @@ f = ws.view(torch.uint8)
 t = f[off_ex + 3 * rows * 4 + 1024: off_ex + 3 * rows * 4 + 1024 + nblk * 128].view(torch.int64).view(nblk, 16).cpu()
 t0 = int(t[0, 0])
 names = {0: "top", 1: "chain0", 2: "chain1", 4: "h_start", 5: "h_pub", 6: "h_stageA", 7: "h_taken", 8: "h_worker", 9: "h_rows", 10: "h_prog"}
-for b in list(range(0, 6)) + [16, 30, 31]:
+for b in [x for x in list(range(0, 6)) + [16, 30, 31] if x < nblk]:
     print(b, " ".join("%s=%.2f" % (names[i], (int(t[b, i]) - t0) / 100.0) for i in names if int(t[b, i]) != 0))
 print("total us", (int(t[nblk - 1, 2]) - t0) / 100.0)
