@@ -287,7 +287,7 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double x) {
 // P_{i+1} = P_i P_i^T / tr(P_i)^2 as before; the sums inside a squaring are taken in another (fixed) order.
 template <int MP>
 __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __restrict__ G, int squarings,
-                                                                double* __restrict__ Pout) {
+                                                                double* __restrict__ Pout, double* __restrict__ out) {
   constexpr int RS = MP + 2, NBK = MP / 16, NBLK = NBK * (NBK + 1) / 2;   // (row pitch = 4 banks mod 64: the operand reads and the mirror writes are conflict-free)
   __shared__ double buf[2][MP * RS];
   __shared__ double trp[2][4];
@@ -350,7 +350,45 @@ __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __
     __syncthreads();
     cur ^= 1;
   }
-  for (int e = tid; e < MP * MP; e += 1024) Pout[e] = buf[cur][(e / MP) * RS + e % MP];
+  if (!out) {
+    for (int e = tid; e < MP * MP; e += 1024) Pout[e] = buf[cur][(e / MP) * RS + e % MP];
+    return;
+  }
+  // out[0] = <G, P>_F / tr(P), the sums of rayleigh_trace_kernel (1024 threads, same chains and trees) with P read
+  // from LDS instead of from the copy a separate launch would need: one launch less behind the squarings
+  __shared__ double shq[1024];
+  const double* const P = buf[cur];
+  double tr = 0.0;
+  for (int i = tid; i < MP; i += 1024) tr += P[i * RS + i];
+  shq[tid] = tr;
+  __syncthreads();
+  for (int s2 = 512; s2 > 0; s2 >>= 1) {
+    if (tid < s2) shq[tid] += shq[tid + s2];
+    __syncthreads();
+  }
+  tr = shq[0];
+  __syncthreads();
+  double acc = 0.0;
+  constexpr int total = MP * MP;
+  for (int e0 = tid; e0 < total; e0 += 8 * 1024) {
+    double gv[8], pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 1024 * u < total ? e0 + 1024 * u : total - 1;
+      gv[u] = G[e];
+      pv[u] = P[(e / MP) * RS + e % MP];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 1024 * u < total) acc = fma(gv[u], pv[u], acc);
+  }
+  shq[tid] = acc;
+  __syncthreads();
+  for (int s2 = 512; s2 > 0; s2 >>= 1) {
+    if (tid < s2) shq[tid] += shq[tid + s2];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = shq[0] / tr;
 }
 
 // C[e] = sum_z part[z][e]  (fixed order)
@@ -710,9 +748,8 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   }
 #endif
   if (mp <= 64 && squarings > 0) {         // small iterate: every squaring in one launch of one workgroup
-    if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);
-    else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0]);
-    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, P[0], mp, out);
+    if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out);
+    else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out);
     return hipGetLastError();
   }
   if (mp <= 256) {                         // the usual case (d or k <= 256): the low-latency squaring kernel

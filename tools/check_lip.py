@@ -11,7 +11,7 @@ def run(lib):
     if lib: nat.use_library(lib)
     eng = HipEngine()
     out = []
-    for (d, k, seed) in [(256, 1024, 0), (256, 1024, 1), (128, 512, 2), (96, 768, 3), (200, 2048, 4), (256, 4096, 5), (192, 1000, 6)]:
+    for (d, k, seed) in [(64, 256, 7), (32, 100, 8), (48, 300, 9), (64, 64, 10), (256, 1024, 0), (256, 1024, 1), (128, 512, 2), (96, 768, 3), (200, 2048, 4), (256, 4096, 5), (192, 1000, 6)]:
         g = torch.Generator().manual_seed(seed)
         W = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
         L = eng.lipschitz(W)
