@@ -173,3 +173,35 @@ def test_ragged_batch_tail_survives_a_busy_gpu():
         assert torch.equal(z, z_ref), trial
         assert (d / d_ref - 1).abs().max().item() <= 2e-6, trial
         assert info["iterations"] == info_ref["iterations"], (trial, info, info_ref)
+
+
+def test_cooperative_mstep_launches_survive_a_busy_gpu():
+    """The atom sweep (sweeper + worker workgroups) and the Lipschitz squarings (a barrier across 64 workgroups) need
+    their workgroups resident at once.  With a second stream saturating the GPU that may not hold: every wait in
+    them is bounded, the grid gives up as a whole and the one-workgroup stand-by launch behind it redoes the work --
+    the same dictionary and lambda_max as on a quiet GPU, no error, no hang."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    g = torch.Generator().manual_seed(11)
+    n, d, k = 4096, 256, 1024
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)).cuda()
+    X = torch.randn(n, d, generator=g).cuda()
+    D = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+    A, B = eng.gram(Z, X, torch.empty(k * k + k * d, device="cuda"))
+    D_ref = D.clone()
+    eng.sweep(A, B, D_ref, None, 1e-10, False)
+    l_ref = float(eng.lipschitz(D_ref))
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    b = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 4 * trial):            # ~10 ms each: the GPU stays busy for a while
+                a = torch.mm(a, b) * 1e-2
+        D1 = D.clone()
+        eng.sweep(A, B, D1, None, 1e-10, False)
+        l1 = float(eng.lipschitz(D1))
+        torch.cuda.synchronize()
+        assert torch.equal(D1, D_ref), trial
+        assert l1 == l_ref, trial
