@@ -1503,19 +1503,21 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
 __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams p) {
   constexpr int JB = kSweepBlock;
   __shared__ float tile[JB][257];
-  __shared__ int s_before[256], s_total[256], s_list[JB];
+  __shared__ int s_list[JB], s_bsum, s_tsum;
   __shared__ float sh[256];
   __shared__ int s_n, s_first;
   const int tid = threadIdx.x, j0 = JB * blockIdx.x, nb_at = min(JB, p.k - j0);
   const int per = (p.k + 255) / 256;
   const int lo = min(tid * per, p.k), hi = min(lo + per, p.k);
+  if (tid == 0) { s_bsum = 0; s_tsum = 0; }
+  __syncthreads();
   int before = 0, total = 0;
   for (int j = lo; j < hi; ++j) {
     const int f = p.degenerate[j] != 0;
     total += f;
     before += (j < j0) ? f : 0;
   }
-  s_before[tid] = before; s_total[tid] = total;
+  if (total) { atomicAdd(&s_tsum, total); atomicAdd(&s_bsum, before); }   // (integer sums: any order; no degenerate atom, no atomic)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = tid + 256 * i, a = e >> 6, c4 = (e & 63) * 4;
@@ -1526,8 +1528,7 @@ __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams 
   }
   __syncthreads();
   if (tid == 0) {
-    int b = 0, t = 0;
-    for (int i = 0; i < 256; ++i) { b += s_before[i]; t += s_total[i]; }
+    const int b = s_bsum, t = s_tsum;
     if (blockIdx.x == 0) p.ndeg_in_out[0] = t;
     int n = 0;
     if (t)
