@@ -574,21 +574,27 @@ __global__ __launch_bounds__(64 * NW) void sweep_block_kernel(const SweepParams 
 // ---------------------------------------------------------------------------
 // The whole sweep in ONE launch (dp == 256): the multi-launch form above spends more than half
 // of its time in the fixed cost of its 2 k/32 dependent launches (~4.8 us each, against 8 us of
-// atom chain per block).  Workgroup 0 ("sweeper") walks the blocks; workgroup r - 2 owns the 32
-// U rows of block r >= 3 ("worker"): it keeps them in MFMA accumulators, applies
-// U_r -= A[r, b] dD_b for b = 0 .. r-3 as each dD_b is published, and hands the rows over.  The
-// sweeper applies the two newest deltas, dD_{r-2} and dD_{r-1}, itself (from LDS), so a worker
-// always has a block time of slack and the chain never waits for it.  Inside the sweeper wave 0
-// runs the chain of block b (U rows and old atoms in registers, no memory wait on the chain);
-// waves 1-3 meanwhile publish the deltas of block b - 1 (LDS -> global, written through, drained,
-// then the flag) and stage block b + 1 (A blocks, old atoms, U rows).
+// atom chain per block).  Workgroup 0 ("sweeper") walks the blocks; a "worker" workgroup owns the 32
+// U rows of block r >= 2: it keeps them in MFMA accumulators, applies U_r -= A[r, b] dD_b for
+// b = 0 .. r-2 as the deltas are published -- in GROUPS of 8 atoms (flags[0] counts groups), so that
+// three quarters of the newest block are in when its last group arrives -- and hands the rows over
+// (quad-interleaved, the layout of the sweeper's LDS tile).  The sweeper applies the newest block,
+// dD_{r-1}, itself from LDS.  Inside the sweeper (round 4):
+//   wave 0   the chain of block b: U rows, old atoms and coefficients in registers, no memory wait;
+//            in-block rank-one updates on v_mfma_f32_4x4x1; a progress word in LDS after every 8 atoms;
+//   wave 1   stages the A blocks of block b + 1, then copies the deltas of block b to global memory
+//            behind the chain, a group at a time (written through, drained, then the group count; the
+//            last group's drain and flag wait until after the loop-top barrier);
+//   waves 2-3 stage the old atoms (from D itself when the caller's dictionary can be read in place)
+//            and the U rows of block b + 1, then apply the first 24 deltas of block b to those rows
+//            while the chain runs; all four waves add the last 8 at the loop top.
 // Hand-offs as in fista_splitk.hip: payload written through (sc1) and drained, then a flag;
 // consumers load past their L1/L2 (sc1).  Every spin is bounded: on a timeout (a workgroup is
 // not resident) the grid raises flags[1] and leaves; a stand-by launch of the same kernel in
-// solo mode (one workgroup doing the workers' updates itself, from the untouched U / Dt)
-// then runs -- it returns at once otherwise.  New atoms go to DtN, never over Dt.
+// solo mode (one workgroup doing the workers' updates itself, from the untouched U / D)
+// then runs -- it returns at once otherwise.  New atoms go to DtN, never over the old ones.
 // Arithmetic of a row block is the same sequence in both modes (updates b = 0 .. r-1 in order,
-// each one v_mfma_f32_16x16x4_f32 chain over the 32 atoms of block b).
+// each one v_mfma_f32_16x16x4_f32 chain over the 32 atoms of block b, whoever issues its k-steps).
 // ---------------------------------------------------------------------------
 constexpr int kSpLdB = 272;     // row stride of the [32][256] LDS tiles: MFMA B-operand reads conflict-free
 constexpr int kSpLdA = 34;      // row stride of the negated off-diagonal A blocks (MFMA A operand)
