@@ -1700,7 +1700,10 @@ bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t 
   const int nb = k / kG3B, blocks = nb * (nb + 1) / 2 + nb * (d / kG3B);
   // Sample splits: one workgroup per CU at a time (LDS), so the launch runs in ceil(blocks * s / cus) rounds; every
   // split also writes and re-reads k (k + d) partial sums.  Pick the s with the least modelled time.
-  const int smax = (int)std::min<size_t>(std::min(n / 512, kGramAbMaxSplits), scratch_bytes / ((size_t)k * (k + d) * 4));
+#ifndef LASSO_GRAM_AB_MIN_ROWS
+#define LASSO_GRAM_AB_MIN_ROWS 256   // (round 4: it was 512; an 8192-row shard then had at most 16 splits = 224 workgroups)
+#endif
+  const int smax = (int)std::min<size_t>(std::min(n / LASSO_GRAM_AB_MIN_ROWS, kGramAbMaxSplits), scratch_bytes / ((size_t)k * (k + d) * 4));
   if (smax < 1) return false;
   const double work = (double)blocks * kG3B * kG3B * 2.0 * n / 130e12, fold = (double)k * (k + d) * 8.0 / 3e12;
   int splits = 1;
@@ -1730,6 +1733,12 @@ static bool gram_use128(const float* P, int64_t ldp, int pc, const float* Q, int
          ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
 }
 
+#ifndef LASSO_GRAM_MIN_ROWS
+#define LASSO_GRAM_MIN_ROWS 128
+#endif
+// samples a split keeps at least (round 4: 128, it was 512 -- an 8192-row shard of a k = 256 dictionary ran its three
+// 128 x 128 blocks of Z^T Z on 48 workgroups, 16 chunks of samples each: 48 us)
+constexpr int kGramMinRows = LASSO_GRAM_MIN_ROWS;
 int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits) {
   int blocks = ((qc + kGB - 1) / kGB) * ((pc + kGB - 1) / kGB);
   if (sym) blocks = blocks / 2 + (pc + kGB - 1) / kGB / 2 + 1;
@@ -1737,11 +1746,11 @@ int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits) {
     const int nbp = (pc + kG2B - 1) / kG2B, nbq = (qc + kG2B - 1) / kG2B;
     blocks = sym ? nbp * (nbp + 1) / 2 : nbp * nbq;
     int s2 = std::max(1, 2 * cus / std::max(blocks, 1));   // one round of resident workgroups, no tail
-    s2 = std::min(s2, std::max(n / 512, 1));
+    s2 = std::min(s2, std::max(n / kGramMinRows, 1));
     return std::max(1, std::min(s2, max_splits));
   }
   int s = (3 * cus + blocks - 1) / std::max(blocks, 1);
-  s = std::min(s, std::max(n / 512, 1));
+  s = std::min(s, std::max(n / kGramMinRows, 1));
   return std::max(1, std::min(s, max_splits));
 }
 
