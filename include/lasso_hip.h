@@ -102,6 +102,12 @@ typedef enum {
  * host wait anywhere: every rank reads the same verdict ("redo" when the rule fired before the last
  * iteration) at its one synchronisation per EM step. */
 #define LASSO_SOLVE_SHARDED 0x8000
+/* OR into stop_mode together with LASSO_SOLVE_ASYNC when the rule is NOT expected to fire before `maxiter`
+ * (<= 64) iterations -- the E-step of an EM loop: the solve is then always enqueued as one chunk on the plain
+ * kernels and judged on the device (the in-kernel rule costs a cross-workgroup exchange per iteration that only
+ * pays when it stops a long solve early).  Same words from lasso_fista_solve_finish / _collect; when the rule
+ * does fire early they say "redo" (LASSO_WARN_ABORTED) exactly as for any other one-chunk solve. */
+#define LASSO_SOLVE_ONE_CHUNK 0x10000
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
  * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device
  * memory -- no host round trip; other paths synchronise once to fetch it. */

@@ -1573,7 +1573,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
-                      const double* lip_dev = nullptr, bool sharded = false) {
+                      const double* lip_dev = nullptr, bool sharded = false, bool one_chunk = false) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1732,7 +1732,10 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     // handshake times out, the kernel aborts as a whole without touching z_out, and the solve
     // is repeated on the chunked path below.
     // (the rule's granule fetch covers 256 tiles: four per lane of one wave)
-    if (ntiles <= std::min(fista_resident_workgroups(kps, pad_d(d, kps), tp.waves), 256)) {
+    // (LASSO_SOLVE_ONE_CHUNK: the caller expects all `maxiter` iterations to run -- the plain kernels + the device
+    // verdict below are cheaper per iteration than the in-kernel rule's exchange)
+    const bool as_chunk = one_chunk && async && maxiter <= kChunkMax && !(z0 && z0 == zout);
+    if (!as_chunk && ntiles <= std::min(fista_resident_workgroups(kps, pad_d(d, kps), tp.waves), 256)) {
       // (granule ring and stop_out were zeroed by the prepare launch)
       if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                            alpha, lr, fast, 0, maxiter, nullptr, st, budget, hint, nullptr, lr_dev))
@@ -1844,7 +1847,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   if (objective_out) *objective_out = NAN;
   const bool async = (stop_mode & LASSO_SOLVE_ASYNC) != 0;
   const bool sharded = (stop_mode & LASSO_SOLVE_SHARDED) != 0;
-  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED);
+  const bool one_chunk = (stop_mode & LASSO_SOLVE_ONE_CHUNK) != 0;
+  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK);
   if (sharded && !(async && tol > 0.0 && maxiter > 0 && n > 0 && fused_shape(d, k)))
     return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: asynchronous fp32 solves with tol > 0 on the fused shapes only");
   if (async && (objective_out || backtrack || dtype != LASSO_F32))
@@ -1881,7 +1885,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded);
+                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)

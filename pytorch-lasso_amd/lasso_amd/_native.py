@@ -20,6 +20,7 @@ STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
 ABI_VERSION = 4
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
+SOLVE_ONE_CHUNK = 0x10000
 SOLVE_SHARDED = 0x8000
 LR_AUTO = -1.0
 

@@ -289,7 +289,10 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
                          shard=shard)
 
 
-_STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE}
+_STOP = {'global': nat.STOP_GLOBAL, 'chunked': nat.STOP_GLOBAL_CHUNKED, 'none': nat.STOP_NONE,
+         # begin=True only: the rule is not expected to fire before maxiter (<= 64) iterations -- one chunk on the plain
+         # kernels, judged on the device (LASSO_SOLVE_ONE_CHUNK); "repeat" when it does fire early
+         'one-chunk': nat.STOP_GLOBAL | nat.SOLVE_ONE_CHUNK}
 _KERNEL = {'auto': nat.KERNEL_AUTO, 'tile': nat.KERNEL_TILE, 'splitk': nat.KERNEL_SPLITK,
            'splitk1': nat.KERNEL_SPLITK | 0x1000, 'splitk2': nat.KERNEL_SPLITK | 0x2000,
            'splitk4': nat.KERNEL_SPLITK | 0x3000,

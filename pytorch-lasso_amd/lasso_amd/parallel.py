@@ -286,11 +286,18 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
         A, B = engine.gram(Z, X, buf)
         return loss_local, sums, A, B
 
+    # An E-step practically never stops before its `maxiter` (default 10) iterations: ask for the one-chunk form of the
+    # asynchronous solve (plain kernels + the verdict on the device) instead of the in-kernel rule's per-iteration
+    # exchange; a step where the rule does fire early is repeated on the chunked path below, like an aborted handshake.
+    begin_kwargs = dict(solver_kwargs)
+    if ('stop_mode' not in begin_kwargs and begin_kwargs.get('algorithm', 'ista') == 'ista'
+            and 0 < int(begin_kwargs.get('maxiter', 10)) <= 64):
+        begin_kwargs['stop_mode'] = 'one-chunk'
     i, Zlast = 0, None
     while i < steps:
         pending, sharded = None, False
         if overlap:
-            Z, pending = engine.encode_begin(X, weight, alpha, Z0, **solver_kwargs)       # :38
+            Z, pending = engine.encode_begin(X, weight, alpha, Z0, **begin_kwargs)        # :38
         elif not ndelta:
             Z = encode_sync()
         else:

@@ -547,3 +547,26 @@ def test_small_dictionaries_sweep_in_one_workgroup():
         assert n1 == n2 == dead, (d, k, n1, n2)
         assert torch.equal(m1, m2) and torch.equal(D1, D2), (d, k)
         assert (D1.norm(dim=0) - 1).abs().max().item() <= 1e-5
+
+
+def test_em_steps_whose_stop_rule_fires_early():
+    """em_loop asks for the one-chunk form of the asynchronous E-step (LASSO_SOLVE_ONE_CHUNK: plain kernels, verdict
+    on the device) because an E-step practically never stops before its 10 iterations.  With a loose tolerance it
+    does: the verdict then says "repeat", the step is redone on the chunked path, and dictionary and losses are those
+    of the in-kernel rule and of the chunked rule asked for explicitly, bit for bit."""
+    from lasso_amd.linear import dict_learning
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(4096, 64, generator=g).cuda()
+    W0 = torch.nn.functional.normalize(torch.randn(64, 256, generator=g), dim=0)
+    outs = []
+    for extra in ({}, {"stop_mode": "global"}, {"stop_mode": "chunked"}):
+        w, losses = dict_learning(X, 256, alpha=0.2, steps=4, init_weight=W0.clone(), lr=0.05, maxiter=10, tol=0.03,
+                                  **extra)
+        outs.append((w.clone(), torch.as_tensor(losses).clone()))
+    # the rule must really have fired early at this tolerance (else the test shows nothing)
+    from lasso_amd.linear.solvers import ista
+    _, info = ista(X, torch.zeros(4096, 256, device="cuda"), W0.cuda(), 0.2, lr=0.05, maxiter=10, tol=0.03,
+                   return_info=True)
+    assert info["iterations"] < 10, info
+    for w, l in outs[1:]:
+        assert torch.equal(w, outs[0][0]) and torch.equal(l, outs[0][1])
