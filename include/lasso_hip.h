@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LASSO_HIP_ABI_VERSION 4
+#define LASSO_HIP_ABI_VERSION 5
 
 typedef enum {
   LASSO_OK = 0,

@@ -17,7 +17,7 @@ LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
 SOLVE_ONE_CHUNK = 0x10000
