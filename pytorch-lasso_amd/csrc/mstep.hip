@@ -222,16 +222,21 @@ __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restr
       }
 }
 
-// sum_s base[s * stride], s = 0 .. splits-1, added in that order; the loads of eight terms are in flight together
-// (with many splits -- small dictionaries -- a load per dependent add was a memory round trip per split)
+// sum_s base[s * stride], s = 0 .. splits-1, added in that order; the loads of kFoldBatch terms are in flight together
+// (with many splits -- small dictionaries, shards -- a load per dependent add was a memory round trip per split;
+// round 4: 16 instead of 8 -- 64 splits of a shard's Gram product are four round trips, not eight)
+#ifndef LASSO_FOLD_BATCH
+#define LASSO_FOLD_BATCH 16
+#endif
+constexpr int kFoldBatch = LASSO_FOLD_BATCH;
 __device__ __forceinline__ float ordered_split_sum(const float* __restrict__ base, int64_t stride, int splits) {
   float acc = 0.0f;
-  for (int s0 = 0; s0 < splits; s0 += 8) {
-    float v[8];
+  for (int s0 = 0; s0 < splits; s0 += kFoldBatch) {
+    float v[kFoldBatch];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s0 + u, splits - 1) * stride];
+    for (int u = 0; u < kFoldBatch; ++u) v[u] = base[(int64_t)min(s0 + u, splits - 1) * stride];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < kFoldBatch; ++u)
       if (s0 + u < splits) acc += v[u];
   }
   return acc;
@@ -250,20 +255,20 @@ __device__ __forceinline__ void sum_splits_sym_body(int block, const float* __re
   while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
   const int tc = tr + rem;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  // this thread's four elements (rows ty + 8 a), each summed over the splits in order; 4 x 8 loads in flight
+  // this thread's four elements (rows ty + 8 a), each summed over the splits in order; 4 x kFoldBatch loads in flight
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int cc = min(32 * tc + tx, pc - 1);
-  for (int s0 = 0; s0 < splits; s0 += 8) {
-    float v[4][8];
+  for (int s0 = 0; s0 < splits; s0 += kFoldBatch) {
+    float v[4][kFoldBatch];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kFoldBatch; ++u)
         v[a][u] = part[(int64_t)min(s0 + u, splits - 1) * split_stride + (int64_t)min(32 * tr + ty + 8 * a, pc - 1) * ldpart + cc];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kFoldBatch; ++u)
         if (s0 + u < splits) acc[a] += v[a][u];
   }
 #pragma unroll
@@ -279,6 +284,25 @@ __device__ __forceinline__ void sum_splits_sym_body(int block, const float* __re
       const int r = 32 * tc + i, c = 32 * tr + tx;          // the mirror tile
       if (r < pc && c < pc) C[(int64_t)r * ldc + c] = t[tx][i];
     }
+}
+
+// The same fold with one element per thread -- four workgroups per 32 x 32 tile (rows ty + 8 a of the tile for
+// workgroup a), the mirror image written directly: a k = 256 dictionary has only 36 tiles, and 36 workgroups cannot
+// pull the splits' 12 MB in fast enough (round 4; used while the tiles are few).  Same sums, same order.
+__global__ __launch_bounds__(256) void sum_splits_sym4_kernel(const float* __restrict__ part, int splits,
+                                                              int64_t split_stride, int64_t ldpart, int pc,
+                                                              float* __restrict__ C, int64_t ldc) {
+  const int nt = (pc + 31) / 32;
+  int rem = blockIdx.x >> 2, tr = 0;
+  while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
+  const int tc = tr + rem, a = blockIdx.x & 3;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r = 32 * tr + ty + 8 * a, c = 32 * tc + tx;
+  const float v = ordered_split_sum(part + (int64_t)min(r, pc - 1) * ldpart + min(c, pc - 1), split_stride, splits);
+  if (r < pc && c < pc) {
+    C[(int64_t)r * ldc + c] = v;
+    if (tr != tc) C[(int64_t)c * ldc + r] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __restrict__ part, int splits,
@@ -1771,9 +1795,13 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
     hipLaunchKernelGGL(gram_tn128_kernel, dim3(blocks, 1, sp), dim3(256), lds, stream, P, ldp, pc, Q, ldq, qc, n, out,
                        old_, sym, rps, stride128);
     if (sym) {
-      const int nt = (pc + 31) / 32;
-      hipLaunchKernelGGL(sum_splits_sym_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, scratch, sp, stride128,
-                         (int64_t)qc, pc, C, ldc);
+      const int nt = (pc + 31) / 32, ntiles = nt * (nt + 1) / 2;
+      if (ntiles < 128)
+        hipLaunchKernelGGL(sum_splits_sym4_kernel, dim3(4 * ntiles), dim3(256), 0, stream, scratch, sp, stride128,
+                           (int64_t)qc, pc, C, ldc);
+      else
+        hipLaunchKernelGGL(sum_splits_sym_kernel, dim3(ntiles), dim3(256), 0, stream, scratch, sp, stride128,
+                           (int64_t)qc, pc, C, ldc);
     } else if (sp > 1) {
       hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((stride128 + 255) / 256)), dim3(256), 0, stream, scratch, sp,
                          stride128, pc, qc, C, ldc);
