@@ -1224,22 +1224,28 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const SweepParams p) {
   auto owner = [](int r) { return 1 + r % 3; };             // the helper wave that keeps row block r up to date
 
   // ---- everything in: U rows (columns >= d and rows >= k are zero), block 0's old atoms and A[0][0]
-  for (int e0 = tid; e0 < nblk * JB * 16; e0 += 8 * 256) {
-    f32x4 rv[8];
+  {
+    // lane = column, wave = quads {w, w + 4} of every block: four coalesced row loads make one conflict-free 16-byte
+    // LDS store (the row-major mapping -- 16-byte loads, four scalar stores each -- was an 8-way bank conflict)
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(p.U, 0, (int)((int64_t)p.k * p.ldu * 4), 0x00020000);
+    const int col = tid & 63;
+    const bool colok = col < p.d;
+    f32x4 rv[kSsMaxBlk][2];                                 // (all loads first: one memory latency, not one per block)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = min(e0 + 256 * i, nblk * JB * 16 - 1), row = e >> 4, c4 = (e & 15) * 4;
-      rv[i] = *(const f32x4*)(p.U + (int64_t)min(row, kl) * p.ldu + c4);
-    }
+    for (int blk = 0; blk < kSsMaxBlk; ++blk)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = e0 + 256 * i, row = e >> 4, c4 = (e & 15) * 4;
-      if (e < nblk * JB * 16) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          Ur[(row >> 5) * JB * 64 + ss_ub(row & 31, c4 + f)] = (row < p.k && c4 + f < p.d) ? rv[i][f] : 0.0f;
-      }
-    }
+        for (int r = 0; r < 4; ++r) {                       // rows >= k (and blocks >= nblk): beyond the descriptor, zero
+          const unsigned off = (unsigned)(((JB * blk + 4 * (w + 4 * j) + r) * (int)p.ldu + col) * 4);
+          rv[blk][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ursrc, off, 0, 0));
+        }
+#pragma unroll
+    for (int blk = 0; blk < kSsMaxBlk; ++blk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (blk < nblk)
+          *(f32x4*)(Ur + blk * JB * 64 + ss_ub(4 * (w + 4 * j), col)) = colok ? rv[blk][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   {
     float rv[4];                                            // A[0][0] and its negation
