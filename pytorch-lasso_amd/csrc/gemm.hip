@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
                                                          const float* __restrict__ B, int64_t ldb,
                                                          const float* __restrict__ C0, int64_t ldc0,
                                                          float* __restrict__ C, int64_t ldc, int m, int nn,
-                                                         int kk, int add, ProxEpilogue ep = ProxEpilogue()) {
+                                                         int kk, int add, ProxEpilogue ep = ProxEpilogue(),
+                                                         int* __restrict__ zero_words = nullptr, int nzero = 0) {
+  // (a caller's flag words cleared on the way: saves the launch behind this one a fill of its own)
+  if (zero_words && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
   constexpr int MI = BM / 32, NJ = BN / 32;          // 16x16 blocks per wave: MI x NJ
   constexpr int PA = BM / 32, PB = BN / 32;          // staged 16-byte chunks per thread and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,7 +241,7 @@ static bool gemm_dma_ok(int64_t, int64_t, int, int, int) { return false; }
 template <int BM, int BN, bool VEC>
 hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
                        int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk, int add,
-                       hipStream_t stream) {
+                       hipStream_t stream, int* zero_words, int nzero) {
   constexpr int lds = 2 * (BM + BN) * 128;
   if (lds > 48 * 1024)
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, VEC>), lds);
@@ -251,12 +255,12 @@ hipError_t launch_tile(const float* A, int64_t lda, const float* B, int64_t ldb,
             e != hipSuccess)
           return e;
       hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, true, false, true>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0,
-                         ldc0, C, ldc, m, nn, kk, add);
+                         ldc0, C, ldc, m, nn, kk, add, ProxEpilogue(), zero_words, nzero);
       return hipGetLastError();
     }
   }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, VEC>), grid, dim3(256), lds, stream, A, lda, B, ldb, C0, ldc0, C,
-                     ldc, m, nn, kk, add);
+                     ldc, m, nn, kk, add, ProxEpilogue(), zero_words, nzero);
   return hipGetLastError();
 }
 
@@ -358,7 +362,7 @@ hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int6
 
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C0,
                               int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk,
-                              hipStream_t stream, int add) {
+                              hipStream_t stream, int add, int* zero_words, int nzero) {
   if (m <= 0 || nn <= 0) return hipSuccess;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
@@ -374,8 +378,8 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
   }
 #define LASSO_GEMM_CASE(BM_, BN_)                                                                              \
   if (bm == BM_ && bn == BN_)                                                                                   \
-    return vec ? launch_tile<BM_, BN_, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)         \
-               : launch_tile<BM_, BN_, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream)
+    return vec ? launch_tile<BM_, BN_, true>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream, zero_words, nzero)         \
+               : launch_tile<BM_, BN_, false>(A, lda, B, ldb, C0, ldc0, C, ldc, m, nn, kk, add, stream, zero_words, nzero)
   LASSO_GEMM_CASE(128, 128);
   LASSO_GEMM_CASE(128, 64);
   LASSO_GEMM_CASE(64, 128);

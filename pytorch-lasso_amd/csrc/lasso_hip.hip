@@ -2174,10 +2174,15 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   // last launch writes the new dictionary: no transposed copies, no clearing of U (four launches off the chain).
   const bool direct = dp == 256 && k % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)D & 15) == 0;
   if (dp != d && !direct) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
-  LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st));
+  void* const extra = dp == 256 ? (void*)((char*)ndeg + 256) : nullptr;
+  // (the product's first workgroup also clears the single-launch sweep's flag words: no fill launch between them)
+  int* const flag_words = extra ? sweep_persist_flags(extra, (int)k) : nullptr;
+  LASSO_HIP_TRY(launch_gemm_nt_sub(a_dev, k, D, ldd, b_dev, d, U, dp, (int)k, (int)d, (int)k, st, 0, flag_words,
+                                   flag_words ? 1024 : 0));
   // Dt[j][dd] = D[dd][j]  (zero padded to dp features)
   if (!direct) LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
   SweepParams p;
+  p.flags_cleared = flag_words != nullptr;
   p.Dsrc = direct ? D : nullptr; p.ldd = ldd;
   p.Dout = direct ? D : nullptr; p.ldo = ldd;
   p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
@@ -2185,7 +2190,6 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
   p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
   float* dt_new = Dt;
-  void* const extra = dp == 256 ? (void*)((char*)ndeg + 256) : nullptr;
   LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
   // D[dd][j] = Dt[j][dd]
   if (!direct) LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));

@@ -88,6 +88,7 @@ struct SweepParams {
   int* ndeg_in_out;                      // [1] running count of degenerate atoms
   int k, d;
   float eps; int positive;
+  int flags_cleared;                     // the caller had the single-launch sweep's flag words cleared (by the launch in front)
 };
 
 // backtracking line search (backtrack.hip)
@@ -214,7 +215,7 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
                           hipStream_t stream);
 hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64_t ldb,
                               const float* C0, int64_t ldc0, float* C, int64_t ldc, int m, int nn,
-                              int kk, hipStream_t stream, int add = 0);
+                              int kk, hipStream_t stream, int add = 0, int* zero_words = nullptr, int nzero = 0);
 // the same GEMM with the proximal step of the unfused FISTA path in its epilogue (gemm.hip)
 int gemm_nt_prox_parts(int m, int nn);
 hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int64_t ldb, float* Z, int64_t ldz,
@@ -228,6 +229,7 @@ hipError_t launch_cd_finish(const float* B, const float* Zt, int kp, float* z_ou
 // persist_extra (sweep_persist_extra_bytes(k) bytes) + dt_out: d <= 256 runs the single-launch sweep,
 // whose new atoms land in *dt_out (rows of 256 floats) instead of p.Dt
 size_t sweep_persist_extra_bytes(int k);
+int* sweep_persist_flags(void* persist_extra, int k);      // the 1024 flag words inside `persist_extra`
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* persist_extra = nullptr,
                              float** dt_out = nullptr);
 // unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 4096

@@ -1862,6 +1862,11 @@ size_t sweep_persist_extra_bytes(int k) {
   return 3 * nblk * kSweepBlock * 256 * 4 + 4096 + nblk * 128;   // DtN, dDg, Uw, flags (+ debug time stamps)
 }
 
+int* sweep_persist_flags(void* persist_extra, int k) {
+  const size_t rows = (size_t)((k + kSweepBlock - 1) / kSweepBlock) * kSweepBlock * 256;
+  return (int*)((float*)persist_extra + 3 * rows);
+}
+
 // dp == 256: the single-launch sweep (+ its stand-by).  `extra` = sweep_persist_extra_bytes(k)
 // bytes; on return *dt_out is where the new atoms are (rows of length 256).
 static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt_out, hipStream_t stream) {
@@ -1878,7 +1883,7 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
   const size_t lds = (size_t)(2 * kSweepBlock * kSweepBlock + 4 * kSweepBlock * kSpLdA + 3 * kSweepBlock * kSpLdB) * 4;
   hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_persist_kernel), lds);
   if (e != hipSuccess) return e;
-  if ((e = hipMemsetAsync(x.flags, 0, 4096, stream)) != hipSuccess) return e;
+  if (!p.flags_cleared && (e = hipMemsetAsync(x.flags, 0, 4096, stream)) != hipSuccess) return e;
   // Workgroups go round the 8 XCDs in launch order: worker i is workgroup 8 i, on the sweeper's XCD -- deltas and
   // rows change hands through that XCD's L2.  The workgroups in between return at once.
 #ifndef LASSO_SWEEP_WG_STRIDE
