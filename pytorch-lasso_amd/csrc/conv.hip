@@ -145,7 +145,10 @@ struct ConvGradProx {
   int tv_shift;                 // TV = 1 << tv_shift
   float inv_plane, inv_rw;      // 1 / (RH RW), 1 / RW: exact index splits of e < 2^14 without integer division
 };
-constexpr int kCgpGtLd = 132;
+// Dictionaries of at most 64 atoms (KW = 64; round 4): a 128-atom tile left two of the four waves multiplying
+// zeros and half of the epilogue's 16-byte pieces out of range, so the tile is turned to 128 pixels x 64 atoms --
+// waves 2 (pixel halves) x 2 (atom halves), the same 4 x 2 MFMA blocks per wave, every z / y piece of the epilogue real.
+// The contraction order per element is unchanged (codes bitwise those of the 128-atom tile).
 #ifndef LASSO_CGP_OCC
 #define LASSO_CGP_OCC 3      // workgroups (4 waves) per SIMD-quad the kernel is compiled for: 3 -> 168 registers
 #endif
@@ -153,17 +156,22 @@ constexpr int kCgpGtLd = 132;
 // load / store in flight (vmcnt(0)), which would serialise the HBM phases with the MFMA phase
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
-template <int S4>
+template <int S4, int KW>
 __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(const ConvGradProx p) {
+  constexpr int TP = 8192 / KW;                             // code pixels of a tile: 64 (KW = 128) or 128 (KW = 64)
+  constexpr int kCgpGtLd = KW + 4;
+  constexpr int NWA = KW / 32;                              // waves side by side along the atoms
+  constexpr int C4 = KW / 4, C4_SHIFT = KW == 128 ? 5 : 4;  // 16-byte pieces per tile row
   extern __shared__ __attribute__((aligned(16))) float cg_smem[];
-  float* const Gt = cg_smem;                                // [64][132]
-  int* const toff = (int*)(Gt + 64 * kCgpGtLd);             // [4 * S4]
+  float* const Gt = cg_smem;                                // [TP][KW + 4]
+  int* const toff = (int*)(Gt + TP * kCgpGtLd);             // [4 * S4]
   float* const S = (float*)(toff + 4 * S4);                 // [C][RH][RW]
   __shared__ float red[256];
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int ckk = g.C * g.kh * g.kw, K = g.K;
-  const int kcol0 = 128 * blockIdx.y + 32 * w;
+  const int wa = w % NWA, wp = w / NWA;                     // this wave's 32 atoms / 64 pixels of the tile
+  const int kcol0 = KW * blockIdx.y + 32 * wa;
   // B fragments of this wave's 32 atoms: B[k][e], e = 4 s + q, zero beyond ckk / K
   float bf[S4][2];
 #pragma unroll
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
   int base_p[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int pix = 16 * mt + l15, tu = pix >> p.tv_shift, tv = pix & (p.TV - 1);
+    const int pix = 64 * wp + 16 * mt + l15, tu = pix >> p.tv_shift, tv = pix & (p.TV - 1);
     base_p[mt] = tu * g.sh * p.RW + tv * g.sw;
   }
   const int tiles_img = p.tiles_u * p.tiles_v, ntiles = g.N * tiles_img;
@@ -235,9 +243,9 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
     if (kvec) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
+        const int idx = tdyn + 256 * h, pix = idx >> C4_SHIFT, c4 = (idx & (C4 - 1)) * 4;
         const int u = u0 + (pix >> p.tv_shift), v = v0 + (pix & (p.TV - 1));
-        const int col = 128 * blockIdx.y + c4;
+        const int col = KW * blockIdx.y + c4;
         const bool ok = u < g.Hz && v < g.Wz && col < K;
         zoff[h] = ok ? (unsigned)(((n * g.Hz + u) * g.Wz + v) * K + col) * 4u : ~0u;
 #ifdef LASSO_ABL_CONV_NOMEM    // timing ablation only (results invalid)
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Gt[(16 * mt + 4 * q + rg) * kCgpGtLd + 32 * w + 16 * nt + l15] = acc[mt][nt][rg];
+        for (int rg = 0; rg < 4; ++rg) Gt[(64 * wp + 16 * mt + 4 * q + rg) * kCgpGtLd + 32 * wa + 16 * nt + l15] = acc[mt][nt][rg];
     LDS_BARRIER();
     if (kvec) {
       f32x4 zo[8];
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
 #endif
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        const int idx = tdyn + 256 * h, pix = idx >> 5, c4 = (idx & 31) * 4;
+        const int idx = tdyn + 256 * h, pix = idx >> C4_SHIFT, c4 = (idx & (C4 - 1)) * 4;
         const bool ok = zoff[h] != ~0u;
         const f32x4 gv = *(const f32x4*)(Gt + pix * kCgpGtLd + c4);
         f32x4 zn, yn;
@@ -305,10 +313,10 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
 #endif
       }
     } else {
-      for (int idx = tid; idx < 64 * 32; idx += 256) {
-        const int pix = idx >> 5, c4 = (idx & 31) * 4;
+      for (int idx = tid; idx < TP * C4; idx += 256) {
+        const int pix = idx >> C4_SHIFT, c4 = (idx & (C4 - 1)) * 4;
         const int u = u0 + (pix >> p.tv_shift), v = v0 + (pix & (p.TV - 1));
-        const int col = 128 * blockIdx.y + c4;
+        const int col = KW * blockIdx.y + c4;
         if (u >= g.Hz || v >= g.Wz || col >= K) continue;
         const int64_t m = ((int64_t)n * g.Hz + u) * g.Wz + v;
         float* const zp = p.Zm + m * K + col;
@@ -522,8 +530,9 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   const int ckk = g.C * g.kh * g.kw;
   if (ckk > 192) return hipSuccess;
   ConvGradProx p;
+  const int kw = g.K <= 64 ? 64 : 128, tp = 8192 / kw;      // atoms x code pixels of a workgroup's tile
   p.TV = g.Wz >= 48 ? 64 : g.Wz >= 24 ? 32 : g.Wz >= 12 ? 16 : 8;
-  p.TU = 64 / p.TV;
+  p.TU = tp / p.TV;
   p.RH = (p.TU - 1) * g.sh + g.kh;
   p.RW = (p.TV - 1) * g.sw + g.kw;
   if ((int64_t)g.C * p.RH * p.RW > 16384) return hipSuccess;
@@ -535,21 +544,20 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   p.tiles_v = (g.Wz + p.TV - 1) / p.TV;
   p.R = r; p.Wp = Wp; p.ldr = ldr; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
   const int64_t ntiles = (int64_t)g.N * p.tiles_u * p.tiles_v;
-  const int gy = (g.K + 127) / 128;
+  const int gy = (g.K + kw - 1) / kw;
   if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
   const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, LASSO_CGP_OCC * cus / gy)));
   const int s4 = ckk <= 64 ? 16 : ckk <= 96 ? 24 : ckk <= 144 ? 36 : 48;
-  const size_t lds = (size_t)(64 * kCgpGtLd + 4 * s4 + g.C * p.RH * p.RW) * 4;
-  const void* fn = s4 == 16 ? (const void*)&conv_grad_prox_kernel<16> : s4 == 24 ? (const void*)&conv_grad_prox_kernel<24>
-                 : s4 == 36 ? (const void*)&conv_grad_prox_kernel<36> : (const void*)&conv_grad_prox_kernel<48>;
-  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  const size_t lds = (size_t)(tp * (kw + 4) + 4 * s4 + g.C * p.RH * p.RW) * 4;
   const dim3 grid(gx, gy);
-  switch (s4) {
-    case 16: hipLaunchKernelGGL(conv_grad_prox_kernel<16>, grid, dim3(256), lds, stream, p); break;
-    case 24: hipLaunchKernelGGL(conv_grad_prox_kernel<24>, grid, dim3(256), lds, stream, p); break;
-    case 36: hipLaunchKernelGGL(conv_grad_prox_kernel<36>, grid, dim3(256), lds, stream, p); break;
-    default: hipLaunchKernelGGL(conv_grad_prox_kernel<48>, grid, dim3(256), lds, stream, p); break;
+#define LASSO_CGP_CASE(S4_, KW_)                                                                             \
+  if (s4 == S4_ && kw == KW_) {                                                                              \
+    if (hipError_t e = ensure_dynamic_lds((const void*)&conv_grad_prox_kernel<S4_, KW_>, lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL((conv_grad_prox_kernel<S4_, KW_>), grid, dim3(256), lds, stream, p);                  \
   }
+  LASSO_CGP_CASE(16, 128) LASSO_CGP_CASE(24, 128) LASSO_CGP_CASE(36, 128) LASSO_CGP_CASE(48, 128)
+  LASSO_CGP_CASE(16, 64) LASSO_CGP_CASE(24, 64) LASSO_CGP_CASE(36, 64) LASSO_CGP_CASE(48, 64)
+#undef LASSO_CGP_CASE
   *count = gx * gy;
   return hipGetLastError();
 }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""A/B of two builds of the library on the convolutional solver: per-iteration time of each and the codes compared
+bitwise.  usage: ab_conv.py <old.so> (run in two processes: the library is chosen once per process)"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64),
+         (128, 1, 32, 5, 2, 1, 15), (96, 2, 48, 3, 1, 1, 20)]
+if len(sys.argv) > 2 and sys.argv[1] == "--child":
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd")]
+    import hashlib, time, torch
+    from lasso_amd import _native as nat
+    if sys.argv[2] != "-":
+        nat.use_library(os.path.abspath(sys.argv[2]))
+    from lasso_amd.conv2d import ista_conv2d
+    out = []
+    for (N, C, K, ks, st, pd, Hz) in CASES:
+        g = torch.Generator().manual_seed(0)
+        w = torch.randn(K, C, ks, ks, generator=g) / ks
+        H = (Hz - 1) * st - 2 * pd + ks
+        x = torch.randn(N, C, H, H, generator=g)
+        lr = 0.5 / w.pow(2).sum().item()
+        xg, wg, zg = x.cuda(), w.cuda(), torch.zeros(N, K, Hz, Hz, device="cuda")
+        z = ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=20, lr=lr, tol=0.0)
+        torch.cuda.synchronize()
+        t = time.perf_counter(); reps = 10
+        for _ in range(reps):
+            ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=20, lr=lr, tol=0.0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / reps / 20
+        out.append({"case": [N, C, K, ks, st, pd, Hz], "us_per_iteration": round(dt * 1e6, 2),
+                    "tflops": round(4.0 * N * Hz * Hz * C * ks * ks * K / dt / 1e12, 2),
+                    "nnz": int((z != 0).sum()), "sha": hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest()[:16]})
+    print(json.dumps(out))
+    sys.exit(0)
+res = {}
+for tag, lib in (("old", sys.argv[1]), ("new", "-")):
+    r = subprocess.run([sys.executable, __file__, "--child", lib], capture_output=True, text=True)
+    if r.returncode:
+        print(r.stderr[-2000:]); sys.exit(1)
+    res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+for o, n in zip(res["old"], res["new"]):
+    print(json.dumps({"case": o["case"], "old_us": o["us_per_iteration"], "new_us": n["us_per_iteration"],
+                      "new_tflops": n["tflops"], "bitwise": o["sha"] == n["sha"], "nnz": n["nnz"]}))
