@@ -152,12 +152,42 @@ struct ConvGradProx {
 #ifndef LASSO_CGP_OCC
 #define LASSO_CGP_OCC 3      // workgroups (4 waves) per SIMD-quad the kernel is compiled for: 3 -> 168 registers
 #endif
+#ifndef LASSO_CGP_OCC16
+#define LASSO_CGP_OCC16 LASSO_CGP_OCC
+#endif
+constexpr int cgp_occ(int s4) { return s4 == 16 ? LASSO_CGP_OCC16 : LASSO_CGP_OCC; }
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global
 // load / store in flight (vmcnt(0)), which would serialise the HBM phases with the MFMA phase
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
-template <int S4, int KW>
-__global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(const ConvGradProx p) {
+// The receptive field of a tile, C x RH x RW residual values (zero outside the image), into LDS: H independent
+// loads in flight per thread.
+template <int H>
+__device__ __forceinline__ void cgp_stage_field(float* __restrict__ S, const float* __restrict__ Rn, const ConvGradProx& p,
+                                                int t0, int region, int plane, int i0, int j0) {
+  const ConvGeom& g = p.g;
+  for (int e0 = t0; e0 < region; e0 += 256 * H) {
+    float sv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int e = min(e0 + 256 * h, region - 1);
+      // e = (c, rr, cc): floor((e + 1/2) / d) in fp32 is exact for e < 2^14 (the distance to the next integer
+      // is at least 1/(2d), the rounding error below 2e-3/d) -- two runtime integer divisions per element were
+      // a third of this kernel's instructions
+      const int c = (int)(((float)e + 0.5f) * p.inv_plane), rem = e - c * plane;
+      const int rr = (int)(((float)rem + 0.5f) * p.inv_rw), cc = rem - rr * p.RW;
+      const int i = i0 + rr, j = j0 + cc;
+      const float v = Rn[((int64_t)c * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)];
+      sv[h] = v * ((i >= 0 && i < g.H && j >= 0 && j < g.W) ? 1.0f : 0.0f);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (e0 + 256 * h < region) S[e0 + 256 * h] = sv[h];
+  }
+}
+
+template <int S4, int KW, bool SKIP>     // SKIP: C kh kw <= 4 S4 - 4, the last MFMA steps would multiply zeros
+__global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const ConvGradProx p) {
   constexpr int TP = 8192 / KW;                             // code pixels of a tile: 64 (KW = 128) or 128 (KW = 64)
   constexpr int kCgpGtLd = KW + 4;
   constexpr int NWA = KW / 32;                              // waves side by side along the atoms
@@ -219,24 +249,10 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
     asm volatile("" : "+v"(tdyn));
     int bp[4] = {base_p[0], base_p[1], base_p[2], base_p[3]};     // (likewise: 4 * S4 operand addresses)
     asm volatile("" : "+v"(bp[0]), "+v"(bp[1]), "+v"(bp[2]), "+v"(bp[3]));
-    for (int e0 = tdyn; e0 < region; e0 += 256 * 8) {        // 8 independent loads in flight per thread
-      float sv[8];
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const int e = min(e0 + 256 * h, region - 1);
-        // e = (c, rr, cc): floor((e + 1/2) / d) in fp32 is exact for e < 2^14 (the distance to the next integer
-        // is at least 1/(2d), the rounding error below 2e-3/d) -- two runtime integer divisions per element were
-        // a third of this kernel's instructions
-        const int c = (int)(((float)e + 0.5f) * p.inv_plane), rem = e - c * plane;
-        const int rr = (int)(((float)rem + 0.5f) * p.inv_rw), cc = rem - rr * p.RW;
-        const int i = i0 + rr, j = j0 + cc;
-        const float v = Rn[((int64_t)c * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)];
-        sv[h] = v * ((i >= 0 && i < g.H && j >= 0 && j < g.W) ? 1.0f : 0.0f);
-      }
-#pragma unroll
-      for (int h = 0; h < 8; ++h)
-        if (e0 + 256 * h < region) S[e0 + 256 * h] = sv[h];
-    }
+    // receptive fields of at most 512 values (one image channel, small kernels) take two loads per thread instead
+    // of eight: the index arithmetic of the six idle slots was a quarter of the kernel's vector instructions there
+    if (S4 <= 24 && region <= 512) cgp_stage_field<2>(S, Rn, p, tdyn, region, plane, i0, j0);
+    else cgp_stage_field<8>(S, Rn, p, tdyn, region, plane, i0, j0);
     // z, y of the tile do not depend on g: fetched now, so that the HBM latency runs under the MFMAs
     f32x4 yo[8];                                              // (z is fetched in the epilogue: registers)
     unsigned zoff[8];                                         // byte offset of this thread's pieces (~0u: outside -> reads 0, writes dropped)
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(256, LASSO_CGP_OCC) void conv_grad_prox_kernel(cons
 #endif
 #pragma unroll
     for (int s = 0; s < S4; ++s) {
+      if (SKIP && 4 * s >= ckk) break;                                // padded steps multiply zeros (uniform branch): 13 of 16 real at 1 x 7 x 7
       const int off = toff[4 * s + q];
       float a[4];
 #pragma unroll
@@ -545,19 +562,22 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   p.R = r; p.Wp = Wp; p.ldr = ldr; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
   const int64_t ntiles = (int64_t)g.N * p.tiles_u * p.tiles_v;
   const int gy = (g.K + kw - 1) / kw;
-  if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
-  const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, LASSO_CGP_OCC * cus / gy)));
   const int s4 = ckk <= 64 ? 16 : ckk <= 96 ? 24 : ckk <= 144 ? 36 : 48;
+  if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
+  const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, cgp_occ(s4) * cus / gy)));
   const size_t lds = (size_t)(tp * (kw + 4) + 4 * s4 + g.C * p.RH * p.RW) * 4;
   const dim3 grid(gx, gy);
-#define LASSO_CGP_CASE(S4_, KW_)                                                                             \
-  if (s4 == S4_ && kw == KW_) {                                                                              \
-    if (hipError_t e = ensure_dynamic_lds((const void*)&conv_grad_prox_kernel<S4_, KW_>, lds); e != hipSuccess) return e; \
-    hipLaunchKernelGGL((conv_grad_prox_kernel<S4_, KW_>), grid, dim3(256), lds, stream, p);                  \
+  const bool skip = ckk <= 4 * s4 - 4;
+#define LASSO_CGP_CASE2(S4_, KW_, SK_)                                                                       \
+  if (s4 == S4_ && kw == KW_ && skip == SK_) {                                                               \
+    if (hipError_t e = ensure_dynamic_lds((const void*)&conv_grad_prox_kernel<S4_, KW_, SK_>, lds); e != hipSuccess) return e; \
+    hipLaunchKernelGGL((conv_grad_prox_kernel<S4_, KW_, SK_>), grid, dim3(256), lds, stream, p);             \
   }
+#define LASSO_CGP_CASE(S4_, KW_) LASSO_CGP_CASE2(S4_, KW_, false) LASSO_CGP_CASE2(S4_, KW_, true)
   LASSO_CGP_CASE(16, 128) LASSO_CGP_CASE(24, 128) LASSO_CGP_CASE(36, 128) LASSO_CGP_CASE(48, 128)
   LASSO_CGP_CASE(16, 64) LASSO_CGP_CASE(24, 64) LASSO_CGP_CASE(36, 64) LASSO_CGP_CASE(48, 64)
 #undef LASSO_CGP_CASE
+#undef LASSO_CGP_CASE2
   *count = gx * gy;
   return hipGetLastError();
 }

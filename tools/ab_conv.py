@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the convolutional solver: per-iteration time of each and the codes compared
-bitwise.  usage: ab_conv.py <old.so> (run in two processes: the library is chosen once per process)"""
+bitwise.  usage: ab_conv.py <other.so> ... (one process per build: the library is chosen once per process)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64),
@@ -33,11 +33,13 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     print(json.dumps(out))
     sys.exit(0)
 res = {}
-for tag, lib in (("old", sys.argv[1]), ("new", "-")):
+libs = [("product", "-")] + [(os.path.basename(l), l) for l in sys.argv[1:]]
+for tag, lib in libs:
     r = subprocess.run([sys.executable, __file__, "--child", lib], capture_output=True, text=True)
     if r.returncode:
         print(r.stderr[-2000:]); sys.exit(1)
     res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
-for o, n in zip(res["old"], res["new"]):
-    print(json.dumps({"case": o["case"], "old_us": o["us_per_iteration"], "new_us": n["us_per_iteration"],
-                      "new_tflops": n["tflops"], "bitwise": o["sha"] == n["sha"], "nnz": n["nnz"]}))
+for i, n in enumerate(res["product"]):
+    print(json.dumps({"case": n["case"], "us": {t: res[t][i]["us_per_iteration"] for t, _ in libs},
+                      "product_tflops": n["tflops"], "bitwise": all(res[t][i]["sha"] == n["sha"] for t, _ in libs),
+                      "nnz": n["nnz"]}))

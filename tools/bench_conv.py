@@ -12,6 +12,9 @@ out = []
 cases = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64)]
 if '--last' in sys.argv:
     cases = cases[-1:]
+if '--case' in sys.argv:                      # one case by index (kernel traces of a single geometry)
+    i = int(sys.argv[sys.argv.index('--case') + 1])
+    cases = cases[i:i + 1]
 for (N, C, K, ks, st, pd, Hz) in cases:
     g = torch.Generator().manual_seed(0)
     w = torch.randn(K, C, ks, ks, generator=g) / ks
