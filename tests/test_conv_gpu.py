@@ -123,7 +123,11 @@ def test_auto_step_and_stop_rule(golden):
     (3, 3, 128, 5, 5, 1, 2, 20, 24), (2, 1, 64, 7, 7, 1, 3, 13, 17), (2, 4, 20, 3, 3, 1, 1, 9, 11),
     (1, 7, 100, 3, 5, 1, (0, 2), 8, 9), (600, 1, 16, 3, 3, 1, 1, 8, 8), (2, 3, 36, 5, 5, 1, 0, 6, 7),
     # same channel counts where it does not apply (stride 2, non-square kernel, C > 16): explicit path
-    (2, 16, 32, 3, 3, 2, 1, 8, 9), (2, 8, 16, 3, 5, 1, 1, 9, 9), (1, 17, 8, 3, 3, 1, 1, 6, 6)])
+    (2, 16, 32, 3, 3, 2, 1, 8, 9), (2, 8, 16, 3, 5, 1, 1, 9, 9), (1, 17, 8, 3, 3, 1, 1, 6, 6),
+    # the gradient kernel's 128-pixel x 64-atom tile (K <= 64) where no MFMA step is padding (63 and 96 taps: the
+    # instantiations without the skip), on a code grid wider than 48 (2 x 64 pixel tiles) and with K <= 64 next to
+    # a second block of atoms (K = 72: 128-atom tiles)
+    (2, 7, 40, 3, 3, 1, 1, 9, 10), (2, 6, 24, 4, 4, 1, 1, 7, 9), (1, 1, 8, 3, 3, 1, 1, 5, 50), (1, 2, 72, 3, 3, 1, 1, 5, 50)])
 def test_shapes_match_oracle(N, C, K, kh, kw, stride, padding, Hz, Wz):
     ista_conv2d, _, _, _, orc = _mods()
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
