@@ -63,11 +63,12 @@ def recipe(n_total):
     return X, W
 
 
-def hbm_traffic_from_profiles():
+def hbm_traffic_from_profiles(kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, profiles/*/hbm_traffic.json):
     PMC counters cannot be collected inside the timed run, so this figure is the latest
-    profile's, and the JSON says which."""
+    profile's, and the JSON says which.  A profile that names the kernel it measured is used only
+    when that is the kernel this run launched (a stale figure is dropped, not reported)."""
     best, src = None, None
     pdir = os.path.join(ROOT, "profiles")
     names = sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []
@@ -77,7 +78,10 @@ def hbm_traffic_from_profiles():
         f = os.path.join(pdir, name, "hbm_traffic.json")
         if os.path.exists(f) and not name.endswith("_splitk"):
             with open(f) as fh:
-                best, src = json.load(fh).get("hbm_bytes_per_launch"), "profiles/%s/hbm_traffic.json" % name
+                rec = json.load(fh)
+            best, src = rec.get("hbm_bytes_per_launch"), "profiles/%s/hbm_traffic.json" % name
+            if kernel and rec.get("kernel") and rec["kernel"] != kernel:
+                best, src = None, src + " names %s, this run launched %s: stale, not reported" % (rec["kernel"], kernel)
     return best, src
 
 
@@ -279,7 +283,7 @@ def run_fista(args, ranks):
         avg_launch_ms = sum(r["kern_ms"]) / len(r["kern_ms"])
         flop_per_launch = 4.0 * r["rows"] * D * K * args.iters          # this rank's launch
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
-        traffic, traffic_src = hbm_traffic_from_profiles()
+        traffic, traffic_src = hbm_traffic_from_profiles(kernel_name(r["rows"]))
         out = {
             "metric": "fista_iterations_per_sec (n=%d d=256 k=1024 fp32, fixed L, tol=0)" % n_rows,
             "value": line(main_mode),
@@ -297,8 +301,9 @@ def run_fista(args, ranks):
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic if world == 1 else None,
-                         "traffic_source": (traffic_src + " (rocprofv3 PMC pass of this command; "
-                                            "not collected in this run)") if traffic_src and world == 1 else None,
+                         "traffic_source": (traffic_src + (" (rocprofv3 PMC pass of this command; not collected in "
+                                                           "this run)" if traffic is not None else ""))
+                                           if traffic_src and world == 1 else None,
                          "kernel": kernel_name(r["rows"]),
                          "flop_per_launch": flop_per_launch, "per": "GPU (rank 0)",
                          "avg_launch_ms": avg_launch_ms,
