@@ -1324,7 +1324,9 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
 // ---------------------------------------------------------------------------
 // convolutional ISTA (conv.hip)
 // ---------------------------------------------------------------------------
-struct ConvWorkspace { float* Wt; float* Wp; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums; size_t bytes; };
+struct ConvWorkspace { float* Wt; float* Wp; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums;
+                       float* Zc; float* Yc;      // (z, y) at the head of a speculated chunk of iterations (stop rule, below)
+                       size_t bytes; };
 
 ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
   ConvWorkspace w;
@@ -1347,6 +1349,8 @@ ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
   w.dpart = (float*)take((size_t)kGenGrid * 2 * 4);
   w.delta = (float*)take(256);
   w.sums = (double*)take(256);
+  w.Zc = (float*)take(M * g.K * 4);
+  w.Yc = (float*)take(M * g.K * 4);
   w.bytes = off;
   return w;
 }
@@ -2409,7 +2413,8 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
-  for (; it < maxiter; ++it) {
+  // one iteration on the stream; the sum |z - z_next| of the iteration (ista.py:44) goes to *delta_slot when given
+  auto iterate = [&](float* delta_slot) -> int {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
     LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
@@ -2424,12 +2429,69 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
       dcount = kGenGrid;
     }
     t_mom = t_next;
-    if (tol > 0.0) {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, dcount, ws.delta);
+    if (delta_slot) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, dcount, delta_slot);
       LASSO_HIP_TRY(hipGetLastError());
-      LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    return LASSO_OK;
+  };
+  if (!(tol > 0.0)) {
+    for (; it < maxiter; ++it)
+      if (int s = iterate(nullptr)) return s;
+  } else {
+    // The stop rule (ista.py:44-46: the first iteration whose sum over ALL code elements is <= budget ends the solve
+    // with that iteration's z) without a host round trip per iteration -- the speculate-and-replay scheme of the
+    // linear solver: a chunk of <= 64 iterations is enqueued with every iteration's sum kept on the
+    // device, the host reads the chunk's sums ONCE; if iteration j of the chunk met the rule and was not the
+    // chunk's last, (z, y) are put back to the chunk's head and exactly j + 1 iterations are replayed -- every kernel
+    // of the path sums in a fixed order, so the replay is bitwise the state the reference stops in.  Chunks after
+    // the first are sized from the decay of the sums, so that the rule is expected to fire at a chunk's end.
+    constexpr int kChunkMax = 64;                    // ws.delta holds 64 sums
+    float deltas[kChunkMax];
+    int chunk = std::min(maxiter, 2);
+    const size_t code_bytes = (size_t)M * g.K * 4;
+    while (it < maxiter) {
+      const int c = std::min(chunk, maxiter - it);
+      const double t_head = t_mom;
+      if (c > 1) {
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.Zc, ws.Zm, code_bytes, hipMemcpyDeviceToDevice, st));
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.Yc, ws.Ym, code_bytes, hipMemcpyDeviceToDevice, st));
+      }
+      for (int j = 0; j < c; ++j)
+        if (int s = iterate(ws.delta + j)) return s;
+      LASSO_HIP_TRY(hipMemcpyAsync(deltas, ws.delta, sizeof(float) * c, hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
-      if (last <= budget) { ++it; break; }                                          // :44-46
+      int hit = -1;
+      for (int j = 0; j < c && hit < 0; ++j)
+        if (deltas[j] <= budget) hit = j;                                          // :44-46 (fp32 compare)
+      if (hit < 0) {
+        it += c;
+        last = deltas[c - 1];
+        // Size of the next chunk.  With a decaying chunk behind us: the iterations the rule is still away at the chunk's
+        // average decay -- that many when it is near (the rule is then expected to fire at the chunk's END: no
+        // replay), half as many when it is far (the sums of a momentum run are not monotone).  Without one (a chunk
+        // of one iteration, sums that grew): as many iterations as are behind us, so that speculation past an early
+        // stop never costs more than the solve itself.  Only speed depends on this estimate.
+        int next = std::min(kChunkMax, std::max(2, it));
+        if (c > 1 && deltas[0] > 0.0f && last > 0.0f && last < deltas[0] && budget > 0.0f) {
+          const double rate = log((double)deltas[0] / (double)last) / (double)(c - 1);
+          const double away = log((double)last / (double)budget) / rate;
+          if (away <= 8.0) next = std::max(1, (int)ceil(away));
+          else next = (int)std::min((double)kChunkMax, away / 2.0);
+        }
+        chunk = next;
+        continue;
+      }
+      last = deltas[hit];
+      if (hit < c - 1) {
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.Zm, ws.Zc, code_bytes, hipMemcpyDeviceToDevice, st));
+        LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Yc, code_bytes, hipMemcpyDeviceToDevice, st));
+        t_mom = t_head;
+        for (int j = 0; j <= hit; ++j)
+          if (int s = iterate(nullptr)) return s;
+      }
+      it += hit + 1;
+      break;
     }
   }
   LASSO_HIP_TRY(launch_conv_relayout(ws.Zm, (float*)z_out_dev, g.N, g.K, P, 0, st));

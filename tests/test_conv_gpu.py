@@ -108,6 +108,44 @@ def test_auto_step_and_stop_rule(golden):
         assert err <= 2e-4 + 3 * sens, (tag, info, rinfo, sens)
 
 
+def test_stop_rule_chunks_replay_the_stopping_iteration():
+    """The rule of ista.py:44-46 is evaluated once per chunk of speculated iterations (lasso_conv_ista_solve); when it
+    fires inside a chunk the solve is put back to the chunk's head and replayed: the codes must be bitwise those of
+    exactly `iterations` iterations without a rule, the count the oracle's, for rules that fire at the first
+    iteration, inside and at the end of later chunks, and never."""
+    ista_conv2d, _, _, _, orc = _mods()
+    g = torch.Generator().manual_seed(11)
+    for (N, C, K, ks, pd, Hz) in ((3, 1, 12, 5, 2, 14), (2, 3, 72, 3, 1, 12), (2, 16, 20, 3, 0, 9)):
+        w = torch.randn(K, C, ks, ks, generator=g) / ks
+        H = (Hz - 1) - 2 * pd + ks
+        x = torch.randn(N, C, H, H, generator=g)
+        z0 = torch.zeros(N, K, Hz, Hz)
+        lr = 0.5 / w.pow(2).sum().item()
+        xg, wg, zg = x.cuda(), w.cuda(), z0.cuda()
+        # the sum of every iteration of a long run (one solve per length: the sums are not returned as a vector)
+        deltas = []
+        for m in range(1, 91):
+            _, info = ista_conv2d(xg, zg, wg, 0.1, padding=pd, maxiter=m, lr=lr, tol=1e-30, return_info=True)
+            assert info["iterations"] == m
+            deltas.append(info["last_delta"])
+        # a rule can fire first at the iterations whose sum is below every earlier one: the first of them, some in
+        # the middle (inside and at the end of speculated chunks) and the last
+        lows = [m for m in range(1, 91) if all(deltas[m - 1] < d for d in deltas[:m - 1])]
+        assert len(lows) >= 4, lows
+        picks = sorted(set([lows[0], lows[1], lows[len(lows) // 3], lows[len(lows) // 2], lows[-2], lows[-1]]))
+        for m in picks:
+            tol = float(np.float32(deltas[m - 1]) * np.float32(1.0 + 1e-6)) / z0.numel()
+            got, info = ista_conv2d(xg, zg, wg, 0.1, padding=pd, maxiter=200, lr=lr, tol=tol, return_info=True)
+            assert info["iterations"] == m and info["last_delta"] == deltas[m - 1], (m, info, lows)
+            plain = ista_conv2d(xg, zg, wg, 0.1, padding=pd, maxiter=m, lr=lr, tol=0.0)
+            assert torch.equal(got, plain), (N, C, K, m, info)
+        _, rinfo = orc.conv_fista(x, z0, w, 0.1, padding=pd, maxiter=200, lr=lr, tol=tol, return_info=True)
+        assert abs(rinfo["iterations"] - picks[-1]) <= 1, (picks, rinfo)   # (a sum within 1e-6 of the budget may fall either side)
+        # a rule that never fires: all maxiter iterations, the codes of the plain run
+        got, info = ista_conv2d(xg, zg, wg, 0.1, padding=pd, maxiter=37, lr=lr, tol=1e-30, return_info=True)
+        assert info["iterations"] == 37 and torch.equal(got, ista_conv2d(xg, zg, wg, 0.1, padding=pd, maxiter=37, lr=lr, tol=0.0))
+
+
 @pytest.mark.parametrize("N,C,K,kh,kw,stride,padding,Hz,Wz", [
     (1, 1, 1, 1, 1, 1, 0, 1, 1), (2, 1, 3, 3, 5, (1, 2), (1, 0), 6, 5), (3, 2, 70, 3, 3, 1, 1, 10, 12),
     (2, 5, 4, 5, 5, 3, 2, 4, 6), (64, 1, 32, 7, 7, 1, 0, 22, 22), (0, 1, 4, 3, 3, 1, 0, 5, 5),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the convolutional solver: per-iteration time of each and the codes compared
-bitwise.  usage: ab_conv.py <other.so> ... (one process per build: the library is chosen once per process)"""
+bitwise.  usage: ab_conv.py <other.so> ... (one process per build: the library is chosen once per process);
+AB_CONV_TOL / AB_CONV_MAXITER in the environment set the stop rule's tolerance (default 0: no rule) and maxiter (20)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64),
@@ -20,16 +21,17 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
         x = torch.randn(N, C, H, H, generator=g)
         lr = 0.5 / w.pow(2).sum().item()
         xg, wg, zg = x.cuda(), w.cuda(), torch.zeros(N, K, Hz, Hz, device="cuda")
-        z = ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=20, lr=lr, tol=0.0)
+        tol, mi = float(os.environ.get("AB_CONV_TOL", "0")), int(os.environ.get("AB_CONV_MAXITER", "20"))
+        z, info = ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=mi, lr=lr, tol=tol, return_info=True)
         torch.cuda.synchronize()
         t = time.perf_counter(); reps = 10
         for _ in range(reps):
-            ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=20, lr=lr, tol=0.0)
+            ista_conv2d(xg, zg, wg, 0.1, stride=st, padding=pd, maxiter=mi, lr=lr, tol=tol)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / reps / 20
+        dt = (time.perf_counter() - t) / reps / max(info["iterations"], 1)
         out.append({"case": [N, C, K, ks, st, pd, Hz], "us_per_iteration": round(dt * 1e6, 2),
                     "tflops": round(4.0 * N * Hz * Hz * C * ks * ks * K / dt / 1e12, 2),
-                    "nnz": int((z != 0).sum()), "sha": hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest()[:16]})
+                    "nnz": int((z != 0).sum()), "iterations": info["iterations"], "sha": hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest()[:16]})
     print(json.dumps(out))
     sys.exit(0)
 res = {}
@@ -42,4 +44,4 @@ for tag, lib in libs:
 for i, n in enumerate(res["product"]):
     print(json.dumps({"case": n["case"], "us": {t: res[t][i]["us_per_iteration"] for t, _ in libs},
                       "product_tflops": n["tflops"], "bitwise": all(res[t][i]["sha"] == n["sha"] for t, _ in libs),
-                      "nnz": n["nnz"]}))
+                      "iterations": [res[t][i]["iterations"] for t, _ in libs], "nnz": n["nnz"]}))
