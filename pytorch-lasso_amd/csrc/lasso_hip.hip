@@ -245,6 +245,18 @@ __global__ void reduce_partial_sets_kernel(const PartialSets ps, float* __restri
 }
 
 // the plain form: delta[i] = sum of row i of a dense [rows][ntiles] array (line search, unfused path)
+// dst[0 .. n) = src[0 .. n) (both 16-byte aligned): the checkpoints of lasso_conv_ista_solve.  A kernel of our own
+// rather than hipMemcpyAsync: with the runtime's device-to-device copies, 2 of 7 timed runs of a 10 / 20-iteration solve
+// on 134 MB codes came out 2-5 ms per solve slow (profiles/r04/ab_conv_stop_rule.txt: none in 4 runs with this kernel;
+// the cause inside the runtime was not established -- a copy engine instead of a blit kernel would fit the figure).
+__global__ __launch_bounds__(256) void copy_words_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    ((v4*)dst)[i] = __builtin_nontemporal_load((const v4*)src + i);
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int ntiles, float* __restrict__ delta) {
   __shared__ float sh[256];
   const float* row = partials + (size_t)blockIdx.x * ntiles;
@@ -2444,18 +2456,20 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
     // linear solver: a chunk of <= 64 iterations is enqueued with every iteration's sum kept on the
     // device, the host reads the chunk's sums ONCE; if iteration j of the chunk met the rule and was not the
     // chunk's last, (z, y) are put back to the chunk's head and exactly j + 1 iterations are replayed -- every kernel
-    // of the path sums in a fixed order, so the replay is bitwise the state the reference stops in.  Chunks after
-    // the first are sized from the decay of the sums, so that the rule is expected to fire at a chunk's end.
+    // of the path sums in a fixed order, so the replay is bitwise the state the reference stops in.
     constexpr int kChunkMax = 64;                    // ws.delta holds 64 sums
     float deltas[kChunkMax];
-    int chunk = std::min(maxiter, 2);
-    const size_t code_bytes = (size_t)M * g.K * 4;
+    int chunk = 1;
+    static const bool trace_chunks = getenv("LASSO_CONV_TRACE") != nullptr;      // the chunks and their verdicts on stderr
+    const int64_t code_words = M * g.K;
+    const int copy_grid = (int)std::min<int64_t>((code_words / 4 + 255) / 256 + 1, (int64_t)cus * 16);
     while (it < maxiter) {
       const int c = std::min(chunk, maxiter - it);
       const double t_head = t_mom;
       if (c > 1) {
-        LASSO_HIP_TRY(hipMemcpyAsync(ws.Zc, ws.Zm, code_bytes, hipMemcpyDeviceToDevice, st));
-        LASSO_HIP_TRY(hipMemcpyAsync(ws.Yc, ws.Ym, code_bytes, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zm, ws.Zc, code_words);
+        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Ym, ws.Yc, code_words);
+        LASSO_HIP_TRY(hipGetLastError());
       }
       for (int j = 0; j < c; ++j)
         if (int s = iterate(ws.delta + j)) return s;
@@ -2464,28 +2478,39 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
       int hit = -1;
       for (int j = 0; j < c && hit < 0; ++j)
         if (deltas[j] <= budget) hit = j;                                          // :44-46 (fp32 compare)
+      if (trace_chunks)
+        fprintf(stderr, "lasso_conv_ista_solve: iterations %d..%d sums %g .. %g budget %g -> %s %d\n", it, it + c - 1,
+                (double)deltas[0], (double)deltas[c - 1], (double)budget, hit < 0 ? "no stop" : "stop at", hit < 0 ? 0 : it + hit + 1);
       if (hit < 0) {
         it += c;
         last = deltas[c - 1];
-        // Size of the next chunk.  With a decaying chunk behind us: the iterations the rule is still away at the chunk's
-        // average decay -- that many when it is near (the rule is then expected to fire at the chunk's END: no
-        // replay), half as many when it is far (the sums of a momentum run are not monotone).  Without one (a chunk
-        // of one iteration, sums that grew): as many iterations as are behind us, so that speculation past an early
-        // stop never costs more than the solve itself.  Only speed depends on this estimate.
-        int next = std::min(kChunkMax, std::max(2, it));
-        if (c > 1 && deltas[0] > 0.0f && last > 0.0f && last < deltas[0] && budget > 0.0f) {
-          const double rate = log((double)deltas[0] / (double)last) / (double)(c - 1);
-          const double away = log((double)last / (double)budget) / rate;
-          if (away <= 8.0) next = std::max(1, (int)ceil(away));
-          else next = (int)std::min((double)kChunkMax, away / 2.0);
+        // Size of the next chunk -- only speed depends on it.  Within a factor 2 of the budget: one iteration at a time
+        // (the reference's own cadence: the sums of a momentum run are not monotone, and an iteration speculated past
+        // the stop costs more than the wait it saves).  Further away: the iterations the rule is still away at the
+        // chunk's average decay -- that many when it is near (so that it fires at the chunk's END: nothing to replay),
+        // half as many when it is far; without a decaying chunk behind us, as many iterations as the solve has
+        // done; never fewer than the sums would need if they halved every iteration.
+        int next = 1;
+        if (last > 2.0f * budget) {
+          next = std::min(kChunkMax, std::max(2, it));
+          if (c > 1 && deltas[0] > 0.0f && last < deltas[0] && budget > 0.0f) {
+            const double rate = log((double)deltas[0] / (double)last) / (double)(c - 1);
+            const double away = log((double)last / (double)budget) / rate;
+            next = away <= 8.0 ? std::max(1, (int)ceil(away)) : (int)std::min((double)kChunkMax, away / 2.0);
+          }
+          // ... nor more than half the iterations behind us (a stop inside a chunk costs one chunk: the speculated
+          // rest plus the replay), unless the halving bound says the stop cannot be that near
+          const int lg = budget > 0.0f ? (int)std::min((double)kChunkMax, log2((double)last / (double)budget)) : kChunkMax;
+          next = std::max(lg, std::min(next, std::max(2, it / 2)));
         }
         chunk = next;
         continue;
       }
       last = deltas[hit];
       if (hit < c - 1) {
-        LASSO_HIP_TRY(hipMemcpyAsync(ws.Zm, ws.Zc, code_bytes, hipMemcpyDeviceToDevice, st));
-        LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Yc, code_bytes, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zc, ws.Zm, code_words);
+        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Yc, ws.Ym, code_words);
+        LASSO_HIP_TRY(hipGetLastError());
         t_mom = t_head;
         for (int j = 0; j <= hit; ++j)
           if (int s = iterate(nullptr)) return s;
