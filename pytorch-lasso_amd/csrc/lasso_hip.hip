@@ -1070,6 +1070,77 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
 }
 
 // ---------------------------------------------------------------------------
+// The stop rule of the multi-launch solvers (ista.py:93 / conv2d/ista.py:44-46: the first iteration whose sum
+// |z - z_next| over ALL elements is <= budget ends the solve with that iteration's z) without a host round trip per
+// iteration -- the speculate-and-replay scheme of DESIGN 3.2 at launch granularity: a chunk of <= 64 iterations is
+// enqueued with every iteration's sum kept on the device (`iterate(slot)` leaves it in *slot), the host reads the
+// chunk's sums ONCE; if iteration j of the chunk met the rule and was not the chunk's last, the state goes back to the
+// chunk's head (`save` / `restore`, the momentum scalar *t_mom with it) and exactly j + 1 iterations are replayed --
+// every kernel of these paths sums in a fixed order, so the replay is bitwise the state the reference stops in.
+// ---------------------------------------------------------------------------
+template <class Iterate, class Save, class Restore>
+int speculate_stop_rule(int maxiter, float budget, float* delta_dev, hipStream_t st, double* t_mom, Iterate iterate,
+                        Save save, Restore restore, int* it_out, float* last_out, const char* who) {
+  constexpr int kChunkMax = 64;                    // delta_dev holds 64 sums
+  static const bool trace_chunks = getenv("LASSO_STOP_TRACE") != nullptr;        // the chunks and their verdicts on stderr
+  float deltas[kChunkMax];
+  float last = NAN;
+  int it = 0, chunk = 1;
+  while (it < maxiter) {
+    const int c = std::min(chunk, maxiter - it);
+    const double t_head = *t_mom;
+    if (c > 1)
+      if (int s = save()) return s;
+    for (int j = 0; j < c; ++j)
+      if (int s = iterate(delta_dev + j)) return s;
+    LASSO_HIP_TRY(hipMemcpyAsync(deltas, delta_dev, sizeof(float) * c, hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    int hit = -1;
+    for (int j = 0; j < c && hit < 0; ++j)
+      if (deltas[j] <= budget) hit = j;                                            // (fp32 compare like the reference)
+    if (trace_chunks)
+      fprintf(stderr, "%s: iterations %d..%d sums %g .. %g budget %g -> %s %d\n", who, it, it + c - 1, (double)deltas[0],
+              (double)deltas[c - 1], (double)budget, hit < 0 ? "no stop" : "stop at", hit < 0 ? 0 : it + hit + 1);
+    if (hit < 0) {
+      it += c;
+      last = deltas[c - 1];
+      // Size of the next chunk -- only speed depends on it; a stop inside a chunk costs one chunk (the speculated rest
+      // plus the replay).  Within a factor 2 of the budget: one iteration at a time (the reference's own cadence: the
+      // sums of a momentum run are not monotone, and an iteration speculated past the stop costs more than the wait it
+      // saves).  Further away: the iterations the rule is still away at the chunk's average decay -- that many when it
+      // is near (so that it fires at the chunk's END: nothing to replay), half as many when it is far; without a
+      // decaying chunk behind us, as many iterations as the solve has done; at most half the iterations done, and
+      // never fewer than the sums would need if they halved every iteration.
+      int next = 1;
+      if (last > 2.0f * budget) {
+        next = std::min(kChunkMax, std::max(2, it));
+        if (c > 1 && deltas[0] > 0.0f && last < deltas[0] && budget > 0.0f) {
+          const double rate = log((double)deltas[0] / (double)last) / (double)(c - 1);
+          const double away = log((double)last / (double)budget) / rate;
+          next = away <= 8.0 ? std::max(1, (int)ceil(away)) : (int)std::min((double)kChunkMax, away / 2.0);
+        }
+        const int lg = budget > 0.0f ? (int)std::min((double)kChunkMax, log2((double)last / (double)budget)) : kChunkMax;
+        next = std::max(lg, std::min(next, std::max(2, it / 2)));
+      }
+      chunk = next;
+      continue;
+    }
+    last = deltas[hit];
+    if (hit < c - 1) {
+      if (int s = restore()) return s;
+      *t_mom = t_head;
+      for (int j = 0; j <= hit; ++j)
+        if (int s = iterate(nullptr)) return s;
+    }
+    it += hit + 1;
+    break;
+  }
+  *it_out = it;
+  *last_out = last;
+  return LASSO_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Unfused path for shapes beyond the fused kernel (d > 256 or k > 1024): two MFMA GEMM
 // launches + one elementwise launch per iteration, state in HBM.  Same arithmetic
 // (ista.py:72-73,90,93,98-102); the stop rule is evaluated on the host every iteration
@@ -1080,6 +1151,7 @@ struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; fl
                       float* C; float* part; int* flags; float* fvals;      // line search only
                       double* sums;                                         // (its five sums of a trial: row shards)
                       float* Wc;                                            // [d][k] copy of W (lasso_fista_prepare / _run)
+                      float* Yc;                                            // y at the head of a speculated chunk (stop rule; z's copy lives in G)
                       size_t bytes; };
 
 GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool backtrack = false) {
@@ -1107,6 +1179,7 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool bac
     w.fvals = take(256);
     w.sums = reinterpret_cast<double*>(take(256));
   }
+  w.Yc = take((size_t)n * k * 4);
   w.bytes = off;
   return w;
 }
@@ -1131,7 +1204,8 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
-  for (; it < maxiter; ++it) {
+  const int parts = gemm_nt_prox_parts((int)n, (int)k);
+  auto iterate = [&](float* delta_slot) -> int {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;
     // NR = x - y W^T  (= -r);   G = 0 - NR Wt^T = r W
@@ -1140,14 +1214,38 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
     LASSO_HIP_TRY(launch_gemm_nt_prox(ws.NR, d, ws.Wt, d, zout, ldz, ws.Y, k, (int)n, (int)k, (int)d, lr_f, lam, coef,
                                       ws.dpart, st));
     t_mom = t_next;
-    if (tol > 0.0) {
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, gemm_nt_prox_parts((int)n, (int)k),
-                         ws.delta);
+    if (delta_slot) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws.dpart, parts, delta_slot);
       LASSO_HIP_TRY(hipGetLastError());
-      LASSO_HIP_TRY(hipMemcpyAsync(&last, ws.delta, sizeof(float), hipMemcpyDeviceToHost, st));
-      LASSO_HIP_TRY(hipStreamSynchronize(st));
-      if (last <= budget) { ++it; break; }
     }
+    return LASSO_OK;
+  };
+  if (!(tol > 0.0)) {
+    for (; it < maxiter; ++it)
+      if (int s = iterate(nullptr)) return s;
+  } else {
+    // the stop rule once per chunk of speculated iterations (speculate_stop_rule above; round 3: a host round trip
+    // per iteration): z's checkpoint lives in G (unused since the proximal step moved into GEMM-2's epilogue), y's in Yc
+    const int64_t words = n * k;
+    const bool compact = ldz == k && ((uintptr_t)zout & 15) == 0;      // (else the runtime's strided copy)
+    const int copy_grid = (int)std::min<int64_t>((words / 4 + 255) / 256 + 1, (int64_t)std::max(device_cus(), 1) * 16);
+    auto save = [&]() -> int {
+      if (compact) hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, zout, ws.G, words);
+      else LASSO_HIP_TRY(hipMemcpy2DAsync(ws.G, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Y, ws.Yc, words);
+      LASSO_HIP_TRY(hipGetLastError());
+      return LASSO_OK;
+    };
+    auto restore = [&]() -> int {
+      if (compact) hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.G, zout, words);
+      else LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, ws.G, k * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Yc, ws.Y, words);
+      LASSO_HIP_TRY(hipGetLastError());
+      return LASSO_OK;
+    };
+    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore, &it, &last,
+                                    "lasso_fista_solve (unfused)"))
+      return s;
   }
   if (iters_out) *iters_out = it;
   if (last_delta_out) *last_delta_out = last;
@@ -2451,73 +2549,23 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
     for (; it < maxiter; ++it)
       if (int s = iterate(nullptr)) return s;
   } else {
-    // The stop rule (ista.py:44-46: the first iteration whose sum over ALL code elements is <= budget ends the solve
-    // with that iteration's z) without a host round trip per iteration -- the speculate-and-replay scheme of the
-    // linear solver: a chunk of <= 64 iterations is enqueued with every iteration's sum kept on the
-    // device, the host reads the chunk's sums ONCE; if iteration j of the chunk met the rule and was not the
-    // chunk's last, (z, y) are put back to the chunk's head and exactly j + 1 iterations are replayed -- every kernel
-    // of the path sums in a fixed order, so the replay is bitwise the state the reference stops in.
-    constexpr int kChunkMax = 64;                    // ws.delta holds 64 sums
-    float deltas[kChunkMax];
-    int chunk = 1;
-    static const bool trace_chunks = getenv("LASSO_CONV_TRACE") != nullptr;      // the chunks and their verdicts on stderr
     const int64_t code_words = M * g.K;
     const int copy_grid = (int)std::min<int64_t>((code_words / 4 + 255) / 256 + 1, (int64_t)cus * 16);
-    while (it < maxiter) {
-      const int c = std::min(chunk, maxiter - it);
-      const double t_head = t_mom;
-      if (c > 1) {
-        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zm, ws.Zc, code_words);
-        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Ym, ws.Yc, code_words);
-        LASSO_HIP_TRY(hipGetLastError());
-      }
-      for (int j = 0; j < c; ++j)
-        if (int s = iterate(ws.delta + j)) return s;
-      LASSO_HIP_TRY(hipMemcpyAsync(deltas, ws.delta, sizeof(float) * c, hipMemcpyDeviceToHost, st));
-      LASSO_HIP_TRY(hipStreamSynchronize(st));
-      int hit = -1;
-      for (int j = 0; j < c && hit < 0; ++j)
-        if (deltas[j] <= budget) hit = j;                                          // :44-46 (fp32 compare)
-      if (trace_chunks)
-        fprintf(stderr, "lasso_conv_ista_solve: iterations %d..%d sums %g .. %g budget %g -> %s %d\n", it, it + c - 1,
-                (double)deltas[0], (double)deltas[c - 1], (double)budget, hit < 0 ? "no stop" : "stop at", hit < 0 ? 0 : it + hit + 1);
-      if (hit < 0) {
-        it += c;
-        last = deltas[c - 1];
-        // Size of the next chunk -- only speed depends on it.  Within a factor 2 of the budget: one iteration at a time
-        // (the reference's own cadence: the sums of a momentum run are not monotone, and an iteration speculated past
-        // the stop costs more than the wait it saves).  Further away: the iterations the rule is still away at the
-        // chunk's average decay -- that many when it is near (so that it fires at the chunk's END: nothing to replay),
-        // half as many when it is far; without a decaying chunk behind us, as many iterations as the solve has
-        // done; never fewer than the sums would need if they halved every iteration.
-        int next = 1;
-        if (last > 2.0f * budget) {
-          next = std::min(kChunkMax, std::max(2, it));
-          if (c > 1 && deltas[0] > 0.0f && last < deltas[0] && budget > 0.0f) {
-            const double rate = log((double)deltas[0] / (double)last) / (double)(c - 1);
-            const double away = log((double)last / (double)budget) / rate;
-            next = away <= 8.0 ? std::max(1, (int)ceil(away)) : (int)std::min((double)kChunkMax, away / 2.0);
-          }
-          // ... nor more than half the iterations behind us (a stop inside a chunk costs one chunk: the speculated
-          // rest plus the replay), unless the halving bound says the stop cannot be that near
-          const int lg = budget > 0.0f ? (int)std::min((double)kChunkMax, log2((double)last / (double)budget)) : kChunkMax;
-          next = std::max(lg, std::min(next, std::max(2, it / 2)));
-        }
-        chunk = next;
-        continue;
-      }
-      last = deltas[hit];
-      if (hit < c - 1) {
-        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zc, ws.Zm, code_words);
-        hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Yc, ws.Ym, code_words);
-        LASSO_HIP_TRY(hipGetLastError());
-        t_mom = t_head;
-        for (int j = 0; j <= hit; ++j)
-          if (int s = iterate(nullptr)) return s;
-      }
-      it += hit + 1;
-      break;
-    }
+    auto save = [&]() -> int {
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zm, ws.Zc, code_words);
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Ym, ws.Yc, code_words);
+      LASSO_HIP_TRY(hipGetLastError());
+      return LASSO_OK;
+    };
+    auto restore = [&]() -> int {
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Zc, ws.Zm, code_words);
+      hipLaunchKernelGGL(copy_words_kernel, dim3(copy_grid), dim3(256), 0, st, ws.Yc, ws.Ym, code_words);
+      LASSO_HIP_TRY(hipGetLastError());
+      return LASSO_OK;
+    };
+    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore, &it, &last,
+                                    "lasso_conv_ista_solve"))
+      return s;
   }
   LASSO_HIP_TRY(launch_conv_relayout(ws.Zm, (float*)z_out_dev, g.N, g.K, P, 0, st));
   if (iters_out) *iters_out = it;

@@ -192,8 +192,11 @@ def test_large_and_empty_shapes(n, d, k):
         tr = orc.FistaTrace()
         z0 = X.new_zeros(n, k)
         orc.fista(X, z0, W, 0.2, lr=lr, maxiter=300, tol=1e-4, trace=tr)
-        _, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.2, lr=lr, maxiter=300, tol=1e-4, return_info=True)
+        zt, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.2, lr=lr, maxiter=300, tol=1e-4, return_info=True)
         assert info["iterations"] == tr.iterations
+        # the rule is evaluated once per chunk of speculated iterations and the stopping iteration replayed
+        # (speculate_stop_rule): bitwise the codes of exactly that many iterations without a rule
+        assert torch.equal(zt, ista(X.cuda(), z0.cuda(), W.cuda(), 0.2, lr=lr, maxiter=info["iterations"], tol=0.0))
         assert abs(sparse_encode(X.cuda(), W.cuda(), alpha=0.2, maxiter=3).cpu()
                    - orc.sparse_encode(X, W, alpha=0.2, maxiter=3)).max().item() <= 1e-4   # lr='auto'
 
