@@ -377,9 +377,11 @@ int lasso_cd_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ld
  * LASSO_ERR_BAD_ARG, the reference's shape RuntimeError at ista.py:19).
  *   lasso_conv_ista_solve: min_z 0.5*||conv_transpose2d(z, W) - x||^2 + alpha*||z||_1 by
  *     (F)ISTA with the fixed step lr; z0_dev == NULL means zero init; the stop rule
- *     sum|z - z_next| <= numel(z)*tol is global (ista.py:16,44) and, when tol > 0, costs
- *     one stream synchronisation per iteration like the reference; tol == 0 runs exactly
- *     maxiter iterations without any.  iters_out / last_delta_out: HOST, nullable.
+ *     sum|z - z_next| <= numel(z)*tol is global (ista.py:16,44) and, when tol > 0, is read
+ *     once per chunk of speculated iterations (the stopping iteration is replayed bitwise
+ *     from the chunk's head: the codes, the count and the last sum are those of a solve
+ *     that checked after every iteration); tol == 0 runs exactly maxiter iterations without
+ *     a synchronisation.  iters_out / last_delta_out: HOST, nullable.
  *   lasso_conv_objective: (0.5*||x - x_hat||^2 + alpha*||z||_1)/N -> loss_dev (ista.py:23-26).
  *   lasso_conv_lip_bound: the Toeplitz bound on lambda_max of the stride-1 operator on a
  *     sample x sample frequency grid (sqrt != 0: its square root); ksize odd (else
