@@ -148,7 +148,8 @@ struct ConvGradProx {
 // Dictionaries of at most 64 atoms (KW = 64; round 4): a 128-atom tile left two of the four waves multiplying
 // zeros and half of the epilogue's 16-byte pieces out of range, so the tile is turned to 128 pixels x 64 atoms --
 // waves 2 (pixel halves) x 2 (atom halves), the same 4 x 2 MFMA blocks per wave, every z / y piece of the epilogue real.
-// The contraction order per element is unchanged (codes bitwise those of the 128-atom tile).
+// The contraction order per element is unchanged (codes bitwise those of the 128-atom tile).  K <= 32 goes one step
+// further the same way: 256 pixels x 32 atoms, the four waves side by side along the pixels (KW = 32).
 #ifndef LASSO_CGP_OCC
 #define LASSO_CGP_OCC 3      // workgroups (4 waves) per SIMD-quad the kernel is compiled for: 3 -> 168 registers
 #endif
@@ -188,10 +189,10 @@ __device__ __forceinline__ void cgp_stage_field(float* __restrict__ S, const flo
 
 template <int S4, int KW, bool SKIP>     // SKIP: C kh kw <= 4 S4 - 4, the last MFMA steps would multiply zeros
 __global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const ConvGradProx p) {
-  constexpr int TP = 8192 / KW;                             // code pixels of a tile: 64 (KW = 128) or 128 (KW = 64)
+  constexpr int TP = 8192 / KW;                             // code pixels of a tile: 64 (KW = 128), 128 (KW = 64), 256 (KW = 32)
   constexpr int kCgpGtLd = KW + 4;
   constexpr int NWA = KW / 32;                              // waves side by side along the atoms
-  constexpr int C4 = KW / 4, C4_SHIFT = KW == 128 ? 5 : 4;  // 16-byte pieces per tile row
+  constexpr int C4 = KW / 4, C4_SHIFT = KW == 128 ? 5 : KW == 64 ? 4 : 3;   // 16-byte pieces per tile row
   extern __shared__ __attribute__((aligned(16))) float cg_smem[];
   float* const Gt = cg_smem;                                // [TP][KW + 4]
   int* const toff = (int*)(Gt + TP * kCgpGtLd);             // [4 * S4]
@@ -547,12 +548,25 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   const int ckk = g.C * g.kh * g.kw;
   if (ckk > 192) return hipSuccess;
   ConvGradProx p;
-  const int kw = g.K <= 64 ? 64 : 128, tp = 8192 / kw;      // atoms x code pixels of a workgroup's tile
-  p.TV = g.Wz >= 48 ? 64 : g.Wz >= 24 ? 32 : g.Wz >= 12 ? 16 : 8;
-  p.TU = tp / p.TV;
-  p.RH = (p.TU - 1) * g.sh + g.kh;
-  p.RW = (p.TV - 1) * g.sw + g.kw;
-  if ((int64_t)g.C * p.RH * p.RW > 16384) return hipSuccess;
+  // Tile of a workgroup: kw atoms x tp = 8192 / kw code pixels (TU x TV of one image).  Every shape costs the same
+  // matrix-pipe time per tile, so the shape with the fewest tiles wins -- narrow atom tiles only for dictionaries
+  // they hold whole (K <= 64 / K <= 32), a receptive field of at most 64 KiB; ties go to the wider atom tile (fewer
+  // pixels: the smaller field to stage), then to the wider pixel row.
+  int kw = 0, tp = 0;
+  int64_t best_tiles = INT64_MAX;
+  for (int kwc : {128, 64, 32}) {
+    if (kwc < 128 && g.K > kwc) continue;
+    const int tpc = 8192 / kwc, gyc = (g.K + kwc - 1) / kwc;
+    for (int tv : {64, 32, 16, 8}) {
+      const int tu = tpc / tv;
+      if (tu < 1) continue;
+      const int rh = (tu - 1) * g.sh + g.kh, rw = (tv - 1) * g.sw + g.kw;
+      if ((int64_t)g.C * rh * rw > 16384) continue;
+      const int64_t tiles = (int64_t)((g.Hz + tu - 1) / tu) * ((g.Wz + tv - 1) / tv) * gyc;
+      if (tiles < best_tiles) { best_tiles = tiles; kw = kwc; tp = tpc; p.TV = tv; p.TU = tu; p.RH = rh; p.RW = rw; }
+    }
+  }
+  if (kw == 0) return hipSuccess;
   p.tv_shift = p.TV == 64 ? 6 : p.TV == 32 ? 5 : p.TV == 16 ? 4 : 3;
   p.inv_plane = 1.0f / (float)(p.RH * p.RW);
   p.inv_rw = 1.0f / (float)p.RW;
@@ -576,6 +590,7 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
 #define LASSO_CGP_CASE(S4_, KW_) LASSO_CGP_CASE2(S4_, KW_, false) LASSO_CGP_CASE2(S4_, KW_, true)
   LASSO_CGP_CASE(16, 128) LASSO_CGP_CASE(24, 128) LASSO_CGP_CASE(36, 128) LASSO_CGP_CASE(48, 128)
   LASSO_CGP_CASE(16, 64) LASSO_CGP_CASE(24, 64) LASSO_CGP_CASE(36, 64) LASSO_CGP_CASE(48, 64)
+  LASSO_CGP_CASE(16, 32) LASSO_CGP_CASE(24, 32) LASSO_CGP_CASE(36, 32) LASSO_CGP_CASE(48, 32)
 #undef LASSO_CGP_CASE
 #undef LASSO_CGP_CASE2
   *count = gx * gy;

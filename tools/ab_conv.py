@@ -5,7 +5,8 @@ AB_CONV_TOL / AB_CONV_MAXITER in the environment set the stop rule's tolerance (
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64),
-         (128, 1, 32, 5, 2, 1, 15), (96, 2, 48, 3, 1, 1, 20)]
+         (128, 1, 32, 5, 2, 1, 15), (96, 2, 48, 3, 1, 1, 20),
+         (2048, 1, 16, 3, 1, 1, 8), (2048, 1, 64, 3, 1, 1, 8), (512, 1, 32, 5, 1, 0, 28), (256, 3, 24, 5, 1, 2, 40)]
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd")]
     import hashlib, time, torch

@@ -2,7 +2,7 @@
 """Seeded sweep over random geometries of the convolutional solver (image channels, atoms either side of the 64 /
 128-atom tiles of the gradient kernel, kernel sizes, strides, paddings, ragged code grids), 6 FISTA and 6 ISTA
 iterations each against the CPU oracle.  Not part of the test suite; prints the worst deviation per family of
-kernels (which synthesis kernel / which gradient tile the geometry takes).  usage: stress_conv.py [trials]"""
+kernels (which synthesis kernel the geometry takes; whether the gradient kernel may pick its 64- / 32-atom tiles).  usage: stress_conv.py [trials]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
@@ -32,7 +32,7 @@ for trial in range(trials):
     z0 = torch.randn(N, K, Hz, Wz, generator=g) * 0.05
     lr = 0.3 / max(w.pow(2).sum().item(), 1e-3)
     ckk = C * kh * kw
-    fam = ("grad:" + ("explicit" if ckk > 192 else "tile%d" % (64 if K <= 64 else 128)) + " synth:" +
+    fam = ("grad:" + ("explicit" if ckk > 192 else ("narrow-tiles-allowed" if K <= 64 else "tile128")) + " synth:" +
            ("synth" if (8 <= C <= 16 and st == 1 and kh == kw and kh in (3, 5, 7)) else
             "few" if (C < 8 and st == 1 and 4 <= K <= 128 and K % 4 == 0 and ckk <= 128) else "explicit"))
     for fast in (True, False):
