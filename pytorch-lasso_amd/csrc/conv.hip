@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void conv_patches_kernel(const float* __restri
 // Fused gradient + proximal step (ista.py:20,29,42,44):  g = conv2d(R, W) as an IMPLICIT GEMM --
 // the patch matrix RC [M][C kh kw] of conv_patches_kernel is never formed, the G matrix never
 // written -- and z, y updated in the epilogue.
-// One workgroup = 4 waves = a tile of 64 code pixels (TU x TV of one image) x 128 atoms; it is
-// persistent over pixel tiles (blockIdx.y = block of 128 atoms), so that each wave keeps the B
+// One workgroup = 4 waves = a tile of 64 code pixels (TU x TV of one image) x 128 atoms (or 128 x 64 / 256 x 32
+// for small dictionaries: the launcher picks the shape with the fewest tiles, see ConvGradProx below); it is
+// persistent over pixel tiles (blockIdx.y = block of KW atoms), so that each wave keeps the B
 // fragments of its 32 atoms -- W [K][C kh kw], contraction order (c, a, b) like the reference --
 // in registers for the whole launch.  Per tile the receptive field of the 64 pixels,
 // C x ((TU-1) sh + kh) x ((TV-1) sw + kw) residual values (zero outside the image), is staged in
