@@ -463,17 +463,21 @@ static hipError_t launch_trials_k(const BtParams& p, const BtSteps& s, int ntria
   return hipGetLastError();
 }
 
+// `ntrials` <= kBtMultiMax trials with the steps of `s`: the tile sums only (the caller launches the decision)
+hipError_t launch_bt_trials_only(const BtParams& p, int kpad, int grid, const BtSteps& s, int ntrials, float* partsM,
+                                 hipStream_t stream) {
+  switch (kpad) {
+    case 256: return launch_trials_k<256>(p, s, ntrials, partsM, grid, stream);
+    case 512: return launch_trials_k<512>(p, s, ntrials, partsM, grid, stream);
+    case 1024: return launch_trials_k<1024>(p, s, ntrials, partsM, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // `ntrials` <= kBtMultiMax trials with the steps of `s` (trial indices first_index ..), then their decisions
 hipError_t launch_bt_trials(const BtParams& p, int kpad, int grid, double alpha, const BtSteps& s, int ntrials,
                             int first_index, float* partsM, hipStream_t stream) {
-  hipError_t e;
-  switch (kpad) {
-    case 256: e = launch_trials_k<256>(p, s, ntrials, partsM, grid, stream); break;
-    case 512: e = launch_trials_k<512>(p, s, ntrials, partsM, grid, stream); break;
-    case 1024: e = launch_trials_k<1024>(p, s, ntrials, partsM, grid, stream); break;
-    default: return hipErrorInvalidValue;
-  }
-  if (e != hipSuccess) return e;
+  if (hipError_t e = launch_bt_trials_only(p, kpad, grid, s, ntrials, partsM, stream); e != hipSuccess) return e;
   hipLaunchKernelGGL(bt_decide_multi_kernel, dim3(1), dim3(1024), 0, stream, p.partials, partsM, p.ntiles, (float)alpha, s,
                      ntrials, first_index, p.flags, p.fvals, p.skip);
   return hipGetLastError();

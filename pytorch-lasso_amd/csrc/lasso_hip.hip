@@ -651,6 +651,7 @@ constexpr int kBtMaxTrials = 1000;   // ista.py:17 (maxiter=1000)
 struct BtWorkspace {
   float* wp; float* wtp; float* partials; float* dpart; float* delta; int* flags; float* fvals;
   float* partsM;   // [kBtMultiMax][4][ntiles] tile sums of the trials of a multi-trial launch (fp32 tensors)
+  float* dtile;    // [ntiles] sum |z - z_next| per tile of bt_iter_kernel's accept step
   double* sums;    // [kBtMaxTrials][5] per-trial sums of a row-sharded solve
   float* G; float* C; float* Y;
   float* Zf;       // bf16 tensors: fp32 working copy of z
@@ -681,6 +682,7 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
   w.partials = take((size_t)5 * std::max<int64_t>(ntiles, 1) * 4);
   w.partsM = take((size_t)kBtMultiMax * 4 * std::max<int64_t>(ntiles, 1) * 4);
   w.dpart = take((size_t)kBtFinishGrid * 4);
+  w.dtile = take((size_t)std::max<int64_t>(ntiles, 1) * 4);
   w.delta = take(256);
   w.flags = reinterpret_cast<int*>(take(256));
   w.fvals = take(256);
@@ -849,10 +851,104 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   constexpr int kBtWindow = 16;
   constexpr int kBtFirst = 5;          // trials of the first multi-trial launch of an iteration
   // multi-trial launches (bt_trials_kernel): fp32 tensors, flat 16-byte-aligned point and gradient
-  const bool multi = !half && can_async && (k & 3) == 0 && k >= 4 && (((uintptr_t)zout) & 15) == 0 &&
+  // (can_async implies ldz == k here, so a row pitch that is not a multiple of 4 floats never reaches them)
+  const bool multi = !half && can_async && (k & 3) == 0 && (ldz & 3) == 0 && k >= 4 && (((uintptr_t)zout) & 15) == 0 &&
                      (((uintptr_t)ws.Y) & 15) == 0 && (((uintptr_t)ws.G) & 15) == 0 && !(bt_hint & 1);
+  // Round 5, fp32 tensors: ONE launch per outer iteration (bt_iter.hip: the accept step of the previous iteration, the
+  // gradient and the first `n_first` trials per tile) + ONE decision launch that also closes the previous iteration;
+  // decisions live in per-iteration slots of ws.flags / ws.fvals (kBtWindow slots of 4 words).  The trials beyond
+  // n_first (old kernel, p and g re-read) are enqueued only after a search of THIS solve has run out of trials once
+  // (`safety`); until then such a search costs one synchronous iteration.  bt_hint & 2: the multi-launch form (A/B).
+  const bool fusedit = multi && !(bt_hint & 2);
+  int n_first = kBtFirst;
+  bool safety = false;
   while (it < maxiter) {
-  if (can_async) {
+  if (can_async && fusedit) {
+    const int win0 = it, wlen = std::min(kBtWindow, maxiter - it);
+    LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, (size_t)kBtWindow * 4 * sizeof(int), st));
+    LASSO_HIP_TRY(hipMemsetAsync(ws.ctl, 0, 4 * sizeof(int), st));
+    BtIterParams q;
+    q.X = x; q.ldx = ldx; q.Wp = ws.wp; q.Wtp = ws.wtp; q.Z = zout; q.Y = ws.Y; q.G = ws.G;
+    q.partials = ws.partials; q.partsM = ws.partsM; q.dpart = ws.dtile; q.skip = ws.ctl;
+    q.n = (int)n; q.d = (int)d; q.k = (int)k; q.ntiles = ntiles; q.fast = fast ? 1 : 0;
+    const float stop_budget = tol > 0.0 ? budget : -1.0f;
+    double tm = t_mom;
+    float coef_prev = 0.0f;
+    BtSteps steps;
+    for (int i = win0; i < win0 + wlen; ++i) {
+      const double t_next = (1.0 + sqrt(1.0 + 4.0 * tm * tm)) / 2.0;                 // :98
+      const float coef = fast ? (float)((tm - 1.0) / t_next) : 0.0f;                 // :99
+      const int slot = i - win0;
+      int* const cur_flags = ws.flags + 4 * slot;
+      float* const cur_fvals = ws.fvals + 4 * slot;
+      const int* const prev_flags = slot > 0 ? ws.flags + 4 * (slot - 1) : nullptr;
+      const float* const prev_fvals = slot > 0 ? ws.fvals + 4 * (slot - 1) : nullptr;
+      double lr = lr0;
+      for (int b = 0; b < n_first; ++b) {
+        steps.lr[b] = (float)lr; steps.lam[b] = (float)(alpha * lr); steps.hol[b] = (float)(0.5 / lr);
+        lr = lr / eta;                                                               // :47
+      }
+      q.acc_flags = prev_flags; q.acc_fvals = prev_fvals; q.coef = coef_prev; q.tail = 0; q.ntrials = n_first;
+      LASSO_HIP_TRY(launch_bt_iter(q, steps, kp, grid, st));
+      const bool more = safety && n_first < kBtBatch;
+      LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, steps, n_first, 0, more ? 0 : 1, cur_flags,
+                                          cur_fvals, prev_flags, prev_fvals, ws.dtile, i - 1, stop_budget, ws.ctl,
+                                          ws.rtrials, ws.rlrs, ws.rfs, st));
+      if (more) {
+        BtSteps rest;
+        const int nb = kBtBatch - n_first;
+        for (int b = 0; b < nb; ++b) {
+          rest.lr[b] = (float)lr; rest.lam[b] = (float)(alpha * lr); rest.hol[b] = (float)(0.5 / lr);
+          lr = lr / eta;
+        }
+        BtParams pb = p;
+        pb.P = fast ? ws.Y : zout; pb.ldp = k; pb.flags = cur_flags; pb.fvals = cur_fvals; pb.skip = ws.ctl;
+        LASSO_HIP_TRY(launch_bt_trials_only(pb, kp, grid, rest, nb, ws.partsM, st));
+        LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, rest, nb, n_first, 1, cur_flags,
+                                            cur_fvals, nullptr, nullptr, nullptr, 0, -1.0f, ws.ctl, ws.rtrials,
+                                            ws.rlrs, ws.rfs, st));
+      }
+      coef_prev = coef;
+      tm = t_next;
+    }
+    {   // the accept step of the window's last iteration, and its record
+      const int slot = wlen - 1;
+      q.acc_flags = ws.flags + 4 * slot; q.acc_fvals = ws.fvals + 4 * slot; q.coef = coef_prev; q.tail = 1; q.ntrials = 0;
+      LASSO_HIP_TRY(launch_bt_iter(q, steps, kp, grid, st));
+      LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, steps, 0, 0, 0, nullptr, nullptr,
+                                          ws.flags + 4 * slot, ws.fvals + 4 * slot, ws.dtile, win0 + wlen - 1,
+                                          stop_budget, ws.ctl, ws.rtrials, ws.rlrs, ws.rfs, st));
+    }
+    int hctl[4] = {0, 0, 0, 0};
+    LASSO_HIP_TRY(hipMemcpyAsync(hctl, ws.ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipStreamSynchronize(st));
+    const int done = hctl[1] > 0 ? hctl[1] : win0;
+    if (done > win0) {
+      const int cnt = done - win0;
+      std::vector<int> ht(cnt);
+      std::vector<float> hl(cnt), hf(cnt);
+      LASSO_HIP_TRY(hipMemcpy(ht.data(), ws.rtrials + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hl.data(), ws.rlrs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      LASSO_HIP_TRY(hipMemcpy(hf.data(), ws.rfs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+      int most = 1;
+      for (int i = 0; i < cnt; ++i) {
+        if (trials_out) trials_out[win0 + i] = ht[i];
+        if (accepted_lr_out) accepted_lr_out[win0 + i] = hl[i];
+        if (accepted_f_out) accepted_f_out[win0 + i] = hf[i];
+        most = std::max(most, ht[i]);
+      }
+      prev_trials = ht[cnt - 1];
+      memcpy(&last, &hctl[2], sizeof(float));
+      for (int i = win0; i < done; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
+      // the next window computes as many trials per tile as this one's longest search took (every computed trial costs
+      // its GEMM whether it is needed or not; a search that outgrows the guess costs one synchronous iteration)
+      n_first = std::min(kBtBatch, std::max(2, most));
+    }
+    it = done;
+    if (hctl[0] == 1) break;     // the stop rule fired at iteration `done` (:93-95)
+    if (hctl[0] != 2) continue;  // the window ran through: next window
+    safety = true;               // a search ran out of trials: that iteration below, from its untouched state
+  } else if (can_async) {
     const int win0 = it, wlen = std::min(kBtWindow, maxiter - it);
     LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, 4 * sizeof(int), st));
     LASSO_HIP_TRY(hipMemsetAsync(ws.ctl, 0, 4 * sizeof(int), st));
@@ -1154,7 +1250,9 @@ struct GenWorkspace { float* Wt; float* Y; float* NR; float* G; float* dpart; fl
                       float* Yc;                                            // y at the head of a speculated chunk (stop rule; z's copy lives in G)
                       size_t bytes; };
 
-GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool backtrack = false) {
+// with_state: room for y's checkpoint at the head of a speculated chunk -- only solves with a live stop rule take it
+// (fixed-iteration solves paid n k words for a buffer they never touch)
+GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool backtrack = false, bool with_state = true) {
   GenWorkspace w;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -1179,7 +1277,7 @@ GenWorkspace carve_generic(void* base, int64_t n, int64_t d, int64_t k, bool bac
     w.fvals = take(256);
     w.sums = reinterpret_cast<double*>(take(256));
   }
-  w.Yc = take((size_t)n * k * 4);
+  w.Yc = with_state ? take((size_t)n * k * 4) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -1188,7 +1286,7 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
                   float* zout, int64_t ldz, int64_t n, int64_t d, int64_t k, double alpha, double lr,
                   int fast, int maxiter, double tol, int32_t* iters_out, float* last_delta_out,
                   void* workspace, size_t ws_bytes, hipStream_t st) {
-  GenWorkspace ws = carve_generic(workspace, n, d, k);
+  GenWorkspace ws = carve_generic(workspace, n, d, k, false, tol > 0.0 && maxiter > 0);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   if (n > INT32_MAX || d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
   LASSO_HIP_TRY(launch_transpose_pad(w, ldw, (int)d, (int)k, ws.Wt, d, (int)k, (int)d, st));
@@ -1259,7 +1357,7 @@ int run_generic(const float* x, int64_t ldx, const float* z_in, int64_t ldz_in,
                 const float* y_in, int64_t ldy_in, float* z_out, int64_t ldz_out, float* y_out, int64_t ldy_out,
                 int64_t n, int64_t d, int64_t k, double alpha, double lr, int fast, int it0, int iters, float* delta_dev,
                 void* workspace, size_t ws_bytes, hipStream_t st) {
-  GenWorkspace ws = carve_generic(workspace, n, d, k);
+  GenWorkspace ws = carve_generic(workspace, n, d, k, false, false);   // (no stop-rule checkpoint here)
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   if (n == 0) return LASSO_OK;
   if (z_in) {
@@ -1304,7 +1402,7 @@ int solve_generic_backtracking(const float* x, int64_t ldx, const float* w, int6
                                lasso_allreduce_fn reduce = nullptr, void* reduce_ctx = nullptr, int64_t n_global = 0) {
   // reduce != nullptr: a row shard -- the five sums of every trial and sum|z - z+| are added over the ranks and the
   // decision of bt_decide_kernel is taken on the host, as in solve_backtracking
-  GenWorkspace ws = carve_generic(workspace, n, d, k, true);
+  GenWorkspace ws = carve_generic(workspace, n, d, k, true, false);
   if (ws_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, ws.bytes);
   if (n > INT32_MAX || d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
   LASSO_HIP_TRY(launch_transpose_pad(w, ldw, (int)d, (int)k, ws.Wt, d, (int)k, (int)d, st));
@@ -1542,11 +1640,11 @@ int lasso_hip_device_cus(int* cus_out) {
 static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                                      int stop_mode, int backtrack) {
   stop_mode &= 0xFF;                                   // kernel hint / LASSO_SOLVE_ASYNC bits ride above
-  if (!fused_shape(d, k)) return carve_generic(nullptr, n, d, k, backtrack != 0).bytes;
+  const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
+  if (!fused_shape(d, k)) return carve_generic(nullptr, n, d, k, backtrack != 0, with_state).bytes;
   const int kp = pad_k(k);
   if (kp < 0) return 0;
   if (backtrack || dtype == LASSO_BF16) return carve_bt(nullptr, n, k, kp, dtype == LASSO_BF16, maxiter).bytes;
-  const bool with_state = tol > 0.0 && stop_mode != LASSO_STOP_NONE && maxiter > 0;
   // Every padded dictionary size solve_geometry() / the kernel hints can pick for this shape: a SMALLER kp means more
   // split-k groups, i.e. a LARGER exchange region (carve(384) needs ~2.2 MiB more than carve(512)), so the size is the
   // maximum over the candidates, not the size at pad_k(k) (an exactly-sized workspace failed at
@@ -1555,7 +1653,7 @@ static size_t solver_workspace_bytes(int64_t n, int64_t d, int64_t k, int dtype,
   if (kp == 512 && k <= 384 && d <= 128) bytes = std::max(bytes, carve(nullptr, n, k, 384, maxiter, with_state).bytes);
   if (kp == 1024 && k <= 768) bytes = std::max(bytes, carve(nullptr, n, k, 768, maxiter, with_state).bytes);
   // (LASSO_KERNEL_UNFUSED / the cost model may send a fused shape down the general-GEMM path: room for either)
-  return std::max(bytes, carve_generic(nullptr, n, d, k, false).bytes);
+  return std::max(bytes, carve_generic(nullptr, n, d, k, false, with_state).bytes);
 }
 
 // region behind the solver's workspace that objective_out needs: the lasso_objective workspace,
@@ -1632,7 +1730,7 @@ int lasso_fista_prepare(const void* w_dev, int64_t ldw, int64_t d, int64_t k, in
   if (ldw < k || maxiter < 0) return fail(LASSO_ERR_BAD_ARG, "ldw < k or maxiter < 0");
   if (!fused_shape(d, k)) {          // unfused path: W^T for the second GEMM (the workspace of solve_generic)
     if (d > INT32_MAX || k > INT32_MAX) return fail(LASSO_ERR_UNSUPPORTED, "shape too large");
-    GenWorkspace gw = carve_generic(workspace_dev, 0, d, k);
+    GenWorkspace gw = carve_generic(workspace_dev, 0, d, k, false, false);
     if (workspace_bytes < gw.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", gw.bytes);
     LASSO_HIP_TRY(launch_transpose_pad((const float*)w_dev, ldw, (int)d, (int)k, gw.Wt, d, (int)k, (int)d,
                                        (hipStream_t)stream));
@@ -1791,7 +1889,10 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                               half_bt ? LASSO_BF16 : LASSO_F32, alpha, lr, fast, maxiter,
                               stop_rule ? tol : 0.0, eta_backtrack,
                               iters_out, last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                              workspace_bytes, st, nullptr, nullptr, 0, (hint & 0x300) == LASSO_KERNEL_TILE ? 1 : 0);
+                              workspace_bytes, st, nullptr, nullptr, 0,
+                              // A/B knobs of the fp32 line search: TILE = one trial per launch, SPLITK = round 4's
+                              // multi-launch form (gradient / trials / accept as separate launches)
+                              (hint & 0x300) == LASSO_KERNEL_TILE ? 1 : (hint & 0x300) == LASSO_KERNEL_SPLITK ? 2 : 0);
   const int kps = pad_k_solve(n, d, k);                  // (fp32 fixed step from here on: 768 atoms have their own tile kernel)
   const NarrowTiles narrow(narrow_tiles(n, d, k, kps, hint));
   Workspace ws = carve(workspace_dev, n, k, kps, maxiter, stop_rule);

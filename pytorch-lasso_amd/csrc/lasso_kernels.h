@@ -174,6 +174,31 @@ constexpr int kBtMultiMax = 8;
 struct BtSteps { float lr[kBtMultiMax]; float lam[kBtMultiMax]; float hol[kBtMultiMax]; };   // step, alpha * step, 0.5 / step
 hipError_t launch_bt_trials(const BtParams& p, int kpad, int grid, double alpha, const BtSteps& s, int ntrials,
                             int first_index, float* partsM /* [kBtMultiMax][4][ntiles] */, hipStream_t stream);
+// one launch per outer iteration (bt_iter.hip): accept step of the previous iteration + gradient + `ntrials` trials per
+// tile, then the decision launch that also closes the previous iteration (record, stop rule)
+struct BtIterParams {
+  const float* X; int64_t ldx;
+  const float* Wp; const float* Wtp;
+  float* Z;                              // [n][k] flat (ld = k, 16-byte aligned): the iterate z
+  float* Y;                              // [n][k] flat: the momentum point y (read and written only when fast)
+  float* G;                              // [n][k] flat: the gradient at the point
+  float* partials;                       // [ntiles] sum r0^2 per tile
+  float* partsM;                         // [kBtMultiMax][4][ntiles] tile sums of the trials
+  float* dpart;                          // [ntiles] sum |z - z_next| per tile of the accept step
+  const int* acc_flags; const float* acc_fvals;   // decision of the previous iteration; nullptr: no accept step (first
+                                         //   iteration of a window: the point is loaded as it is)
+  const int* skip;                       // nullable: *skip != 0 -> no-op
+  int n, d, k, ntiles;
+  int fast, tail, ntrials;               // tail: accept step only (behind the last iteration of a window)
+  float coef;                            // momentum coefficient of the iteration being accepted
+};
+hipError_t launch_bt_iter(const BtIterParams& p, const BtSteps& s, int kpad, int grid, hipStream_t stream);
+hipError_t launch_bt_iter_decide(const float* partials, const float* partsM, int ntiles, double alpha, const BtSteps& s,
+                                 int ntrials, int first_index, int last_batch, int* cur_flags, float* cur_fvals,
+                                 const int* prev_flags, const float* prev_fvals, const float* dpart, int it_prev,
+                                 float budget, int* ctl, int* trials, float* lrs, float* fs, hipStream_t stream);
+hipError_t launch_bt_trials_only(const BtParams& p, int kpad, int grid, const BtSteps& s, int ntrials, float* partsM,
+                                 hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,
                            int trial_index, int force, hipStream_t stream, double* sums_out = nullptr);
 hipError_t launch_bt_decide(const BtParams& p, double alpha, double lr, int trial_index, int force,

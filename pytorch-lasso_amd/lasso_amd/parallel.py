@@ -305,6 +305,11 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                 Z = Z0 if Z0 is not None else X.new_zeros(0, k)
                 pending = _EmptyShardPending(ndelta, k, tol, X.device) if tol > 0 else None
             else:
+                # (Z0 is None or a code this engine returned: besides sharded_async_ok(), which every rank agreed on
+                # before the loop, encode_begin_sharded only asks for a start on the device -- make that hold here
+                # rather than leave one rank raising while its peers wait in the step's all-reduce)
+                if Z0 is not None and Z0.device != X.device:
+                    Z0 = Z0.to(X.device)
                 began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs)
                 if began is None:       # sharded_async_ok() said yes on every rank: this is a bug, not a fallback
                     raise RuntimeError("encode_begin_sharded refused arguments sharded_async_ok accepted")

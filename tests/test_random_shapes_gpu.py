@@ -57,6 +57,26 @@ def test_stop_rule_random_shapes():
         assert info["iterations"] == tr.iterations, (n, d, k, info, tr.iterations)
 
 
+def test_stop_rule_on_a_ragged_batch_against_the_oracle():
+    """n in (4096, 8192) at d=256, k=1024 is the range where run_impl splits a batch into full rounds on
+    the tile kernel and a ragged tail on the split-k kernel (another order of the per-iteration sums of |z - z_next|):
+    the iteration at which the exact rule fires, and the codes, against the CPU oracle -- not against another kernel."""
+    from lasso_amd.linear.solvers import ista
+    from lasso_amd import _native as nat
+    from oracle import lasso_oracle as orc
+    n, d, k = 4900, 256, 1024
+    assert b"split" in nat.lib().lasso_fista_kernel_name(n, d, k, nat.LASSO_F32, 0)      # the hybrid dispatch is what runs
+    X, W = _problem(n, d, k, 77)
+    lr = 1.0 / max(orc.lipschitz_constant(W, "exact"), 1e-3)
+    z0 = torch.zeros(n, k)
+    tr = orc.FistaTrace()
+    ref = orc.fista(X, z0, W, 0.4, lr=lr, maxiter=60, tol=3e-4, trace=tr)
+    assert 5 < tr.iterations < 60                       # the rule does fire inside the budget
+    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.4, lr=lr, maxiter=60, tol=3e-4, return_info=True)
+    assert info["iterations"] == tr.iterations, (info, tr.iterations)
+    assert (got.cpu() - ref).abs().max().item() <= 5e-5
+
+
 def test_cd_random_shapes():
     from lasso_amd.linear.solvers import coord_descent
     from oracle import lasso_oracle as orc

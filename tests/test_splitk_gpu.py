@@ -208,8 +208,24 @@ def test_narrow_tiles_for_short_rows_and_large_dictionaries(n, d, k):
         assert info["iterations"] == tr.iterations, (mode, info, tr.iterations)
 
 
-@pytest.mark.parametrize("n,k", [(4100, 1024), (5000, 1024), (6200, 1024), (8200, 1024), (4500, 512), (9000, 300)])
-def test_ragged_batches_run_their_last_round_on_the_split_kernel(n, k):
+def _device_cus():
+    import ctypes
+    from lasso_amd import _native as nat
+    c = ctypes.c_int(0)
+    assert nat.lib().lasso_hip_device_cus(ctypes.byref(c)) == 0
+    return c.value
+
+
+# (rounds of 16-row tiles on the device's CUs, rows past the last full round, atoms): sized from the CU count, so the
+# cases are ragged on any part (the sizes were written for 256 CUs)
+@pytest.mark.parametrize("rounds,extra,k", [(1, 4, 1024), (1, 904, 1024), (1, 2104, 1024), (2, 8, 1024), (1, 404, 512),
+                                            (2, 808, 300)])
+def test_ragged_batches_run_their_last_round_on_the_split_kernel(rounds, extra, k):
+    n = _device_cus() * 16 * rounds + extra
+    _ragged_case(n, k, _device_cus() * 32)
+
+
+def _ragged_case(n, k, n_whole):
     """More tiles than CUs, the last round partly filled: the full rounds run on the tile kernel, the tail's tiles on
     the split-k kernel (lasso_hip.hip run_impl).  Codes bitwise those of the tile kernel alone -- cold and warm start,
     FISTA and ISTA --; the per-iteration sums of |z - z_next| (tile rows + split-k rows) agree with it to fp32 rounding,
@@ -220,7 +236,7 @@ def test_ragged_batches_run_their_last_round_on_the_split_kernel(n, k):
     from lasso_amd import _native as nat
     name = nat.lib().lasso_fista_kernel_name(n, 256, k, nat.LASSO_F32, 0)
     assert b"split-k" in name or b"splitk" in name          # (tiny tails: the cost model may give the whole batch to split-k)
-    assert b"split-k" not in nat.lib().lasso_fista_kernel_name(8192, 256, k, nat.LASSO_F32, 0)      # whole rounds: tile kernel only
+    assert b"split-k" not in nat.lib().lasso_fista_kernel_name(n_whole, 256, k, nat.LASSO_F32, 0)   # whole rounds: tile kernel only
     X, W = _case(n, 256, k, seed=n + k)
     Xg, Wg = X.cuda(), W.cuda()
     lr = 0.9 / ((k / 256) * (1.0 + (256 / k) ** 0.5) ** 2)

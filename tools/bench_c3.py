@@ -44,7 +44,8 @@ if __name__ == "__main__":
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 10
     res = {"workload": "config 3: backtracking FISTA n=16384 d=256 k=1024, 10 outer iterations"}
     if "--bf16-only" not in sys.argv:
-        res["fp32"] = run(torch.float32, reps)
+        res["fp32"] = run(torch.float32, reps)                         # one launch per outer iteration (bt_iter.hip)
+        res["fp32_multilaunch"] = run(torch.float32, reps, kernel='splitk')   # round 4's gradient / trials / accept launches
     res["bf16_api"] = run(torch.bfloat16, reps)                       # persistent single-launch kernel
     res["bf16_multilaunch"] = run(torch.bfloat16, reps, kernel='tile')  # the grad / trial / decide / finish launches
     if "--fixed" in sys.argv:      # same data, fixed step 1/L, 10 iterations: fp32 fused kernel vs bf16 path
