@@ -158,13 +158,20 @@ def world_from_env(args):
 class Ranks:
     """barrier + max-over-ranks timing, on RCCL ('nccl') or -- launcher self-test -- gloo."""
 
-    def __init__(self, rank, world, device, backend):
+    def __init__(self, rank, world, device, backend, force=False):
         self.rank, self.world, self.device, self.dist, self.backend = rank, world, device, None, backend
-        if world > 1:
+        # force (--force-dist, N = 1 only): a ONE-rank process group, so that the collectives of the N > 1 paths -- RCCL
+        # on device tensors when the backend is nccl -- execute on a one-GPU box (lasso_amd.parallel._sharded)
+        if world > 1 or force:
             import torch.distributed as dist
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                os.environ["LASSO_FORCE_COLLECTIVES"] = "1"
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
             self.dist = dist
+        self.sharded = self.dist is not None       # the multi-rank code paths run (N > 1, or --force-dist)
 
     def sync(self):
         import torch
@@ -260,7 +267,7 @@ def run_fista(args, ranks):
         n_total = r["rows"] * world
 
         def to_tol():
-            if world == 1:
+            if not ranks.sharded:
                 return ista(r["Xg"], r["z0"], r["Wg"], ALPHA, lr=lr, maxiter=2000, tol=1e-5, return_info=True)
             return parallel.sharded_encode(eng, r["Xg"], r["Wg"], ALPHA, None, lr=lr, maxiter=2000, tol=1e-5,
                                            n_global=n_total, return_info=True)
@@ -271,7 +278,7 @@ def run_fista(args, ranks):
         torch.cuda.synchronize()
         ttt = {"ms": 1e3 * ranks.max(time.perf_counter() - t1), "iterations": info["iterations"], "tol": 1e-5,
                "rows_total": n_total, "rows_per_gpu": r["rows"],
-               "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), global over all ranks" if world > 1 else
+               "rule": "sum|z-z_next| <= n*k*tol (ista.py:64,93), global over all ranks" if ranks.sharded else
                        "sum|z-z_next| <= n*k*tol (ista.py:64,93), global (one rank holds the whole batch)",
                "reference_iterations": 263 if n_total == N_ROWS else None}
     out = None
@@ -506,7 +513,7 @@ def run_c3(args, ranks):
     kw = dict(lr=1.0, maxiter=C3_OUTER, tol=0.0, backtrack=True)
 
     def solve(info=False):
-        if world == 1:
+        if not ranks.sharded:
             return ista(Xg, z0, Wg, ALPHA, return_info=info, **kw)
         return parallel.sharded_encode(eng, Xg, Wg, ALPHA, z0, n_global=n_all, return_info=info, **kw)
     elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
@@ -531,7 +538,7 @@ def run_c3(args, ranks):
                                "lr0=1.0, %d outer iterations; step = one solve" % (n_all, args.dtype, C3_OUTER) +
                                ("" if n_all == C3_ROWS else " (NOT the 16384-row batch of config 3)"),
                    "rows_per_gpu": rows, "rows_total": n_all,
-                   "parallelism": "row-sharded x%d%s" % (world, ", every F<=Q decision on all-reduced sums" if world > 1 else "")},
+                   "parallelism": "row-sharded x%d%s" % (world, ", every F<=Q decision on all-reduced sums" if ranks.sharded else "")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "kernel": name.decode() if name else None,
                      "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
@@ -575,6 +582,9 @@ def parser():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="c3 workload: tensor dtype")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collectives: nccl (= RCCL, the product) or gloo (host-staged; tests on a one-GPU box)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: create a ONE-rank process group (RCCL with --backend nccl) and run the multi-rank "
+                         "code paths on it -- every collective of an N > 1 run executes on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on cuda:0 (needs --backend gloo): executes the multi-rank code paths on ONE GPU")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -595,6 +605,8 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.share_gpu and args.backend != "gloo":
         raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL wants one GPU per rank)")
+    if args.force_dist and args.gpus != 1:
+        raise SystemExit("bench.py: --force-dist is for --gpus 1 (N > 1 runs its collectives anyway)")
     if args.workload == "fista" and args.rows is None:
         args.rows = N_ROWS
 
@@ -618,11 +630,14 @@ def main():
         if torch.cuda.device_count() <= gpu:
             raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(gpu)
-        ranks = Ranks(rank, world, torch.device("cuda", gpu), args.backend)
+        ranks = Ranks(rank, world, torch.device("cuda", gpu), args.backend, force=args.force_dist)
         out = {"em": run_em, "c3": run_c3, "fista": run_fista}[args.workload](args, ranks)
-        if out is not None and world > 1:
+        if out is not None and ranks.sharded:
             out["backend"] = args.backend + (" (all ranks share cuda:0: a code-path run, not a performance figure)"
-                                             if args.share_gpu else " (RCCL over xGMI)" if args.backend == "nccl" else "")
+                                             if args.share_gpu else
+                                             " (ONE-rank process group, --force-dist: the N > 1 code paths and their "
+                                             "collectives on one GPU -- a code-path run, not a scaling figure)"
+                                             if world == 1 else " (RCCL over xGMI)" if args.backend == "nccl" else "")
     ranks.close()
     if rank == 0:
         print(json.dumps(out))

@@ -12,7 +12,8 @@
 //                             g stays in REGISTERS (MFMA C layout, 32 per lane) for the trials
 //   trials t = 0 .. nt-1      z+ = S(p_i - lr_t g) into the LDS tile, r1 = z+ W^T - x,
 //                             tile sums {sum r1^2, sum |z+|, sum dz g, sum dz^2}                   (:26-35,:40)
-//   g -> G                    through the LDS tile as 16-byte row pieces (the next launch's accept reads it)
+//   g -> G                    from the registers, behind the last trial's MFMAs (the next launch's accept reads it);
+//                             the NEXT tile's z / g / y / x loads are issued at the same point
 //
 // bt_iter_decide_kernel then closes iteration i-1 (sum |z - z_i| over the tiles, the iteration's record, the stop
 // rule :93-95) and takes the decision of iteration i (first trial with F <= Q, :45) -- TWO launches per outer
@@ -21,11 +22,47 @@
 // per ~120 us of matrix work instead of once per launch.  The last iteration of a window is accepted by the same kernel
 // in `tail` mode (accept only).  Arithmetic per element is the sequence of backtrack.hip's kernels (each product and
 // sum rounded separately like the reference's ATen ops); the tile sums are taken in another (fixed) order.
+#include <algorithm>
 #include "tile_device.hpp"
+
+#ifdef LASSO_BTI_TIMING
+// debug build (tools/bti_timeline.py): wall-clock stamps (100 MHz) of ONE tile of every workgroup in the last
+// launch that ran the accept step and the trials, 16 per workgroup
+__device__ unsigned long long lasso_bti_stamps[1024 * 16];
+extern "C" int lasso_debug_bti_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_bti_stamps), sizeof(lasso_bti_stamps));
+}
+#define BTI_STAMP(slot) do { if (stamp_on && threadIdx.x == 0) lasso_bti_stamps[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define BTI_STAMP(slot) do { } while (0)
+#endif
 
 namespace lasso {
 
-template <int K>
+// 4 x 4 transpose inside every lane quad: on entry lane j of a quad holds v[0..3] = M[j][0..3], on exit M[0..3][j].
+// Two butterfly stages (lane bit 0 with element bit 0, lane bit 1 with element bit 1), one DPP move per exchanged
+// element.  Used to turn the MFMA C layout (a lane owns FOUR ROWS of one column) into 16-byte row pieces.
+__device__ __forceinline__ void quad_transpose(f32x4& v, int j) {
+  const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {            // pairs (0,1), (2,3): exchange with lane j ^ 1
+    const float send = b0 ? v[2 * h] : v[2 * h + 1];
+    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));  // quad_perm:[1,0,3,2]
+    if (b0) v[2 * h] = recv; else v[2 * h + 1] = recv;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {            // pairs (0,2), (1,3): exchange with lane j ^ 2
+    const float send = b1 ? v[h] : v[h + 2];
+    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, true));  // quad_perm:[2,3,0,1]
+    if (b1) v[h] = recv; else v[h + 2] = recv;
+  }
+}
+
+// ACCEPT: the launch opens with the accept step of the previous iteration (false: first iteration of a window -- the
+// point is loaded as it is).  A compile-time switch, like everything else that decides WHICH registers a tile's
+// prefetch defines: a load under a run-time condition keeps the old value alive across the whole tile (720 spilled
+// registers in the first version of the prefetch).
+template <int K, bool ACCEPT>
 __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterParams p, const BtSteps s) {
   constexpr int D = kFistaD;
   constexpr int NW = kFistaWaves;
@@ -39,7 +76,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
   lds_char* const rt = pt + kTileM * K * 4;
   lds_f32* const red = (lds_f32*)(rt + kTileM * D * 4);
   if (p.skip && *p.skip != 0) return;
-  const bool accept = p.acc_flags != nullptr;
+  constexpr bool accept = ACCEPT;
   float lr_a = 0.0f, lam_a = 0.0f;
   if (accept) {
     if (p.acc_flags[0] == 0) return;       // no trial of the previous iteration passed: the state stays as it is
@@ -51,51 +88,97 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
   c.init(p.Wp, p.Wtp, rings);
   const int tid = threadIdx.x;
   const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
-  if (!p.tail) {
-    dma_step(c.w1, c.voff1, c.ring);
-    dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
-  }
-  float* const P = p.fast ? p.Y : p.Z;     // the point: y (FISTA) or z (ISTA), flat [n][k]
-  // LDS byte offset of this lane's C-layout element (row 4q+rg, column colbase+n) of the [16][K] tile: tile_off()
-  int ep_rg[4];
+  dma_step(c.w1, c.voff1, c.ring);
+  dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
+  float* const P = p.fast ? p.Y : p.Z;     // the point: y (FISTA) or z (ISTA: the loads of p then repeat those of z), flat [n][k]
+
+  // The operands of a tile's accept step (z, g and -- FISTA -- y: ITER 16-byte pieces per thread each) and its block of
+  // x, all in flight together, clamped addresses (masked where they are used).  Issued for tile j+1 behind the LAST
+  // GEMM of tile j: the loads travel under that trial's sums, its barrier and the g stores, and no hand-counted wait of
+  // an LDS-DMA ring (in-order vmcnt) ever has them in front of it.
+  // Addresses: a uniform per-tile base (SGPR pair) + a 32-bit byte offset built from two thread constants with one
+  // min and one multiply-add per piece -- nothing worth hoisting out of the tile loop.  (The first version clamped
+  // 64-bit addresses per piece; the compiler hoisted the per-piece parts, spilled them, and every scratch reload
+  // between two prefetch loads waited for the loads in front of it: eight HBM round trips in a row, 10 us per tile.)
+  constexpr int RSTEP = kFistaThreads / (K / 4);             // rows between a thread's consecutive pieces
+  const int r0 = tid / (K / 4);
+  const int cl = min((tid - r0 * (K / 4)) * 4, p.k - 4);     // first column of the thread's pieces (clamped; masked in use)
+  f32x4 pa[ITER], ga[ITER], za[ITER], xr[2];
+  auto fetch_tile = [&](int tile) {
+    const int row0 = tile * kTileM;
+    const int last = min(kTileM, p.n - row0) - 1;            // last valid row of the tile (uniform)
+    if constexpr (ACCEPT) {
+      const char* const zb = (const char*)(p.Z + (int64_t)row0 * p.k);
+      const char* const gb = (const char*)(p.G + (int64_t)row0 * p.k);
+      const char* const pb = (const char*)(P + (int64_t)row0 * p.k);
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) ep_rg[rg] = (4 * q + rg) * (K * 4) + (((n >> 2) ^ rg) << 4) + ((n & 3) << 2);
-  auto ep_addr = [&](int ps, int cb, int rg) {
-    const int colbase = wid * KW + 32 * ps + 16 * cb;           // wave-uniform
-    return (lds_f32*)(pt + ep_rg[rg] + ((((colbase >> 4) & 3) ^ q) << 6) + (colbase >> 6) * 256);
+      for (int i = 0; i < ITER; ++i) {
+        const unsigned off = (unsigned)(min(r0 + RSTEP * i, last) * p.k + cl) * 4u;
+        za[i] = *reinterpret_cast<const f32x4*>(zb + off);
+        ga[i] = *reinterpret_cast<const f32x4*>(gb + off);
+        pa[i] = *reinterpret_cast<const f32x4*>(pb + off);
+      }
+    }
+    const char* const xb = (const char*)(p.X + (int64_t)row0 * p.ldx);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        xr[cb][rg] = *reinterpret_cast<const float*>(
+            xb + (unsigned)(min(4 * q + rg, last) * (int)p.ldx + min(32 * wid + 16 * cb + n, p.d - 1)) * 4u);
   };
+  if ((int)blockIdx.x < p.ntiles) fetch_tile(blockIdx.x);
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int row0 = tile * kTileM;
+    const int next_tile = min(tile + (int)gridDim.x, p.ntiles - 1);   // (past the end: a harmless repeat of the last tile)
     float dsum = 0.0f;
-    if (accept) {
-      // ---- the accept step of the previous iteration on this tile; all pieces of a thread in flight together
-      f32x4 pa[ITER], ga[ITER], za[ITER];
+#ifdef LASSO_BTI_TIMING
+    const bool stamp_on = accept && tile == (int)(blockIdx.x + (LASSO_BTI_TIMING) * gridDim.x);   // -DLASSO_BTI_TIMING=<j>: the workgroup's j-th tile
+#endif
+    BTI_STAMP(0);
+    // Per-tile copies of the lane coordinates the compiler cannot see through: everything derived from them (the LDS
+    // addresses of the C layout, the offsets of the accept step's stores) is then computed where a tile uses it
+    // instead of once per launch -- hoisted out of the tile loop those ~60 values were live across every GEMM and
+    // spilled, and a scratch reload behind the prefetch waits for the prefetch (in-order vmcnt).
+    int qo = q, no = n, r0o = r0, tido = tid;
+    asm volatile("" : "+v"(qo), "+v"(no), "+v"(r0o), "+v"(tido));
+    // LDS byte offset of this lane's C-layout element (row 4q+rg, column colbase+n) of the [16][K] tile: tile_off()
+    int ep_rg[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) ep_rg[rg] = (4 * qo + rg) * (K * 4) + (((no >> 2) ^ rg) << 4) + ((no & 3) << 2);
+    auto ep_addr = [&](int ps, int cb, int rg) {
+      const int colbase = wid * KW + 32 * ps + 16 * cb;           // wave-uniform
+      return (lds_f32*)(pt + ep_rg[rg] + ((((colbase >> 4) & 3) ^ qo) << 6) + (colbase >> 6) * 256);
+    };
+    f32x4 negx[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        negx[cb][rg] = ((row0 + 4 * q + rg) < p.n && (32 * wid + 16 * cb + n) < p.d) ? -xr[cb][rg] : 0.0f;
+    if constexpr (ACCEPT) {
+      // ---- the accept step of the previous iteration on this tile
+      char* const zb = (char*)(p.Z + (int64_t)row0 * p.k);
+      char* const yb = (char*)(p.Y + (int64_t)row0 * p.k);
+      const int cc = (tido - r0o * (K / 4)) * 4;
 #pragma unroll
       for (int i = 0; i < ITER; ++i) {
-        const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
-        const int64_t off = (int64_t)min(row0 + r, p.n - 1) * p.k + min(cc, p.k - 4);
-        za[i] = *reinterpret_cast<const f32x4*>(p.Z + off);
-        ga[i] = *reinterpret_cast<const f32x4*>(p.G + off);
-        if (p.fast) pa[i] = *reinterpret_cast<const f32x4*>(p.Y + off);
-      }
-#pragma unroll
-      for (int i = 0; i < ITER; ++i) {
-        const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
+        const int r = r0o + RSTEP * i;
         const bool ok = (row0 + r) < p.n && cc < p.k;
         f32x4 zn = {0.f, 0.f, 0.f, 0.f}, yn = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float zo = za[i][e];
-            const float pv = p.fast ? pa[i][e] : zo;
+            const float pv = pa[i][e];
             zn[e] = soft_threshold(__fsub_rn(pv, __fmul_rn(lr_a, ga[i][e])), lam_a);        // ista.py:40
             dsum += __builtin_fabsf(__fsub_rn(zo, zn[e]));                                    // :93
             yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo)));                // :99-100
           }
-          const int64_t off = (int64_t)(row0 + r) * p.k + cc;
-          *reinterpret_cast<f32x4*>(p.Z + off) = zn;                                          // :102
-          if (p.fast) *reinterpret_cast<f32x4*>(p.Y + off) = yn;
+          const unsigned off = (unsigned)(r * p.k + cc) * 4u;
+          *reinterpret_cast<f32x4*>(zb + off) = zn;                                           // :102
+          if (p.fast) *reinterpret_cast<f32x4*>(yb + off) = yn;
         }
         *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = p.fast ? yn : zn;
       }
@@ -104,45 +187,24 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
         *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = v;
       });
     }
-    if (p.tail) {
-      dsum = wave_sum(dsum);
-      if (lane == 0) red[NW + wid] = dsum;
-      LASSO_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();
-      if (tid == 0) {
-        float a = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) a += red[NW + w];
-        p.dpart[tile] = a;
-      }
-      __builtin_amdgcn_s_barrier();
-      continue;
-    }
-    f32x4 negx[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
-        float v = 0.0f;
-        if ((row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
-        negx[cb][rg] = -v;
-      }
+    BTI_STAMP(1);
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
+    BTI_STAMP(2);
 
     // ---- gradient at the point: r0 = p W^T - x, g = r0 W (ista.py:22-24)
     f32x4 gk[NP][2];
     {
       f32x4 acc[2] = {negx[0], negx[1]};
       gemm1_stream_sp<K>(c, pt, acc, c.w2, c.w2 + 32, c.voff2);
+      BTI_STAMP(3);
       float rss = 0.0f;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           rss = fmaf(acc[cb][rg], acc[cb][rg], rss);
-          *(lds_f32*)(rt + tile_off<D>(4 * q + rg, 32 * wid + 16 * cb + n)) = acc[cb][rg];
+          *(lds_f32*)(rt + tile_off<D>(4 * qo + rg, 32 * wid + 16 * cb + no)) = acc[cb][rg];
         }
       rss = wave_sum(rss);
       dsum = wave_sum(dsum);
@@ -158,14 +220,12 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       }
       f32x4 rf[D / 32][2];
       load_r_frags<K>(c, rt, rf);
-      static_for<NP>([&](auto ps_c) {
-        constexpr int ps = decltype(ps_c)::value;
-        gk[ps][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gk[ps][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gemm2_pass<K, ps>(c, rf, gk[ps]);
-      });
+      BTI_STAMP(4);
+      gemm2_stream_sp<K>(c, rf, gk);
+      BTI_STAMP(5);
     }
-    // the point in the C layout (this lane's 32 elements of the tile; every lane reads and later overwrites only its own)
+    // the point in the C layout (this lane's 32 elements of the tile; every lane reads and later overwrites only its
+    // own, and every wave passed the r-tile barrier after its last read of the tile as GEMM-1's operand)
     f32x4 pk[NP][2];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps)
@@ -173,13 +233,16 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) pk[ps][cb][rg] = *ep_addr(ps, cb, rg);
-    __builtin_amdgcn_s_barrier();          // red[] of the gradient phase has been read
+    BTI_STAMP(6);
 
-    // ---- the trials of this iteration on the tile (ista.py:38-47: same p, same g, steps lr0 / eta^t)
-#pragma unroll 1
-    for (int t = 0; t < p.ntrials; ++t) {
+    // ---- the trials of this iteration on the tile (ista.py:38-47: same p, same g, steps lr0 / eta^t).
+    // The candidate of trial t+1 is formed in registers right behind the MFMAs of trial t -- while the other wave of the
+    // SIMD still runs its own (the waves of a workgroup drift apart by ~3 us per GEMM) -- and goes into the LDS tile
+    // once every wave is through GEMM-1 of trial t (the barrier that also completes that trial's tile sums).
+    f32x4 zn[NP][2];
+    auto cand = [&](int t, float& l1, float& dzg, float& dz2) {
       const float lr = s.lr[t], lam = s.lam[t];
-      float l1 = 0.0f, dzg = 0.0f, dz2 = 0.0f;
+      l1 = 0.0f; dzg = 0.0f; dz2 = 0.0f;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
@@ -187,17 +250,28 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const float pv = pk[ps][cb][rg], g = gk[ps][cb][rg];
-            const float zn = soft_threshold(__fsub_rn(pv, __fmul_rn(lr, g)), lam);             // ista.py:40
-            const float dz = __fsub_rn(zn, pv);                                                  // :31
-            l1 += __builtin_fabsf(zn);
+            const float v = soft_threshold(__fsub_rn(pv, __fmul_rn(lr, g)), lam);              // ista.py:40
+            const float dz = __fsub_rn(v, pv);                                                   // :31
+            l1 += __builtin_fabsf(v);
             dzg = __fadd_rn(dzg, __fmul_rn(dz, g));
             dz2 = __fadd_rn(dz2, __fmul_rn(dz, dz));
-            *ep_addr(ps, cb, rg) = zn;
+            zn[ps][cb][rg] = v;
           }
-      f32x4 acc[2] = {negx[0], negx[1]};
+    };
+    f32x4 acc[2];
+    auto trial_front = [&]() {             // candidate -> LDS tile, r1 = z+ W^T - x
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) *ep_addr(ps, cb, rg) = zn[ps][cb][rg];
+      acc[0] = negx[0]; acc[1] = negx[1];
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       gemm1_stream_sp<K>(c, pt, acc, c.w1, c.w1 + 32, c.voff1);
+    };
+    auto trial_back = [&](int t, float l1, float dzg, float dz2) {   // the trial's four tile sums
       float rss = 0.0f;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -206,33 +280,65 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       rss = wave_sum(rss); l1 = wave_sum(l1); dzg = wave_sum(dzg); dz2 = wave_sum(dz2);
       if (lane == 0) { red[4 * wid] = rss; red[4 * wid + 1] = l1; red[4 * wid + 2] = dzg; red[4 * wid + 3] = dz2; }
       LASSO_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();        // red[] complete; every wave is through this trial's reads of the LDS tile
       if (tid < 4) {
         float a = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) a += red[4 * w + tid];
         p.partsM[((int64_t)t * 4 + tid) * p.ntiles + tile] = a;
       }
-      __builtin_amdgcn_s_barrier();        // the tile / red reuse by the next trial
+      // (no barrier here: the next writes of red[] come after the next trial's candidate barrier, which wave 0 reaches
+      //  only after these reads)
+    };
+    auto tile_end = [&]() {
+      // the next tile's operands, then this tile's gradient g -> G (the accept step of the NEXT launch reads it).  In
+      // the C layout a lane owns four rows of one column: a 4 x 4 transpose inside each lane quad turns that into four
+      // consecutive columns of one row -- 8 stores of 16 bytes per lane instead of 32 of 4 (32 prefetch loads + 32
+      // stores overran the 63 vector-memory operations a wave may have in flight: the stores then waited for the
+      // prefetch, 7-10 us per tile).
+      fetch_tile(next_tile);
+      char* const g_base = (char*)(p.G + (int64_t)row0 * p.k);
+      const int j = no & 3;
+      const int colq = wid * KW + (no & 12);                               // first of this lane's four columns
+      const bool whole = row0 + kTileM <= p.n && wid * KW + KW <= p.k;      // wave-uniform: no masks on the usual path
+      char* const gr = g_base + (unsigned)((4 * qo + j) * p.k + colq) * 4u;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x4 v = gk[ps][cb];
+          quad_transpose(v, j);
+          if (whole || ((row0 + 4 * qo + j) < p.n && (colq + 32 * ps + 16 * cb) < p.k))     // (k % 4 == 0: a piece is in or out)
+            *reinterpret_cast<f32x4*>(gr + (32 * ps + 16 * cb) * 4) = v;
+        }
+    };
+    if (p.ntrials > 0) {
+      float l1, dzg, dz2;
+      cand(0, l1, dzg, dz2);
+#pragma unroll 1
+      for (int t = 0; t + 1 < p.ntrials; ++t) {
+        if (t == 0) BTI_STAMP(7);
+        trial_front();
+        if (t == 0) BTI_STAMP(9);
+        float l1n, dzgn, dz2n;
+        cand(t + 1, l1n, dzgn, dz2n);
+        trial_back(t, l1, dzg, dz2);
+        l1 = l1n; dzg = dzgn; dz2 = dz2n;
+        if (t == 0) BTI_STAMP(10);
+      }
+      trial_front();
+      BTI_STAMP(11);
+      tile_end();
+      trial_back(p.ntrials - 1, l1, dzg, dz2);
+    } else {
+      tile_end();
     }
-
-    // ---- g -> G through the LDS tile: 16-byte row pieces (the accept step of the next launch reads them)
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) *ep_addr(ps, cb, rg) = gk[ps][cb][rg];
-    LASSO_WAIT_LGKM0();
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-      const int idx = tid + kFistaThreads * i, r = idx / (K / 4), cc = (idx - r * (K / 4)) * 4;
-      const f32x4 v = *(const lds_f32x4*)(pt + tile_chunk_off<K>(r, cc));
-      if ((row0 + r) < p.n && cc < p.k) *reinterpret_cast<f32x4*>(p.G + (int64_t)(row0 + r) * p.k + cc) = v;
-    }
-    // (the next tile's prologue writes the chunks of the LDS tile this same thread has just read: program order)
+    __builtin_amdgcn_s_barrier();          // the last reads of red[] / the LDS tile before the next tile's prologue
+    BTI_STAMP(12);
   }
+#ifdef LASSO_BTI_TIMING
+  if (accept && threadIdx.x == 0) lasso_bti_stamps[blockIdx.x * 16 + 13] = wall_clock64();
+#endif
   LASSO_WAIT_VMCNT(0);
 }
 
@@ -322,15 +428,61 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
   if (last_batch) ctl[0] = 2;
 }
 
+// The accept step alone, behind the last iteration of a window (ista.py:40,93,99-102): an element-wise pass over
+// 16-row tiles with the tile sums of |z - z_next| in bt_iter_kernel's place (dpart[tile]); HBM-bound.
+__global__ __launch_bounds__(256) void bt_accept_tail_kernel(const BtIterParams p) {
+  __shared__ float sh[4];
+  if (p.skip && *p.skip != 0) return;
+  if (p.acc_flags[0] == 0) return;
+  const float lr_a = p.acc_fvals[2], lam_a = p.acc_fvals[3];
+  const float* const P = p.fast ? p.Y : p.Z;
+  const int tid = threadIdx.x, k4 = p.k >> 2;
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int row0 = tile * kTileM;
+    float dsum = 0.0f;
+    for (int idx = tid; idx < kTileM * k4; idx += 256) {
+      const int r = idx / k4, cc = (idx - r * k4) * 4;
+      if (row0 + r >= p.n) break;
+      const int64_t off = (int64_t)(row0 + r) * p.k + cc;
+      const f32x4 zo = *reinterpret_cast<const f32x4*>(p.Z + off);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.G + off);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(P + off);
+      f32x4 zn, yn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        zn[e] = soft_threshold(__fsub_rn(pv[e], __fmul_rn(lr_a, g[e])), lam_a);               // ista.py:40
+        dsum += __builtin_fabsf(__fsub_rn(zo[e], zn[e]));                                        // :93
+        yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo[e])));                    // :99-100
+      }
+      *reinterpret_cast<f32x4*>(p.Z + off) = zn;                                                 // :102
+      if (p.fast) *reinterpret_cast<f32x4*>(p.Y + off) = yn;
+    }
+    dsum = wave_sum(dsum);
+    if ((tid & 63) == 0) sh[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) p.dpart[tile] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+  }
+}
+
 template <int K>
 static hipError_t launch_iter_k(const BtIterParams& p, const BtSteps& s, int grid, hipStream_t stream) {
   const size_t lds = (size_t)kTileM * K * 4 + (size_t)kTileM * kFistaD * 4 + (size_t)kFistaWaves * kRingBytesPerWave + 256;
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_iter_kernel<K>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(bt_iter_kernel<K>, dim3(grid), dim3(kFistaThreads), lds, stream, p, s);
+  if (p.acc_flags) {
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_iter_kernel<K, true>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((bt_iter_kernel<K, true>), dim3(grid), dim3(kFistaThreads), lds, stream, p, s);
+  } else {
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bt_iter_kernel<K, false>), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((bt_iter_kernel<K, false>), dim3(grid), dim3(kFistaThreads), lds, stream, p, s);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_bt_iter(const BtIterParams& p, const BtSteps& s, int kpad, int grid, hipStream_t stream) {
+  if (p.tail) {
+    hipLaunchKernelGGL(bt_accept_tail_kernel, dim3(std::min(p.ntiles, 4096)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+  }
   switch (kpad) {
     case 256: return launch_iter_k<256>(p, s, grid, stream);
     case 512: return launch_iter_k<512>(p, s, grid, stream);

@@ -452,6 +452,60 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
   trip(S1 / 2 - 1, tail1, tail_voff, tail1, tail_voff, T{});
 }
 
+// Pipelined GEMM-2 without an epilogue (round 5, bt_iter.hip): all NP passes of
+//   g[ps][cb] = r_tile[16][256] * Wtp[wid*K/8 + 32*ps + 16*cb .. +16][256]^T
+// with the fragment reads of step U+1 under the MFMAs of step U and the ring refill spread between them -- the step
+// machinery of GEMM-1.  Same MFMA order per accumulator as gemm2_pass (bitwise the same g).
+// Pre:  ring slots 0/1 have W^T steps 0/1 of this wave in flight (the tails of gemm1_stream_sp).
+// Post: ring slots 0/1 have steps 0/1 of the next GEMM-1 (c.w1) in flight.
+template <int K>
+__device__ __forceinline__ void gemm2_stream_sp(const TileCtx<K>& c, const f32x4 (&rf)[kFistaD / 32][2],
+                                                f32x4 (&g)[(K / kFistaWaves) / 32][2]) {
+  constexpr int D = kFistaD;
+  constexpr int T2 = D / 32;
+  constexpr int NP = (K / kFistaWaves) / 32;
+  constexpr int S2 = NP * T2;
+  static_assert(S2 % 2 == 0 && S2 >= 4, "geometry");
+  lds_char* const slot0 = c.ring;
+  lds_char* const slot1 = c.ring + kStepBytes;
+  sp::Frag X, Y;
+  LASSO_WAIT_VMCNT(4);
+  sp::load_b(c, X, slot0);
+  LASSO_WAIT_LGKM0();
+  dma_step(c.w2 + (size_t)(32 * (2 / T2)) * D + 32 * (2 % T2), c.voff2, slot0);
+  auto nothing = [] {};
+  static_for<S2>([&](auto u_c) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr int ps = U / T2, t = U % T2;
+    sp::Frag& cur = (U & 1) ? Y : X;
+    sp::Frag& nxt = (U & 1) ? X : Y;
+    lds_char* const nslot = (U & 1) ? slot0 : slot1;     // slot of step U+1
+    if constexpr (t == 0) {
+      g[ps][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      g[ps][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (U + 1 < S2) {
+      LASSO_WAIT_VMCNT(4);
+      sp::load_b(c, nxt, nslot);
+      if constexpr (U + 3 < S2) {
+        constexpr int pn = (U + 3) / T2, tn = (U + 3) % T2;
+        sp::step_body(g[ps], rf[t], cur, c.w2 + (size_t)(32 * pn) * D + 32 * tn, c.voff2, nslot, nothing, nothing,
+                      nothing, nothing);
+      } else {
+        sp::step_body(g[ps], rf[t], cur, c.w1 + 32 * (U + 3 - S2), c.voff1, nslot, nothing, nothing, nothing, nothing);
+      }
+    } else {
+      LASSO_PIN();
+      sp::mfma_range<0, 16>(g[ps], rf[t], cur);
+      LASSO_PIN();
+    }
+    // Anchor: both accumulator chains of a pass are "read" where the pass ends.  Without it instruction selection
+    // (which sched_barrier does not bind) let the second chain float to its first real use, behind ALL passes, with
+    // every B fragment it needs spilled on the way (392 scratch registers).
+    if constexpr (t == T2 - 1) asm volatile("" :: "v"(g[ps][0]), "v"(g[ps][1]));
+  });
+}
+
 // wave-wide sum (wave-uniform result), fixed order, on the ALU path: DPP row_shr 1,2,4,8
 // leaves each 16-lane row's total in its last lane; four readlanes finish the job (the
 // ds_bpermute route of __shfl_xor costs ~6 LDS round trips instead).

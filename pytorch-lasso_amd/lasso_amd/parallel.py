@@ -29,6 +29,21 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _sharded(group):
+    """True when the multi-rank code paths run: more than one rank -- or (LASSO_FORCE_COLLECTIVES=1) ONE rank with an
+    initialised process group.  The second form exists so that every line a multi-GPU run executes -- the RCCL arms of
+    _all_reduce / _broadcast on device tensors, the sharded E-step with its stop-rule sums in the M-step message, the
+    line search's all-reduce callback -- has run on hardware before an 8-GPU node sees it: a 1-rank RCCL group on one
+    GPU reduces over itself (tests/test_bench_gpu.py, bench.py --force-dist), and the first N > 1 run then differs
+    from tested code in N only."""
+    world, _ = _world(group)
+    if world > 1:
+        return True
+    import os
+    return (os.environ.get("LASSO_FORCE_COLLECTIVES", "0") == "1" and dist is not None and dist.is_available()
+            and dist.is_initialized())
+
+
 def _host_staged(t, group):
     """gloo moves host memory: device tensors are staged through the host explicitly (the
     production backend is 'nccl' = RCCL, which reduces device buffers over xGMI in place)."""
@@ -36,8 +51,7 @@ def _host_staged(t, group):
 
 
 def _all_reduce(t, group):
-    world, _ = _world(group)
-    if world > 1:
+    if _sharded(group):
         if _host_staged(t, group):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
@@ -83,7 +97,7 @@ def constrained_mstep(engine, A, B, D, eps=1e-10, positive=False, group=None):
     if ndeg == 0:
         return None
     cand = draw_directions(D.shape[0], ndeg).to(D.device)      # every rank advances its generator alike
-    if world > 1:   # every rank must use rank 0's directions
+    if _sharded(group):   # every rank must use rank 0's directions
         _broadcast(cand, group)
     engine.fill_degenerate(D, mask, cand, positive)
     return mask
@@ -93,8 +107,7 @@ def sharded_encode(engine, X, W, alpha, z0, group=None, **kw):
     """E-step on this rank's shard.  world == 1: plain sparse_encode.  world > 1 with an
     active stop rule: exact GLOBAL rule through chunked speculation + one all-reduce of
     the chunk's delta vector (see module docstring)."""
-    world, _ = _world(group)
-    if world == 1 or kw.get('algorithm', 'ista') == 'cd':
+    if not _sharded(group) or kw.get('algorithm', 'ista') == 'cd':
         # coordinate descent stops every row on its own (coordinate_descent.py:45-48): a row
         # shard needs no collective and reproduces the full batch exactly
         kw.pop('n_global', None)
@@ -222,12 +235,13 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     ``weight`` [d,k] must be identical on every rank.  Returns (weight, losses[steps])."""
     solver_kwargs = dict(solver_kwargs or {})
     world, rank = _world(group)
+    multi = _sharded(group)          # (world > 1, or one rank with LASSO_FORCE_COLLECTIVES=1: the same code paths)
     n_local, d = X.shape
     k = weight.shape[1]
     # Which form the E-step takes must not depend on anything rank-local (a rank on another path would issue
     # other collectives than its peers: hang or corruption), so "this rank cannot take the asynchronous sharded
     # form" is summed over the ranks next to the row count, once, before the loop.
-    can_async = (world > 1 and hasattr(engine, 'encode_begin_sharded') and hasattr(engine, 'sweep_begin')
+    can_async = (multi and hasattr(engine, 'encode_begin_sharded') and hasattr(engine, 'sweep_begin')
                  and getattr(engine, 'sharded_async_ok', lambda *a, **kw: True)(X, weight, **solver_kwargs))
     n_glob = torch.tensor([float(n_local), 0.0 if can_async else 1.0], dtype=torch.float64, device=X.device)
     _all_reduce(n_glob, group)
@@ -237,13 +251,13 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     # One GPU: the step is enqueued without waiting on it -- the stop rule's outcome and the
     # sweep's count of degenerate atoms are collected at ONE host wait per step, placed where the
     # objective and the Gram product are still queued, so the GPU does not idle behind the host.
-    overlap = world == 1 and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
+    overlap = not multi and hasattr(engine, 'encode_begin') and hasattr(engine, 'sweep_begin')
     # Several ranks: the same, with the stop rule's per-iteration sums (ista.py:93 sums over the rows of ALL
     # ranks) riding in the tail of the M-step message -- E-step (lr='auto' and the solve on the stream),
     # objective, Gram product, ONE all-reduce, the rule judged on the device from the summed vector -- and
     # the one host wait per step behind all of it.  (RCCL reduces on the stream; gloo, used when ranks
     # share a GPU in tests, stages the message through the host -- that copy is then the wait.)
-    shard_async = world > 1 and every_rank_async
+    shard_async = multi and every_rank_async
     ndelta = int(solver_kwargs.get('maxiter', 10)) if shard_async else 0
     if not 0 < ndelta <= 64:
         ndelta = 0
@@ -265,7 +279,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
 
     def repair(mask, ndeg, Zprev):
         cand = draw_directions(d, ndeg).to(weight.device)       # every rank advances its generator alike
-        if world > 1:
+        if multi:
             _broadcast(cand, group)                              # ... and uses rank 0's directions
         engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
         if Zprev is not None and Zprev.shape[0] > 0:
@@ -278,7 +292,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
 
     def local_stats(Z, **kw):
         """(loss, {sum r^2, sum |z|}, A, B) of this rank's rows; a rank without rows contributes zeros"""
-        if n_local == 0 and world > 1:
+        if n_local == 0 and multi:
             buf[:k * k + k * d].zero_()
             return (torch.zeros((), device=X.device), torch.zeros(2, dtype=torch.float64, device=X.device),
                     buf[:k * k].view(k, k), buf[k * k:k * k + k * d].view(k, d))
@@ -317,7 +331,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             sharded = pending is not None
             if stats is not None:
                 stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
-        direct = world == 1 and getattr(engine, 'objective_loss_out', False)   # losses[i] written in place: no copy launch
+        direct = not multi and getattr(engine, 'objective_loss_out', False)   # losses[i] written in place: no copy launch
         loss_local, sums, A, B = local_stats(Z, **(dict(loss_out=losses[i]) if direct else {}))
         if deferred is not None:
             mask, ndeg = deferred()
@@ -332,7 +346,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
             loss_local, sums, A, B = local_stats(Z)
             direct = False
-        if world > 1:
+        if multi:
             tail.copy_(sums)                 # the two objective sums ride in the Gram message
             if sharded:
                 dtail.copy_(pending.deltas)  # ... and so do this shard's stop-rule sums
@@ -394,7 +408,7 @@ def dict_learning_sharded(X_shard, n_components, alpha=1.0, constrained=True, pe
         weight = init_weight.detach().clone()
     Xd = engine.to_device(X_shard)
     weight = engine.to_device(weight).clone()
-    if world > 1:
+    if _sharded(group):
         _broadcast(weight, group)
     return em_loop(engine, Xd, weight, alpha, constrained=constrained, persist=persist,
                    lambd=lambd, steps=steps, progbar=progbar, solver_kwargs=solver_kwargs,

@@ -82,3 +82,36 @@ def test_one_rank_lines_of_configs_3_and_5():
         assert 0 < out["roofline"]["frac"] < 1
     out = _bench(["--workload", "em", "--shape", "c5", "--steps", "5", "--warmup", "2"])
     assert out["n_gpus"] == 1 and out["all_reduce_ms"]["per_step"] == 0.0
+
+
+# ---- the RCCL arms, executed: ONE rank, a real nccl (= RCCL) process group, LASSO_FORCE_COLLECTIVES ------------------
+# `--force-dist` makes the N = 1 run take every multi-rank code path (lasso_amd.parallel._sharded): the in-place
+# all-reduce of DEVICE tensors, Ranks.max on a device tensor, the sharded E-step with its stop-rule sums in the M-step
+# message, the line search's all-reduce callback through a device buffer.  The first 8-GPU run then differs from code
+# that has run on hardware in N only.  Same numbers as the plain one-rank run are required.
+FORCED = ["--gpus", "1", "--backend", "nccl", "--force-dist", "--steps", "2", "--warmup", "1"]
+
+
+def test_one_rank_rccl_group_fista_line():
+    out = _bench(FORCED + ["--workload", "fista", "--no-cpu-baseline", "--no-shards", "--no-extras"])
+    assert out["n_gpus"] == 1 and "ONE-rank process group" in out["backend"] and out["backend"].startswith("nccl")
+    assert abs(out["objective_after_100"] - 63.609337) <= 2e-6 * 63.609337        # sums all-reduced on the device
+    t = out["time_to_tol"]                                                        # parallel.sharded_encode: chunks +
+    assert t["iterations"] == 263 and "global over all ranks" in t["rule"]        # one all-reduce of the sums each
+
+
+def test_one_rank_rccl_group_em_line():
+    plain = _bench(["--workload", "em", "--steps", "2", "--warmup", "1"])
+    out = _bench(FORCED + ["--workload", "em"])
+    ar = out["all_reduce_ms"]
+    assert ar["per_step"] == 1.0 and ar["bytes_sent"] == [4 * (1024 * 1024 + 1024 * 256 + 12)]   # ONE RCCL message per EM step
+    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
+    assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
+    assert plain["all_reduce_ms"]["per_step"] == 0.0
+
+
+def test_one_rank_rccl_group_line_search_line():
+    out = _bench(FORCED + ["--workload", "c3", "--dtype", "f32"])
+    assert "every F<=Q decision on all-reduced sums" in out["config"]["parallelism"]
+    assert out["trials"] == [5, 3, 5, 4, 4, 4, 4, 3, 5, 5]                        # lasso_fista_solve_sharded + the callback
+    assert abs(out["objective"] - 64.142166) <= 1e-5 * 64.142166
