@@ -85,6 +85,62 @@ def hbm_traffic_from_profiles(kernel=None):
     return best, src
 
 
+def sources_digest():
+    """sha1 over the kernel sources (pytorch-lasso_amd/csrc/*.hip, *.hpp, *.h, the Makefile): a traffic figure measured
+    on one build is reported only while the sources are the ones that were measured."""
+    import hashlib
+    h = hashlib.sha1()
+    cdir = os.path.join(ROOT, "pytorch-lasso_amd", "csrc")
+    for name in sorted(os.listdir(cdir)):
+        if name.endswith((".hip", ".hpp", ".h")) or name == "Makefile":
+            with open(os.path.join(cdir, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def hbm_traffic_for(tag):
+    """(bytes per step, source note) of a workload from the PMC passes committed for it (tools/prof_hbm.sh:
+    profiles/rNN_<tag>/hbm_traffic.json; the scratch copy under gpurun_out/ first, so that a profiling call finds its
+    own measurement).  None + the reason when no profile exists or when the kernel sources have changed since."""
+    cands = []
+    for base in ("gpurun_out", "profiles"):
+        bdir = os.path.join(ROOT, base)
+        if os.path.isdir(bdir):
+            cands += [os.path.join(base, n) for n in sorted(os.listdir(bdir), reverse=True)
+                      if n.startswith("r") and n.endswith("_" + tag)]
+    why = "no profile of this workload (profiles/rNN_%s/hbm_traffic.json)" % tag
+    for c in cands:
+        f = os.path.join(ROOT, c, "hbm_traffic.json")
+        if not os.path.exists(f):
+            continue
+        with open(f) as fh:
+            rec = json.load(fh)
+        if "hbm_bytes_per_step" not in rec:
+            continue
+        if rec.get("sources_digest") != sources_digest():
+            why = "%s/hbm_traffic.json was measured on other kernel sources: stale, not reported" % c
+            continue
+        top = ", ".join("%s %.1f MB" % (r["kernel"].replace("lasso::", "")[:48], r["hbm_bytes_per_step"] / 1e6)
+                        for r in rec.get("kernels", [])[:3])
+        return rec["hbm_bytes_per_step"], ("%s/hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE of `%s`, all "
+                                           "dispatches / %g steps; not collected in this run; largest: %s)"
+                                           % (c, rec.get("command", "?"), rec.get("steps_divisor", 0), top))
+    return None, why
+
+
+def with_traffic(roofline, tag, avg_ms, algorithmic_bytes=None):
+    """fill roofline.traffic / hbm_gbps (north_star: achieved HBM GB/s) from the workload's committed PMC profile"""
+    traffic, src = hbm_traffic_for(tag) if tag else (None, "not one of the profiled batch sizes")
+    roofline["traffic"] = traffic
+    roofline["traffic_source"] = src
+    roofline["hbm_gbps"] = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
+    roofline["hbm_peak_gbps"] = 8000.0
+    if algorithmic_bytes is not None:
+        roofline["algorithmic_bytes"] = algorithmic_bytes
+        roofline["traffic_over_algorithmic"] = (traffic / algorithmic_bytes) if traffic else None
+    return roofline
+
+
 def cpu_baseline(X, W, lr, budget_s=12.0):
     """Time the CPU oracle (restatement of the reference, same ATen ops) on the host
     cores of this box on a bounded sample of the same workload."""
@@ -290,7 +346,9 @@ def run_fista(args, ranks):
         avg_launch_ms = sum(r["kern_ms"]) / len(r["kern_ms"])
         flop_per_launch = 4.0 * r["rows"] * D * K * args.iters          # this rank's launch
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
-        traffic, traffic_src = hbm_traffic_from_profiles(kernel_name(r["rows"]))
+        traffic, traffic_src = hbm_traffic_for("fista") if (r["rows"] == N_ROWS and world == 1) else (None, None)
+        if traffic is None:
+            traffic, traffic_src = hbm_traffic_from_profiles(kernel_name(r["rows"]))
         out = {
             "metric": "fista_iterations_per_sec (n=%d d=256 k=1024 fp32, fixed L, tol=0)" % n_rows,
             "value": line(main_mode),
@@ -311,6 +369,10 @@ def run_fista(args, ranks):
                          "traffic_source": (traffic_src + (" (rocprofv3 PMC pass of this command; not collected in "
                                                            "this run)" if traffic is not None else ""))
                                            if traffic_src and world == 1 else None,
+                         "hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and world == 1) else None,
+                         "hbm_peak_gbps": 8000.0,
+                         # resident-state model: x, W read, z0 read, z written -- per launch
+                         "algorithmic_bytes": 4.0 * (r["rows"] * D + D * K + 2 * r["rows"] * K),
                          "kernel": kernel_name(r["rows"]),
                          "flop_per_launch": flop_per_launch, "per": "GPU (rank 0)",
                          "avg_launch_ms": avg_launch_ms,
@@ -475,12 +537,18 @@ def run_em(args, ranks):
                               "note": "device time of the one RCCL all-reduce "
                               "per EM step -- [A | B | objective sums | the E-step's 10 stop-rule sums] -- (0 at N=1: "
                               "no collective)"},
-            "roofline": {"bound": "mfma", "achieved": flop / (dev_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel": "whole EM step (E-step kernel dominates; the Lipschitz squarings "
-                                                    "and the atom sweep are latency chains)",
-                         "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": dev_ms,
-                         "avg_launch_note": "HIP events around the K timed EM steps / K"},
+            "roofline": with_traffic(
+                {"bound": "mfma", "achieved": flop / (dev_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                 "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                 "kernel": "whole EM step (E-step kernel dominates; the Lipschitz squarings "
+                           "and the atom sweep are latency chains)",
+                 "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": dev_ms,
+                 "avg_launch_note": "HIP events around the K timed EM steps / K"},
+                ("em_%s%s" % (args.shape, "" if n_all == n_default else "_shard"))
+                if (world == 1 and n_all in (n_default, 8192)) else None, dev_ms,
+                # per EM step (resident-state model): X read by the E-step, the objective and the Gram product (3x),
+                # Z written once and read twice, the dictionary-sized operands (W, A, B, U: a few k^2 + k d words)
+                algorithmic_bytes=4.0 * (3 * rows * d + 3 * rows * k + 4 * k * k + 6 * k * d)),
             "em_path": dict(eng.em_stats),
             "objective_last_step": float(state["loss"][-1]),
         }
@@ -539,12 +607,16 @@ def run_c3(args, ranks):
                                ("" if n_all == C3_ROWS else " (NOT the 16384-row batch of config 3)"),
                    "rows_per_gpu": rows, "rows_total": n_all,
                    "parallelism": "row-sharded x%d%s" % (world, ", every F<=Q decision on all-reduced sums" if ranks.sharded else "")},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel": name.decode() if name else None,
-                     "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
-                     "flop_note": "(4 per outer iteration + 2 per trial) n d k as executed: %d outer iterations, "
-                                  "%d trials" % (len(trials), sum(trials)),
-                     "avg_launch_note": "HIP events around the K timed solves / K"},
+        "roofline": with_traffic(
+            {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+             "kernel": name.decode() if name else None,
+             "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
+             "flop_note": "(4 per outer iteration + 2 per trial) n d k as executed: %d outer iterations, "
+                          "%d trials" % (len(trials), sum(trials)),
+             "avg_launch_note": "HIP events around the K timed solves / K"},
+            ("c3_%s" % args.dtype) if (world == 1 and n_all == C3_ROWS) else None, kern_ms[0],
+            # resident-state model: x, W, z0 read, z written, once per solve
+            algorithmic_bytes=(2.0 if args.dtype == "bf16" else 4.0) * (rows * D + D * K + 2 * rows * K)),
         "trials": trials, "reference_trials_fp32": C3_TRIALS,
         "objective": obj, "objective_reference": C3_OBJ[args.dtype][0],
     }

@@ -182,6 +182,23 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
         }
         *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = p.fast ? yn : zn;
       }
+    } else if (p.zero_start) {
+      // the solve starts from z = y = 0 (z0 == NULL): the tile is zeros, and this launch writes them to Z (and Y) for
+      // the accept step that follows -- instead of two fill launches over [n][k] in front of the solve
+      char* const zb = (char*)(p.Z + (int64_t)row0 * p.k);
+      char* const yb = (char*)(p.Y + (int64_t)row0 * p.k);
+      const int cc = (tido - r0o * (K / 4)) * 4;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+        const int r = r0o + RSTEP * i;
+        if ((row0 + r) < p.n && cc < p.k) {
+          const unsigned off = (unsigned)(r * p.k + cc) * 4u;
+          *reinterpret_cast<f32x4*>(zb + off) = zero;
+          if (p.fast) *reinterpret_cast<f32x4*>(yb + off) = zero;
+        }
+        *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = zero;
+      }
     } else {
       visit_tile4<K, kFistaThreads>(P, p.k, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
         *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = v;
@@ -333,7 +350,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
     } else {
       tile_end();
     }
-    __builtin_amdgcn_s_barrier();          // the last reads of red[] / the LDS tile before the next tile's prologue
+    // (no barrier: every wave is through its last read of the LDS tile at the last trial's barrier, and red[] is next
+    //  written behind the next tile's own barriers, which wave 0 reaches only after its reads above)
     BTI_STAMP(12);
   }
 #ifdef LASSO_BTI_TIMING
@@ -358,8 +376,7 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
                                                               const int* __restrict__ prev_flags,
                                                               const float* __restrict__ prev_fvals,
                                                               const float* __restrict__ dpart, int it_prev, float budget,
-                                                              int* __restrict__ ctl, int* __restrict__ trials,
-                                                              float* __restrict__ lrs, float* __restrict__ fs) {
+                                                              int* __restrict__ ctl, float* __restrict__ rec) {
   if (ctl[0] != 0) return;
   __shared__ double sh[kBtMultiMax][5][128];
   __shared__ float shd[256];
@@ -379,9 +396,9 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
       const float delta = shd[0];
       int fired = 0;
       if (prev_flags[0] != 0) {
-        trials[it_prev] = prev_flags[2] + 1;
-        lrs[it_prev] = prev_fvals[2];
-        fs[it_prev] = prev_fvals[0];
+        rec[4 * it_prev] = __int_as_float(prev_flags[2] + 1);        // {trials, accepted step, F of the accepted trial}
+        rec[4 * it_prev + 1] = prev_fvals[2];
+        rec[4 * it_prev + 2] = prev_fvals[0];
         ctl[1] = it_prev + 1;
         ctl[2] = __float_as_int(delta);
         if (budget >= 0.0f && delta <= budget) { ctl[0] = 1; fired = 1; }                    // ista.py:93-95
@@ -494,10 +511,10 @@ hipError_t launch_bt_iter(const BtIterParams& p, const BtSteps& s, int kpad, int
 hipError_t launch_bt_iter_decide(const float* partials, const float* partsM, int ntiles, double alpha, const BtSteps& s,
                                  int ntrials, int first_index, int last_batch, int* cur_flags, float* cur_fvals,
                                  const int* prev_flags, const float* prev_fvals, const float* dpart, int it_prev,
-                                 float budget, int* ctl, int* trials, float* lrs, float* fs, hipStream_t stream) {
+                                 float budget, int* ctl, float* rec, hipStream_t stream) {
   hipLaunchKernelGGL(bt_iter_decide_kernel, dim3(1), dim3(1024), 0, stream, partials, partsM, ntiles, (float)alpha, s,
                      ntrials, first_index, last_batch, cur_flags, cur_fvals, prev_flags, prev_fvals, dpart, it_prev,
-                     budget, ctl, trials, lrs, fs);
+                     budget, ctl, rec);
   return hipGetLastError();
 }
 

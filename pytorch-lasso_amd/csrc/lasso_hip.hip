@@ -664,6 +664,7 @@ struct BtWorkspace {
   int* ptrials; float* plrs; float* pfvals;   // [maxiter] each
   int* rtrials; float* rlrs; float* rfs;      // [maxiter] each: record of a multi-launch solve enqueued without host waits
   int* ctl;                                   // its control words (bt_iter_end_kernel)
+  float* rrec;                                // [maxiter][4] the same record, one 16-byte entry per iteration (bt_iter_decide_kernel)
   size_t bytes;
 };
 
@@ -710,6 +711,7 @@ BtWorkspace carve_bt(void* base, int64_t n, int64_t k, int kp, bool half = false
     w.rlrs = take((size_t)cap * 4);
     w.rfs = take((size_t)cap * 4);
     w.ctl = reinterpret_cast<int*>(take(256));
+    w.rrec = take((size_t)cap * 16);
   }
   w.bytes = off;
   return w;
@@ -801,6 +803,11 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   const float* x = (const float*)x_any;
   float* zout = half ? ws.Zf : (float*)zout_any;
   const int64_t ldz = half ? k : ldz_any;
+  // fp32 tensors, one process, flat 16-byte-aligned state: the one-launch-per-iteration kernels (bt_iter.hip) run the
+  // solve; with an all-zero start (z0 == NULL) their first launch writes the zeros of z and y itself
+  const bool fused_form = !half && !reduce && ldz == k && (k & 3) == 0 && k >= 4 && (((uintptr_t)zout) & 15) == 0 &&
+                          (((uintptr_t)ws.Y) & 15) == 0 && (((uintptr_t)ws.G) & 15) == 0 && !(bt_hint & 3);
+  const bool zero_in_kernel = fused_form && !z0_any && maxiter > 0;
   if (half) {
     LASSO_HIP_TRY(launch_pack_w_bf16(w_any, ldw, (int)d, (int)k, kp, 1, ws.wp, ws.wtp, st));
     if (z0_any) LASSO_HIP_TRY(launch_cvt_bf16(z0_any, ldz0, zout, k, (int)n, (int)k, 1, st));
@@ -814,11 +821,12 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     if (z0) {
       if (z0 != zout)
         LASSO_HIP_TRY(hipMemcpy2DAsync(zout, ldz * 4, z0, ldz0 * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
-    } else {
+    } else if (!zero_in_kernel) {
       LASSO_HIP_TRY(hipMemset2DAsync(zout, ldz * 4, 0, k * 4, n, st));
     }
   }
-  LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
+  if (!zero_in_kernel)
+    LASSO_HIP_TRY(hipMemcpy2DAsync(ws.Y, k * 4, zout, ldz * 4, k * 4, n, hipMemcpyDeviceToDevice, st));
 
   BtParams p;
   p.X = x; p.ldx = ldx; p.Wp = ws.wp; p.Wtp = ws.wtp;
@@ -859,7 +867,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   // decisions live in per-iteration slots of ws.flags / ws.fvals (kBtWindow slots of 4 words).  The trials beyond
   // n_first (old kernel, p and g re-read) are enqueued only after a search of THIS solve has run out of trials once
   // (`safety`); until then such a search costs one synchronous iteration.  bt_hint & 2: the multi-launch form (A/B).
-  const bool fusedit = multi && !(bt_hint & 2);
+  const bool fusedit = multi && !(bt_hint & 2);      // (== fused_form above)
   int n_first = kBtFirst;
   bool safety = false;
   while (it < maxiter) {
@@ -871,6 +879,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
     q.X = x; q.ldx = ldx; q.Wp = ws.wp; q.Wtp = ws.wtp; q.Z = zout; q.Y = ws.Y; q.G = ws.G;
     q.partials = ws.partials; q.partsM = ws.partsM; q.dpart = ws.dtile; q.skip = ws.ctl;
     q.n = (int)n; q.d = (int)d; q.k = (int)k; q.ntiles = ntiles; q.fast = fast ? 1 : 0;
+    q.zero_start = (zero_in_kernel && it == 0) ? 1 : 0;
     const float stop_budget = tol > 0.0 ? budget : -1.0f;
     double tm = t_mom;
     float coef_prev = 0.0f;
@@ -893,7 +902,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       const bool more = safety && n_first < kBtBatch;
       LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, steps, n_first, 0, more ? 0 : 1, cur_flags,
                                           cur_fvals, prev_flags, prev_fvals, ws.dtile, i - 1, stop_budget, ws.ctl,
-                                          ws.rtrials, ws.rlrs, ws.rfs, st));
+                                          ws.rrec, st));
       if (more) {
         BtSteps rest;
         const int nb = kBtBatch - n_first;
@@ -905,8 +914,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
         pb.P = fast ? ws.Y : zout; pb.ldp = k; pb.flags = cur_flags; pb.fvals = cur_fvals; pb.skip = ws.ctl;
         LASSO_HIP_TRY(launch_bt_trials_only(pb, kp, grid, rest, nb, ws.partsM, st));
         LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, rest, nb, n_first, 1, cur_flags,
-                                            cur_fvals, nullptr, nullptr, nullptr, 0, -1.0f, ws.ctl, ws.rtrials,
-                                            ws.rlrs, ws.rfs, st));
+                                            cur_fvals, nullptr, nullptr, nullptr, 0, -1.0f, ws.ctl, ws.rrec, st));
       }
       coef_prev = coef;
       tm = t_next;
@@ -917,27 +925,28 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       LASSO_HIP_TRY(launch_bt_iter(q, steps, kp, grid, st));
       LASSO_HIP_TRY(launch_bt_iter_decide(ws.partials, ws.partsM, ntiles, alpha, steps, 0, 0, 0, nullptr, nullptr,
                                           ws.flags + 4 * slot, ws.fvals + 4 * slot, ws.dtile, win0 + wlen - 1,
-                                          stop_budget, ws.ctl, ws.rtrials, ws.rlrs, ws.rfs, st));
+                                          stop_budget, ws.ctl, ws.rrec, st));
     }
+    // the window's control words and its per-iteration records: two small copies, ONE wait
     int hctl[4] = {0, 0, 0, 0};
+    float hrec[kBtWindow * 4];
     LASSO_HIP_TRY(hipMemcpyAsync(hctl, ws.ctl, sizeof(hctl), hipMemcpyDeviceToHost, st));
+    LASSO_HIP_TRY(hipMemcpyAsync(hrec, ws.rrec + 4 * (size_t)win0, (size_t)wlen * 16, hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
     const int done = hctl[1] > 0 ? hctl[1] : win0;
     if (done > win0) {
       const int cnt = done - win0;
-      std::vector<int> ht(cnt);
-      std::vector<float> hl(cnt), hf(cnt);
-      LASSO_HIP_TRY(hipMemcpy(ht.data(), ws.rtrials + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-      LASSO_HIP_TRY(hipMemcpy(hl.data(), ws.rlrs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-      LASSO_HIP_TRY(hipMemcpy(hf.data(), ws.rfs + win0, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-      int most = 1;
+      int most = 1, last_trials = 1;
       for (int i = 0; i < cnt; ++i) {
-        if (trials_out) trials_out[win0 + i] = ht[i];
-        if (accepted_lr_out) accepted_lr_out[win0 + i] = hl[i];
-        if (accepted_f_out) accepted_f_out[win0 + i] = hf[i];
-        most = std::max(most, ht[i]);
+        int tr;
+        memcpy(&tr, &hrec[4 * i], sizeof(int));
+        if (trials_out) trials_out[win0 + i] = tr;
+        if (accepted_lr_out) accepted_lr_out[win0 + i] = hrec[4 * i + 1];
+        if (accepted_f_out) accepted_f_out[win0 + i] = hrec[4 * i + 2];
+        most = std::max(most, tr);
+        last_trials = tr;
       }
-      prev_trials = ht[cnt - 1];
+      prev_trials = last_trials;
       memcpy(&last, &hctl[2], sizeof(float));
       for (int i = win0; i < done; ++i) t_mom = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;
       // the next window computes as many trials per tile as this one's longest search took (every computed trial costs

@@ -190,13 +190,15 @@ struct BtIterParams {
   const int* skip;                       // nullable: *skip != 0 -> no-op
   int n, d, k, ntiles;
   int fast, tail, ntrials;               // tail: accept step only (behind the last iteration of a window)
+  int zero_start;                        // no accept step and z = y = 0: the launch writes the zeros to Z / Y itself
   float coef;                            // momentum coefficient of the iteration being accepted
 };
 hipError_t launch_bt_iter(const BtIterParams& p, const BtSteps& s, int kpad, int grid, hipStream_t stream);
 hipError_t launch_bt_iter_decide(const float* partials, const float* partsM, int ntiles, double alpha, const BtSteps& s,
                                  int ntrials, int first_index, int last_batch, int* cur_flags, float* cur_fvals,
                                  const int* prev_flags, const float* prev_fvals, const float* dpart, int it_prev,
-                                 float budget, int* ctl, int* trials, float* lrs, float* fs, hipStream_t stream);
+                                 float budget, int* ctl, float* rec /* [iterations][4]: trials, step, F */,
+                                 hipStream_t stream);
 hipError_t launch_bt_trials_only(const BtParams& p, int kpad, int grid, const BtSteps& s, int ntrials, float* partsM,
                                  hipStream_t stream);
 hipError_t launch_bt_trial(const BtParams& p, int kpad, int grid, double alpha, double lr,

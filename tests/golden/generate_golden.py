@@ -139,6 +139,38 @@ def g2():
     save("g2_c2_fista", **out)
 
 
+def g2b():
+    """C2 at alpha = 0.1 (iterations-to-tol FISTA 766 / ISTA 1963 with tol=1e-5): the reference's iteration
+    counts, objectives and one z block with the explicit step 1/lambda_max (bitwise reproducible)."""
+    X, W = recipe_xw(4096, 256, 1024)
+    lr = 1.0 / LAMBDA_MAX_C2
+    z0 = X.new_zeros(4096, 1024)
+    out = {}
+    for name, fast, cap in (("fista", True, 3000), ("ista", False, 6000)):
+        # the reference returns no iteration count: count the evaluations of its stop test (ista.py:93) by watching
+        # torch.Tensor.abs on [n, k] operands inside the call
+        count = {"n": 0}
+        orig_abs = torch.Tensor.abs
+
+        def counting_abs(self, *a, **kw):
+            if self.dim() == 2 and self.shape == (4096, 1024):
+                count["n"] += 1
+            return orig_abs(self, *a, **kw)
+        torch.Tensor.abs = counting_abs
+        try:
+            t0 = time.time()
+            z = ref_ista(X, z0, W, 0.1, fast=fast, lr=lr, maxiter=cap, tol=1e-5)
+        finally:
+            torch.Tensor.abs = orig_abs
+        s = zstats(z)
+        out[name + "_iterations"] = np.array(count["n"])
+        out[name + "_obj"] = ref_loss(X, z, W, 0.1).item()
+        out[name + "_stats"] = np.array([s["sum"], s["abssum"], s["nnz"]])
+        out[name + "_z_block"] = z[:64, :64].numpy().copy()
+        print("G2b alpha=0.1 %s: %d iterations, obj %.6f, %.1f s" % (name, count["n"], out[name + "_obj"], time.time() - t0), s)
+    save("g2b_c2_alpha01", **out)
+
+
 def g3():
     """C3: FISTA + backtracking, n=16384 d=256 k=1024."""
     X, W = recipe_xw(16384, 256, 1024)

@@ -161,6 +161,78 @@ def test_c2_iterations_to_tol(golden):
     assert info_i["iterations"] == 450, info_i                        # ISTA 450
 
 
+def test_c2_reference_answers_that_only_the_oracle_met(golden):
+    """answers of the REAL reference at full config-2 size that were asserted for the oracle only
+    (tests/test_oracle.py) -- a warm start from a 5-iteration code, the 1000-iteration code, the ISTA code at its
+    stopping iteration -- now asserted on the HIP path, deviations recorded next to the bars."""
+    sparse_encode, ista, orc = _mods()
+    from margins import record_margins
+    g = golden("g2_c2_fista")
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / LAMBDA_MAX_C2
+    got = {}
+    # warm start (ista.py:76-78: y0 = z0, t = 1): 5 iterations from the code of 5 iterations
+    zw = sparse_encode(Xg, Wg, alpha=0.5, lr=lr, maxiter=5, tol=0.0)
+    z = sparse_encode(Xg, Wg, alpha=0.5, z0=zw, lr=lr, maxiter=5, tol=0.0).cpu()
+    obj = orc.lasso_objective(X, z, W, 0.5).item()
+    got["warm"] = {"max_dz": (z[:64, :64] - torch.from_numpy(g["warm_z_block"])).abs().max().item(),
+                   "rel_dobjective": abs(obj - float(g["warm_obj"])) / obj}
+    assert got["warm"]["max_dz"] <= Z_ATOL / 10 and got["warm"]["rel_dobjective"] <= OBJ_RTOL
+    # M = 1000 (the last row of the fixture's trajectory)
+    i = list(g["Ms"]).index(1000)
+    z = sparse_encode(Xg, Wg, alpha=0.5, lr=lr, maxiter=1000, tol=0.0).cpu()
+    obj = orc.lasso_objective(X, z, W, 0.5).item()
+    got["M1000"] = {"max_dz": max((z[:64, :64] - torch.from_numpy(g["z_block_M1000"])).abs().max().item(),
+                                  (z[::64, ::16] - torch.from_numpy(g["z_strided_M1000"])).abs().max().item()),
+                    "rel_dobjective": abs(obj - g["objective"][i]) / obj,
+                    "rel_dabssum": abs(z.double().abs().sum().item() - g["stats"][i][1]) / g["stats"][i][1]}
+    assert got["M1000"]["max_dz"] <= Z_ATOL_263 and got["M1000"]["rel_dobjective"] <= OBJ_RTOL
+    assert got["M1000"]["rel_dabssum"] <= 1e-5
+    # ISTA to tolerance: the CODE the reference stops with, not only its iteration count (450)
+    z, info = ista(Xg, torch.zeros(4096, 1024, device="cuda"), Wg, 0.5, fast=False, lr=lr, maxiter=3000, tol=1e-5,
+                   return_info=True)
+    z = z.cpu()
+    obj = orc.lasso_objective(X, z, W, 0.5).item()
+    st = g["tol_ista_stats"]
+    got["tol_ista"] = {"iterations": info["iterations"], "rel_dobjective": abs(obj - float(g["tol_ista_obj"])) / obj,
+                       "rel_dabssum": abs(z.double().abs().sum().item() - st[1]) / st[1],
+                       "rel_dnnz": abs(int((z != 0).sum()) - st[2]) / st[2]}
+    record_margins("c2_reference_answers", got)
+    assert info["iterations"] == 450
+    assert got["tol_ista"]["rel_dobjective"] <= OBJ_RTOL and got["tol_ista"]["rel_dabssum"] <= 1e-5
+    assert got["tol_ista"]["rel_dnnz"] <= 2e-5           # (the support: entries within an ulp of the threshold may fall either way)
+
+
+def test_c2_alpha_01_iterations_to_tol(golden):
+    """at alpha = 0.1 the reference needs 766 (FISTA) / 1963 (ISTA) iterations to tol = 1e-5.  Fixture
+    g2b_c2_alpha01 holds what the real reference does with the explicit step 1/lambda_max: iteration counts, objective,
+    a z block, code statistics (tests/golden/generate_golden.py g2b)."""
+    sparse_encode, ista, orc = _mods()
+    from margins import record_margins
+    g = golden("g2b_c2_alpha01")
+    X, W = recipe_xw(4096)
+    Xg, Wg = X.cuda(), W.cuda()
+    lr = 1.0 / LAMBDA_MAX_C2
+    got = {}
+    for name, fast, cap in (("fista", True, 3000), ("ista", False, 6000)):
+        z, info = ista(Xg, torch.zeros(4096, 1024, device="cuda"), Wg, 0.1, fast=fast, lr=lr, maxiter=cap, tol=1e-5,
+                       return_info=True)
+        z = z.cpu()
+        obj = orc.lasso_objective(X, z, W, 0.1).item()
+        st = g[name + "_stats"]
+        got[name] = {"iterations": info["iterations"], "reference_iterations": int(g[name + "_iterations"]),
+                     "max_dz": (z[:64, :64] - torch.from_numpy(g[name + "_z_block"])).abs().max().item(),
+                     "rel_dobjective": abs(obj - float(g[name + "_obj"])) / obj,
+                     "rel_dabssum": abs(z.double().abs().sum().item() - st[1]) / st[1]}
+    record_margins("c2_alpha01_to_tol", got)
+    for name in ("fista", "ista"):
+        assert got[name]["iterations"] == got[name]["reference_iterations"], got
+        assert got[name]["rel_dobjective"] <= OBJ_RTOL and got[name]["rel_dabssum"] <= 1e-5, got
+        assert got[name]["max_dz"] <= Z_ATOL, got
+    assert abs(got["fista"]["reference_iterations"] - 766) <= 2 and abs(got["ista"]["reference_iterations"] - 1963) <= 3
+
+
 def test_errors_and_unsupported():
     sparse_encode, ista, orc = _mods()
     x, w = torch.randn(4, 3).cuda(), torch.randn(3, 5).cuda()

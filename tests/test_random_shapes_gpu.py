@@ -70,9 +70,9 @@ def test_stop_rule_on_a_ragged_batch_against_the_oracle():
     lr = 1.0 / max(orc.lipschitz_constant(W, "exact"), 1e-3)
     z0 = torch.zeros(n, k)
     tr = orc.FistaTrace()
-    ref = orc.fista(X, z0, W, 0.4, lr=lr, maxiter=60, tol=3e-4, trace=tr)
+    ref = orc.fista(X, z0, W, 0.4, lr=lr, maxiter=60, tol=1e-3, trace=tr)        # (~42 iterations)
     assert 5 < tr.iterations < 60                       # the rule does fire inside the budget
-    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.4, lr=lr, maxiter=60, tol=3e-4, return_info=True)
+    got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.4, lr=lr, maxiter=60, tol=1e-3, return_info=True)
     assert info["iterations"] == tr.iterations, (info, tr.iterations)
     assert (got.cpu() - ref).abs().max().item() <= 5e-5
 
