@@ -36,6 +36,9 @@ extern "C" int lasso_debug_bti_stamps(unsigned long long* host_out) {
 #else
 #define BTI_STAMP(slot) do { } while (0)
 #endif
+#ifndef LASSO_BTI_STAGGER
+#define LASSO_BTI_STAGGER 2     // measured on config 3: 5.208 (0) -> 5.129 (2) / 5.133 (4) ms per solve
+#endif
 
 namespace lasso {
 
@@ -58,10 +61,17 @@ __device__ __forceinline__ void quad_transpose(f32x4& v, int j) {
   }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // ACCEPT: the launch opens with the accept step of the previous iteration (false: first iteration of a window -- the
 // point is loaded as it is).  A compile-time switch, like everything else that decides WHICH registers a tile's
 // prefetch defines: a load under a run-time condition keeps the old value alive across the whole tile (720 spilled
 // registers in the first version of the prefetch).
+//
+// Memory traffic of a tile goes through BUFFER descriptors of the tile's valid rows: a piece outside the matrix
+// (ragged last tile, padded columns) reads as zero and is dropped on store, so no load or store sits under a branch
+// and every wave issues EXACTLY the same number of vector-memory operations per tile -- which is what lets the GEMMs
+// behind them start with `vmcnt(4 + EXTRA)` waits (tile_device.hpp) instead of draining those operations first.
 template <int K, bool ACCEPT>
 __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterParams p, const BtSteps s) {
   constexpr int D = kFistaD;
@@ -69,6 +79,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
   constexpr int KW = K / NW;
   constexpr int NP = KW / 32;
   constexpr int ITER = kTileM * (K / 4) / kFistaThreads;
+  constexpr unsigned kOOR = 0x80000000u;   // a byte offset beyond every tile descriptor
   static_assert(ITER >= 1 && (kTileM * (K / 4)) % kFistaThreads == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const rings = (lds_char*)smem;
@@ -88,44 +99,53 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
   c.init(p.Wp, p.Wtp, rings);
   const int tid = threadIdx.x;
   const int lane = c.lane, wid = c.wid, n = c.n, q = c.q;
+#if LASSO_BTI_STAGGER > 0
+  // Workgroups enter in 8 groups LASSO_BTI_STAGGER x ~0.45 us apart, so that the per-tile bursts of the 256 workgroups
+  // (50 MB of prefetch at the same instant: 8-10 us until the last piece is in) spread out; tiles take the same time in
+  // every workgroup, so the offsets last for the launch
+  for (int i = (int)((blockIdx.x >> 3) & 7) * LASSO_BTI_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(16);
+#endif
   dma_step(c.w1, c.voff1, c.ring);
   dma_step(c.w1 + 32, c.voff1, c.ring + kStepBytes);
   float* const P = p.fast ? p.Y : p.Z;     // the point: y (FISTA) or z (ISTA: the loads of p then repeat those of z), flat [n][k]
 
-  // The operands of a tile's accept step (z, g and -- FISTA -- y: ITER 16-byte pieces per thread each) and its block of
-  // x, all in flight together, clamped addresses (masked where they are used).  Issued for tile j+1 behind the LAST
-  // GEMM of tile j: the loads travel under that trial's sums, its barrier and the g stores, and no hand-counted wait of
-  // an LDS-DMA ring (in-order vmcnt) ever has them in front of it.
-  // Addresses: a uniform per-tile base (SGPR pair) + a 32-bit byte offset built from two thread constants with one
-  // min and one multiply-add per piece -- nothing worth hoisting out of the tile loop.  (The first version clamped
+  // descriptor of rows [row0, row0 + 16) n [0, n) of a row-major matrix with row pitch ld (floats)
+  auto tile_rsrc = [&](const float* base, int row0, int64_t ld) {
+    const int rows = min(kTileM, p.n - row0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)row0 * ld), 0, rows * (int)ld * 4,
+                                             0x00020000);
+  };
+  // The operands of a tile's accept step (z, g, p: ITER 16-byte pieces per thread each) and its block of x, all in
+  // flight together.  Issued for tile j+1 in front of the LAST trial of tile j (see there).  Offsets: two thread
+  // constants and one multiply-add per piece -- nothing worth hoisting out of the tile loop.  (The first version clamped
   // 64-bit addresses per piece; the compiler hoisted the per-piece parts, spilled them, and every scratch reload
   // between two prefetch loads waited for the loads in front of it: eight HBM round trips in a row, 10 us per tile.)
   constexpr int RSTEP = kFistaThreads / (K / 4);             // rows between a thread's consecutive pieces
   const int r0 = tid / (K / 4);
-  const int cl = min((tid - r0 * (K / 4)) * 4, p.k - 4);     // first column of the thread's pieces (clamped; masked in use)
+  const int cc0 = (tid - r0 * (K / 4)) * 4;                  // first column of the thread's pieces
   f32x4 pa[ITER], ga[ITER], za[ITER], xr[2];
   auto fetch_tile = [&](int tile) {
     const int row0 = tile * kTileM;
-    const int last = min(kTileM, p.n - row0) - 1;            // last valid row of the tile (uniform)
     if constexpr (ACCEPT) {
-      const char* const zb = (const char*)(p.Z + (int64_t)row0 * p.k);
-      const char* const gb = (const char*)(p.G + (int64_t)row0 * p.k);
-      const char* const pb = (const char*)(P + (int64_t)row0 * p.k);
+      const auto rz = tile_rsrc(p.Z, row0, p.k), rg = tile_rsrc(p.G, row0, p.k), rp = tile_rsrc(P, row0, p.k);
+      const unsigned coff = cc0 < p.k ? (unsigned)cc0 * 4u : kOOR;
 #pragma unroll
       for (int i = 0; i < ITER; ++i) {
-        const unsigned off = (unsigned)(min(r0 + RSTEP * i, last) * p.k + cl) * 4u;
-        za[i] = *reinterpret_cast<const f32x4*>(zb + off);
-        ga[i] = *reinterpret_cast<const f32x4*>(gb + off);
-        pa[i] = *reinterpret_cast<const f32x4*>(pb + off);
+        const unsigned off = (unsigned)((r0 + RSTEP * i) * p.k) * 4u + coff;
+        za[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, off, 0, 0));
+        ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+        pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0));
       }
     }
-    const char* const xb = (const char*)(p.X + (int64_t)row0 * p.ldx);
+    const auto rx = tile_rsrc(p.X, row0, p.ldx);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = 32 * wid + 16 * cb + n;
+      const unsigned coff = col < p.d ? (unsigned)col * 4u : kOOR;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
-        xr[cb][rg] = *reinterpret_cast<const float*>(
-            xb + (unsigned)(min(4 * q + rg, last) * (int)p.ldx + min(32 * wid + 16 * cb + n, p.d - 1)) * 4u);
+        xr[cb][rg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (unsigned)((4 * q + rg) * (int)p.ldx) * 4u + coff, 0, 0));
+    }
   };
   if ((int)blockIdx.x < p.ntiles) fetch_tile(blockIdx.x);
 
@@ -141,8 +161,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
     // addresses of the C layout, the offsets of the accept step's stores) is then computed where a tile uses it
     // instead of once per launch -- hoisted out of the tile loop those ~60 values were live across every GEMM and
     // spilled, and a scratch reload behind the prefetch waits for the prefetch (in-order vmcnt).
-    int qo = q, no = n, r0o = r0, tido = tid;
-    asm volatile("" : "+v"(qo), "+v"(no), "+v"(r0o), "+v"(tido));
+    int qo = q, no = n, r0o = r0, cco = cc0;
+    asm volatile("" : "+v"(qo), "+v"(no), "+v"(r0o), "+v"(cco));
     // LDS byte offset of this lane's C-layout element (row 4q+rg, column colbase+n) of the [16][K] tile: tile_off()
     int ep_rg[4];
 #pragma unroll
@@ -155,49 +175,39 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        negx[cb][rg] = ((row0 + 4 * q + rg) < p.n && (32 * wid + 16 * cb + n) < p.d) ? -xr[cb][rg] : 0.0f;
+      for (int rg = 0; rg < 4; ++rg) negx[cb][rg] = __fsub_rn(0.0f, xr[cb][rg]);      // (x beyond the matrix read as 0)
+    const auto rz = tile_rsrc(p.Z, row0, p.k), ry = tile_rsrc(p.Y, row0, p.k);
+    const unsigned soff = (unsigned)(r0o * p.k) * 4u + (cco < p.k ? (unsigned)cco * 4u : kOOR);   // the thread's piece 0 in Z / Y
+    // z_i / y_i of the accept step stay in registers through the gradient's GEMM-1 and go to memory behind it: stores in
+    // front of that GEMM sat in front of its hand-counted ring waits (in-order vmcnt) and stalled it for their 3-4 us
+    // of drain; behind it they drain under the r-tile exchange and GEMM-2's first steps.
+    f32x4 zs[ACCEPT ? ITER : 1], ys[ACCEPT ? ITER : 1];
     if constexpr (ACCEPT) {
-      // ---- the accept step of the previous iteration on this tile
-      char* const zb = (char*)(p.Z + (int64_t)row0 * p.k);
-      char* const yb = (char*)(p.Y + (int64_t)row0 * p.k);
-      const int cc = (tido - r0o * (K / 4)) * 4;
+      // ---- the accept step of the previous iteration on this tile (pieces outside the matrix are zeros and stay zeros)
 #pragma unroll
       for (int i = 0; i < ITER; ++i) {
-        const int r = r0o + RSTEP * i;
-        const bool ok = (row0 + r) < p.n && cc < p.k;
-        f32x4 zn = {0.f, 0.f, 0.f, 0.f}, yn = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
+        f32x4 zn, yn;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float zo = za[i][e];
-            const float pv = pa[i][e];
-            zn[e] = soft_threshold(__fsub_rn(pv, __fmul_rn(lr_a, ga[i][e])), lam_a);        // ista.py:40
-            dsum += __builtin_fabsf(__fsub_rn(zo, zn[e]));                                    // :93
-            yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo)));                // :99-100
-          }
-          const unsigned off = (unsigned)(r * p.k + cc) * 4u;
-          *reinterpret_cast<f32x4*>(zb + off) = zn;                                           // :102
-          if (p.fast) *reinterpret_cast<f32x4*>(yb + off) = yn;
+        for (int e = 0; e < 4; ++e) {
+          const float zo = za[i][e];
+          const float pv = pa[i][e];
+          zn[e] = soft_threshold(__fsub_rn(pv, __fmul_rn(lr_a, ga[i][e])), lam_a);          // ista.py:40
+          dsum += __builtin_fabsf(__fsub_rn(zo, zn[e]));                                      // :93
+          yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo)));                  // :99-100
         }
-        *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = p.fast ? yn : zn;
+        zs[i] = zn; ys[i] = yn;
+        *(lds_f32x4*)(pt + tile_chunk_off<K>(r0o + RSTEP * i, cco)) = p.fast ? yn : zn;
       }
     } else if (p.zero_start) {
-      // the solve starts from z = y = 0 (z0 == NULL): the tile is zeros, and this launch writes them to Z (and Y) for
+      // the solve starts from z = y = 0 (z0 == NULL): the tile is zeros, and this launch writes them to Z and Y for
       // the accept step that follows -- instead of two fill launches over [n][k] in front of the solve
-      char* const zb = (char*)(p.Z + (int64_t)row0 * p.k);
-      char* const yb = (char*)(p.Y + (int64_t)row0 * p.k);
-      const int cc = (tido - r0o * (K / 4)) * 4;
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < ITER; ++i) {
-        const int r = r0o + RSTEP * i;
-        if ((row0 + r) < p.n && cc < p.k) {
-          const unsigned off = (unsigned)(r * p.k + cc) * 4u;
-          *reinterpret_cast<f32x4*>(zb + off) = zero;
-          if (p.fast) *reinterpret_cast<f32x4*>(yb + off) = zero;
-        }
-        *(lds_f32x4*)(pt + tile_chunk_off<K>(r, cc)) = zero;
+        const unsigned off = soff + (unsigned)(RSTEP * i * p.k) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(zero, rz, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(zero, ry, off, 0, 0);
+        *(lds_f32x4*)(pt + tile_chunk_off<K>(r0o + RSTEP * i, cco)) = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     } else {
       visit_tile4<K, kFistaThreads>(P, p.k, row0, p.n, p.k, [&](int r, int cc, const f32x4& v) {
@@ -215,6 +225,14 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       f32x4 acc[2] = {negx[0], negx[1]};
       gemm1_stream_sp<K>(c, pt, acc, c.w2, c.w2 + 32, c.voff2);
       BTI_STAMP(3);
+      if constexpr (ACCEPT) {              // z_i -> Z (:102), y_i -> Y: exactly 2 ITER stores per wave
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+          const unsigned off = soff + (unsigned)(RSTEP * i * p.k) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zs[i]), rz, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ys[i]), ry, off, 0, 0);
+        }
+      }
       float rss = 0.0f;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -238,7 +256,8 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       f32x4 rf[D / 32][2];
       load_r_frags<K>(c, rt, rf);
       BTI_STAMP(4);
-      gemm2_stream_sp<K>(c, rf, gk);
+      // (2 ITER stores -- wave 0: two more -- went out since the ring's steps 0/1: GEMM-2's first two steps do not wait for them)
+      gemm2_stream_sp<K, ACCEPT ? 2 * ITER : 0>(c, rf, gk);
       BTI_STAMP(5);
     }
     // the point in the C layout (this lane's 32 elements of the tile; every lane reads and later overwrites only its
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
           }
     };
     f32x4 acc[2];
-    auto trial_front = [&]() {             // candidate -> LDS tile, r1 = z+ W^T - x
+    auto trial_front = [&](auto extra_c) {     // candidate -> LDS tile, r1 = z+ W^T - x
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       acc[0] = negx[0]; acc[1] = negx[1];
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
-      gemm1_stream_sp<K>(c, pt, acc, c.w1, c.w1 + 32, c.voff1);
+      gemm1_stream_sp<K, decltype(extra_c)::value>(c, pt, acc, c.w1, c.w1 + 32, c.voff1);
     };
     auto trial_back = [&](int t, float l1, float dzg, float dz2) {   // the trial's four tile sums
       float rss = 0.0f;
@@ -307,27 +326,29 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       // (no barrier here: the next writes of red[] come after the next trial's candidate barrier, which wave 0 reaches
       //  only after these reads)
     };
+    // This tile's gradient g -> G (the accept step of the NEXT launch reads it) and the next tile's operands.  In the C
+    // layout a lane owns four rows of one column: a 4 x 4 transpose inside each lane quad turns that into four
+    // consecutive columns of one row -- 2 NP stores of 16 bytes per lane instead of 8 NP of 4.  Issued BEHIND the last
+    // trial's MFMAs: the loads travel under that trial's sums and its barrier.  (In front of the last trial -- with
+    // vmcnt(4 + the operation count) for its first two steps -- was measured and is slower, 5.22 against 5.18 ms per
+    // solve: from step 2 on the ring's in-order waits make the GEMM wait out the prefetch, and with all 256 workgroups
+    // in step that burst of 50 MB takes 8-10 us.)
     auto tile_end = [&]() {
-      // the next tile's operands, then this tile's gradient g -> G (the accept step of the NEXT launch reads it).  In
-      // the C layout a lane owns four rows of one column: a 4 x 4 transpose inside each lane quad turns that into four
-      // consecutive columns of one row -- 8 stores of 16 bytes per lane instead of 32 of 4 (32 prefetch loads + 32
-      // stores overran the 63 vector-memory operations a wave may have in flight: the stores then waited for the
-      // prefetch, 7-10 us per tile).
-      fetch_tile(next_tile);
-      char* const g_base = (char*)(p.G + (int64_t)row0 * p.k);
+      const auto rgd = tile_rsrc(p.G, row0, p.k);
       const int j = no & 3;
       const int colq = wid * KW + (no & 12);                               // first of this lane's four columns
-      const bool whole = row0 + kTileM <= p.n && wid * KW + KW <= p.k;      // wave-uniform: no masks on the usual path
-      char* const gr = g_base + (unsigned)((4 * qo + j) * p.k + colq) * 4u;
+      const unsigned roff = (unsigned)((4 * qo + j) * p.k) * 4u;
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           f32x4 v = gk[ps][cb];
           quad_transpose(v, j);
-          if (whole || ((row0 + 4 * qo + j) < p.n && (colq + 32 * ps + 16 * cb) < p.k))     // (k % 4 == 0: a piece is in or out)
-            *reinterpret_cast<f32x4*>(gr + (32 * ps + 16 * cb) * 4) = v;
+          const int col = colq + 32 * ps + 16 * cb;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rgd,
+                                                 roff + (col < p.k ? (unsigned)col * 4u : kOOR), 0, 0);
         }
+      fetch_tile(next_tile);
     };
     if (p.ntrials > 0) {
       float l1, dzg, dz2;
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
 #pragma unroll 1
       for (int t = 0; t + 1 < p.ntrials; ++t) {
         if (t == 0) BTI_STAMP(7);
-        trial_front();
+        trial_front(std::integral_constant<int, 0>{});
         if (t == 0) BTI_STAMP(9);
         float l1n, dzgn, dz2n;
         cand(t + 1, l1n, dzgn, dz2n);
@@ -343,8 +364,9 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
         l1 = l1n; dzg = dzgn; dz2 = dz2n;
         if (t == 0) BTI_STAMP(10);
       }
-      trial_front();
       BTI_STAMP(11);
+      trial_front(std::integral_constant<int, 0>{});
+      BTI_STAMP(14);
       tile_end();
       trial_back(p.ntrials - 1, l1, dzg, dz2);
     } else {
@@ -378,22 +400,23 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
                                                               const float* __restrict__ dpart, int it_prev, float budget,
                                                               int* __restrict__ ctl, float* __restrict__ rec) {
   if (ctl[0] != 0) return;
-  __shared__ double sh[kBtMultiMax][5][128];
-  __shared__ float shd[256];
+  // wave-level reductions (shuffles in a fixed order), ONE block barrier per part: as LDS trees with a barrier per
+  // level this launch took ~10 us, x 11 per config-3 solve
+  __shared__ double sh[kBtMultiMax][5][2];
+  __shared__ float shd[4];
   __shared__ int stop;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (prev_flags) {
     if (threadIdx.x < 256) {
       float acc = 0.0f;
       for (int t = threadIdx.x; t < ntiles; t += 256) acc += dpart[t];
-      shd[threadIdx.x] = acc;
+#pragma unroll
+      for (int st = 32; st > 0; st >>= 1) acc += __shfl_down(acc, st, 64);
+      if (lane == 0) shd[wave] = acc;
     }
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st) shd[threadIdx.x] += shd[threadIdx.x + st];
-      __syncthreads();
-    }
     if (threadIdx.x == 0) {
-      const float delta = shd[0];
+      const float delta = (shd[0] + shd[1]) + (shd[2] + shd[3]);
       int fired = 0;
       if (prev_flags[0] != 0) {
         rec[4 * it_prev] = __int_as_float(prev_flags[2] + 1);        // {trials, accepted step, F of the accepted trial}
@@ -410,7 +433,7 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
   }
   if (ntrials <= 0) return;
   if (cur_flags[0] != 0) return;           // a trial of an earlier batch of this iteration was accepted
-  const int t = threadIdx.x >> 7, l = threadIdx.x & 127;
+  const int t = threadIdx.x >> 7, l = threadIdx.x & 127;    // 128 threads = 2 waves per trial
   double acc[5] = {0, 0, 0, 0, 0};
   if (t < ntrials)
     for (int tl = l; tl < ntiles; tl += 128) {
@@ -419,18 +442,17 @@ __global__ __launch_bounds__(1024) void bt_iter_decide_kernel(const float* __res
       for (int q = 0; q < 4; ++q) acc[1 + q] += partsM[((size_t)t * 4 + q) * ntiles + tl];
     }
 #pragma unroll
-  for (int q = 0; q < 5; ++q) sh[t][q][l] = acc[q];
-  __syncthreads();
-  for (int st = 64; st > 0; st >>= 1) {
-    if (l < st)
+  for (int q = 0; q < 5; ++q) {
 #pragma unroll
-      for (int q = 0; q < 5; ++q) sh[t][q][l] += sh[t][q][l + st];
-    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) acc[q] += __shfl_down(acc[q], st, 64);
+    if (lane == 0) sh[t][q][wave & 1] = acc[q];
   }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   for (int u = 0; u < ntrials; ++u) {
-    const float rss0 = (float)sh[u][0][0], rss1 = (float)sh[u][1][0], l1 = (float)sh[u][2][0];
-    const float dzg = (float)sh[u][3][0], dz2 = (float)sh[u][4][0];
+    const float rss0 = (float)(sh[u][0][0] + sh[u][0][1]), rss1 = (float)(sh[u][1][0] + sh[u][1][1]);
+    const float l1 = (float)(sh[u][2][0] + sh[u][2][1]);
+    const float dzg = (float)(sh[u][3][0] + sh[u][3][1]), dz2 = (float)(sh[u][4][0] + sh[u][4][1]);
     const float f0 = __fmul_rn(0.5f, rss0);                                        // ista.py:23
     const float al1 = __fmul_rn(alpha, l1);
     const float F = __fadd_rn(__fmul_rn(0.5f, rss1), al1);                         // :28

@@ -406,18 +406,23 @@ __device__ __forceinline__ void no_stage() {}
 //   acc[cb] += A_tile[16][K] * Wp[32*wid + 16*cb .. +16][K]^T
 // Pre:  ring slots 0/1 hold (or have in flight) W steps 0/1 of this wave.
 // Post: ring slots 0/1 have `tail0` / `tail1` (+ tail_voff) in flight.
-template <int K>
+// EXTRA: vector-memory operations (loads, stores) the caller issued AFTER the ring's steps 0/1 went out and before this
+// call.  vmcnt retires in order, so "step 0 / step 1 have landed" is then vmcnt(4 + EXTRA), not vmcnt(4): the first
+// two steps run while those operations are still in flight; from step 2 on the waits are the usual ones (and do
+// imply that the caller's operations have completed).
+template <int K, int EXTRA = 0>
 __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* at, f32x4 (&acc)[2],
                                                 const float* tail0, const float* tail1,
                                                 const unsigned (&tail_voff)[4]) {
   constexpr int S1 = K / 32;
   static_assert(S1 % 2 == 0 && S1 >= 6, "geometry");
+  static_assert(EXTRA >= 0 && 8 + EXTRA <= 63, "vmcnt is a 6-bit counter");
   lds_char* const slot0 = c.ring;
   lds_char* const slot1 = c.ring + kStepBytes;
   const lds_char* const arow = at + c.n * (K * 4);
   sp::Frag X, Y;
   // prologue: fragments of step 0 into X, slot0 refilled with step 2
-  LASSO_WAIT_VMCNT(4);
+  LASSO_WAIT_VMCNT(4 + EXTRA);
   sp::load_b(c, X, slot0);
   sp::load_a(c, X, arow, 0);
   LASSO_WAIT_LGKM0();
@@ -425,9 +430,9 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
   auto nothing = [] {};
   // MODE 0: both refills from given sources; 1: only the even step refills (odd = last step)
   auto trip = [&](int s2, const float* srcE, const unsigned (&voffE)[4], const float* srcO,
-                  const unsigned (&voffO)[4], auto last_c) {
+                  const unsigned (&voffO)[4], auto last_c, auto extra_c) {
     constexpr bool last = decltype(last_c)::value;
-    LASSO_WAIT_VMCNT(4);
+    LASSO_WAIT_VMCNT(4 + decltype(extra_c)::value);
     sp::load_b(c, Y, slot1);
     sp::load_a(c, Y, arow + s2 * 256, 1);
     sp::step_body(acc, X.a, X, srcE, voffE, slot1, nothing, nothing, nothing, nothing);
@@ -444,12 +449,20 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
   };
   using F = std::false_type;
   using T = std::true_type;
+  using E0 = std::integral_constant<int, 0>;
+  if constexpr (EXTRA > 0) {               // the first trip on its own: its even step still has the caller's operations in front
+    trip(0, c.w1 + 96, c.voff1, c.w1 + 128, c.voff1, F{}, std::integral_constant<int, EXTRA>{});
 #pragma unroll 1
-  for (int s2 = 0; s2 < S1 / 2 - 2; ++s2)
-    trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{});
+    for (int s2 = 1; s2 < S1 / 2 - 2; ++s2)
+      trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{}, E0{});
+  } else {
+#pragma unroll 1
+    for (int s2 = 0; s2 < S1 / 2 - 2; ++s2)
+      trip(s2, c.w1 + 64 * s2 + 96, c.voff1, c.w1 + 64 * s2 + 128, c.voff1, F{}, E0{});
+  }
   // steps S1-4 / S1-3: refills = W step S1-1 and tail0;  steps S1-2 / S1-1: refill = tail1 / none
-  trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, tail0, tail_voff, F{});
-  trip(S1 / 2 - 1, tail1, tail_voff, tail1, tail_voff, T{});
+  trip(S1 / 2 - 2, c.w1 + 32 * (S1 - 1), c.voff1, tail0, tail_voff, F{}, E0{});
+  trip(S1 / 2 - 1, tail1, tail_voff, tail1, tail_voff, T{}, E0{});
 }
 
 // Pipelined GEMM-2 without an epilogue (round 5, bt_iter.hip): all NP passes of
@@ -458,7 +471,8 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
 // machinery of GEMM-1.  Same MFMA order per accumulator as gemm2_pass (bitwise the same g).
 // Pre:  ring slots 0/1 have W^T steps 0/1 of this wave in flight (the tails of gemm1_stream_sp).
 // Post: ring slots 0/1 have steps 0/1 of the next GEMM-1 (c.w1) in flight.
-template <int K>
+// EXTRA: as in gemm1_stream_sp (operations issued between the ring's steps 0/1 and this call).
+template <int K, int EXTRA = 0>
 __device__ __forceinline__ void gemm2_stream_sp(const TileCtx<K>& c, const f32x4 (&rf)[kFistaD / 32][2],
                                                 f32x4 (&g)[(K / kFistaWaves) / 32][2]) {
   constexpr int D = kFistaD;
@@ -469,7 +483,7 @@ __device__ __forceinline__ void gemm2_stream_sp(const TileCtx<K>& c, const f32x4
   lds_char* const slot0 = c.ring;
   lds_char* const slot1 = c.ring + kStepBytes;
   sp::Frag X, Y;
-  LASSO_WAIT_VMCNT(4);
+  LASSO_WAIT_VMCNT(4 + EXTRA);
   sp::load_b(c, X, slot0);
   LASSO_WAIT_LGKM0();
   dma_step(c.w2 + (size_t)(32 * (2 / T2)) * D + 32 * (2 % T2), c.voff2, slot0);
@@ -485,7 +499,7 @@ __device__ __forceinline__ void gemm2_stream_sp(const TileCtx<K>& c, const f32x4
       g[ps][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (U + 1 < S2) {
-      LASSO_WAIT_VMCNT(4);
+      LASSO_WAIT_VMCNT(4 + (U == 0 ? EXTRA : 0));
       sp::load_b(c, nxt, nslot);
       if constexpr (U + 3 < S2) {
         constexpr int pn = (U + 3) / T2, tn = (U + 3) % T2;

@@ -29,7 +29,7 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16)[:256].astype(np.float6
 t0 = t[:, 0].min()
 names = ['tile start', 'accept done (stores issued)', 'barrier', 'GEMM-1 done', 'r tile + fragments', 'GEMM-2 done',
          'p in registers + barrier', 'trial0 candidate written', 'trial0 barrier', 'trial0 GEMM-1 done', 'trial0 end',
-         'all trials done', 'g stored (tile end)', 'kernel end']
+         'trials but the last done', 'tile end', 'kernel end', 'last GEMM-1 issued']
 print('%-30s %8s %8s %8s   (us from the first workgroup entering the launch)' % ('stamp', 'min', 'median', 'max'))
 for i, nme in enumerate(names):
     print('%-30s %8.2f %8.2f %8.2f' % (nme, t[:, i].min() - t0, np.median(t[:, i]) - t0, t[:, i].max() - t0))
@@ -38,7 +38,8 @@ print('%-34s %7s %7s %7s' % ('phase (per workgroup, first tile)', 'min', 'median
 for a, b, label in ((0, 1, 'accept: loads, math, stores'), (1, 2, 'barrier'), (2, 3, 'GEMM-1 (gradient)'),
                     (3, 4, 'r tile, barrier, fragments'), (4, 5, 'GEMM-2'), (5, 6, 'p -> registers, barrier'),
                     (6, 7, 'candidate 0 in registers'), (7, 9, 'trial0 cand. write, barrier, GEMM-1'),
-                    (9, 10, 'candidate 1 + trial0 sums, barrier'), (6, 11, 'all trials up to the last GEMM-1'), (11, 12, 'prefetch, g stores, last sums, barrier'),
+                    (9, 10, 'candidate 1 + trial0 sums, barrier'), (6, 11, 'all trials but the last'), (11, 14, 'g stores, prefetch, cand. write, barrier, last GEMM-1'),
+                    (14, 12, 'last sums, barrier'),
                     (0, 12, 'whole tile'), (0, 13, 'whole launch (4 tiles)')):
     dt = t[:, b] - t[:, a]
     print('%-34s %7.2f %7.2f %7.2f' % (label, dt.min(), np.median(dt), dt.max()))

@@ -21,7 +21,7 @@ def collect(d, counter):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
                 acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return acc
 fetch, write = collect("/tmp/hbm_f", "FETCH_SIZE"), collect("/tmp/hbm_w", "WRITE_SIZE")
