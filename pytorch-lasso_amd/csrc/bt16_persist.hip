@@ -67,6 +67,7 @@ namespace {
 using namespace bf16dev;
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -507,26 +508,35 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       // (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured here: 1.047 -> 1.011 ms per config-3 solve
       // with the packed form of rounds 2-3 replaced); this file is built with -fno-slp-vectorize so that the compiler
       // does not re-pack them.  The two sums accumulate by fma.
-      auto cand2 = [&](const float (&pv)[8], const float (&gv)[8], float (&zn)[8], int e2) __attribute__((always_inline)) {
+      // (round 5: the pair is rounded to bf16 by ONE v_cvt_pk_bf16_f32 whose result IS the staged operand; the rounded
+      // values the sums need are its two halves shifted / masked back to fp32 -- before, every element was converted on
+      // its own and the eight of a pass converted again for the store: 12 conversions per pass instead of 4)
+      auto cand2 = [&](const float (&pv)[8], const float (&gv)[8], u32x4& zn, int e2) __attribute__((always_inline)) {
+        const int e = 2 * e2;
+        const float v0 = soft_threshold(__fsub_rn(pv[e], __fmul_rn(lr, gv[e])), lam);                    // ista.py:40
+        const float v1 = soft_threshold(__fsub_rn(pv[e + 1], __fmul_rn(lr, gv[e + 1])), lam);
+        unsigned pk;                             // {bf16(v0), bf16(v1)}, round to nearest even -- one instruction for the pair
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v0), "v"(v1));
+        const float ze[2] = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
 #pragma unroll
-        for (int e = 2 * e2; e < 2 * e2 + 2; ++e) {
-          const float ze = bf16_round(soft_threshold(__fsub_rn(pv[e], __fmul_rn(lr, gv[e])), lam));     // ista.py:40
-          const float de = __fsub_rn(ze, pv[e]);                                                         // :31
-          l1 += __builtin_fabsf(ze);
-          dzg2[e & 1] = fmaf(de, gv[e], dzg2[e & 1]);
-          dz22[e & 1] = fmaf(de, de, dz22[e & 1]);
-          zn[e] = ze;
+        for (int h = 0; h < 2; ++h) {
+          const float de = __fsub_rn(ze[h], pv[e + h]);                                                  // :31
+          l1 += __builtin_fabsf(ze[h]);
+          dzg2[h] = fmaf(de, gv[e + h], dzg2[h]);
+          dz22[h] = fmaf(de, de, dz22[h]);
         }
+        zn[e2] = pk;
       };
       // candidate values of pass j (this thread: one row, 8 atoms) -> staging tile j & 1
       auto candidates = [&](int j, int par) __attribute__((always_inline)) {
-        float pv[8], gv[8], zn[8];
+        float pv[8], gv[8];
+        u32x4 zn;
         unpack8(*(const lds_u32x4*)(pt + (par ? ptO : ptE) + 256 * (j >> 1)), pv);
         unpack8(gq[par], gv);
         gq[par] = load_g8(min(j + 2, NP - 1));
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) cand2(pv, gv, zn, e2);
-        *(lds_u32x4*)(st + par * kStageBytes + stW) = pack8(zn);
+        *(lds_u32x4*)(st + par * kStageBytes + stW) = zn;
       };
       // Between two barriers a wave holds the MFMAs of pass jm (staging tile pm) and the
       // element-wise work of pass jc (-> staging tile pm ^ 1): independent streams, written out
@@ -542,7 +552,8 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb) a[u][rb] = *(const lds_bf16x8*)(sb + (u ? stA1 : stA0) + 2048 * rb);
-        float pv[8], gv[8], zn[8];
+        float pv[8], gv[8];
+        u32x4 zn;
         unpack8(*(const lds_u32x4*)(pt + (pc ? ptO : ptE) + 256 * (jc >> 1)), pv);
         unpack8(gq[pc], gv);
         gq[pc] = load_g8(min(jc + 2, NP - 1));
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
           cand2(pv, gv, zn, e2);
           __builtin_amdgcn_sched_barrier(0);
         }
-        *(lds_u32x4*)(st + pc * kStageBytes + stW) = pack8(zn);
+        *(lds_u32x4*)(st + pc * kStageBytes + stW) = zn;
         const unsigned fn = (unsigned)(min(jm + 2, NP - 1) * 4) * 1024u;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
