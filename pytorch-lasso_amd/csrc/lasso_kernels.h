@@ -151,6 +151,9 @@ hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 hipError_t launch_fista_tile_sp(const FistaTileParams& p, int kpad, int dpad, int grid, hipStream_t stream,
                                 int waves = kFistaWaves);
+// the same kernel without the all-padding feature chunks of GEMM-2 (fista_tile_sp_ds.hip); hipErrorInvalidValue = none
+hipError_t launch_fista_tile_sp_ds(const FistaTileParams& p, int kpad, int dpad, int dsteps, int grid, hipStream_t stream,
+                                   int waves);
 // workgroups of the stop-rule instantiation the occupancy query admits per CU
 hipError_t fista_tile_sp_occupancy(int kpad, int dpad, int* blocks_per_cu, int waves = kFistaWaves);
 // small-batch variant: a 16-row tile shared by Kpad/128 workgroups (fista_splitk.hip); needs

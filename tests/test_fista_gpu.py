@@ -233,6 +233,29 @@ def test_c2_alpha_01_iterations_to_tol(golden):
     assert abs(got["fista"]["reference_iterations"] - 766) <= 2 and abs(got["ista"]["reference_iterations"] - 1963) <= 3
 
 
+@pytest.mark.parametrize("n,d,k", [(4200, 64, 1024), (300, 64, 512), (4100, 96, 1024), (700, 90, 512), (4100, 150, 1024),
+                                   (4100, 192, 1024), (600, 192, 512), (4100, 200, 1000), (500, 222, 256), (4100, 130, 768)])
+def test_short_rows_leave_the_padding_chunks_out(n, d, k):
+    """Rows with fewer features than the tile's padded width (round 5, fista_tile_sp_ds.hip): GEMM-2 contracts over
+    ceil(d / 32) feature chunks instead of D / 32 -- the chunks left out multiply exact zeros.  Codes against the CPU
+    oracle, FISTA and ISTA, cold and warm start (shapes that have no such instantiation run the full-width kernel and
+    pass alike)."""
+    sparse_encode, ista, orc = _mods()
+    X, W = _case(n, d, k, seed=n + d)
+    lr = 1.0 / orc.lipschitz_constant(W, "exact")
+    ref = orc.sparse_encode(X, W, alpha=0.3, lr=lr, maxiter=12, tol=0.0)
+    got = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, lr=lr, maxiter=12, tol=0.0)
+    assert (got.cpu() - ref).abs().max().item() <= Z_ATOL
+    ref2 = orc.sparse_encode(X, W, alpha=0.3, z0=ref, fast=False, lr=lr, maxiter=5, tol=0.0)
+    got2 = sparse_encode(X.cuda(), W.cuda(), alpha=0.3, z0=got, fast=False, lr=lr, maxiter=5, tol=0.0)
+    assert (got2.cpu() - ref2).abs().max().item() <= Z_ATOL
+    # the tile kernel of the same shape forced to the wide 16 x 256 tile (no instantiation for these chunk counts
+    # below 5): bitwise the same codes
+    if d <= 128:
+        wide = ista(X.cuda(), torch.zeros(n, k, device="cuda"), W.cuda(), 0.3, lr=lr, maxiter=12, tol=0.0, kernel='tile')
+        assert torch.equal(got, wide)
+
+
 def test_errors_and_unsupported():
     sparse_encode, ista, orc = _mods()
     x, w = torch.randn(4, 3).cuda(), torch.randn(3, 5).cuda()
