@@ -78,6 +78,30 @@ def test_c3_fp32_full_size(golden):
     assert abs(obj - float(g["fp32_ista_bt_obj"])) <= 1e-5 * obj
 
 
+@pytest.mark.parametrize("fast", [True, False])
+def test_c3_fp32_one_launch_per_iteration_is_bitwise_the_multi_launch_form(fast):
+    """Round 5: config 3 in fp32 runs as ONE launch per outer iteration (csrc/bt_iter.hip: accept + gradient + trials
+    per 16-row tile) + one decision launch.  Per element it is the arithmetic of the multi-launch kernels of round 4
+    (kernel='splitk' keeps them reachable): codes bit for bit, the same trials and accepted steps; F of the accepted
+    trial to fp32 rounding (the tile sums are taken in another order)."""
+    from lasso_amd.linear.solvers import ista
+    X, W = recipe_xw(16384)
+    Xg, Wg, z0 = X.cuda(), W.cuda(), torch.zeros(16384, 1024, device="cuda")
+    a, ia = ista(Xg, z0, Wg, 0.5, fast=fast, lr=1.0, maxiter=10, tol=0.0, backtrack=True, return_info=True)
+    b, ib = ista(Xg, z0, Wg, 0.5, fast=fast, lr=1.0, maxiter=10, tol=0.0, backtrack=True, return_info=True, kernel='splitk')
+    assert torch.equal(a, b)
+    assert ia["trials"] == ib["trials"] and ia["accepted_lr"] == ib["accepted_lr"]
+    assert np.allclose(ia["accepted_f"], ib["accepted_f"], rtol=2e-6)
+    # warm start, ragged batch, a dictionary between the templates (k = 1000 -> K = 1024), the stop rule
+    X2, W2 = recipe_xw(5000, 200, 1000)
+    z1 = ista(X2.cuda(), torch.zeros(5000, 1000, device="cuda"), W2.cuda(), 0.5, fast=fast, lr=0.5, maxiter=3, tol=0.0,
+              backtrack=True)
+    a, ia = ista(X2.cuda(), z1, W2.cuda(), 0.5, fast=fast, lr=0.5, maxiter=60, tol=1e-4, backtrack=True, return_info=True)
+    b, ib = ista(X2.cuda(), z1, W2.cuda(), 0.5, fast=fast, lr=0.5, maxiter=60, tol=1e-4, backtrack=True, return_info=True,
+                 kernel='splitk')
+    assert ia["iterations"] == ib["iterations"] and ia["trials"] == ib["trials"] and torch.equal(a, b)
+
+
 def test_eta_and_failure_semantics():
     from lasso_amd.linear import sparse_encode
     from oracle import lasso_oracle as orc
@@ -420,6 +444,26 @@ def test_windows_of_the_enqueued_line_search(dtype):
         assert (got.cpu() - ref).abs().max().item() <= 5e-5
     else:
         assert sum(abs(a - b) for a, b in zip(info["trials"], tr.trials)) <= 2
+    if dtype == torch.float32:
+        # (c) round 5, the one-launch-per-iteration form (bt_iter.hip) computes 5 trials per tile: searches of 6-8 trials
+        # (lr0 = 2.5) run out of them once, take ONE synchronous iteration, and from then on the windows carry the second
+        # trial batch (trials 5-7 on the multi-launch kernel, same state) and size the first batch from the window
+        # before; lr0 = 4 mixes 5 ... 9 trials -- more than both batches hold -- so synchronous iterations and windows
+        # alternate.  The oracle's traces and codes.
+        for lr0, lo, hi in ((2.5, 4, 8), (4.0, 5, 9)):
+            tr = orc.FistaTrace()
+            ref = orc.fista(Xr, z0r, Wr, 0.3, lr=lr0, maxiter=40, tol=0.0, backtrack=True, trace=tr)
+            assert min(tr.trials) >= lo and max(tr.trials) <= hi and max(tr.trials) > 5
+            got, info = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, lr=lr0, maxiter=40, tol=0.0, backtrack=True,
+                             return_info=True)
+            assert info["iterations"] == 40 and info["trials"] == list(tr.trials), (lr0, info["trials"], list(tr.trials))
+            # 40 accelerated iterations at steps far above 1/L amplify last-ulp differences: the fp32 oracle is 1e-2 from
+            # the fp64 oracle here (HIP vs fp32 oracle: 8e-5 / 7e-4 measured, 1e-6 after 10 iterations).  The sharp checks
+            # are the traces above and the multi-launch form of round 4 (gradient / trials / accept as separate
+            # launches, kernel='splitk'): the one-launch-per-iteration form returns its codes BIT FOR BIT
+            assert (got.cpu() - ref).abs().max().item() <= 5e-3
+            old = ista(X.cuda(), z0.cuda(), W.cuda(), 0.3, lr=lr0, maxiter=40, tol=0.0, backtrack=True, kernel='splitk')
+            assert torch.equal(got, old)
 
 
 def test_bf16_fixed_step_beyond_the_persistent_kernels_capacity():
