@@ -19,6 +19,18 @@
 #define LASSO_SLICE_UNROLL 2
 #endif
 
+#ifdef LASSO_FISTA_TIMING
+// debug build (tools/fista_timeline.py): wall-clock stamps (100 MHz) of workgroup tid 0: [0] kernel entry, [1] first
+// tile staged, then one per iteration start (first tile only), 64 per workgroup
+__device__ unsigned long long lasso_fista_stamps[1024 * 64];
+extern "C" int lasso_debug_fista_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_fista_stamps), sizeof(lasso_fista_stamps));
+}
+#define FISTA_STAMP(slot) do { if (threadIdx.x == 0 && (slot) < 64) lasso_fista_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FISTA_STAMP(slot) do { } while (0)
+#endif
+
 namespace lasso {
 namespace sp {
 
@@ -72,6 +84,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
   // stand-by launch behind a split-k launch: nothing to do unless that kernel gave up
   if (p.run_if != nullptr && __hip_atomic_load(p.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
 
+  FISTA_STAMP(0);
   TileCtx<K, D> c;
   c.init(p.Wp, p.Wtp, rings);
   const int tid = threadIdx.x;
@@ -134,7 +147,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
     __builtin_amdgcn_s_barrier();
 
     bool stopped = false, aborted = false;
+    if (tile == (int)blockIdx.x) FISTA_STAMP(1);
     for (int it = 0; it < p.iters; ++it) {
+      if (tile == (int)blockIdx.x) FISTA_STAMP(2 + it);
       const float coef = p.coef[it];
       float dsum = 0.0f;
       int no = n, qo = q;
@@ -400,6 +415,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
       }
     }
     if (STOP && aborted) break;     // z_out untouched: the host re-runs the solve
+    if (tile == (int)blockIdx.x) FISTA_STAMP(2 + p.iters);
 
     {
       int no = n, qo = q;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
     }
     LASSO_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
+    if (tile == (int)blockIdx.x) FISTA_STAMP(3 + p.iters);
   }
   LASSO_WAIT_VMCNT(0);
 }
