@@ -36,6 +36,9 @@ extern "C" int lasso_debug_bti_stamps(unsigned long long* host_out) {
 #else
 #define BTI_STAMP(slot) do { } while (0)
 #endif
+#ifndef LASSO_BTI_HOOK
+#define LASSO_BTI_HOOK 0        // 1: the next candidate is formed in the MFMA gaps of the current trial's GEMM-1 (A/B knob)
+#endif
 #ifndef LASSO_BTI_STAGGER
 #define LASSO_BTI_STAGGER 2     // measured on config 3: 5.208 (0) -> 5.129 (2) / 5.133 (4) ms per solve
 #endif
@@ -295,6 +298,26 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
           }
     };
     f32x4 acc[2];
+    // the candidate of trial t + 1, one element per four MFMA gaps of trial t's GEMM-1 (LASSO_BTI_HOOK, bt_iter.hip
+    // header): stage 0 v = p - lr g, 1 softshrink, 2 dz and |z+|, 3 the two products.  hs_*: the sums it accumulates.
+    float hs_lr = 0.0f, hs_lam = 0.0f, hs_l1 = 0.0f, hs_dzg = 0.0f, hs_dz2 = 0.0f, hs_v = 0.0f, hs_dz = 0.0f;
+    auto cand_stage = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value, e = i >> 2, st = i & 3;
+      constexpr int ps = e >> 3, cb = (e >> 2) & 1, rg = e & 3;
+      if constexpr (ps < NP) {
+        const float pv = pk[ps][cb][rg], g = gk[ps][cb][rg];
+        if constexpr (st == 0) hs_v = __fsub_rn(pv, __fmul_rn(hs_lr, g));
+        else if constexpr (st == 1) hs_v = soft_threshold(hs_v, hs_lam);                       // ista.py:40
+        else if constexpr (st == 2) {
+          hs_dz = __fsub_rn(hs_v, pv);                                                          // :31
+          hs_l1 += __builtin_fabsf(hs_v);
+          zn[ps][cb][rg] = hs_v;
+        } else {
+          hs_dzg = __fadd_rn(hs_dzg, __fmul_rn(hs_dz, g));
+          hs_dz2 = __fadd_rn(hs_dz2, __fmul_rn(hs_dz, hs_dz));
+        }
+      }
+    };
     auto trial_front = [&](auto extra_c) {     // candidate -> LDS tile, r1 = z+ W^T - x
 #pragma unroll
       for (int ps = 0; ps < NP; ++ps)
@@ -306,6 +329,19 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
       LASSO_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       gemm1_stream_sp<K, decltype(extra_c)::value>(c, pt, acc, c.w1, c.w1 + 32, c.voff1);
+    };
+    auto trial_front_hooked = [&](int tnext) {   // the same, with the candidate of trial `tnext` formed inside the GEMM
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) *ep_addr(ps, cb, rg) = zn[ps][cb][rg];
+      acc[0] = negx[0]; acc[1] = negx[1];
+      hs_lr = s.lr[tnext]; hs_lam = s.lam[tnext]; hs_l1 = 0.0f; hs_dzg = 0.0f; hs_dz2 = 0.0f;
+      LASSO_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      gemm1_stream_hooked<K>(c, pt, acc, c.w1, c.w1 + 32, c.voff1, cand_stage);
     };
     auto trial_back = [&](int t, float l1, float dzg, float dz2) {   // the trial's four tile sums
       float rss = 0.0f;
@@ -356,12 +392,19 @@ __global__ __launch_bounds__(kFistaThreads, 2) void bt_iter_kernel(const BtIterP
 #pragma unroll 1
       for (int t = 0; t + 1 < p.ntrials; ++t) {
         if (t == 0) BTI_STAMP(7);
+#if LASSO_BTI_HOOK
+        trial_front_hooked(t + 1);
+        if (t == 0) BTI_STAMP(9);
+        trial_back(t, l1, dzg, dz2);
+        l1 = hs_l1; dzg = hs_dzg; dz2 = hs_dz2;
+#else
         trial_front(std::integral_constant<int, 0>{});
         if (t == 0) BTI_STAMP(9);
         float l1n, dzgn, dz2n;
         cand(t + 1, l1n, dzgn, dz2n);
         trial_back(t, l1, dzg, dz2);
         l1 = l1n; dzg = dzgn; dz2 = dz2n;
+#endif
         if (t == 0) BTI_STAMP(10);
       }
       BTI_STAMP(11);

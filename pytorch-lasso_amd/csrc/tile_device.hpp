@@ -465,6 +465,62 @@ __device__ __forceinline__ void gemm1_stream_sp(const TileCtx<K>& c, lds_char* a
   trip(S1 / 2 - 1, tail1, tail_voff, tail1, tail_voff, T{}, E0{});
 }
 
+// gemm1_stream_sp with all S1 steps written out and a caller's stage `hook(integral_constant<int, i>)`, i = 0 .. 4 S1 - 1,
+// run in the gaps between the MFMAs of a step (four per step, the slots of the FISTA kernel's staged epilogue):
+// element-wise work that is independent of this product -- the NEXT line-search candidate -- issued where the matrix
+// pipe is busy anyway instead of in front of a barrier where it idles.  Same MFMA order, same ring protocol.
+template <int K, typename Hook>
+__device__ __forceinline__ void gemm1_stream_hooked(const TileCtx<K>& c, lds_char* at, f32x4 (&acc)[2],
+                                                    const float* tail0, const float* tail1,
+                                                    const unsigned (&tail_voff)[4], Hook&& hook) {
+  constexpr int S1 = K / 32;
+  static_assert(S1 % 2 == 0 && S1 >= 6, "geometry");
+  lds_char* const slot0 = c.ring;
+  lds_char* const slot1 = c.ring + kStepBytes;
+  const lds_char* const arow = at + c.n * (K * 4);
+  sp::Frag X, Y;
+  LASSO_WAIT_VMCNT(4);
+  sp::load_b(c, X, slot0);
+  sp::load_a(c, X, arow, 0);
+  LASSO_WAIT_LGKM0();
+  dma_step(c.w1 + 64, c.voff1, slot0);
+  static_for<S1 / 2>([&](auto s2_c) {
+    constexpr int s2 = decltype(s2_c)::value;
+    constexpr bool last = s2 == S1 / 2 - 1;
+    auto h = [&](auto i_c) { return [&] { hook(std::integral_constant<int, 8 * s2 + decltype(i_c)::value>{}); }; };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+    LASSO_WAIT_VMCNT(4);
+    sp::load_b(c, Y, slot1);
+    sp::load_a(c, Y, arow + s2 * 256, 1);
+    if constexpr (s2 < S1 / 2 - 2)
+      sp::step_body(acc, X.a, X, c.w1 + 64 * s2 + 96, c.voff1, slot1, h(I0{}), h(I1{}), h(I2{}), h(I3{}));
+    else if constexpr (s2 == S1 / 2 - 2)
+      sp::step_body(acc, X.a, X, c.w1 + 32 * (S1 - 1), c.voff1, slot1, h(I0{}), h(I1{}), h(I2{}), h(I3{}));
+    else
+      sp::step_body(acc, X.a, X, tail1, tail_voff, slot1, h(I0{}), h(I1{}), h(I2{}), h(I3{}));
+    if constexpr (!last) {
+      LASSO_WAIT_VMCNT(4);
+      sp::load_b(c, X, slot0);
+      sp::load_a(c, X, arow + (s2 + 1) * 256, 0);
+      if constexpr (s2 < S1 / 2 - 2)
+        sp::step_body(acc, Y.a, Y, c.w1 + 64 * s2 + 128, c.voff1, slot0, h(I4{}), h(I5{}), h(I6{}), h(I7{}));
+      else
+        sp::step_body(acc, Y.a, Y, tail0, tail_voff, slot0, h(I4{}), h(I5{}), h(I6{}), h(I7{}));
+    } else {
+      LASSO_PIN();
+      sp::mfma_range<0, 8>(acc, Y.a, Y);
+      LASSO_PIN();
+      h(I4{})(); h(I5{})();
+      sp::mfma_range<8, 16>(acc, Y.a, Y);
+      LASSO_PIN();
+      h(I6{})(); h(I7{})();
+    }
+  });
+}
+
 // Pipelined GEMM-2 without an epilogue (round 5, bt_iter.hip): all NP passes of
 //   g[ps][cb] = r_tile[16][256] * Wtp[wid*K/8 + 32*ps + 16*cb .. +16][256]^T
 // with the fragment reads of step U+1 under the MFMAs of step U and the ring refill spread between them -- the step
