@@ -347,6 +347,7 @@ def run_fista(args, ranks):
         flop_per_launch = 4.0 * r["rows"] * D * K * args.iters          # this rank's launch
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
         traffic, traffic_src = hbm_traffic_for("fista") if (r["rows"] == N_ROWS and world == 1) else (None, None)
+        new_format = traffic is not None
         if traffic is None:
             traffic, traffic_src = hbm_traffic_from_profiles(kernel_name(r["rows"]))
         out = {
@@ -367,12 +368,14 @@ def run_fista(args, ranks):
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic if world == 1 else None,
                          "traffic_source": (traffic_src + (" (rocprofv3 PMC pass of this command; not collected in "
-                                                           "this run)" if traffic is not None else ""))
+                                                           "this run)" if traffic is not None and not new_format else ""))
                                            if traffic_src and world == 1 else None,
                          "hbm_gbps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and world == 1) else None,
                          "hbm_peak_gbps": 8000.0,
                          # resident-state model: x, W read, z0 read, z written -- per launch
                          "algorithmic_bytes": 4.0 * (r["rows"] * D + D * K + 2 * r["rows"] * K),
+                         "traffic_over_algorithmic": (traffic / (4.0 * (r["rows"] * D + D * K + 2 * r["rows"] * K)))
+                                                     if (traffic and world == 1) else None,
                          "kernel": kernel_name(r["rows"]),
                          "flop_per_launch": flop_per_launch, "per": "GPU (rank 0)",
                          "avg_launch_ms": avg_launch_ms,
