@@ -46,6 +46,9 @@
 #ifndef LASSO_BT16_ACCEPT_BATCH
 #define LASSO_BT16_ACCEPT_BATCH 8   // passes of the accept step whose loads are in flight together
 #endif
+#ifndef LASSO_BT16_ACCEPT_PIPE
+#define LASSO_BT16_ACCEPT_PIPE 0
+#endif
 #ifndef LASSO_BT16_CHECK
 #define LASSO_BT16_CHECK 2     // double passes of a speculative trial before its predecessor's verdict is read
 #endif
@@ -691,6 +694,50 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
     float dsum = 0.0f;
     // AB passes at a time, ALL their g and z loads in flight together (kept packed: 8 registers per pass): the
     // phase is a chain of memory round trips, and with four passes per trip it took 14.8 us at K = 1024
+    auto accept_pass = [&](int j, u32x4 gq1, u32x4 zq1) __attribute__((always_inline)) {
+      float pv[8], gv[8], zn[8], yn[8], zo1[8];
+      lds_u32x4* const pp = (lds_u32x4*)(pt + pt_off(j));
+      unpack8(*pp, pv);
+      unpack8(gq1, gv);
+      unpack8(zq1, zo1);
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        zn[e8] = bf16_round(soft_threshold(__fsub_rn(pv[e8], __fmul_rn(lr_acc, gv[e8])), lam_acc));
+        dsum += __builtin_fabsf(__fsub_rn(zo1[e8], zn[e8]));                        // :93
+        yn[e8] = __fadd_rn(zn[e8], __fmul_rn(coef, __fsub_rn(zn[e8], zo1[e8])));    // :99-100
+      }
+      store_z8(j, zn);                                                              // :102
+      *pp = pack8(yn);                                                              // next point, in place
+    };
+#if LASSO_BT16_ACCEPT_PIPE
+    // A/B knob: batches of 4 passes, the loads of batch b + 2 issued before batch b is worked on (two batches in flight
+    // under every batch's arithmetic instead of two serial round trips of 8 passes)
+    {
+      constexpr int AB2 = NP < 4 ? NP : 4, NBT = NP / AB2;
+      u32x4 gq[NBT][AB2], zq[NBT][AB2];
+      int tok = 0;                               // an opaque zero in every load address: the loads of batch b + 2 cannot
+                                                 // be moved in front of batch b - 1's arithmetic (hipcc hoists them all otherwise)
+      auto issue = [&](auto b_c) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_c)::value;
+#pragma unroll
+        for (int u = 0; u < AB2; ++u) gq[b][u] = *reinterpret_cast<const u32x4*>(grow + kPass * (AB2 * b + u) + tok);
+#pragma unroll
+        for (int u = 0; u < AB2; ++u)
+          zq[b][u] = it == 0 ? load_z8p(Z0g + tok, p.ldz0, z0vec, AB2 * b + u) : load_z8p(Zg + tok, p.ldz, zvec, AB2 * b + u);
+      };
+      issue(std::integral_constant<int, 0>{});
+      if constexpr (NBT > 1) issue(std::integral_constant<int, 1>{});
+      static_for<NBT>([&](auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+        if constexpr (b + 2 < NBT) issue(std::integral_constant<int, b + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < AB2; ++u) accept_pass(AB2 * b + u, gq[b][u], zq[b][u]);
+        asm volatile("" : "+v"(tok) : "v"(dsum));
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+#else
     constexpr int AB = NP < LASSO_BT16_ACCEPT_BATCH ? NP : LASSO_BT16_ACCEPT_BATCH;
     static_assert(NP % AB == 0, "accept batch must divide the passes");
 #pragma unroll 1
@@ -718,6 +765,7 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         *pp = pack8(yn);                                                              // next point, in place
       }
     }
+#endif
     iterations = it + 1;
     __syncthreads();                            // the p tile is complete for the next gradient
     BT16_STAMP(10);
