@@ -203,6 +203,49 @@ def g3():
     save("g3_c3_backtrack", **out)
 
 
+def g3b():
+    """C3 on bf16 tensors, the FIRST iterations of the real reference (the bf16 kernels were anchored to
+    the reference by one scalar).  After one or two iterations the reference's bf16 arithmetic (bf16 tensors, the
+    GEMMs' results rounded to bf16) and a kernel that keeps g and z in bf16 can differ only by roundings that fall the
+    other way -- there is no trajectory yet for a borderline decision to steer.  Stored: z blocks (as float32; they are
+    bf16 values) and code statistics after 1, 2, 3 fixed-step iterations, and after 1 and 2 line-search iterations with
+    the trials / accepted steps of those iterations."""
+    X, W = recipe_xw(16384, 256, 1024)
+    Xb, Wb = X.bfloat16(), W.bfloat16()
+    z0 = Xb.new_zeros(16384, 1024)
+    out = {}
+    for M in (1, 2, 3):
+        z = ref_ista(Xb, z0, Wb, 0.5, fast=True, lr=1.0 / LAMBDA_MAX_C2, maxiter=M, tol=0.0)
+        assert z.dtype == torch.bfloat16
+        s = zstats(z.float())
+        out["fixed_M%d_block" % M] = z[:64, :64].float().numpy().copy()
+        out["fixed_M%d_strided" % M] = z[::256, ::16].float().numpy().copy()
+        out["fixed_M%d_stats" % M] = np.array([s["sum"], s["abssum"], s["nnz"]])
+        out["fixed_M%d_obj" % M] = ref_loss(Xb.float(), z.float(), Wb.float(), 0.5).item()
+        print("G3b fixed M=%d" % M, s, out["fixed_M%d_obj" % M])
+    orig = ref_ista_mod.backtracking
+    for M in (1, 2):
+        log = []
+
+        def wrapped(z, x_, weight, alpha, lr0, eta=1.5, maxiter=1000, verbose=False):
+            z_next, lr = orig(z, x_, weight, alpha, lr0, eta, maxiter, verbose)
+            log.append(lr)
+            return z_next, lr
+        ref_ista_mod.backtracking = wrapped
+        try:
+            z = ref_ista(Xb, z0, Wb, 0.5, fast=True, lr=1.0, maxiter=M, tol=0.0, backtrack=True)
+        finally:
+            ref_ista_mod.backtracking = orig
+        s = zstats(z.float())
+        out["bt_M%d_block" % M] = z[:64, :64].float().numpy().copy()
+        out["bt_M%d_strided" % M] = z[::256, ::16].float().numpy().copy()
+        out["bt_M%d_stats" % M] = np.array([s["sum"], s["abssum"], s["nnz"]])
+        out["bt_M%d_lr" % M] = np.array(log, dtype=np.float64)
+        out["bt_M%d_obj" % M] = ref_loss(Xb.float(), z.float(), Wb.float(), 0.5).item()
+        print("G3b bt M=%d" % M, log, s, out["bt_M%d_obj" % M])
+    save("g3b_c3_bf16_steps", **out)
+
+
 def g3trace():
     """Line-search trace of the C3 recipe: trials per outer iteration and the
     accepted step, recorded by wrapping the reference's own `backtracking` at run time (ista()

@@ -78,6 +78,63 @@ def test_c3_fp32_full_size(golden):
     assert abs(obj - float(g["fp32_ista_bt_obj"])) <= 1e-5 * obj
 
 
+def test_c3_bf16_first_iterations_against_the_reference(golden):
+    """The bf16 kernels against the REFERENCE's own bf16 run, element by element, where that is meaningful: the first
+    1-3 fixed-step and 1-2 line-search iterations of config 3 (fixture g3b: the real reference on bf16 tensors).
+    Measured (profiles/r05/parity_margins.json): already after ONE iteration a third of the entries differ by one
+    bf16 step.  That is not a rounding that fell the other way -- the reference rounds EVERY intermediate tensor to bf16
+    (lr * grad, then z - that, then the shrink: ista.py:90 on bf16 tensors), the kernel keeps the chain in fp32 and
+    rounds the code once (tests/bf16_model.py states its arithmetic).  What can be asserted against the reference:
+    (a) the line search takes the reference's steps, (b) no entry is further than a few bf16 steps from the reference's,
+    the supports agree to a few 1e-3, the code statistics to 1e-3, and (c) the kernel's code is at least as close to
+    the EXACT (fp32) iterate on the same bf16 inputs as the reference's bf16 code is."""
+    from lasso_amd.linear.solvers import ista
+    from oracle import lasso_oracle as orc
+    from margins import record_margins
+    g = golden("g3b_c3_bf16_steps")
+    X, W = recipe_xw(16384)
+    Xb, Wb = X.bfloat16(), W.bfloat16()
+    Xg, Wg = Xb.cuda(), Wb.cuda()
+    z0 = torch.zeros(16384, 1024, device="cuda", dtype=torch.bfloat16)
+    got = {}
+
+    def compare(tag, z, exact, lam):
+        z = z.float().cpu()
+        out = {}
+        for name, sl in (("block", (slice(0, 64), slice(0, 64))), ("strided", (slice(None, None, 256), slice(None, None, 16)))):
+            view, ref, ex = z[sl], T(g["%s_%s" % (tag, name)]), exact[sl]
+            diff = (view - ref).abs()
+            # a code entry is (pre-shrink value) - lam: its rounding grain is a bf16 step of |z| + lam, not of |z|
+            steps = diff / ((torch.maximum(view.abs(), ref.abs()) + lam) * 2.0 ** -8)
+            out[name] = {"fraction_differing": float((diff > 0).float().mean()), "max_abs": float(diff.max()),
+                         "max_in_bf16_steps_of_the_preshrink_value": float(steps.max()),
+                         "support_mismatch": float(((view != 0) != (ref != 0)).float().mean()),
+                         "mean_abs_error_vs_fp32_iterate": float((view - ex).abs().mean()),
+                         "reference_bf16_mean_abs_error_vs_fp32_iterate": float((ref - ex).abs().mean())}
+        st = g[tag + "_stats"]
+        out["rel_dabssum"] = abs(z.double().abs().sum().item() - st[1]) / st[1]
+        out["rel_dnnz"] = abs(int((z != 0).sum()) - st[2]) / st[2]
+        got[tag] = out
+
+    z032 = torch.zeros(16384, 1024)
+    for M in (1, 2, 3):
+        exact = orc.fista(Xb.float(), z032, Wb.float(), 0.5, lr=1.0 / LAMBDA_MAX_C2, maxiter=M, tol=0.0)
+        compare("fixed_M%d" % M, ista(Xg, z0, Wg, 0.5, lr=1.0 / LAMBDA_MAX_C2, maxiter=M, tol=0.0), exact, 0.5 / LAMBDA_MAX_C2)
+    for M in (1, 2):
+        z, info = ista(Xg, z0, Wg, 0.5, lr=1.0, maxiter=M, tol=0.0, backtrack=True, return_info=True)
+        exact = orc.fista(Xb.float(), z032, Wb.float(), 0.5, lr=1.0, maxiter=M, tol=0.0, backtrack=True)
+        compare("bt_M%d" % M, z, exact, 0.5 * info["accepted_lr"][-1])
+        got["bt_M%d" % M]["accepted_lr"] = info["accepted_lr"]
+        assert np.allclose(info["accepted_lr"], g["bt_M%d_lr" % M], rtol=1e-6), (info["accepted_lr"], g["bt_M%d_lr" % M])   # (a)
+    record_margins("c3_bf16_first_iterations_vs_reference", got)
+    for tag, o in got.items():
+        for name in ("block", "strided"):
+            v = o[name]
+            assert v["max_in_bf16_steps_of_the_preshrink_value"] <= 8.0 and v["support_mismatch"] <= 5e-3, (tag, name, v)   # (b)
+            assert v["mean_abs_error_vs_fp32_iterate"] <= 1.05 * v["reference_bf16_mean_abs_error_vs_fp32_iterate"], (tag, name, v)   # (c)
+        assert o["rel_dabssum"] <= 2e-3 and o["rel_dnnz"] <= 6e-3, (tag, o)
+
+
 @pytest.mark.parametrize("fast", [True, False])
 def test_c3_fp32_one_launch_per_iteration_is_bitwise_the_multi_launch_form(fast):
     """Round 5: config 3 in fp32 runs as ONE launch per outer iteration (csrc/bt_iter.hip: accept + gradient + trials
