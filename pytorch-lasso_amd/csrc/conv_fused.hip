@@ -1,0 +1,459 @@
+// One launch per iteration of the convolutional solver for SMALL IMAGES WITH FEW CHANNELS (reference
+// lasso/conv2d/ista.py:18-29,41-46): the synthesis x_hat = conv_transpose2d(y, W), the residual, its
+// adjoint g = conv2d(x_hat - x, W), the proximal step, the momentum step and the iteration's sum |z - z+|, with ONE
+// WORKGROUP PER IMAGE.  What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the
+// residual never leaves the CU (it lives in LDS, zero-padded by the convolution's padding, and is the A operand of the
+// gradient GEMM where it lies -- no receptive fields staged per tile), the gradient block never goes through LDS (the
+// transposed product's accumulators ARE 16-byte row pieces), the overlap-add reads its taps with
+// compile-time offsets from zero-padded rows (no bounds per tap), one launch instead of two, both W fragment tables
+// pre-packed once per solve.
+//
+//   phase A  (synthesis)  rows = code pixels, columns = the C kh kw taps, contraction over the K atoms:
+//            COLS[pixel][tap] = sum_k Ym[pixel][k] W[k][tap] for a chunk of R whole code rows, each wave a 16-pixel
+//            MFMA row block at a time, the block stored to LDS at [row][v + kw - 1][tap] (kw - 1 zero columns either
+//            side); then every thread adds the taps that reach its <= 8 output pixels, kept in registers across chunks.
+//   phase B  (gradient + prox)  rows = code pixels, columns = the K atoms, contraction over the taps: every wave takes
+//            16-pixel blocks of the image on its own (no barrier): the pixel operand = one ds_read_b32 per MFMA step from
+//            the residual image, the atom operand = the W fragments in registers; the product is issued TRANSPOSED (atoms
+//            x pixels), which leaves every lane with 16-byte row pieces of g -- the epilogue works on the pieces of z, y
+//            fetched one block ahead.
+//
+// Bitwise the codes of the two-kernel form: the same lane -> atom / tap assignment in both GEMMs (every MFMA contracts the
+// same four values in the same slots, steps in the same order), the overlap-add in conv_synth_few_kernel's order -- code
+// rows ascending, taps b ascending, and where that kernel's 128-pixel chunks cut a code row in two, the first part's taps
+// before the second part's (the `split` case below) -- and the element-wise steps written with the same operations.
+// Only the iteration's sum |z - z+| is added in another (fixed) order.
+// Eligibility (launcher): stride 1, C < 8, K <= 64 a multiple of 4, C kh kw <= 80, kw <= 7, C H W <= 4096, and N >= the
+// number of CUs (one image per CU and launch; below that the banded two-kernel form fills the chip better -- and its
+// bands would put the chunk cuts elsewhere).
+// Roofline: MFMA (2 M (16 NT + 4 ceil(C kh kw / 4)) 16 KQ flop per iteration with the padding); HBM: z, y read and written
+// once, y read a second time by phase B (L2 / MALL).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
+#include "lasso_kernels.h"
+
+#ifdef LASSO_CF_TIMING     // debug build (tools/conv_fused_timeline.py): wall-clock stamps of the first image's phases
+__device__ unsigned long long lasso_cf_stamps[1024 * 64];
+extern "C" int lasso_debug_cf_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_cf_stamps), sizeof(lasso_cf_stamps));
+}
+#define CF_STAMP(slot) do { if (threadIdx.x == 0 && n == (int)blockIdx.x && (slot) < 64) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define CF_STAMP_WAVE(slot) do { if ((threadIdx.x & 63) == 0 && n == (int)blockIdx.x) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define CF_STAMP(slot) do { } while (0)
+#define CF_STAMP_WAVE(slot) do { } while (0)
+#endif
+
+namespace lasso {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+constexpr int kCfWaves = 8, kCfThreads = 64 * kCfWaves, kCfMaxOut = 8, kCfMaxKw = 7;
+constexpr unsigned kCfOor = 0xfffffff0u;       // buffer offset beyond every image: reads 0, stores dropped
+
+struct ConvFused {
+  const float* Wf1;    // synthesis B fragments [NT KQ][64 lanes][4]
+  const float* Wf2;    // gradient B fragments  [4 NT][64 lanes][4]
+  const int* toff;     // [16 NT] tap offsets into the padded residual image
+  const float* x;      // [N][C][H][W]
+  float* Zm; float* Ym;
+  float lr, lam, coef;
+  float* dpart;
+  ConvGeom g;
+  int R, WP, RH, RW;   // code rows per chunk; padded row widths: COLS rows Wz + 2 (kw - 1), residual image H + 2 ph x W + 2 pw
+  float inv_wz;
+};
+
+// W[k][tap] -> the two fragment tables and the tap offsets (once per solve)
+__global__ __launch_bounds__(256) void conv_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ wf1,
+                                                              float* __restrict__ wf2, int* __restrict__ toff,
+                                                              const ConvGeom g, int NT, int KQ, int RH, int RW) {
+  const int ckk = g.C * g.kh * g.kw;
+  const int n1 = NT * KQ * 256, n2 = NT * 1024, n3 = 16 * NT;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n1 + n2 + n3; idx += gridDim.x * 256) {
+    if (idx < n1) {                    // bf1[c][4 t + e] of lane (l15, q): W[k = 16 t + 4 q + e][tap = 16 c + l15]
+      const int e = idx & 3, lane = (idx >> 2) & 63, ct = idx >> 8, t = ct % KQ, c = ct / KQ;
+      const int tap = 16 * c + (lane & 15), k = 16 * t + 4 * (lane >> 4) + e;
+      wf1[idx] = (tap < ckk && k < g.K) ? w[(int64_t)k * ckk + tap] : 0.0f;
+    } else if (idx < n1 + n2) {        // bf2[s][nt] of lane (l15, q): W[k = 16 nt + l15][tap = 4 s + q]
+      const int i2 = idx - n1, nt = i2 & 3, lane = (i2 >> 2) & 63, s = i2 >> 8;
+      const int k = 16 * nt + (lane & 15), e = 4 * s + (lane >> 4);
+      wf2[i2] = (nt < KQ && k < g.K && e < ckk) ? w[(int64_t)k * ckk + e] : 0.0f;
+    } else {
+      const int e = idx - n1 - n2;
+      int off = 0;
+      if (e < ckk) {
+        const int b = e % g.kw, a = (e / g.kw) % g.kh, c = e / (g.kw * g.kh);
+        off = (c * RH + a) * RW + b;
+      }
+      toff[e] = off;
+    }
+  }
+}
+
+template <int NT, int KQ>
+__global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused p) {
+  constexpr int PITCH = 16 * NT + 1, TS = PITCH - 1, S4 = 4 * NT;
+  extern __shared__ __attribute__((aligned(16))) float cf_smem[];
+  lds_f32* const f1 = (lds_f32*)cf_smem;                     // [NT KQ][64][4]
+  lds_f32* const f2 = f1 + NT * KQ * 256;                    // [S4][64][4]
+  lds_i32* const tofl = (lds_i32*)(f2 + S4 * 256);           // [4 S4]
+  lds_f32* const rimg = (lds_f32*)(tofl + 4 * S4);           // [C][RH][RW]
+  const ConvGeom& g = p.g;
+  const int rimg_words = (g.C * p.RH * p.RW + 3) & ~3;
+  lds_f32* const cols = rimg + rimg_words;                   // [R WP + kCfMaxKw][PITCH]
+  __shared__ float red[kCfWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int ckk = g.C * g.kh * g.kw, K = g.K, P = g.Hz * g.Wz, Wz = g.Wz;
+  const int outs = g.C * g.H * g.W, mcount = (outs + kCfThreads - 1) / kCfThreads, nsteps = (ckk + 3) >> 2;
+
+  // ---- once per launch: fragment tables, tap offsets, zeros (the padding of both LDS images is never written again) ----
+  for (int e = tid; e < NT * KQ * 64; e += kCfThreads)
+    *(lds_f32x4*)(f1 + 4 * e) = *(const f32x4*)(p.Wf1 + 4 * e);
+  for (int e = tid; e < S4 * 64; e += kCfThreads)
+    *(lds_f32x4*)(f2 + 4 * e) = *(const f32x4*)(p.Wf2 + 4 * e);
+  for (int e = tid; e < 4 * S4; e += kCfThreads) tofl[e] = p.toff[e];
+  {
+    const int zero_words = rimg_words + (p.R * p.WP + kCfMaxKw) * PITCH;
+    for (int e = tid; e < zero_words; e += kCfThreads) rimg[e] = 0.0f;
+  }
+  // this thread's outputs o = tid + 512 m = ((ch H + u) W + v):  u | (v + pw) << 12 | ch << 24,  -1 = none
+  int oinfo[kCfMaxOut];
+  {
+    const float inv_w = 1.0f / (float)g.W, inv_h = 1.0f / (float)g.H;
+#pragma unroll
+    for (int m = 0; m < kCfMaxOut; ++m) {
+      const int o = tid + kCfThreads * m;
+      // floor((o + 1/2) / d) in fp32 is exact for o < 2^14 (conv.hip, cgp_stage_field)
+      const int rest = (int)(((float)o + 0.5f) * inv_w), v = o - rest * g.W;
+      const int ch = (int)(((float)rest + 0.5f) * inv_h), u = rest - ch * g.H;
+      oinfo[m] = o < outs ? (u | ((v + g.pw) << 12) | (ch << 24)) : -1;
+    }
+  }
+  __syncthreads();
+
+  float dsum = 0.0f;
+  { const int n = blockIdx.x; CF_STAMP(0); }
+  __syncthreads();
+  for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
+    CF_STAMP(1);
+    const int64_t img_words = (int64_t)P * K;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Ym + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(p.Zm + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
+    // ======================= phase A: residual image of image n =======================
+    float acc[kCfMaxOut], xr[kCfMaxOut];
+#pragma unroll
+    for (int m = 0; m < kCfMaxOut; ++m) {
+      acc[m] = 0.0f;
+      xr[m] = 0.0f;
+      if (m < mcount && oinfo[m] >= 0) xr[m] = p.x[(int64_t)n * outs + tid + kCfThreads * m];
+    }
+    float bf1[NT][4 * KQ];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int t = 0; t < KQ; ++t) {
+        const f32x4 v = *(const lds_f32x4*)(f1 + ((c * KQ + t) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf1[c][4 * t + e] = v[e];
+      }
+    // A operand of a 16-pixel row block: 16-byte pieces of the Ym rows straight into the lanes' MFMA slots
+    auto load_a = [&](int i_c, int blk, f32x4 (&a)[KQ]) {
+      const int npx = min(p.R, g.Hz - i_c) * Wz, f = 16 * blk + l15;
+      const unsigned rowoff = (unsigned)((i_c * Wz + f) * K + 4 * q) * 4u;
+#pragma unroll
+      for (int t = 0; t < KQ; ++t) {
+        const bool ok = f < npx && 16 * t + 4 * q < K;                       // (K % 4 == 0)
+        unsigned o = ok ? rowoff + 64u * t : kCfOor;
+        asm volatile("" : "+v"(o));         // (opaque: hipcc otherwise turns the select into a branch round a second load
+                                            // of the same registers, with an s_waitcnt vmcnt(0) in front of it)
+        a[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, o, 0, 0));
+      }
+    };
+    f32x4 av[KQ];
+    load_a(0, wid, av);
+    for (int i_c = 0; i_c < g.Hz; i_c += p.R) {
+      const int rows = min(p.R, g.Hz - i_c), npx = rows * Wz, nblk = (npx + 15) >> 4;
+      // ---- COLS of the chunk's code rows: 16-pixel row blocks, wave w takes blocks w, w + 8, ... ----
+      CF_STAMP(2 + 3 * (i_c / p.R));
+      for (int blk = wid; blk < nblk; blk += kCfWaves) {
+        f32x4 an[KQ];
+        load_a(i_c, blk + kCfWaves, an);                                       // (beyond the chunk: every piece out of range)
+        __builtin_amdgcn_sched_barrier(0);                                     // ... issued BEFORE this block's MFMAs
+        f32x4 cacc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KQ; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+              cacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bf1[c][4 * t + e], cacc[c], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int fp = 16 * blk + 4 * q + rg;
+          if (fp < npx) {
+            const int ii = (int)(((float)fp + 0.5f) * p.inv_wz), v = fp - ii * Wz;
+            lds_f32* const dst = cols + (ii * p.WP + v + g.kw - 1) * PITCH + l15;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) dst[16 * c] = cacc[c][rg];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) av[t] = an[t];
+      }
+      load_a(i_c + p.R, wid, av);                                              // the next chunk's first block: in flight under the taps
+      __syncthreads();
+      CF_STAMP(3 + 3 * (i_c / p.R));
+      // ---- overlap-add: code rows ascending, taps b ascending (rr = kw - 1 - b descending) ----
+      // KW = the kernel width when it is 3, 5 or 7 (no per-tap masks), else 0: widths up to 7 behind masks
+      auto add_taps = [&](auto kw_tag) {
+        constexpr int KW = decltype(kw_tag)::value;
+        constexpr int NR = KW ? KW : kCfMaxKw;
+#pragma unroll
+        for (int m = 0; m < kCfMaxOut; ++m) {
+          const int oi = oinfo[m];
+          if (m >= mcount || oi < 0) continue;
+          const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
+          float s = acc[m];
+          const int a0 = u + g.ph - i_c;                                       // tap row a = a0 - ii of chunk row ii
+          for (int ii = 0; ii < rows; ++ii) {
+            const int a = a0 - ii;
+            if (a < 0 || a >= g.kh) continue;
+            // tap (a, b) of this output comes from code pixel (i_c + ii, jb - b), stored at padded column jb - b + kw - 1:
+            // b = kw - 1 - rr sits at lo + rr TS
+            const lds_f32* const lo = cols + (ii * p.WP + jb) * PITCH + (ch * g.kh + a) * g.kw + g.kw - 1;
+            float val[NR];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) val[rr] = lo[rr * TS];             // (rr >= kw: inside the buffer, not used)
+            // conv_synth_few_kernel walks the image's code pixels in chunks of 128: a code row that holds a multiple of
+            // 128 strictly inside gives its first part's taps (pixels v < vs, the larger b) before the second part's
+            const int f0 = (i_c + ii) * Wz, fb = (f0 + Wz - 1) & ~127;
+            if (fb <= f0) {
+#pragma unroll
+              for (int rr = NR - 1; rr >= 0; --rr)
+                if (KW || rr < g.kw) s += val[rr];
+            } else {
+              const int r1 = g.kw - 2 - jb + (fb - f0);                        // first part: b >= jb - vs + 1  <=>  rr <= r1
+#pragma unroll
+              for (int rr = NR - 1; rr >= 0; --rr)
+                if (KW || rr < g.kw) s += rr <= r1 ? val[rr] : 0.0f;
+#pragma unroll
+              for (int rr = NR - 1; rr >= 0; --rr)
+                if (KW || rr < g.kw) s += rr > r1 ? val[rr] : 0.0f;
+            }
+          }
+          acc[m] = s;
+        }
+      };
+      switch (g.kw) {
+        case 3: add_taps(std::integral_constant<int, 3>{}); break;
+        case 5: add_taps(std::integral_constant<int, 5>{}); break;
+        case 7: add_taps(std::integral_constant<int, 7>{}); break;
+        default: add_taps(std::integral_constant<int, 0>{}); break;
+      }
+      __syncthreads();
+      CF_STAMP(4 + 3 * (i_c / p.R));
+    }
+#pragma unroll
+    for (int m = 0; m < kCfMaxOut; ++m) {
+      const int oi = oinfo[m];
+      if (m >= mcount || oi < 0) continue;
+      const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
+      rimg[(ch * p.RH + u + g.ph) * p.RW + jb] = acc[m] - xr[m];
+    }
+    __syncthreads();
+    CF_STAMP(26);
+
+    // ======================= phase B: gradient, prox, momentum =======================
+    float bf2[S4][KQ];
+    int to[S4];
+#pragma unroll
+    for (int s = 0; s < S4; ++s) {
+      const f32x4 v = *(const lds_f32x4*)(f2 + (s * 64 + lane) * 4);
+#pragma unroll
+      for (int nt = 0; nt < KQ; ++nt) bf2[s][nt] = v[nt];
+      to[s] = tofl[4 * s + q];
+    }
+    const int nb = (P + 15) >> 4;
+    // z, y of a block as 16-byte pieces: the gradient GEMM is issued TRANSPOSED (atoms x pixels: the W fragment is the A
+    // operand), so lane (l15, q) ends up with pixel l15, atoms 16 nt + 4 q .. + 3 in the four registers of accumulator nt
+    auto fetch_zy = [&](int blk, unsigned (&off)[KQ], f32x4 (&yo)[KQ], f32x4 (&zo)[KQ]) {
+      const int prow = 16 * blk + l15;
+#pragma unroll
+      for (int nt = 0; nt < KQ; ++nt) {
+        const int col = 16 * nt + 4 * q;
+        off[nt] = (prow < P && col < K) ? (unsigned)(prow * K + col) * 4u : kCfOor;
+        asm volatile("" : "+v"(off[nt]));
+        yo[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, off[nt], 0, 0));
+        zo[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, off[nt], 0, 0));
+      }
+    };
+    unsigned off[KQ];
+    f32x4 yo[KQ], zo[KQ];
+    fetch_zy(wid, off, yo, zo);
+    CF_STAMP(27);
+    for (int blk = wid; blk < nb; blk += kCfWaves) {
+      CF_STAMP(32 + blk / kCfWaves);
+      unsigned offn[KQ];
+      f32x4 yn_[KQ], zn_[KQ];
+      fetch_zy(blk + kCfWaves, offn, yn_, zn_);                                // the next block's pieces: in flight under the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      const int pl = min(16 * blk + l15, P - 1);
+      const int pu = (int)(((float)pl + 0.5f) * p.inv_wz), pv = pl - pu * Wz;
+      const int bp = pu * p.RW + pv;
+      f32x4 acc2[KQ];
+#pragma unroll
+      for (int nt = 0; nt < KQ; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float ar[S4];                                                            // A operands of all steps in one batch of LDS reads
+#pragma unroll
+      for (int s = 0; s < S4; ++s) ar[s] = rimg[to[s] + bp];
+      int ns = nsteps;                                                         // (opaque per block: sixteen loop-invariant
+      asm volatile("" : "+s"(ns));                                             // step masks would live in spilled SGPR pairs)
+#pragma unroll
+      for (int s = 0; s < S4; ++s) {
+        if (s < ns) {                                                          // (padded steps would multiply zeros; uniform)
+#pragma unroll
+          for (int nt = 0; nt < KQ; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf2[s][nt], ar[s], acc2[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < KQ; ++nt) {
+        const f32x4 gv = acc2[nt];
+        f32x4 zn, yn;
+        float ds = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = __fsub_rn(yo[nt][e], __fmul_rn(p.lr, gv[e]));
+          zn[e] = __fsub_rn(t, __builtin_amdgcn_fmed3f(t, -p.lam, p.lam));
+          ds += __builtin_fabsf(__fsub_rn(zo[nt][e], zn[e]));
+          yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo[nt][e])));
+        }
+        dsum += off[nt] != kCfOor ? ds : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zn), zrs, off[nt], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yn), yrs, off[nt], 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < KQ; ++nt) { off[nt] = offn[nt]; yo[nt] = yn_[nt]; zo[nt] = zn_[nt]; }
+    }
+    CF_STAMP(29);
+    CF_STAMP_WAVE(48 + wid);
+    // (no barrier: the next image's first LDS writes are COLS blocks, last read before the barrier that closed phase A;
+    // its residual is written behind two more barriers)
+  }
+  // sum |z - z+| of the workgroup in a fixed order: lanes by xor-shuffle, then the eight waves in turn
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+  if (lane == 0) red[wid] = dsum;
+  __syncthreads();
+  { const int n = blockIdx.x; CF_STAMP(30); }
+  if (tid == 0) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kCfWaves; ++w) s += red[w];
+    p.dpart[blockIdx.x] = s;
+  }
+}
+
+struct FusedPlan { int NT, KQ, R; size_t lds; };
+
+// false when the geometry is not covered
+bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
+  if (const char* e = getenv("LASSO_CONV_FUSED"); e && e[0] == '0') return false;      // A/B and test switch: the two-kernel form
+  const int ckk = g.C * g.kh * g.kw;
+  if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 64 || ckk > 80 || g.kw > kCfMaxKw) return false;
+  if ((int64_t)g.C * g.H * g.W > kCfMaxOut * kCfThreads || g.Wz > 128 || cus <= 0 || g.N < cus) return false;
+  if ((int64_t)g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31) || g.H >= 4096 || g.W + g.pw >= 4096) return false;
+  pl->NT = (ckk + 15) / 16;
+  pl->KQ = g.K <= 16 ? 1 : g.K <= 32 ? 2 : 4;
+  const int pitch = 16 * pl->NT + 1, wp = g.Wz + 2 * (g.kw - 1);
+  const size_t fixed = (size_t)(pl->NT * pl->KQ * 256 + pl->NT * 1024 + 16 * pl->NT +
+                                ((g.C * (g.H + 2 * g.ph) * (g.W + 2 * g.pw) + 3) & ~3) + kCfMaxKw * pitch) * 4;
+  const size_t budget = 150 * 1024;
+  if (fixed + (size_t)wp * pitch * 4 > budget) return false;
+  const int rmax = (int)std::min<size_t>((budget - fixed) / ((size_t)wp * pitch * 4), (size_t)g.Hz);
+  // rows per chunk: the fewest rounds of eight 16-pixel blocks over the image, then the fewest chunks
+  int best = 0;
+  int64_t best_rounds = INT64_MAX;
+  for (int r = rmax; r >= 1; --r) {
+    int64_t rounds = 0;
+    for (int i = 0; i < g.Hz; i += r) rounds += ((std::min(r, g.Hz - i) * g.Wz + 15) / 16 + kCfWaves - 1) / kCfWaves;
+    if (rounds < best_rounds) { best_rounds = rounds; best = r; }
+  }
+  pl->R = best;
+  pl->lds = fixed + (size_t)best * wp * pitch * 4;
+  return true;
+}
+
+template <int NT, int KQ>
+hipError_t fused_launch(const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
+  const void* fn = reinterpret_cast<const void*>(&conv_fused_kernel<NT, KQ>);
+  if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((conv_fused_kernel<NT, KQ>), dim3(grid), dim3(kCfThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+template <int NT>
+hipError_t fused_launch_kq(int kq, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
+  if (kq == 1) return fused_launch<NT, 1>(p, grid, lds, stream);
+  if (kq == 2) return fused_launch<NT, 2>(p, grid, lds, stream);
+  return fused_launch<NT, 4>(p, grid, lds, stream);
+}
+
+}  // namespace
+
+size_t conv_fused_table_bytes() { return (size_t)(5 * 4 * 256 + 5 * 1024 + 16 * 5) * 4; }
+
+// The fragment tables of the fused kernel into `tables` (conv_fused_table_bytes()); *covered = false -> the geometry
+// takes the two-kernel form and nothing is written.
+hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& g, int cus, bool* covered,
+                                  hipStream_t stream) {
+  FusedPlan pl;
+  *covered = fused_plan(g, cus, &pl);
+  if (!*covered) return hipSuccess;
+  float* wf1 = (float*)tables;
+  float* wf2 = wf1 + pl.NT * pl.KQ * 256;
+  int* toff = (int*)(wf2 + pl.NT * 1024);
+  const int total = pl.NT * pl.KQ * 256 + pl.NT * 1024 + 16 * pl.NT;
+  hipLaunchKernelGGL(conv_fused_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wf1, wf2, toff, g,
+                     pl.NT, pl.KQ, g.H + 2 * g.ph, g.W + 2 * g.pw);
+  return hipGetLastError();
+}
+
+// One iteration (ista.py:19-20,29,41-46); *count = number of dpart entries written (one per workgroup).
+hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam, float coef,
+                             float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count, hipStream_t stream) {
+  *count = 0;
+  FusedPlan pl;
+  if (!fused_plan(g, cus, &pl)) return hipErrorInvalidValue;
+  ConvFused p;
+  p.Wf1 = (const float*)tables;
+  p.Wf2 = p.Wf1 + pl.NT * pl.KQ * 256;
+  p.toff = (const int*)(p.Wf2 + pl.NT * 1024);
+  p.x = x; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
+  p.R = pl.R; p.WP = g.Wz + 2 * (g.kw - 1); p.RH = g.H + 2 * g.ph; p.RW = g.W + 2 * g.pw;
+  p.inv_wz = 1.0f / (float)g.Wz;
+  const int grid = std::min({g.N, cus, dpart_cap});
+  if (grid <= 0) return hipErrorInvalidValue;
+  hipError_t e = hipErrorInvalidValue;
+  switch (pl.NT) {
+    case 1: e = fused_launch_kq<1>(pl.KQ, p, grid, pl.lds, stream); break;
+    case 2: e = fused_launch_kq<2>(pl.KQ, p, grid, pl.lds, stream); break;
+    case 3: e = fused_launch_kq<3>(pl.KQ, p, grid, pl.lds, stream); break;
+    case 4: e = fused_launch_kq<4>(pl.KQ, p, grid, pl.lds, stream); break;
+    case 5: e = fused_launch_kq<5>(pl.KQ, p, grid, pl.lds, stream); break;
+  }
+  if (e == hipSuccess) *count = grid;
+  return e;
+}
+
+}  // namespace lasso

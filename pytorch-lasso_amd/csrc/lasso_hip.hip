@@ -1541,7 +1541,7 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
 // ---------------------------------------------------------------------------
 // convolutional ISTA (conv.hip)
 // ---------------------------------------------------------------------------
-struct ConvWorkspace { float* Wt; float* Wp; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums;
+struct ConvWorkspace { float* Wt; float* Wp; void* Wf; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums;
                        float* Zc; float* Yc;      // (z, y) at the head of a speculated chunk of iterations (stop rule, below)
                        size_t bytes; };
 
@@ -1558,6 +1558,7 @@ ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
   const size_t ldr = (ckk + 3) / 4 * 4;       // row stride of the pixel-major patch matrix
   w.Wt = (float*)take(ckk * g.K * 4);
   w.Wp = (float*)take(ldr * g.K * 4);
+  w.Wf = take(conv_fused_table_bytes());
   w.Zm = (float*)take(M * g.K * 4);
   w.Ym = (float*)take(M * g.K * 4);
   w.G = (float*)take(M * g.K * 4);
@@ -2630,6 +2631,8 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   const float lr_f = (float)lr, lam = (float)(alpha * lr);
   const int cus = std::max(device_cus(), 1);
   const float* const conv_w = (const float*)w_dev;
+  bool fused = false;                     // conv_fused.hip: the whole iteration in one launch, a workgroup per image
+  LASSO_HIP_TRY(launch_conv_fused_pack(conv_w, ws.Wf, g, cus, &fused, st));
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
@@ -2637,11 +2640,16 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   auto iterate = [&](float* delta_slot) -> int {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
-    LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
-    // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
     int dcount = 0;
-    LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
-                                        &dcount, st));                                            // :20,:29,:42,:44
+    if (fused) {                                                                                    // :19-20,:29,:42,:44
+      LASSO_HIP_TRY(launch_conv_fused(ws.Wf, (const float*)x_dev, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g,
+                                      cus, &dcount, st));
+    } else {
+      LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
+      // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
+      LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
+                                          &dcount, st));                                          // :20,:29,:42,:44
+    }
     if (dcount == 0) {
       LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wp, ws.PT, ldr, ws.G, g, st));                  // :20
       LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,

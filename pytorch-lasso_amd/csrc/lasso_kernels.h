@@ -285,6 +285,14 @@ hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, fl
 // of 4, C kh kw <= 128
 hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
                                  bool* done, hipStream_t stream);
+// conv_fused.hip: synthesis + gradient + prox of one iteration in ONE launch, a workgroup per image (stride 1, C < 8,
+// K <= 64, small images, N >= CUs); `tables` = conv_fused_table_bytes() of workspace filled once per solve by
+// launch_conv_fused_pack (*covered = false -> not covered, use the two-kernel form)
+size_t conv_fused_table_bytes();
+hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& g, int cus, bool* covered,
+                                  hipStream_t stream);
+hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam, float coef,
+                             float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count, hipStream_t stream);
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
                                  hipStream_t stream);

@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the convolutional solver: per-iteration time of each and the codes compared
-bitwise.  usage: ab_conv.py <other.so> ... (one process per build: the library is chosen once per process);
+bitwise.  usage: ab_conv.py <other.so | env:NAME=VALUE> ... (one process per build: the library is chosen once per
+process; env:... runs the product library with that variable set, e.g. env:LASSO_CONV_FUSED=0);
 AB_CONV_TOL / AB_CONV_MAXITER in the environment set the stop rule's tolerance (default 0: no rule) and maxiter (20)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (32, 16, 256, 3, 1, 1, 64),
          (128, 1, 32, 5, 2, 1, 15), (96, 2, 48, 3, 1, 1, 20),
          (2048, 1, 16, 3, 1, 1, 8), (2048, 1, 64, 3, 1, 1, 8), (512, 1, 32, 5, 1, 0, 28), (256, 3, 24, 5, 1, 2, 40)]
+if os.environ.get("AB_CONV_CASES") == "fused":     # geometries of the one-launch kernel (conv_fused.hip): N >= CUs, small images
+    CASES = [(256, 1, 64, 7, 1, 0, 26), (2048, 1, 16, 3, 1, 1, 8), (2048, 1, 64, 3, 1, 1, 8), (512, 1, 32, 5, 1, 0, 28),
+             (256, 3, 32, 5, 1, 2, 32), (300, 2, 48, 3, 1, 1, 20), (256, 1, 64, 7, 1, 3, 32), (777, 1, 24, 5, 1, 1, 13),
+             (256, 4, 12, 3, 1, 0, 30), (1024, 1, 40, 7, 1, 2, 16)]
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd")]
     import hashlib, time, torch
@@ -36,9 +41,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     print(json.dumps(out))
     sys.exit(0)
 res = {}
-libs = [("product", "-")] + [(os.path.basename(l), l) for l in sys.argv[1:]]
+libs = [("product", "-")] + [(l if l.startswith("env:") else os.path.basename(l), l) for l in sys.argv[1:]]
 for tag, lib in libs:
-    r = subprocess.run([sys.executable, __file__, "--child", lib], capture_output=True, text=True)
+    env = dict(os.environ)
+    if lib.startswith("env:"):
+        k, v = lib[4:].split("=", 1)
+        env[k] = v
+        lib = "-"
+    r = subprocess.run([sys.executable, __file__, "--child", lib], capture_output=True, text=True, env=env)
     if r.returncode:
         print(r.stderr[-2000:]); sys.exit(1)
     res[tag] = json.loads(r.stdout.strip().splitlines()[-1])
