@@ -1,7 +1,9 @@
-// One launch per iteration of the convolutional solver for SMALL IMAGES WITH FEW CHANNELS (reference
+// Up to 64 iterations per launch of the convolutional solver for SMALL IMAGES WITH FEW CHANNELS (reference
 // lasso/conv2d/ista.py:18-29,41-46): the synthesis x_hat = conv_transpose2d(y, W), the residual, its
 // adjoint g = conv2d(x_hat - x, W), the proximal step, the momentum step and the iteration's sum |z - z+|, with ONE
-// WORKGROUP PER IMAGE.  What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the
+// WORKGROUP PER IMAGE -- images are independent, so a workgroup carries its image through all the iterations of the launch
+// (the stop rule's per-iteration sums are written out per workgroup and added up afterwards: lasso_conv_ista_solve's
+// speculate-and-replay scheme reads them once per chunk).  What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the
 // residual never leaves the CU (it lives in LDS, zero-padded by the convolution's padding, and is the A operand of the
 // gradient GEMM where it lies -- no receptive fields staged per tile), the gradient block never goes through LDS (the
 // transposed product's accumulators ARE 16-byte row pieces), the overlap-add reads its taps with
@@ -30,6 +32,7 @@
 // once, y read a second time by phase B (L2 / MALL).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -40,8 +43,8 @@ __device__ unsigned long long lasso_cf_stamps[1024 * 64];
 extern "C" int lasso_debug_cf_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_cf_stamps), sizeof(lasso_cf_stamps));
 }
-#define CF_STAMP(slot) do { if (threadIdx.x == 0 && n == (int)blockIdx.x && (slot) < 64) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
-#define CF_STAMP_WAVE(slot) do { if ((threadIdx.x & 63) == 0 && n == (int)blockIdx.x) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define CF_STAMP(slot) do { if (threadIdx.x == 0 && n == (int)blockIdx.x && it == p.iters - 1 && (slot) < 64) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define CF_STAMP_WAVE(slot) do { if ((threadIdx.x & 63) == 0 && n == (int)blockIdx.x && it == p.iters - 1) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
 #else
 #define CF_STAMP(slot) do { } while (0)
 #define CF_STAMP_WAVE(slot) do { } while (0)
@@ -56,7 +59,7 @@ typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
-constexpr int kCfWaves = 8, kCfThreads = 64 * kCfWaves, kCfMaxOut = 8, kCfMaxKw = 7;
+constexpr int kCfWaves = 8, kCfThreads = 64 * kCfWaves, kCfMaxOut = 8, kCfMaxKw = 7, kCfMaxIters = 64;
 constexpr unsigned kCfOor = 0xfffffff0u;       // buffer offset beyond every image: reads 0, stores dropped
 
 struct ConvFused {
@@ -65,8 +68,10 @@ struct ConvFused {
   const int* toff;     // [16 NT] tap offsets into the padded residual image
   const float* x;      // [N][C][H][W]
   float* Zm; float* Ym;
-  float lr, lam, coef;
-  float* dpart;
+  float lr, lam;
+  float* dpart;        // [iters][gridDim.x] sums |z - z+| of the workgroup's images, one row per iteration
+  int iters;           // iterations of this launch (<= kCfMaxIters), every image carried through all of them in turn
+  float coef[kCfMaxIters];   // momentum factor (t_k - 1) / t_{k+1} of each iteration (ista.py:41-42); 0 = ISTA
   ConvGeom g;
   int R, WP, RH, RW;   // code rows per chunk; padded row widths: COLS rows Wz + 2 (kw - 1), residual image H + 2 ph x W + 2 pw
   float inv_wz;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_fused_pack_kernel(const float* __res
   }
 }
 
-template <int NT, int KQ>
+template <int NT, int KQ, int MC>      // MC: output pixels of the residual image per thread (C H W <= 512 MC)
 __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused p) {
   constexpr int PITCH = 16 * NT + 1, TS = PITCH - 1, S4 = 4 * NT;
   extern __shared__ __attribute__((aligned(16))) float cf_smem[];
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
   const ConvGeom& g = p.g;
   const int rimg_words = (g.C * p.RH * p.RW + 3) & ~3;
   lds_f32* const cols = rimg + rimg_words;                   // [R WP + kCfMaxKw][PITCH]
-  __shared__ float red[kCfWaves];
+  __shared__ float wred[kCfMaxIters][kCfWaves];      // sums |z - z+| per iteration and wave (each wave adds to its own column)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int ckk = g.C * g.kh * g.kw, K = g.K, P = g.Hz * g.Wz, Wz = g.Wz;
   const int outs = g.C * g.H * g.W, mcount = (outs + kCfThreads - 1) / kCfThreads, nsteps = (ckk + 3) >> 2;
@@ -126,11 +131,11 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
     for (int e = tid; e < zero_words; e += kCfThreads) rimg[e] = 0.0f;
   }
   // this thread's outputs o = tid + 512 m = ((ch H + u) W + v):  u | (v + pw) << 12 | ch << 24,  -1 = none
-  int oinfo[kCfMaxOut];
+  int oinfo[MC];
   {
     const float inv_w = 1.0f / (float)g.W, inv_h = 1.0f / (float)g.H;
 #pragma unroll
-    for (int m = 0; m < kCfMaxOut; ++m) {
+    for (int m = 0; m < MC; ++m) {
       const int o = tid + kCfThreads * m;
       // floor((o + 1/2) / d) in fp32 is exact for o < 2^14 (conv.hip, cgp_stage_field)
       const int rest = (int)(((float)o + 0.5f) * inv_w), v = o - rest * g.W;
@@ -140,22 +145,25 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
   }
   __syncthreads();
 
-  float dsum = 0.0f;
-  { const int n = blockIdx.x; CF_STAMP(0); }
+  for (int e = tid; e < kCfMaxIters * kCfWaves; e += kCfThreads) (&wred[0][0])[e] = 0.0f;
+  { const int n = blockIdx.x, it = 0; CF_STAMP(0); }
   __syncthreads();
   for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
-    CF_STAMP(1);
     const int64_t img_words = (int64_t)P * K;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Ym + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(p.Zm + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
-    // ======================= phase A: residual image of image n =======================
-    float acc[kCfMaxOut], xr[kCfMaxOut];
+    float xr[MC];                        // x at this thread's outputs: the same in every iteration
 #pragma unroll
-    for (int m = 0; m < kCfMaxOut; ++m) {
-      acc[m] = 0.0f;
+    for (int m = 0; m < MC; ++m) {
       xr[m] = 0.0f;
       if (m < mcount && oinfo[m] >= 0) xr[m] = p.x[(int64_t)n * outs + tid + kCfThreads * m];
     }
+   for (int it = 0; it < p.iters; ++it) {
+    CF_STAMP(1);
+    // ======================= phase A: residual image of image n =======================
+    float acc[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) acc[m] = 0.0f;
     float bf1[NT][4 * KQ];
 #pragma unroll
     for (int c = 0; c < NT; ++c)
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         constexpr int KW = decltype(kw_tag)::value;
         constexpr int NR = KW ? KW : kCfMaxKw;
 #pragma unroll
-        for (int m = 0; m < kCfMaxOut; ++m) {
+        for (int m = 0; m < MC; ++m) {
           const int oi = oinfo[m];
           if (m >= mcount || oi < 0) continue;
           const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       CF_STAMP(4 + 3 * (i_c / p.R));
     }
 #pragma unroll
-    for (int m = 0; m < kCfMaxOut; ++m) {
+    for (int m = 0; m < MC; ++m) {
       const int oi = oinfo[m];
       if (m >= mcount || oi < 0) continue;
       const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
@@ -285,6 +293,8 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       to[s] = tofl[4 * s + q];
     }
     const int nb = (P + 15) >> 4;
+    const float coef = p.coef[it];
+    float dsum = 0.0f;
     // z, y of a block as 16-byte pieces: the gradient GEMM is issued TRANSPOSED (atoms x pixels: the W fragment is the A
     // operand), so lane (l15, q) ends up with pixel l15, atoms 16 nt + 4 q .. + 3 in the four registers of accumulator nt
     auto fetch_zy = [&](int blk, unsigned (&off)[KQ], f32x4 (&yo)[KQ], f32x4 (&zo)[KQ]) {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
           const float t = __fsub_rn(yo[nt][e], __fmul_rn(p.lr, gv[e]));
           zn[e] = __fsub_rn(t, __builtin_amdgcn_fmed3f(t, -p.lam, p.lam));
           ds += __builtin_fabsf(__fsub_rn(zo[nt][e], zn[e]));
-          yn[e] = __fadd_rn(zn[e], __fmul_rn(p.coef, __fsub_rn(zn[e], zo[nt][e])));
+          yn[e] = __fadd_rn(zn[e], __fmul_rn(coef, __fsub_rn(zn[e], zo[nt][e])));
         }
         dsum += off[nt] != kCfOor ? ds : 0.0f;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zn), zrs, off[nt], 0, 0);
@@ -347,21 +357,38 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
     }
     CF_STAMP(29);
     CF_STAMP_WAVE(48 + wid);
-    // (no barrier: the next image's first LDS writes are COLS blocks, last read before the barrier that closed phase A;
-    // its residual is written behind two more barriers)
-  }
-  // sum |z - z+| of the workgroup in a fixed order: lanes by xor-shuffle, then the eight waves in turn
+    // sum |z - z+| of this image and iteration: lanes by xor-shuffle, into the wave's own column (a fixed order)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
-  if (lane == 0) red[wid] = dsum;
-  __syncthreads();
-  { const int n = blockIdx.x; CF_STAMP(30); }
-  if (tid == 0) {
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+    if (lane == 0) wred[it][wid] += dsum;
+    // the next iteration's synthesis reads the y rows the other waves have just written: their stores complete
+    // (vmcnt(0)) before the barrier, and the CU's vector L1 is shared by the workgroup's waves
+    __syncthreads();
+   }
+  }
+  { const int n = blockIdx.x, it = p.iters - 1; CF_STAMP(30); }
+  if (tid < p.iters) {
     float s = 0.0f;
 #pragma unroll
-    for (int w = 0; w < kCfWaves; ++w) s += red[w];
-    p.dpart[blockIdx.x] = s;
+    for (int w = 0; w < kCfWaves; ++w) s += wred[tid][w];
+    p.dpart[tid * gridDim.x + blockIdx.x] = s;
   }
+}
+
+// delta[it] = sum of row it of the partial sums, in index order (deterministic); one workgroup per iteration
+__global__ __launch_bounds__(256) void conv_fused_sums_kernel(const float* __restrict__ dpart, int count,
+                                                              float* __restrict__ delta) {
+  __shared__ float red[256];
+  const float* row = dpart + (int64_t)blockIdx.x * count;
+  float s = 0.0f;
+  for (int e = threadIdx.x; e < count; e += 256) s += row[e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) delta[blockIdx.x] = red[0];
 }
 
 struct FusedPlan { int NT, KQ, R; size_t lds; };
@@ -394,19 +421,25 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   return true;
 }
 
-template <int NT, int KQ>
+template <int NT, int KQ, int MC>
 hipError_t fused_launch(const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
-  const void* fn = reinterpret_cast<const void*>(&conv_fused_kernel<NT, KQ>);
+  const void* fn = reinterpret_cast<const void*>(&conv_fused_kernel<NT, KQ, MC>);
   if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((conv_fused_kernel<NT, KQ>), dim3(grid), dim3(kCfThreads), lds, stream, p);
+  hipLaunchKernelGGL((conv_fused_kernel<NT, KQ, MC>), dim3(grid), dim3(kCfThreads), lds, stream, p);
   return hipGetLastError();
 }
 
+template <int NT, int KQ>
+hipError_t fused_launch_mc(int outs, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
+  if (outs <= 2 * kCfThreads) return fused_launch<NT, KQ, 2>(p, grid, lds, stream);
+  return fused_launch<NT, KQ, kCfMaxOut>(p, grid, lds, stream);
+}
+
 template <int NT>
-hipError_t fused_launch_kq(int kq, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
-  if (kq == 1) return fused_launch<NT, 1>(p, grid, lds, stream);
-  if (kq == 2) return fused_launch<NT, 2>(p, grid, lds, stream);
-  return fused_launch<NT, 4>(p, grid, lds, stream);
+hipError_t fused_launch_kq(int kq, int outs, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
+  if (kq == 1) return fused_launch_mc<NT, 1>(outs, p, grid, lds, stream);
+  if (kq == 2) return fused_launch_mc<NT, 2>(outs, p, grid, lds, stream);
+  return fused_launch_mc<NT, 4>(outs, p, grid, lds, stream);
 }
 
 }  // namespace
@@ -429,31 +462,48 @@ hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& 
   return hipGetLastError();
 }
 
-// One iteration (ista.py:19-20,29,41-46); *count = number of dpart entries written (one per workgroup).
-hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam, float coef,
-                             float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count, hipStream_t stream) {
-  *count = 0;
+int conv_fused_max_iters() { return kCfMaxIters; }
+
+// the instantiation launch_conv_fused would run for this geometry (the name rocprofv3 reports), or null
+const char* conv_fused_kernel_name(const ConvGeom& g, int cus) {
   FusedPlan pl;
-  if (!fused_plan(g, cus, &pl)) return hipErrorInvalidValue;
+  if (!fused_plan(g, cus, &pl)) return nullptr;
+  static thread_local char name[64];
+  snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ,
+           g.C * g.H * g.W <= 2 * kCfThreads ? 2 : kCfMaxOut);
+  return name;
+}
+
+// `iters` <= conv_fused_max_iters() iterations (ista.py:19-20,29,41-46) in one launch, iteration i with the momentum factor
+// coefs[i]; delta_out (device, may be null) receives the sum |z - z+| of each.  dpart: iters x min(N, cus) words.
+hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam,
+                             const float* coefs, int iters, float* dpart, int dpart_cap, float* delta_out,
+                             const ConvGeom& g, int cus, hipStream_t stream) {
+  FusedPlan pl;
+  if (iters < 1 || iters > kCfMaxIters || !fused_plan(g, cus, &pl)) return hipErrorInvalidValue;
   ConvFused p;
   p.Wf1 = (const float*)tables;
   p.Wf2 = p.Wf1 + pl.NT * pl.KQ * 256;
   p.toff = (const int*)(p.Wf2 + pl.NT * 1024);
-  p.x = x; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
+  p.x = x; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.dpart = dpart; p.g = g;
+  p.iters = iters;
+  for (int i = 0; i < kCfMaxIters; ++i) p.coef[i] = i < iters ? coefs[i] : 0.0f;
   p.R = pl.R; p.WP = g.Wz + 2 * (g.kw - 1); p.RH = g.H + 2 * g.ph; p.RW = g.W + 2 * g.pw;
   p.inv_wz = 1.0f / (float)g.Wz;
-  const int grid = std::min({g.N, cus, dpart_cap});
-  if (grid <= 0) return hipErrorInvalidValue;
+  const int grid = std::min(g.N, cus);
+  if (grid <= 0 || (int64_t)grid * iters > dpart_cap) return hipErrorInvalidValue;
+  const int outs = g.C * g.H * g.W;
   hipError_t e = hipErrorInvalidValue;
   switch (pl.NT) {
-    case 1: e = fused_launch_kq<1>(pl.KQ, p, grid, pl.lds, stream); break;
-    case 2: e = fused_launch_kq<2>(pl.KQ, p, grid, pl.lds, stream); break;
-    case 3: e = fused_launch_kq<3>(pl.KQ, p, grid, pl.lds, stream); break;
-    case 4: e = fused_launch_kq<4>(pl.KQ, p, grid, pl.lds, stream); break;
-    case 5: e = fused_launch_kq<5>(pl.KQ, p, grid, pl.lds, stream); break;
+    case 1: e = fused_launch_kq<1>(pl.KQ, outs, p, grid, pl.lds, stream); break;
+    case 2: e = fused_launch_kq<2>(pl.KQ, outs, p, grid, pl.lds, stream); break;
+    case 3: e = fused_launch_kq<3>(pl.KQ, outs, p, grid, pl.lds, stream); break;
+    case 4: e = fused_launch_kq<4>(pl.KQ, outs, p, grid, pl.lds, stream); break;
+    case 5: e = fused_launch_kq<5>(pl.KQ, outs, p, grid, pl.lds, stream); break;
   }
-  if (e == hipSuccess) *count = grid;
-  return e;
+  if (e != hipSuccess || !delta_out) return e;
+  hipLaunchKernelGGL(conv_fused_sums_kernel, dim3(iters), dim3(256), 0, stream, dpart, grid, delta_out);
+  return hipGetLastError();
 }
 
 }  // namespace lasso

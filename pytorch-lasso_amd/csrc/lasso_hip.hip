@@ -1183,9 +1183,11 @@ int solve_fixed_bf16(const void* x_any, int64_t ldx, const void* w_any, int64_t 
 // chunk's head (`save` / `restore`, the momentum scalar *t_mom with it) and exactly j + 1 iterations are replayed --
 // every kernel of these paths sums in a fixed order, so the replay is bitwise the state the reference stops in.
 // ---------------------------------------------------------------------------
-template <class Iterate, class Save, class Restore>
+// `flush` puts iterations that `iterate` only queued on the stream (the convolutional solver's many-iterations-per-launch
+// kernel); solvers that launch in `iterate` pass a no-op.
+template <class Iterate, class Save, class Restore, class Flush>
 int speculate_stop_rule(int maxiter, float budget, float* delta_dev, hipStream_t st, double* t_mom, Iterate iterate,
-                        Save save, Restore restore, int* it_out, float* last_out, const char* who) {
+                        Save save, Restore restore, Flush flush, int* it_out, float* last_out, const char* who) {
   constexpr int kChunkMax = 64;                    // delta_dev holds 64 sums
   static const bool trace_chunks = getenv("LASSO_STOP_TRACE") != nullptr;        // the chunks and their verdicts on stderr
   float deltas[kChunkMax];
@@ -1198,6 +1200,7 @@ int speculate_stop_rule(int maxiter, float budget, float* delta_dev, hipStream_t
       if (int s = save()) return s;
     for (int j = 0; j < c; ++j)
       if (int s = iterate(delta_dev + j)) return s;
+    if (int s = flush()) return s;
     LASSO_HIP_TRY(hipMemcpyAsync(deltas, delta_dev, sizeof(float) * c, hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
     int hit = -1;
@@ -1236,6 +1239,7 @@ int speculate_stop_rule(int maxiter, float budget, float* delta_dev, hipStream_t
       *t_mom = t_head;
       for (int j = 0; j <= hit; ++j)
         if (int s = iterate(nullptr)) return s;
+      if (int s = flush()) return s;
     }
     it += hit + 1;
     break;
@@ -1350,8 +1354,8 @@ int solve_generic(const float* x, int64_t ldx, const float* w, int64_t ldw, cons
       LASSO_HIP_TRY(hipGetLastError());
       return LASSO_OK;
     };
-    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore, &it, &last,
-                                    "lasso_fista_solve (unfused)"))
+    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore,
+                                    [] { return (int)LASSO_OK; }, &it, &last, "lasso_fista_solve (unfused)"))
       return s;
   }
   if (iters_out) *iters_out = it;
@@ -1541,6 +1545,7 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
 // ---------------------------------------------------------------------------
 // convolutional ISTA (conv.hip)
 // ---------------------------------------------------------------------------
+constexpr int kConvDpart = 64 * 1024;      // partial sums |z - z+|: 64 iterations per launch x up to 1024 workgroups (conv_fused.hip)
 struct ConvWorkspace { float* Wt; float* Wp; void* Wf; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums;
                        float* Zc; float* Yc;      // (z, y) at the head of a speculated chunk of iterations (stop rule, below)
                        size_t bytes; };
@@ -1564,7 +1569,7 @@ ConvWorkspace carve_conv(void* base, const ConvGeom& g) {
   w.G = (float*)take(M * g.K * 4);
   w.PT = (float*)take(ldr * M * 4);
   w.R = (float*)take((size_t)g.N * g.C * g.H * g.W * 4);
-  w.dpart = (float*)take((size_t)kGenGrid * 2 * 4);
+  w.dpart = (float*)take((size_t)kConvDpart * 4);
   w.delta = (float*)take(256);
   w.sums = (double*)take(256);
   w.Zc = (float*)take(M * g.K * 4);
@@ -2605,6 +2610,15 @@ size_t lasso_conv_ista_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t 
   return carve_conv(nullptr, g).bytes;
 }
 
+const char* lasso_conv_ista_kernel_name(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz,
+                                        int kh, int kw, int sh, int sw, int ph, int pw) {
+  const ConvGeom g = make_geom(N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw);
+  if (N <= 0 || check_conv(g, LASSO_F32)) return "";
+  if (const char* fused = conv_fused_kernel_name(g, std::max(device_cus(), 1))) return fused;
+  return "synthesis (lasso::conv_synth_kernel / conv_synth_few_kernel / gemm + conv_residual_kernel) + "
+         "lasso::conv_grad_prox_kernel (or patches + gemm + generic_prox_kernel)";
+}
+
 int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_dev, void* z_out_dev, int64_t N,
                           int64_t C, int64_t H, int64_t W, int64_t K, int64_t Hz, int64_t Wz, int kh, int kw,
                           int sh, int sw, int ph, int pw, int dtype, double alpha, double lr, int fast,
@@ -2636,20 +2650,38 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
+  // conv_fused.hip takes up to 64 iterations per launch: `iterate` only queues them (momentum factor + where the sum
+  // goes; a chunk's slots are consecutive), `flush` launches what is queued
+  float q_coef[64];
+  int queued = 0;
+  float* q_slot0 = nullptr;
+  auto flush = [&]() -> int {
+    if (queued == 0) return LASSO_OK;
+    LASSO_HIP_TRY(launch_conv_fused(ws.Wf, (const float*)x_dev, ws.Zm, ws.Ym, lr_f, lam, q_coef, queued, ws.dpart,
+                                    kConvDpart, q_slot0, g, cus, st));                             // :19-20,:29,:42,:44
+    queued = 0;
+    q_slot0 = nullptr;
+    return LASSO_OK;
+  };
   // one iteration on the stream; the sum |z - z_next| of the iteration (ista.py:44) goes to *delta_slot when given
   auto iterate = [&](float* delta_slot) -> int {
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
-    int dcount = 0;
-    if (fused) {                                                                                    // :19-20,:29,:42,:44
-      LASSO_HIP_TRY(launch_conv_fused(ws.Wf, (const float*)x_dev, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g,
-                                      cus, &dcount, st));
-    } else {
-      LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
-      // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
-      LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
-                                          &dcount, st));                                          // :20,:29,:42,:44
+    if (fused) {
+      const bool fits = queued < std::min(64, conv_fused_max_iters()) &&
+                        (delta_slot ? (q_slot0 && delta_slot == q_slot0 + queued) : q_slot0 == nullptr);
+      if (queued > 0 && !fits)
+        if (int s = flush()) return s;
+      if (queued == 0) q_slot0 = delta_slot;
+      q_coef[queued++] = coef;
+      t_mom = t_next;
+      return LASSO_OK;
     }
+    int dcount = 0;
+    LASSO_HIP_TRY(launch_conv_residual(ws.Ym, ws.Wt, conv_w, (const float*)x_dev, ws.PT, ws.R, g, cus, st));   // :19
+    // gradient + prox: the fused implicit-GEMM kernel when the geometry fits, else patches + GEMM + prox
+    LASSO_HIP_TRY(launch_conv_grad_prox(ws.R, ws.Wp, ldr, ws.Zm, ws.Ym, lr_f, lam, coef, ws.dpart, kGenGrid, g, cus,
+                                        &dcount, st));                                            // :20,:29,:42,:44
     if (dcount == 0) {
       LASSO_HIP_TRY(launch_conv_gradient(ws.R, ws.Wp, ws.PT, ldr, ws.G, g, st));                  // :20
       LASSO_HIP_TRY(launch_generic_prox(ws.Zm, g.K, ws.Ym, ws.G, (int)M, g.K, lr_f, lam, coef, ws.dpart,
@@ -2666,6 +2698,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   if (!(tol > 0.0)) {
     for (; it < maxiter; ++it)
       if (int s = iterate(nullptr)) return s;
+    if (int s = flush()) return s;
   } else {
     const int64_t code_words = M * g.K;
     const int copy_grid = (int)std::min<int64_t>((code_words / 4 + 255) / 256 + 1, (int64_t)cus * 16);
@@ -2681,7 +2714,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
       LASSO_HIP_TRY(hipGetLastError());
       return LASSO_OK;
     };
-    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore, &it, &last,
+    if (int s = speculate_stop_rule(maxiter, budget, ws.delta, st, &t_mom, iterate, save, restore, flush, &it, &last,
                                     "lasso_conv_ista_solve"))
       return s;
   }

@@ -17,7 +17,7 @@ LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
 LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
 SOLVE_ONE_CHUNK = 0x10000
@@ -133,6 +133,8 @@ def _declare(lib):
     geom = [i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32]
     lib.lasso_conv_ista_workspace_bytes.restype = sz
     lib.lasso_conv_ista_workspace_bytes.argtypes = geom
+    lib.lasso_conv_ista_kernel_name.restype = C.c_char_p
+    lib.lasso_conv_ista_kernel_name.argtypes = geom
     lib.lasso_conv_ista_solve.restype = i32
     lib.lasso_conv_ista_solve.argtypes = [vp, vp, vp, vp] + geom + [i32, dbl, dbl, i32, i32, dbl, pi32,
                                                                     C.POINTER(C.c_float), vp, sz, vp]

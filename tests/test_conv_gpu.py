@@ -184,6 +184,73 @@ def test_shapes_match_oracle(N, C, K, kh, kw, stride, padding, Hz, Wz):
             assert (got.cpu() - ref).abs().max().item() <= Z_ATOL
 
 
+def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
+    return (N, C, (Hz - 1) - 2 * ph + kh, (Wz - 1) - 2 * pw + kw, K, Hz, Wz, kh, kw, 1, 1, ph, pw)
+
+
+@pytest.mark.parametrize("extra,C,K,kh,kw,padding,Hz,Wz", [
+    # the BASELINE-like geometry: 49 taps in four column blocks, 64 atoms, 26-pixel code rows -- rows 4, 9, 14, ... hold
+    # a multiple of 128 code pixels (the two-kernel form's chunk cuts, whose order of the taps the kernel reproduces)
+    (0, 1, 64, 7, 7, 0, 12, 26),
+    # 75 taps (five column blocks), K % 16 != 0, padding, three channels; more than two outputs per thread
+    (5, 3, 24, 5, 5, 2, 10, 12),
+    # non-square kernel and code grid, asymmetric padding, K <= 16, more images than workgroups
+    (300, 2, 12, 3, 5, (1, 0), 20, 9),
+    # one tap column block, K = 4, an image smaller than one MFMA row block
+    (1, 1, 4, 3, 3, 1, 3, 4),
+    # kernel width outside {3, 5, 7} (the masked tap loop), 48 atoms
+    (2, 1, 48, 4, 4, 1, 9, 11)])
+def test_many_iterations_per_launch_kernel(extra, C, K, kh, kw, padding, Hz, Wz):
+    """conv_fused.hip: N >= the number of CUs small few-channel images run whole iterations -- up to 64 per launch -- in one
+    kernel, a workgroup per image.  Against the oracle (the usual fp32 bound), BITWISE against the two-kernel form
+    (LASSO_CONV_FUSED=0: same lane -> operand assignment in both GEMMs, same order of the overlap-add), across the
+    64-iteration launch boundary, from a warm start, with ISTA and FISTA, and under the stop rule (count and last sum
+    of the two-kernel form... whose sums are added in another order: compared through the replayed plain run)."""
+    import os
+    from lasso_amd import _native as nat
+    ista_conv2d, _, _, _, orc = _mods()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N = cus + extra
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    assert b"conv_fused_kernel" in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz))
+    assert b"conv_fused_kernel" not in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(cus - 1, C, K, kh, kw, ph, pw, Hz, Wz))
+    g = torch.Generator().manual_seed(K * 7 + Hz)
+    w = torch.randn(K, C, kh, kw, generator=g) / (kh * kw) ** 0.5
+    x = torch.randn(N, C, (Hz - 1) - 2 * ph + kh, (Wz - 1) - 2 * pw + kw, generator=g)
+    z0 = torch.randn(N, K, Hz, Wz, generator=g) * 0.05
+    lr = 0.3 / max(w.pow(2).sum().item(), 1e-3)
+    xg, wg, zg = x.cuda(), w.cuda(), z0.cuda()
+
+    def both(**kw_):
+        os.environ.pop("LASSO_CONV_FUSED", None)
+        a = ista_conv2d(xg, zg, wg, 0.1, padding=padding, lr=lr, **kw_)
+        os.environ["LASSO_CONV_FUSED"] = "0"
+        try:
+            b = ista_conv2d(xg, zg, wg, 0.1, padding=padding, lr=lr, **kw_)
+        finally:
+            os.environ.pop("LASSO_CONV_FUSED", None)
+        return a, b
+
+    n_ref = min(N, 24)                                   # (the oracle on the first images: they are independent)
+    for fast in (True, False):
+        ref = orc.conv_fista(x[:n_ref], z0[:n_ref], w, 0.1, padding=padding, fast=fast, maxiter=9, lr=lr, tol=0.0)
+        one, two = both(fast=fast, maxiter=9, tol=0.0)
+        assert (one[:n_ref].cpu() - ref).abs().max().item() <= Z_ATOL
+        assert torch.equal(one, two), (fast, (one - two).abs().max().item())
+    one, two = both(maxiter=70, tol=0.0)                 # 64 + 6 iterations: two launches
+    assert torch.equal(one, two)
+    # the stop rule: a budget the sums cross inside a speculated chunk (just above the sum of iteration 23)
+    _, probe = ista_conv2d(xg, zg, wg, 0.1, padding=padding, lr=lr, maxiter=23, tol=1e-30, return_info=True)
+    tol = float(np.float32(probe["last_delta"]) * np.float32(1.0 + 1e-4)) / z0.numel()
+    (one, info1), (two, info2) = both(maxiter=150, tol=tol, return_info=True)
+    assert 1 < info1["iterations"] <= 23, info1
+    assert abs(info1["iterations"] - info2["iterations"]) <= 1, (info1, info2)     # (sums added in another order)
+    os.environ.pop("LASSO_CONV_FUSED", None)
+    plain = ista_conv2d(xg, zg, wg, 0.1, padding=padding, lr=lr, maxiter=info1["iterations"], tol=0.0)
+    assert torch.equal(one, plain)
+    assert abs(info1["last_delta"] - info2["last_delta"]) <= 1e-5 * abs(info2["last_delta"]) or info1["iterations"] != info2["iterations"]
+
+
 def test_errors_and_edge_cases():
     ista_conv2d, _, _, _, _ = _mods()
     w = torch.randn(4, 2, 3, 3, device="cuda")

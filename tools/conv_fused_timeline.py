@@ -30,8 +30,8 @@ assert lib.lasso_debug_cf_stamps(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 64).astype(np.float64) / 100.0
 used = min(N, 256)
 t = t[:used]
-t0 = t[:, 0].min()
-names = {0: "tables in LDS", 1: "image starts", 26: "residual image written", 27: "gradient fragments loaded",
+t0 = t[:, 1].min()
+names = {1: "image starts", 26: "residual image written", 27: "gradient fragments loaded",
          29: "gradient blocks done (wave 0)", 30: "sum reduced"}
 for b in range(12):
     names[32 + b] = "wave 0 starts its gradient block %d" % b
