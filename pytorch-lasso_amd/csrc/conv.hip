@@ -31,23 +31,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Zm[(n,u,v)][k] <- z[n][k][u][v]   (to_rows != 0)   or the inverse: per image a K x P
-// matrix transpose through a 32 x 33 LDS tile (both sides coalesced); blockIdx.z = image.
+// matrix transpose through a 64 x 65 LDS tile (256-byte pieces on both sides); blockIdx.z = image.  dst2 (may be null)
+// receives the same rows: the solver's y starts as a copy of z.
 __global__ __launch_bounds__(256) void conv_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                            int K, int P, int to_rows) {
-  __shared__ float t[32][33];
+                                                            float* __restrict__ dst2, int K, int P, int to_rows) {
+  __shared__ float t[64][65];
   const int64_t img = (int64_t)blockIdx.z * K * P;
   // source matrix of this image: rows x cols, destination: cols x rows
   const int rows = to_rows ? K : P, cols = to_rows ? P : K;
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
     t[i][tx] = (r < rows && c < cols) ? src[img + (int64_t)r * cols + c] : 0.0f;
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;        // destination row = c, column = r
-    if (c < cols && r < rows) dst[img + (int64_t)c * rows + r] = t[tx][i];
+    if (c < cols && r < rows) {
+      const float v = t[tx][i];
+      dst[img + (int64_t)c * rows + r] = v;
+      if (dst2) dst2[img + (int64_t)c * rows + r] = v;
+    }
   }
 }
 
@@ -491,13 +498,15 @@ inline int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255)
 
 }  // namespace
 
-hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream) {
+hipError_t launch_conv_relayout(const float* src, float* dst, float* dst2, int N, int K, int P, int to_rows,
+                                hipStream_t stream) {
   if ((int64_t)N * K * P == 0) return hipSuccess;
   const int rows = to_rows ? K : P, cols = to_rows ? P : K;
   for (int n0 = 0; n0 < N; n0 += 65535) {        // gridDim.z limit
     const int nb = std::min(N - n0, 65535);
-    hipLaunchKernelGGL(conv_relayout_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, nb), dim3(256), 0, stream,
-                       src + (int64_t)n0 * K * P, dst + (int64_t)n0 * K * P, K, P, to_rows);
+    const int64_t o = (int64_t)n0 * K * P;
+    hipLaunchKernelGGL(conv_relayout_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, nb), dim3(256), 0, stream,
+                       src + o, dst + o, dst2 ? dst2 + o : nullptr, K, P, to_rows);
   }
   return hipGetLastError();
 }

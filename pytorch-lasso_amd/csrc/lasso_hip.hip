@@ -2637,16 +2637,19 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
   const int64_t M = (int64_t)g.N * P;
   const int ldr = (ckk + 3) / 4 * 4;
-  LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, ws.Wp, g.K, ckk, ldr, st));
-  if (z0_dev) LASSO_HIP_TRY(launch_conv_relayout((const float*)z0_dev, ws.Zm, g.N, g.K, P, 1, st));
-  else LASSO_HIP_TRY(hipMemsetAsync(ws.Zm, 0, (size_t)M * g.K * 4, st));
-  LASSO_HIP_TRY(hipMemcpyAsync(ws.Ym, ws.Zm, (size_t)M * g.K * 4, hipMemcpyDeviceToDevice, st));
-  const float budget = (float)((double)M * (double)g.K * tol);     // ista.py:16, compared in fp32
-  const float lr_f = (float)lr, lam = (float)(alpha * lr);
   const int cus = std::max(device_cus(), 1);
   const float* const conv_w = (const float*)w_dev;
-  bool fused = false;                     // conv_fused.hip: the whole iteration in one launch, a workgroup per image
+  bool fused = false;                     // conv_fused.hip: whole iterations in one launch, a workgroup per image
   LASSO_HIP_TRY(launch_conv_fused_pack(conv_w, ws.Wf, g, cus, &fused, st));
+  if (!fused) LASSO_HIP_TRY(launch_conv_pack_w(conv_w, ws.Wt, ws.Wp, g.K, ckk, ldr, st));
+  if (z0_dev) {
+    LASSO_HIP_TRY(launch_conv_relayout((const float*)z0_dev, ws.Zm, ws.Ym, g.N, g.K, P, 1, st));     // y0 = z0 in the same pass
+  } else {
+    LASSO_HIP_TRY(hipMemsetAsync(ws.Zm, 0, (size_t)M * g.K * 4, st));
+    LASSO_HIP_TRY(hipMemsetAsync(ws.Ym, 0, (size_t)M * g.K * 4, st));
+  }
+  const float budget = (float)((double)M * (double)g.K * tol);     // ista.py:16, compared in fp32
+  const float lr_f = (float)lr, lam = (float)(alpha * lr);
   double t_mom = 1.0;
   float last = NAN;
   int it = 0;
@@ -2718,7 +2721,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
                                     "lasso_conv_ista_solve"))
       return s;
   }
-  LASSO_HIP_TRY(launch_conv_relayout(ws.Zm, (float*)z_out_dev, g.N, g.K, P, 0, st));
+  LASSO_HIP_TRY(launch_conv_relayout(ws.Zm, (float*)z_out_dev, nullptr, g.N, g.K, P, 0, st));
   if (iters_out) *iters_out = it;
   if (last_delta_out) *last_delta_out = last;
   return LASSO_OK;
@@ -2739,7 +2742,7 @@ int lasso_conv_objective(const void* x_dev, const void* w_dev, const void* z_dev
   const int ckk = g.C * g.kh * g.kw, P = g.Hz * g.Wz;
   const int64_t M = (int64_t)g.N * P;
   LASSO_HIP_TRY(launch_conv_pack_w((const float*)w_dev, ws.Wt, ws.Wp, g.K, ckk, (ckk + 3) / 4 * 4, st));
-  LASSO_HIP_TRY(launch_conv_relayout((const float*)z_dev, ws.Zm, g.N, g.K, P, 1, st));
+  LASSO_HIP_TRY(launch_conv_relayout((const float*)z_dev, ws.Zm, nullptr, g.N, g.K, P, 1, st));
   LASSO_HIP_TRY(launch_conv_residual(ws.Zm, ws.Wt, (const float*)w_dev, (const float*)x_dev, ws.PT, ws.R, g,
                                      std::max(device_cus(), 1), st));
   LASSO_HIP_TRY(launch_objective_reduce(ws.R, (int64_t)g.N * g.C * g.H * g.W, ws.Zm, g.K, (int)M, g.K, ws.dpart,

@@ -273,7 +273,9 @@ hipError_t launch_bw_prox(float* zb_next, float* zb_cur, const float* yb, const 
 hipError_t launch_bw_point(const float* z, const float* z_prev, float* y, int64_t total, float c, hipStream_t stream);
 hipError_t launch_bw_axpy(float* a, const float* b, float s1, const float* c, float s2, int64_t total,
                           hipStream_t stream);
-hipError_t launch_conv_relayout(const float* src, float* dst, int N, int K, int P, int to_rows, hipStream_t stream);
+// dst2 (may be null): a second copy of the destination
+hipError_t launch_conv_relayout(const float* src, float* dst, float* dst2, int N, int K, int P, int to_rows,
+                                hipStream_t stream);
 hipError_t launch_conv_pack_w(const float* w, float* wt, float* wp, int K, int ckk, int ldr, hipStream_t stream);
 hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w, const float* x, float* colst, float* r,
                                 const ConvGeom& g, int cus, hipStream_t stream);
