@@ -37,6 +37,9 @@
 #include <algorithm>
 #include <type_traits>
 #include "lasso_kernels.h"
+#ifndef LASSO_CF_ABL
+#define LASSO_CF_ABL 0      // timing ablations of tools/ab_conv_fused_phases.sh (results invalid when != 0)
+#endif
 
 #ifdef LASSO_CF_TIMING     // debug build (tools/conv_fused_timeline.py): wall-clock stamps of the first image's phases
 __device__ unsigned long long lasso_cf_stamps[1024 * 64];
@@ -205,7 +208,11 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int c = 0; c < NT; ++c)
+#if LASSO_CF_ABL & 1
+              cacc[c][0] += av[t][e] * 1e-30f;
+#else
               cacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bf1[c][4 * t + e], cacc[c], 0, 0, 0);
+#endif
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int fp = 16 * blk + 4 * q + rg;
@@ -263,6 +270,9 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
           acc[m] = s;
         }
       };
+#if LASSO_CF_ABL & 2
+      if (p.lr < -1e30f)
+#endif
       switch (g.kw) {
         case 3: add_taps(std::integral_constant<int, 3>{}); break;
         case 5: add_taps(std::integral_constant<int, 5>{}); break;
@@ -304,8 +314,12 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         const int col = 16 * nt + 4 * q;
         off[nt] = (prow < P && col < K) ? (unsigned)(prow * K + col) * 4u : kCfOor;
         asm volatile("" : "+v"(off[nt]));
+#if LASSO_CF_ABL & 16
+        yo[nt] = f32x4{(float)off[nt], 0.f, 1.f, 2.f}; zo[nt] = yo[nt];
+#else
         yo[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, off[nt], 0, 0));
         zo[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, off[nt], 0, 0));
+#endif
       }
     };
     unsigned off[KQ];
@@ -333,7 +347,11 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       for (int s = 0; s < S4; ++s) {
         if (s < ns) {                                                          // (padded steps would multiply zeros; uniform)
 #pragma unroll
+#if LASSO_CF_ABL & 4
+          for (int nt = 0; nt < KQ; ++nt) acc2[nt][s & 3] += ar[s];
+#else
           for (int nt = 0; nt < KQ; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf2[s][nt], ar[s], acc2[nt], 0, 0, 0);
+#endif
         }
       }
 #pragma unroll
@@ -341,6 +359,9 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         const f32x4 gv = acc2[nt];
         f32x4 zn, yn;
         float ds = 0.0f;
+#if LASSO_CF_ABL & 8
+        zn = gv + yo[nt]; yn = zo[nt]; ds = gv[0];
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float t = __fsub_rn(yo[nt][e], __fmul_rn(p.lr, gv[e]));
@@ -348,9 +369,14 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
           ds += __builtin_fabsf(__fsub_rn(zo[nt][e], zn[e]));
           yn[e] = __fadd_rn(zn[e], __fmul_rn(coef, __fsub_rn(zn[e], zo[nt][e])));
         }
+#endif
         dsum += off[nt] != kCfOor ? ds : 0.0f;
+#if LASSO_CF_ABL & 16
+        dsum += zn[1] + yn[2];
+#else
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zn), zrs, off[nt], 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yn), yrs, off[nt], 0, 0);
+#endif
       }
 #pragma unroll
       for (int nt = 0; nt < KQ; ++nt) { off[nt] = offn[nt]; yo[nt] = yn_[nt]; zo[nt] = zn_[nt]; }

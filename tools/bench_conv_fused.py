@@ -13,6 +13,8 @@ from lasso_amd.conv2d import ista_conv2d
 CASES = [(256, 1, 64, 7, 0, 26), (256, 1, 64, 7, 3, 32), (256, 3, 32, 5, 2, 32), (512, 1, 32, 5, 0, 28), (1024, 1, 40, 7, 2, 16),
          (2048, 1, 64, 3, 1, 8), (2048, 1, 16, 3, 1, 8), (300, 2, 48, 3, 1, 20)]
 out = []
+if "--first" in sys.argv:
+    CASES = CASES[:1]
 for (N, C, K, ks, pd, Hz) in CASES:
     g = torch.Generator().manual_seed(0)
     w = torch.randn(K, C, ks, ks, generator=g) / ks
