@@ -46,8 +46,8 @@ __device__ unsigned long long lasso_cf_stamps[1024 * 64];
 extern "C" int lasso_debug_cf_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lasso_cf_stamps), sizeof(lasso_cf_stamps));
 }
-#define CF_STAMP(slot) do { if (threadIdx.x == 0 && n == (int)blockIdx.x && it == p.iters - 1 && (slot) < 64) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
-#define CF_STAMP_WAVE(slot) do { if ((threadIdx.x & 63) == 0 && n == (int)blockIdx.x && it == p.iters - 1) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define CF_STAMP(slot) do { if (threadIdx.x == 0 && item == (int)blockIdx.x && it == p.iters - 1 && (slot) < 64) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#define CF_STAMP_WAVE(slot) do { if ((threadIdx.x & 63) == 0 && item == (int)blockIdx.x && it == p.iters - 1) lasso_cf_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
 #else
 #define CF_STAMP(slot) do { } while (0)
 #define CF_STAMP_WAVE(slot) do { } while (0)
@@ -67,32 +67,36 @@ constexpr unsigned kCfOor = 0xfffffff0u;       // buffer offset beyond every ima
 
 struct ConvFused {
   const float* Wf1;    // synthesis B fragments [NT KQ][64 lanes][4]
-  const float* Wf2;    // gradient B fragments  [4 NT][64 lanes][4]
-  const int* toff;     // [16 NT] tap offsets into the padded residual image
+  const float* Wf2;    // gradient B fragments  [4 NT][64 lanes][NTP]   (NTP = 4, or 8 when K > 64)
+  const int* toff;     // [16 NT] tap offsets into the band's padded residual image
   const float* x;      // [N][C][H][W]
-  float* Zm; float* Ym;
+  float* Zm;
+  const float* Yin; float* Yout;   // y read / written: the same buffer for whole images, two buffers when images are cut
+                                   // into bands (a band's synthesis reads its neighbours' rows of the OLD y)
   float lr, lam;
-  float* dpart;        // [iters][gridDim.x] sums |z - z+| of the workgroup's images, one row per iteration
-  int iters;           // iterations of this launch (<= kCfMaxIters), every image carried through all of them in turn
+  float* dpart;        // [iters][gridDim.x] sums |z - z+| of the workgroup's items, one row per iteration
+  int iters;           // iterations of this launch (<= kCfMaxIters; 1 when images are cut into bands)
   float coef[kCfMaxIters];   // momentum factor (t_k - 1) / t_{k+1} of each iteration (ista.py:41-42); 0 = ISTA
   ConvGeom g;
-  int R, WP, RH, RW;   // code rows per chunk; padded row widths: COLS rows Wz + 2 (kw - 1), residual image H + 2 ph x W + 2 pw
-  float inv_wz;
+  int R, WP, RHB, RW;  // code rows per chunk; COLS row width Wz + 2 (kw - 1); residual band BR + kh - 1 rows x W + 2 pw
+  int BR, bands;       // code rows per band, bands per image (1: whole images)
+  int old_rb;          // image rows per band of conv_synth_few_kernel's launch for this problem (its chunk origins)
+  float inv_wz, inv_w, inv_old_rb;
 };
 
 // W[k][tap] -> the two fragment tables and the tap offsets (once per solve)
 __global__ __launch_bounds__(256) void conv_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ wf1,
                                                               float* __restrict__ wf2, int* __restrict__ toff,
-                                                              const ConvGeom g, int NT, int KQ, int RH, int RW) {
-  const int ckk = g.C * g.kh * g.kw;
-  const int n1 = NT * KQ * 256, n2 = NT * 1024, n3 = 16 * NT;
+                                                              const ConvGeom g, int NT, int KQ, int RHB, int RW) {
+  const int ckk = g.C * g.kh * g.kw, ntp = KQ > 4 ? 8 : 4;
+  const int n1 = NT * KQ * 256, n2 = 4 * NT * 64 * ntp, n3 = 16 * NT;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n1 + n2 + n3; idx += gridDim.x * 256) {
     if (idx < n1) {                    // bf1[c][4 t + e] of lane (l15, q): W[k = 16 t + 4 q + e][tap = 16 c + l15]
       const int e = idx & 3, lane = (idx >> 2) & 63, ct = idx >> 8, t = ct % KQ, c = ct / KQ;
       const int tap = 16 * c + (lane & 15), k = 16 * t + 4 * (lane >> 4) + e;
       wf1[idx] = (tap < ckk && k < g.K) ? w[(int64_t)k * ckk + tap] : 0.0f;
     } else if (idx < n1 + n2) {        // bf2[s][nt] of lane (l15, q): W[k = 16 nt + l15][tap = 4 s + q]
-      const int i2 = idx - n1, nt = i2 & 3, lane = (i2 >> 2) & 63, s = i2 >> 8;
+      const int i2 = idx - n1, nt = i2 % ntp, lane = (i2 / ntp) & 63, s = i2 / (ntp * 64);
       const int k = 16 * nt + (lane & 15), e = 4 * s + (lane >> 4);
       wf2[i2] = (nt < KQ && k < g.K && e < ckk) ? w[(int64_t)k * ckk + e] : 0.0f;
     } else {
@@ -100,85 +104,109 @@ __global__ __launch_bounds__(256) void conv_fused_pack_kernel(const float* __res
       int off = 0;
       if (e < ckk) {
         const int b = e % g.kw, a = (e / g.kw) % g.kh, c = e / (g.kw * g.kh);
-        off = (c * RH + a) * RW + b;
+        off = (c * RHB + a) * RW + b;
       }
       toff[e] = off;
     }
   }
 }
 
-template <int NT, int KQ, int MC>      // MC: output pixels of the residual image per thread (C H W <= 512 MC)
+template <int NT, int KQ, int MC>      // MC: output pixels of the residual band per thread (C rows W <= 512 MC)
 __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused p) {
   constexpr int PITCH = 16 * NT + 1, TS = PITCH - 1, S4 = 4 * NT;
+  // K > 64: the synthesis contracts the atoms in two halves (its W fragments are re-read from LDS per block and half:
+  // 160 registers otherwise).  K > 32: the gradient phase's waves split the atoms two or four ways (KQW = 2 groups of
+  // 16 atoms per wave: the W fragments of all four / eight groups would be 64+ registers beside eight outputs' state)
+  constexpr int KH = KQ > 4 ? 2 : 1, KQH = KQ / KH;
+  constexpr int NTP = KQ > 4 ? 8 : 4, KQW = KQ >= 4 ? 2 : KQ, AG = KQ / KQW, WPG = kCfWaves / AG;
   extern __shared__ __attribute__((aligned(16))) float cf_smem[];
   lds_f32* const f1 = (lds_f32*)cf_smem;                     // [NT KQ][64][4]
-  lds_f32* const f2 = f1 + NT * KQ * 256;                    // [S4][64][4]
-  lds_i32* const tofl = (lds_i32*)(f2 + S4 * 256);           // [4 S4]
-  lds_f32* const rimg = (lds_f32*)(tofl + 4 * S4);           // [C][RH][RW]
+  lds_f32* const f2 = f1 + NT * KQ * 256;                    // [S4][64][NTP]
+  lds_i32* const tofl = (lds_i32*)(f2 + S4 * 64 * NTP);      // [4 S4]
+  lds_f32* const rimg = (lds_f32*)(tofl + 4 * S4);           // [C][RHB][RW]
   const ConvGeom& g = p.g;
-  const int rimg_words = (g.C * p.RH * p.RW + 3) & ~3;
+  const int rimg_words = (g.C * p.RHB * p.RW + 3) & ~3;
   lds_f32* const cols = rimg + rimg_words;                   // [R WP + kCfMaxKw][PITCH]
   __shared__ float wred[kCfMaxIters][kCfWaves];      // sums |z - z+| per iteration and wave (each wave adds to its own column)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int ckk = g.C * g.kh * g.kw, K = g.K, P = g.Hz * g.Wz, Wz = g.Wz;
-  const int outs = g.C * g.H * g.W, mcount = (outs + kCfThreads - 1) / kCfThreads, nsteps = (ckk + 3) >> 2;
+  const int nsteps = (ckk + 3) >> 2;
 
-  // ---- once per launch: fragment tables, tap offsets, zeros (the padding of both LDS images is never written again) ----
+  // ---- once per launch: fragment tables, tap offsets, zeros (the column padding of both LDS images is never written) ----
   for (int e = tid; e < NT * KQ * 64; e += kCfThreads)
     *(lds_f32x4*)(f1 + 4 * e) = *(const f32x4*)(p.Wf1 + 4 * e);
-  for (int e = tid; e < S4 * 64; e += kCfThreads)
+  for (int e = tid; e < S4 * 16 * NTP; e += kCfThreads)
     *(lds_f32x4*)(f2 + 4 * e) = *(const f32x4*)(p.Wf2 + 4 * e);
   for (int e = tid; e < 4 * S4; e += kCfThreads) tofl[e] = p.toff[e];
   {
     const int zero_words = rimg_words + (p.R * p.WP + kCfMaxKw) * PITCH;
     for (int e = tid; e < zero_words; e += kCfThreads) rimg[e] = 0.0f;
   }
-  // this thread's outputs o = tid + 512 m = ((ch H + u) W + v):  u | (v + pw) << 12 | ch << 24,  -1 = none
-  int oinfo[MC];
-  {
-    const float inv_w = 1.0f / (float)g.W, inv_h = 1.0f / (float)g.H;
-#pragma unroll
-    for (int m = 0; m < MC; ++m) {
-      const int o = tid + kCfThreads * m;
-      // floor((o + 1/2) / d) in fp32 is exact for o < 2^14 (conv.hip, cgp_stage_field)
-      const int rest = (int)(((float)o + 0.5f) * inv_w), v = o - rest * g.W;
-      const int ch = (int)(((float)rest + 0.5f) * inv_h), u = rest - ch * g.H;
-      oinfo[m] = o < outs ? (u | ((v + g.pw) << 12) | (ch << 24)) : -1;
-    }
-  }
+  for (int e = tid; e < kCfMaxIters * kCfWaves; e += kCfThreads) (&wred[0][0])[e] = 0.0f;
+  { const int item = blockIdx.x, it = 0; CF_STAMP(0); }
   __syncthreads();
 
-  for (int e = tid; e < kCfMaxIters * kCfWaves; e += kCfThreads) (&wred[0][0])[e] = 0.0f;
-  { const int n = blockIdx.x, it = 0; CF_STAMP(0); }
-  __syncthreads();
-  for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
+  const int items = g.N * p.bands;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int n = item / p.bands, band = item - n * p.bands;
+    // the band's code rows [c0, c1), the rows of the residual it needs (image rows [r0, r1): padded rows c0 .. c1 + kh - 2
+    // minus the convolution's zero padding) and the code rows that reach into those, [s0, s1)
+    const int c0 = band * p.BR, c1 = min(g.Hz, c0 + p.BR);
+    const int r0 = max(0, c0 - g.ph), r1 = min(g.H, c1 + g.kh - 1 - g.ph), nrows = r1 - r0;
+    const int s0 = max(0, c0 - g.kh + 1), s1 = min(g.Hz, c1 + g.kh - 1);
+    const int outs = g.C * nrows * g.W, mcount = (outs + kCfThreads - 1) / kCfThreads;
     const int64_t img_words = (int64_t)P * K;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.Ym + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Yin) + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yws = __builtin_amdgcn_make_buffer_rsrc(p.Yout + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(p.Zm + (int64_t)n * img_words, 0, (int)(img_words * 4), 0x00020000);
-    float xr[MC];                        // x at this thread's outputs: the same in every iteration
+    // this thread's outputs o = tid + 512 m = ((ch nrows + rr) W + v) of the band's residual rows:
+    // padded row pr = r0 + rr + ph | (v + pw) << 12 | ch << 24,  -1 = none;  x at them (the same in every iteration)
+    int oinfo[MC];
+    float xr[MC];
+    {
+      const float inv_nr = 1.0f / (float)nrows;
 #pragma unroll
-    for (int m = 0; m < MC; ++m) {
-      xr[m] = 0.0f;
-      if (m < mcount && oinfo[m] >= 0) xr[m] = p.x[(int64_t)n * outs + tid + kCfThreads * m];
+      for (int m = 0; m < MC; ++m) {
+        const int o = tid + kCfThreads * m;
+        // floor((o + 1/2) / d) in fp32 is exact for o < 2^14 (conv.hip, cgp_stage_field)
+        const int rest = (int)(((float)o + 0.5f) * p.inv_w), v = o - rest * g.W;
+        const int ch = (int)(((float)rest + 0.5f) * inv_nr), rr = rest - ch * nrows;
+        const bool ok = m < mcount && o < outs;
+        oinfo[m] = ok ? ((r0 + rr + g.ph) | ((v + g.pw) << 12) | (ch << 24)) : -1;
+        xr[m] = 0.0f;
+        if (ok) xr[m] = p.x[(((int64_t)n * g.C + ch) * g.H + r0 + rr) * g.W + v];
+      }
+    }
+    if (p.bands > 1) {
+      // rows of the band's LDS image that lie in the convolution's zero padding (first / last band): another band's
+      // residual may be left there
+      const int top = max(0, g.ph - c0), bot = r1 + g.ph - c0;                  // band rows [0, top) and [bot, RHB)
+      for (int e = tid; e < g.C * p.RHB * p.RW; e += kCfThreads) {
+        const int row = (e / p.RW) % p.RHB;
+        if (row < top || row >= bot) rimg[e] = 0.0f;
+      }
     }
    for (int it = 0; it < p.iters; ++it) {
     CF_STAMP(1);
-    // ======================= phase A: residual image of image n =======================
+    // ======================= phase A: residual rows of the band =======================
     float acc[MC];
 #pragma unroll
     for (int m = 0; m < MC; ++m) acc[m] = 0.0f;
-    float bf1[NT][4 * KQ];
+    float bf1[NT][4 * KQH];
+    auto load_bf1 = [&](int h) {
 #pragma unroll
-    for (int c = 0; c < NT; ++c)
+      for (int c = 0; c < NT; ++c)
 #pragma unroll
-      for (int t = 0; t < KQ; ++t) {
-        const f32x4 v = *(const lds_f32x4*)(f1 + ((c * KQ + t) * 64 + lane) * 4);
+        for (int t = 0; t < KQH; ++t) {
+          const f32x4 v = *(const lds_f32x4*)(f1 + ((c * KQ + KQH * h + t) * 64 + lane) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bf1[c][4 * t + e] = v[e];
-      }
+          for (int e = 0; e < 4; ++e) bf1[c][4 * t + e] = v[e];
+        }
+    };
+    if (KH == 1) load_bf1(0);
     // A operand of a 16-pixel row block: 16-byte pieces of the Ym rows straight into the lanes' MFMA slots
     auto load_a = [&](int i_c, int blk, f32x4 (&a)[KQ]) {
-      const int npx = min(p.R, g.Hz - i_c) * Wz, f = 16 * blk + l15;
+      const int npx = min(p.R, s1 - i_c) * Wz, f = 16 * blk + l15;
       const unsigned rowoff = (unsigned)((i_c * Wz + f) * K + 4 * q) * 4u;
 #pragma unroll
       for (int t = 0; t < KQ; ++t) {
@@ -190,11 +218,11 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       }
     };
     f32x4 av[KQ];
-    load_a(0, wid, av);
-    for (int i_c = 0; i_c < g.Hz; i_c += p.R) {
-      const int rows = min(p.R, g.Hz - i_c), npx = rows * Wz, nblk = (npx + 15) >> 4;
+    load_a(s0, wid, av);
+    for (int i_c = s0; i_c < s1; i_c += p.R) {
+      const int rows = min(p.R, s1 - i_c), npx = rows * Wz, nblk = (npx + 15) >> 4;
       // ---- COLS of the chunk's code rows: 16-pixel row blocks, wave w takes blocks w, w + 8, ... ----
-      CF_STAMP(2 + 3 * (i_c / p.R));
+      CF_STAMP(2 + 3 * ((i_c - s0) / p.R));
       for (int blk = wid; blk < nblk; blk += kCfWaves) {
         f32x4 an[KQ];
         load_a(i_c, blk + kCfWaves, an);                                       // (beyond the chunk: every piece out of range)
@@ -203,16 +231,20 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
 #pragma unroll
         for (int c = 0; c < NT; ++c) cacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < KQ; ++t)
+        for (int h = 0; h < KH; ++h) {
+          if (KH > 1) load_bf1(h);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int t = 0; t < KQH; ++t)
 #pragma unroll
-            for (int c = 0; c < NT; ++c)
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < NT; ++c)
 #if LASSO_CF_ABL & 1
-              cacc[c][0] += av[t][e] * 1e-30f;
+                cacc[c][0] += av[KQH * h + t][e] * 1e-30f;
 #else
-              cacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bf1[c][4 * t + e], cacc[c], 0, 0, 0);
+                cacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[KQH * h + t][e], bf1[c][4 * t + e], cacc[c], 0, 0, 0);
 #endif
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int fp = 16 * blk + 4 * q + rg;
@@ -228,7 +260,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       }
       load_a(i_c + p.R, wid, av);                                              // the next chunk's first block: in flight under the taps
       __syncthreads();
-      CF_STAMP(3 + 3 * (i_c / p.R));
+      CF_STAMP(3 + 3 * ((i_c - s0) / p.R));
       // ---- overlap-add: code rows ascending, taps b ascending (rr = kw - 1 - b descending) ----
       // KW = the kernel width when it is 3, 5 or 7 (no per-tap masks), else 0: widths up to 7 behind masks
       auto add_taps = [&](auto kw_tag) {
@@ -236,11 +268,17 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         constexpr int NR = KW ? KW : kCfMaxKw;
 #pragma unroll
         for (int m = 0; m < MC; ++m) {
-          const int oi = oinfo[m];
+          int oi = oinfo[m];
+          asm volatile("" : "+v"(oi));      // (opaque per chunk: hipcc otherwise hoists every output's decoded fields and
+                                            // tap addresses out of the chunk and iteration loops -- 150 registers at MC = 8)
           if (m >= mcount || oi < 0) continue;
-          const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
+          const int pr = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
           float s = acc[m];
-          const int a0 = u + g.ph - i_c;                                       // tap row a = a0 - ii of chunk row ii
+          const int a0 = pr - i_c;                                             // tap row a = a0 - ii of chunk row ii
+          // conv_synth_few_kernel walks the code pixels that reach into ITS band of image rows (old_rb of them; the
+          // band of this output) in chunks of 128 from that band's first code row: a code row that holds a chunk
+          // boundary strictly inside gives its first part's taps (pixels v < vs, the larger b) before the second part's
+          const int ob = (int)(((float)(pr - g.ph) + 0.5f) * p.inv_old_rb), i_lo = max(0, ob * p.old_rb + g.ph - (g.kh - 1));
           for (int ii = 0; ii < rows; ++ii) {
             const int a = a0 - ii;
             if (a < 0 || a >= g.kh) continue;
@@ -250,21 +288,20 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
             float val[NR];
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) val[rr] = lo[rr * TS];             // (rr >= kw: inside the buffer, not used)
-            // conv_synth_few_kernel walks the image's code pixels in chunks of 128: a code row that holds a multiple of
-            // 128 strictly inside gives its first part's taps (pixels v < vs, the larger b) before the second part's
-            const int f0 = (i_c + ii) * Wz, fb = (f0 + Wz - 1) & ~127;
-            if (fb <= f0) {
+            const int f0 = (i_c + ii - i_lo) * Wz, fb = (f0 + Wz - 1) & ~127;
+            const bool split = fb > f0;
+            if (__builtin_amdgcn_ballot_w64(split) == 0) {
 #pragma unroll
               for (int rr = NR - 1; rr >= 0; --rr)
                 if (KW || rr < g.kw) s += val[rr];
             } else {
-              const int r1 = g.kw - 2 - jb + (fb - f0);                        // first part: b >= jb - vs + 1  <=>  rr <= r1
+              const int r1s = split ? g.kw - 2 - jb + (fb - f0) : NR;          // first part: b >= jb - vs + 1  <=>  rr <= r1s
 #pragma unroll
               for (int rr = NR - 1; rr >= 0; --rr)
-                if (KW || rr < g.kw) s += rr <= r1 ? val[rr] : 0.0f;
+                if (KW || rr < g.kw) s += rr <= r1s ? val[rr] : 0.0f;
 #pragma unroll
               for (int rr = NR - 1; rr >= 0; --rr)
-                if (KW || rr < g.kw) s += rr > r1 ? val[rr] : 0.0f;
+                if (KW || rr < g.kw) s += rr > r1s ? val[rr] : 0.0f;
             }
           }
           acc[m] = s;
@@ -280,39 +317,46 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         default: add_taps(std::integral_constant<int, 0>{}); break;
       }
       __syncthreads();
-      CF_STAMP(4 + 3 * (i_c / p.R));
+      CF_STAMP(4 + 3 * ((i_c - s0) / p.R));
     }
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
-      const int oi = oinfo[m];
+      int oi = oinfo[m];
+      asm volatile("" : "+v"(oi));
       if (m >= mcount || oi < 0) continue;
-      const int u = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
-      rimg[(ch * p.RH + u + g.ph) * p.RW + jb] = acc[m] - xr[m];
+      const int pr = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
+      rimg[(ch * p.RHB + pr - c0) * p.RW + jb] = acc[m] - xr[m];
     }
     __syncthreads();
     CF_STAMP(26);
 
-    // ======================= phase B: gradient, prox, momentum =======================
-    float bf2[S4][KQ];
+    // ======================= phase B: gradient, prox, momentum of the band's code rows =======================
+    // A wave works on 16-pixel blocks x KQW 16-atom groups: all atoms of every eighth block, or (K > 32) a half / a
+    // quarter of the atoms of every fourth / second block.  The product is issued TRANSPOSED (atoms x pixels: the W fragment is the A
+    // operand), so lane (l15, q) ends up with pixel l15, atoms 16 nt + 4 q .. + 3 in the four registers of accumulator nt
+    const int ag = wid / WPG, bfirst = wid % WPG;
+    float bf2[S4][KQW];
     int to[S4];
 #pragma unroll
     for (int s = 0; s < S4; ++s) {
-      const f32x4 v = *(const lds_f32x4*)(f2 + (s * 64 + lane) * 4);
 #pragma unroll
-      for (int nt = 0; nt < KQ; ++nt) bf2[s][nt] = v[nt];
+      for (int h = 0; h < (KQW + 3) / 4; ++h) {
+        const f32x4 v = *(const lds_f32x4*)(f2 + (s * 64 + lane) * NTP + (KQW * ag / 4 + h) * 4);
+#pragma unroll
+        for (int nt = 0; nt < KQW; ++nt)
+          if (nt / 4 == h) bf2[s][nt] = KQW < 4 ? v[(KQW * ag) % 4 + nt] : v[nt % 4];
+      }
       to[s] = tofl[4 * s + q];
     }
-    const int nb = (P + 15) >> 4;
+    const int bpx = (c1 - c0) * Wz, nb = (bpx + 15) >> 4;                      // the band's code pixels, 16-pixel blocks
     const float coef = p.coef[it];
     float dsum = 0.0f;
-    // z, y of a block as 16-byte pieces: the gradient GEMM is issued TRANSPOSED (atoms x pixels: the W fragment is the A
-    // operand), so lane (l15, q) ends up with pixel l15, atoms 16 nt + 4 q .. + 3 in the four registers of accumulator nt
-    auto fetch_zy = [&](int blk, unsigned (&off)[KQ], f32x4 (&yo)[KQ], f32x4 (&zo)[KQ]) {
+    auto fetch_zy = [&](int blk, unsigned (&off)[KQW], f32x4 (&yo)[KQW], f32x4 (&zo)[KQW]) {
       const int prow = 16 * blk + l15;
 #pragma unroll
-      for (int nt = 0; nt < KQ; ++nt) {
-        const int col = 16 * nt + 4 * q;
-        off[nt] = (prow < P && col < K) ? (unsigned)(prow * K + col) * 4u : kCfOor;
+      for (int nt = 0; nt < KQW; ++nt) {
+        const int col = 16 * (KQW * ag + nt) + 4 * q;
+        off[nt] = (prow < bpx && col < K) ? (unsigned)((c0 * Wz + prow) * K + col) * 4u : kCfOor;
         asm volatile("" : "+v"(off[nt]));
 #if LASSO_CF_ABL & 16
         yo[nt] = f32x4{(float)off[nt], 0.f, 1.f, 2.f}; zo[nt] = yo[nt];
@@ -322,23 +366,23 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
 #endif
       }
     };
-    unsigned off[KQ];
-    f32x4 yo[KQ], zo[KQ];
-    fetch_zy(wid, off, yo, zo);
+    unsigned off[KQW];
+    f32x4 yo[KQW], zo[KQW];
+    fetch_zy(bfirst, off, yo, zo);
     CF_STAMP(27);
-    for (int blk = wid; blk < nb; blk += kCfWaves) {
-      CF_STAMP(32 + blk / kCfWaves);
-      unsigned offn[KQ];
-      f32x4 yn_[KQ], zn_[KQ];
-      fetch_zy(blk + kCfWaves, offn, yn_, zn_);                                // the next block's pieces: in flight under the MFMAs
+    for (int blk = bfirst; blk < nb; blk += WPG) {
+      CF_STAMP(32 + (blk - bfirst) / WPG);
+      unsigned offn[KQW];
+      f32x4 yn_[KQW], zn_[KQW];
+      fetch_zy(blk + WPG, offn, yn_, zn_);                                     // the next block's pieces: in flight under the MFMAs
       __builtin_amdgcn_sched_barrier(0);
-      const int pl = min(16 * blk + l15, P - 1);
+      const int pl = min(16 * blk + l15, bpx - 1);
       const int pu = (int)(((float)pl + 0.5f) * p.inv_wz), pv = pl - pu * Wz;
       const int bp = pu * p.RW + pv;
-      f32x4 acc2[KQ];
+      f32x4 acc2[KQW];
 #pragma unroll
-      for (int nt = 0; nt < KQ; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      float ar[S4];                                                            // A operands of all steps in one batch of LDS reads
+      for (int nt = 0; nt < KQW; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float ar[S4];                                                            // the pixel operands of all steps in one batch of LDS reads
 #pragma unroll
       for (int s = 0; s < S4; ++s) ar[s] = rimg[to[s] + bp];
       int ns = nsteps;                                                         // (opaque per block: sixteen loop-invariant
@@ -348,14 +392,14 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         if (s < ns) {                                                          // (padded steps would multiply zeros; uniform)
 #pragma unroll
 #if LASSO_CF_ABL & 4
-          for (int nt = 0; nt < KQ; ++nt) acc2[nt][s & 3] += ar[s];
+          for (int nt = 0; nt < KQW; ++nt) acc2[nt][s & 3] += ar[s];
 #else
-          for (int nt = 0; nt < KQ; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf2[s][nt], ar[s], acc2[nt], 0, 0, 0);
+          for (int nt = 0; nt < KQW; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf2[s][nt], ar[s], acc2[nt], 0, 0, 0);
 #endif
         }
       }
 #pragma unroll
-      for (int nt = 0; nt < KQ; ++nt) {
+      for (int nt = 0; nt < KQW; ++nt) {
         const f32x4 gv = acc2[nt];
         f32x4 zn, yn;
         float ds = 0.0f;
@@ -375,15 +419,15 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         dsum += zn[1] + yn[2];
 #else
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zn), zrs, off[nt], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yn), yrs, off[nt], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yn), yws, off[nt], 0, 0);
 #endif
       }
 #pragma unroll
-      for (int nt = 0; nt < KQ; ++nt) { off[nt] = offn[nt]; yo[nt] = yn_[nt]; zo[nt] = zn_[nt]; }
+      for (int nt = 0; nt < KQW; ++nt) { off[nt] = offn[nt]; yo[nt] = yn_[nt]; zo[nt] = zn_[nt]; }
     }
     CF_STAMP(29);
     CF_STAMP_WAVE(48 + wid);
-    // sum |z - z+| of this image and iteration: lanes by xor-shuffle, into the wave's own column (a fixed order)
+    // sum |z - z+| of this item and iteration: lanes by xor-shuffle, into the wave's own column (a fixed order)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
     if (lane == 0) wred[it][wid] += dsum;
@@ -392,7 +436,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
     __syncthreads();
    }
   }
-  { const int n = blockIdx.x, it = p.iters - 1; CF_STAMP(30); }
+  { const int item = blockIdx.x, it = p.iters - 1; CF_STAMP(30); }
   if (tid < p.iters) {
     float s = 0.0f;
 #pragma unroll
@@ -417,29 +461,51 @@ __global__ __launch_bounds__(256) void conv_fused_sums_kernel(const float* __res
   if (threadIdx.x == 0) delta[blockIdx.x] = red[0];
 }
 
-struct FusedPlan { int NT, KQ, R; size_t lds; };
+struct FusedPlan { int NT, KQ, R, BR, bands, old_rb, outs_max; size_t lds; };
 
 // false when the geometry is not covered
 bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   if (const char* e = getenv("LASSO_CONV_FUSED"); e && e[0] == '0') return false;      // A/B and test switch: the two-kernel form
   const int ckk = g.C * g.kh * g.kw;
-  if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 64 || ckk > 80 || g.kw > kCfMaxKw) return false;
-  if ((int64_t)g.C * g.H * g.W > kCfMaxOut * kCfThreads || g.Wz > 128 || cus <= 0 || g.N < cus) return false;
-  if ((int64_t)g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31) || g.H >= 4096 || g.W + g.pw >= 4096) return false;
+  if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 128 || ckk > 80 || g.kw > kCfMaxKw) return false;
+  if (g.ph >= g.kh || g.pw >= g.kw || g.Wz > 128 || cus <= 0 || g.N <= 0 || (int64_t)g.C * g.W > kCfMaxOut * kCfThreads) return false;
+  if ((int64_t)g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31) || (int64_t)g.Hz * g.Wz >= 16384 || g.H + g.ph >= 4096 || g.W + g.pw >= 4096) return false;
   pl->NT = (ckk + 15) / 16;
-  pl->KQ = g.K <= 16 ? 1 : g.K <= 32 ? 2 : 4;
-  const int pitch = 16 * pl->NT + 1, wp = g.Wz + 2 * (g.kw - 1);
-  const size_t fixed = (size_t)(pl->NT * pl->KQ * 256 + pl->NT * 1024 + 16 * pl->NT +
-                                ((g.C * (g.H + 2 * g.ph) * (g.W + 2 * g.pw) + 3) & ~3) + kCfMaxKw * pitch) * 4;
+  pl->KQ = g.K <= 16 ? 1 : g.K <= 32 ? 2 : g.K <= 64 ? 4 : 8;
+  // whole images when there is one for every CU; else bands of code rows (each synthesises kh - 1 code rows of halo on
+  // either side again: only while that is at most 60 % more synthesis)
+  pl->bands = 1;
+  pl->BR = g.Hz;
+  if (g.N < cus) {
+    const int want = (cus + g.N - 1) / g.N;
+    pl->BR = (g.Hz + want - 1) / want;
+    pl->bands = (g.Hz + pl->BR - 1) / pl->BR;
+    if (pl->bands < 2 || 10 * (pl->BR + 2 * (g.kh - 1)) > 16 * pl->BR) return false;
+    if (const char* e = getenv("LASSO_CONV_FUSED_BANDS"); e && e[0] == '0') return false;
+  }
+  const int rhb = pl->BR + g.kh - 1;
+  pl->outs_max = g.C * std::min(g.H, rhb) * g.W;
+  if (pl->outs_max > kCfMaxOut * kCfThreads) return false;
+  // conv_synth_few_kernel's bands of image rows for this problem (launch_conv_synth_few): the order of its overlap-add
+  {
+    int rb = std::min(g.H, (kCfMaxOut * kCfThreads) / (g.C * g.W));
+    const int want = (cus + g.N - 1) / g.N;
+    if (want > 1) rb = std::min(rb, std::max(std::min(g.kh, g.H), (g.H + want - 1) / want));
+    pl->old_rb = std::max(rb, 1);
+  }
+  const int pitch = 16 * pl->NT + 1, wp = g.Wz + 2 * (g.kw - 1), ntp = pl->KQ > 4 ? 8 : 4;
+  const size_t fixed = (size_t)(pl->NT * pl->KQ * 256 + 4 * pl->NT * 64 * ntp + 16 * pl->NT +
+                                ((g.C * rhb * (g.W + 2 * g.pw) + 3) & ~3) + kCfMaxKw * pitch) * 4;
   const size_t budget = 150 * 1024;
   if (fixed + (size_t)wp * pitch * 4 > budget) return false;
-  const int rmax = (int)std::min<size_t>((budget - fixed) / ((size_t)wp * pitch * 4), (size_t)g.Hz);
-  // rows per chunk: the fewest rounds of eight 16-pixel blocks over the image, then the fewest chunks
+  const int srows = std::min(g.Hz, pl->BR + (pl->bands > 1 ? 2 * (g.kh - 1) : 0));      // code rows a band synthesises
+  const int rmax = (int)std::min<size_t>((budget - fixed) / ((size_t)wp * pitch * 4), (size_t)srows);
+  // rows per chunk: the fewest rounds of eight 16-pixel blocks over the band, then the fewest chunks
   int best = 0;
   int64_t best_rounds = INT64_MAX;
   for (int r = rmax; r >= 1; --r) {
     int64_t rounds = 0;
-    for (int i = 0; i < g.Hz; i += r) rounds += ((std::min(r, g.Hz - i) * g.Wz + 15) / 16 + kCfWaves - 1) / kCfWaves;
+    for (int i = 0; i < srows; i += r) rounds += ((std::min(r, srows - i) * g.Wz + 15) / 16 + kCfWaves - 1) / kCfWaves;
     if (rounds < best_rounds) { best_rounds = rounds; best = r; }
   }
   pl->R = best;
@@ -465,12 +531,13 @@ template <int NT>
 hipError_t fused_launch_kq(int kq, int outs, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
   if (kq == 1) return fused_launch_mc<NT, 1>(outs, p, grid, lds, stream);
   if (kq == 2) return fused_launch_mc<NT, 2>(outs, p, grid, lds, stream);
-  return fused_launch_mc<NT, 4>(outs, p, grid, lds, stream);
+  if (kq == 4) return fused_launch_mc<NT, 4>(outs, p, grid, lds, stream);
+  return fused_launch_mc<NT, 8>(outs, p, grid, lds, stream);
 }
 
 }  // namespace
 
-size_t conv_fused_table_bytes() { return (size_t)(5 * 4 * 256 + 5 * 1024 + 16 * 5) * 4; }
+size_t conv_fused_table_bytes() { return (size_t)(5 * 8 * 256 + 4 * 5 * 64 * 8 + 16 * 5) * 4; }
 
 // The fragment tables of the fused kernel into `tables` (conv_fused_table_bytes()); *covered = false -> the geometry
 // takes the two-kernel form and nothing is written.
@@ -479,53 +546,69 @@ hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& 
   FusedPlan pl;
   *covered = fused_plan(g, cus, &pl);
   if (!*covered) return hipSuccess;
+  const int ntp = pl.KQ > 4 ? 8 : 4;
   float* wf1 = (float*)tables;
   float* wf2 = wf1 + pl.NT * pl.KQ * 256;
-  int* toff = (int*)(wf2 + pl.NT * 1024);
-  const int total = pl.NT * pl.KQ * 256 + pl.NT * 1024 + 16 * pl.NT;
+  int* toff = (int*)(wf2 + 4 * pl.NT * 64 * ntp);
+  const int total = pl.NT * pl.KQ * 256 + 4 * pl.NT * 64 * ntp + 16 * pl.NT;
   hipLaunchKernelGGL(conv_fused_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wf1, wf2, toff, g,
-                     pl.NT, pl.KQ, g.H + 2 * g.ph, g.W + 2 * g.pw);
+                     pl.NT, pl.KQ, pl.BR + g.kh - 1, g.W + 2 * g.pw);
   return hipGetLastError();
 }
 
-int conv_fused_max_iters() { return kCfMaxIters; }
+// iterations one launch may take: 64 for whole images; 1 when images are cut into bands (a band's synthesis needs its
+// neighbours' rows of the previous iteration: the launch boundary is the grid-wide barrier)
+int conv_fused_max_iters(const ConvGeom& g, int cus) {
+  FusedPlan pl;
+  if (!fused_plan(g, cus, &pl)) return 0;
+  return pl.bands > 1 ? 1 : kCfMaxIters;
+}
+
+// != 0: y is read from Yin and written to Yout, two DIFFERENT buffers (bands); 0: in place
+int conv_fused_two_y_buffers(const ConvGeom& g, int cus) {
+  FusedPlan pl;
+  return fused_plan(g, cus, &pl) && pl.bands > 1;
+}
 
 // the instantiation launch_conv_fused would run for this geometry (the name rocprofv3 reports), or null
 const char* conv_fused_kernel_name(const ConvGeom& g, int cus) {
   FusedPlan pl;
   if (!fused_plan(g, cus, &pl)) return nullptr;
   static thread_local char name[64];
-  snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ,
-           g.C * g.H * g.W <= 2 * kCfThreads ? 2 : kCfMaxOut);
+  snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ, pl.outs_max <= 2 * kCfThreads ? 2 : kCfMaxOut);
   return name;
 }
 
 // `iters` <= conv_fused_max_iters() iterations (ista.py:19-20,29,41-46) in one launch, iteration i with the momentum factor
-// coefs[i]; delta_out (device, may be null) receives the sum |z - z+| of each.  dpart: iters x min(N, cus) words.
-hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam,
-                             const float* coefs, int iters, float* dpart, int dpart_cap, float* delta_out,
+// coefs[i]; delta_out (device, may be null) receives the sum |z - z+| of each.  dpart: iters x min(items, cus) words.
+// Yin / Yout: see conv_fused_two_y_buffers.
+hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, const float* Yin, float* Yout, float lr,
+                             float lam, const float* coefs, int iters, float* dpart, int dpart_cap, float* delta_out,
                              const ConvGeom& g, int cus, hipStream_t stream) {
   FusedPlan pl;
   if (iters < 1 || iters > kCfMaxIters || !fused_plan(g, cus, &pl)) return hipErrorInvalidValue;
+  if (pl.bands > 1 && (iters != 1 || Yin == Yout)) return hipErrorInvalidValue;
+  const int ntp = pl.KQ > 4 ? 8 : 4;
   ConvFused p;
   p.Wf1 = (const float*)tables;
   p.Wf2 = p.Wf1 + pl.NT * pl.KQ * 256;
-  p.toff = (const int*)(p.Wf2 + pl.NT * 1024);
-  p.x = x; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.dpart = dpart; p.g = g;
+  p.toff = (const int*)(p.Wf2 + 4 * pl.NT * 64 * ntp);
+  p.x = x; p.Zm = Zm; p.Yin = Yin; p.Yout = Yout; p.lr = lr; p.lam = lam; p.dpart = dpart; p.g = g;
   p.iters = iters;
   for (int i = 0; i < kCfMaxIters; ++i) p.coef[i] = i < iters ? coefs[i] : 0.0f;
-  p.R = pl.R; p.WP = g.Wz + 2 * (g.kw - 1); p.RH = g.H + 2 * g.ph; p.RW = g.W + 2 * g.pw;
-  p.inv_wz = 1.0f / (float)g.Wz;
-  const int grid = std::min(g.N, cus);
+  p.R = pl.R; p.WP = g.Wz + 2 * (g.kw - 1); p.RHB = pl.BR + g.kh - 1; p.RW = g.W + 2 * g.pw;
+  p.BR = pl.BR; p.bands = pl.bands; p.old_rb = pl.old_rb;
+  p.inv_wz = 1.0f / (float)g.Wz; p.inv_w = 1.0f / (float)g.W; p.inv_old_rb = 1.0f / (float)pl.old_rb;
+  const int64_t items = (int64_t)g.N * pl.bands;
+  const int grid = (int)std::min<int64_t>(items, cus);
   if (grid <= 0 || (int64_t)grid * iters > dpart_cap) return hipErrorInvalidValue;
-  const int outs = g.C * g.H * g.W;
   hipError_t e = hipErrorInvalidValue;
   switch (pl.NT) {
-    case 1: e = fused_launch_kq<1>(pl.KQ, outs, p, grid, pl.lds, stream); break;
-    case 2: e = fused_launch_kq<2>(pl.KQ, outs, p, grid, pl.lds, stream); break;
-    case 3: e = fused_launch_kq<3>(pl.KQ, outs, p, grid, pl.lds, stream); break;
-    case 4: e = fused_launch_kq<4>(pl.KQ, outs, p, grid, pl.lds, stream); break;
-    case 5: e = fused_launch_kq<5>(pl.KQ, outs, p, grid, pl.lds, stream); break;
+    case 1: e = fused_launch_kq<1>(pl.KQ, pl.outs_max, p, grid, pl.lds, stream); break;
+    case 2: e = fused_launch_kq<2>(pl.KQ, pl.outs_max, p, grid, pl.lds, stream); break;
+    case 3: e = fused_launch_kq<3>(pl.KQ, pl.outs_max, p, grid, pl.lds, stream); break;
+    case 4: e = fused_launch_kq<4>(pl.KQ, pl.outs_max, p, grid, pl.lds, stream); break;
+    case 5: e = fused_launch_kq<5>(pl.KQ, pl.outs_max, p, grid, pl.lds, stream); break;
   }
   if (e != hipSuccess || !delta_out) return e;
   hipLaunchKernelGGL(conv_fused_sums_kernel, dim3(iters), dim3(256), 0, stream, dpart, grid, delta_out);

@@ -2658,10 +2658,13 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
   float q_coef[64];
   int queued = 0;
   float* q_slot0 = nullptr;
+  const int q_max = fused ? std::min(64, conv_fused_max_iters(g, cus)) : 0;
+  const bool two_y = fused && conv_fused_two_y_buffers(g, cus);     // bands: y ping-pongs between Ym and G
   auto flush = [&]() -> int {
     if (queued == 0) return LASSO_OK;
-    LASSO_HIP_TRY(launch_conv_fused(ws.Wf, (const float*)x_dev, ws.Zm, ws.Ym, lr_f, lam, q_coef, queued, ws.dpart,
-                                    kConvDpart, q_slot0, g, cus, st));                             // :19-20,:29,:42,:44
+    LASSO_HIP_TRY(launch_conv_fused(ws.Wf, (const float*)x_dev, ws.Zm, ws.Ym, two_y ? ws.G : ws.Ym, lr_f, lam, q_coef,
+                                    queued, ws.dpart, kConvDpart, q_slot0, g, cus, st));            // :19-20,:29,:42,:44
+    if (two_y) std::swap(ws.Ym, ws.G);           // (save / restore below copy whatever ws.Ym is at the time)
     queued = 0;
     q_slot0 = nullptr;
     return LASSO_OK;
@@ -2671,7 +2674,7 @@ int lasso_conv_ista_solve(const void* x_dev, const void* w_dev, const void* z0_d
     const double t_next = (1.0 + sqrt(1.0 + 4.0 * t_mom * t_mom)) / 2.0;           // :41
     const float coef = fast ? (float)((t_mom - 1.0) / t_next) : 0.0f;               // :42
     if (fused) {
-      const bool fits = queued < std::min(64, conv_fused_max_iters()) &&
+      const bool fits = queued < q_max &&
                         (delta_slot ? (q_slot0 && delta_slot == q_slot0 + queued) : q_slot0 == nullptr);
       if (queued > 0 && !fits)
         if (int s = flush()) return s;

@@ -287,18 +287,21 @@ hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, fl
 // of 4, C kh kw <= 128
 hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
                                  bool* done, hipStream_t stream);
-// conv_fused.hip: synthesis + gradient + prox of up to 64 iterations in ONE launch, a workgroup per image (stride 1, C < 8,
-// K <= 64, small images, N >= CUs); `tables` = conv_fused_table_bytes() of workspace filled once per solve by
+// conv_fused.hip: synthesis + gradient + prox of up to 64 iterations in ONE launch, a workgroup per image or band of an
+// image (stride 1, C < 8, K <= 128, small images or bands); `tables` = conv_fused_table_bytes() of workspace filled once per solve by
 // launch_conv_fused_pack (*covered = false -> not covered, use the two-kernel form)
 size_t conv_fused_table_bytes();
 hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& g, int cus, bool* covered,
                                   hipStream_t stream);
-int conv_fused_max_iters();
+// iterations one launch may take for this geometry (64 for whole images, 1 for images cut into bands; 0: not covered)
+int conv_fused_max_iters(const ConvGeom& g, int cus);
+// != 0: the launch reads y from one buffer and writes the next y to ANOTHER (bands: neighbours read the old rows)
+int conv_fused_two_y_buffers(const ConvGeom& g, int cus);
 const char* conv_fused_kernel_name(const ConvGeom& g, int cus);   // null: not covered
 // `iters` iterations in one launch, momentum factor coefs[i] in iteration i; delta_out[i] (device, may be null) = the
-// iteration's sum |z - z+|; dpart: iters x min(N, cus) words
-hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, float* Ym, float lr, float lam,
-                             const float* coefs, int iters, float* dpart, int dpart_cap, float* delta_out,
+// iteration's sum |z - z+|; dpart: iters x min(N bands, cus) words
+hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, const float* Yin, float* Yout, float lr,
+                             float lam, const float* coefs, int iters, float* dpart, int dpart_cap, float* delta_out,
                              const ConvGeom& g, int cus, hipStream_t stream);
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,

@@ -11,7 +11,9 @@ CASES = [(256, 1, 64, 7, 1, 0, 26), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1,
 if os.environ.get("AB_CONV_CASES") == "fused":     # geometries of the one-launch kernel (conv_fused.hip): N >= CUs, small images
     CASES = [(256, 1, 64, 7, 1, 0, 26), (2048, 1, 16, 3, 1, 1, 8), (2048, 1, 64, 3, 1, 1, 8), (512, 1, 32, 5, 1, 0, 28),
              (256, 3, 32, 5, 1, 2, 32), (300, 2, 48, 3, 1, 1, 20), (256, 1, 64, 7, 1, 3, 32), (777, 1, 24, 5, 1, 1, 13),
-             (256, 4, 12, 3, 1, 0, 30), (1024, 1, 40, 7, 1, 2, 16)]
+             (256, 4, 12, 3, 1, 0, 30), (1024, 1, 40, 7, 1, 2, 16),
+             # K = 128 (atoms contracted in two halves), and N < CUs: bands of code rows with their halos, one launch per iteration
+             (256, 3, 128, 5, 1, 2, 32), (300, 1, 128, 7, 1, 0, 20), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (96, 2, 48, 3, 1, 1, 20)]
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd")]
     import hashlib, time, torch
