@@ -1,35 +1,42 @@
-// Up to 64 iterations per launch of the convolutional solver for SMALL IMAGES WITH FEW CHANNELS (reference
+// Whole iterations of the convolutional solver in ONE kernel for SMALL IMAGES WITH FEW CHANNELS (reference
 // lasso/conv2d/ista.py:18-29,41-46): the synthesis x_hat = conv_transpose2d(y, W), the residual, its
 // adjoint g = conv2d(x_hat - x, W), the proximal step, the momentum step and the iteration's sum |z - z+|, with ONE
-// WORKGROUP PER IMAGE -- images are independent, so a workgroup carries its image through all the iterations of the launch
+// WORKGROUP PER IMAGE -- images are independent, so a workgroup carries its image through up to 64 iterations of a launch
 // (the stop rule's per-iteration sums are written out per workgroup and added up afterwards: lasso_conv_ista_solve's
-// speculate-and-replay scheme reads them once per chunk).  What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the
-// residual never leaves the CU (it lives in LDS, zero-padded by the convolution's padding, and is the A operand of the
-// gradient GEMM where it lies -- no receptive fields staged per tile), the gradient block never goes through LDS (the
-// transposed product's accumulators ARE 16-byte row pieces), the overlap-add reads its taps with
-// compile-time offsets from zero-padded rows (no bounds per tap), one launch instead of two, both W fragment tables
-// pre-packed once per solve.
+// speculate-and-replay scheme reads them once per chunk).  With fewer images than CUs (and K <= 64) an image is cut into
+// BANDS of code rows, one work item each: a band synthesises the kh - 1 code rows of halo on either side again (only
+// while that is <= 60 % more synthesis), reads its neighbours' rows of the OLD y (so y goes from one buffer to another)
+// and the launch boundary is the grid-wide barrier: one iteration per launch.
+// What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the residual never leaves the
+// CU (it lives in LDS, zero-padded by the convolution's padding, and is the pixel operand of the gradient GEMM where it
+// lies -- no receptive fields staged per tile), the gradient block never goes through LDS (the transposed product's
+// accumulators ARE 16-byte row pieces), the overlap-add reads its taps with compile-time offsets from zero-padded rows (no
+// bounds per tap), both W fragment tables are packed once per solve, one launch per <= 64 iterations instead of two per
+// iteration.
 //
-//   phase A  (synthesis)  rows = code pixels, columns = the C kh kw taps, contraction over the K atoms:
-//            COLS[pixel][tap] = sum_k Ym[pixel][k] W[k][tap] for a chunk of R whole code rows, each wave a 16-pixel
-//            MFMA row block at a time, the block stored to LDS at [row][v + kw - 1][tap] (kw - 1 zero columns either
-//            side); then every thread adds the taps that reach its <= 8 output pixels, kept in registers across chunks.
+//   phase A  (synthesis)  rows = code pixels, columns = the C kh kw taps, contraction over the K atoms (in two halves
+//            when K > 64): COLS[pixel][tap] = sum_k Ym[pixel][k] W[k][tap] for a chunk of R whole code rows, each wave a
+//            16-pixel MFMA row block at a time, the block stored to LDS at [row][v + kw - 1][tap] (kw - 1 zero columns
+//            either side); then every thread adds the taps that reach its <= 8 output pixels, kept in registers across
+//            chunks.
 //   phase B  (gradient + prox)  rows = code pixels, columns = the K atoms, contraction over the taps: every wave takes
-//            16-pixel blocks of the image on its own (no barrier): the pixel operand = one ds_read_b32 per MFMA step from
-//            the residual image, the atom operand = the W fragments in registers; the product is issued TRANSPOSED (atoms
-//            x pixels), which leaves every lane with 16-byte row pieces of g -- the epilogue works on the pieces of z, y
-//            fetched one block ahead.
+//            16-pixel blocks (x all atoms, or x a half / a quarter of them when K > 32) on its own (no barrier): the
+//            pixel operand = one ds_read_b32 per MFMA step from the residual image, the atom operand = the W fragments in
+//            registers; the product is issued TRANSPOSED (atoms x pixels), which leaves every lane with 16-byte row
+//            pieces of g -- the epilogue works on the pieces of z, y fetched one block ahead.
 //
 // Bitwise the codes of the two-kernel form: the same lane -> atom / tap assignment in both GEMMs (every MFMA contracts the
-// same four values in the same slots, steps in the same order), the overlap-add in conv_synth_few_kernel's order -- code
-// rows ascending, taps b ascending, and where that kernel's 128-pixel chunks cut a code row in two, the first part's taps
-// before the second part's (the `split` case below) -- and the element-wise steps written with the same operations.
+// same four values in the same slots, steps in the same order; the transposed product swaps the operands, not the slots),
+// the overlap-add in conv_synth_few_kernel's order -- code rows ascending, taps b ascending, and where that kernel's
+// 128-pixel chunks (counted from the first code row of ITS band of image rows) cut a code row in two, the first part's
+// taps before the second part's (the `split` case below) -- and the element-wise steps written with the same operations.
 // Only the iteration's sum |z - z+| is added in another (fixed) order.
-// Eligibility (launcher): stride 1, C < 8, K <= 64 a multiple of 4, C kh kw <= 80, kw <= 7, C H W <= 4096, and N >= the
-// number of CUs (one image per CU and launch; below that the banded two-kernel form fills the chip better -- and its
-// bands would put the chunk cuts elsewhere).
-// Roofline: MFMA (2 M (16 NT + 4 ceil(C kh kw / 4)) 16 KQ flop per iteration with the padding); HBM: z, y read and written
-// once, y read a second time by phase B (L2 / MALL).
+// Eligibility (launcher): stride 1, C < 8, K <= 128 a multiple of 4, C kh kw <= 80, kw <= 7, at most 4096 residual values
+// per item, N >= the number of CUs or (K <= 64) bands whose halo costs <= 60 %.
+// Roofline: HBM -- z, y read and written once, y read a second time by phase B (+ the bands' halo rows): 9.8 flop per
+// byte at 1 x 7 x 7 taps and 64 atoms, below the fp32 MFMA ridge.
+// Measured and not kept: the gradient blocks of the rows a chunk completes right behind that chunk,
+// their z, y requested a chunk ahead (no separate memory-bound phase: 40.0 against 37.2 us per iteration).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -481,6 +488,9 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
     pl->BR = (g.Hz + want - 1) / want;
     pl->bands = (g.Hz + pl->BR - 1) / pl->BR;
     if (pl->bands < 2 || 10 * (pl->BR + 2 * (g.kh - 1)) > 16 * pl->BR) return false;
+    // measured (profiles/r05/ab_conv_fused.txt): N=64 3x64x64 images in four bands, 64 atoms 105 against 123 us per
+    // iteration of the two-kernel form, 128 atoms 224 against 211 -- the synthesis in two halves does not carry the halo
+    if (pl->KQ > 4) return false;
     if (const char* e = getenv("LASSO_CONV_FUSED_BANDS"); e && e[0] == '0') return false;
   }
   const int rhb = pl->BR + g.kh - 1;

@@ -188,7 +188,9 @@ def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
     return (N, C, (Hz - 1) - 2 * ph + kh, (Wz - 1) - 2 * pw + kw, K, Hz, Wz, kh, kw, 1, 1, ph, pw)
 
 
-@pytest.mark.parametrize("extra,C,K,kh,kw,padding,Hz,Wz", [
+@pytest.mark.parametrize("n_spec,C,K,kh,kw,padding,Hz,Wz", [
+    # n_spec >= 0: N = CUs + n_spec images (a workgroup per image, up to 64 iterations per launch);
+    # n_spec < 0: N = CUs // -n_spec images, each cut into bands of code rows (one launch per iteration)
     # the BASELINE-like geometry: 49 taps in four column blocks, 64 atoms, 26-pixel code rows -- rows 4, 9, 14, ... hold
     # a multiple of 128 code pixels (the two-kernel form's chunk cuts, whose order of the taps the kernel reproduces)
     (0, 1, 64, 7, 7, 0, 12, 26),
@@ -199,21 +201,32 @@ def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
     # one tap column block, K = 4, an image smaller than one MFMA row block
     (1, 1, 4, 3, 3, 1, 3, 4),
     # kernel width outside {3, 5, 7} (the masked tap loop), 48 atoms
-    (2, 1, 48, 4, 4, 1, 9, 11)])
-def test_many_iterations_per_launch_kernel(extra, C, K, kh, kw, padding, Hz, Wz):
-    """conv_fused.hip: N >= the number of CUs small few-channel images run whole iterations -- up to 64 per launch -- in one
-    kernel, a workgroup per image.  Against the oracle (the usual fp32 bound), BITWISE against the two-kernel form
-    (LASSO_CONV_FUSED=0: same lane -> operand assignment in both GEMMs, same order of the overlap-add), across the
-    64-iteration launch boundary, from a warm start, with ISTA and FISTA, and under the stop rule (count and last sum
-    of the two-kernel form... whose sums are added in another order: compared through the replayed plain run)."""
+    (2, 1, 48, 4, 4, 1, 9, 11),
+    # more than 64 atoms: contracted in two halves by the synthesis, split four ways over the gradient waves; K % 16 != 0
+    (0, 3, 128, 5, 5, 2, 10, 12), (3, 1, 100, 3, 3, 1, 9, 9),
+    # fewer images than CUs: four bands of ten code rows with one row of halo either side (first / last band: rows of
+    # the convolution's zero padding), y through two buffers
+    (-4, 2, 48, 3, 3, 1, 40, 24),
+    # two bands of twenty rows, 7 x 7 taps: the two-kernel form's chunk cuts counted from the first code row of ITS bands
+    (-2, 1, 32, 7, 7, 3, 40, 26)])
+def test_many_iterations_per_launch_kernel(n_spec, C, K, kh, kw, padding, Hz, Wz):
+    """conv_fused.hip: small few-channel images run whole iterations in one kernel, a workgroup per image (up to 64
+    iterations per launch) or per band of an image (one per launch).  Against the oracle (the usual fp32 bound), BITWISE
+    against the two-kernel form (LASSO_CONV_FUSED=0: same lane -> operand assignment in both GEMMs, same order of the
+    overlap-add), across the 64-iteration launch boundary, from a warm start, with ISTA and FISTA, and under the stop rule
+    (the two-kernel form adds the sums in another order: compared through the replayed plain run)."""
     import os
     from lasso_amd import _native as nat
     ista_conv2d, _, _, _, orc = _mods()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    N = cus + extra
+    N = cus + n_spec if n_spec >= 0 else cus // -n_spec
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     assert b"conv_fused_kernel" in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz))
-    assert b"conv_fused_kernel" not in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(cus - 1, C, K, kh, kw, ph, pw, Hz, Wz))
+    os.environ["LASSO_CONV_FUSED"] = "0"
+    try:
+        assert b"conv_fused_kernel" not in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz))
+    finally:
+        os.environ.pop("LASSO_CONV_FUSED", None)
     g = torch.Generator().manual_seed(K * 7 + Hz)
     w = torch.randn(K, C, kh, kw, generator=g) / (kh * kw) ** 0.5
     x = torch.randn(N, C, (Hz - 1) - 2 * ph + kh, (Wz - 1) - 2 * pw + kw, generator=g)

@@ -28,7 +28,7 @@ lib = C.CDLL(LIB)
 buf = (C.c_uint64 * (1024 * 64))()
 assert lib.lasso_debug_cf_stamps(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 64).astype(np.float64) / 100.0
-used = min(N, 256)
+used = 256 if N < 256 else min(N, 256)
 t = t[:used]
 t0 = t[:, 1].min()
 names = {1: "image starts", 26: "residual image written", 27: "gradient fragments loaded",
