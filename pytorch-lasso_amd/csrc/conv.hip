@@ -212,15 +212,22 @@ __global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const 
   const int wa = w % NWA, wp = w / NWA;                     // this wave's 32 atoms / 64 pixels of the tile
   const int kcol0 = KW * blockIdx.y + 32 * wa;
   // B fragments of this wave's 32 atoms: B[k][e], e = 4 s + q, zero beyond ckk / K
+  // (buffer loads, offset out of range where the fragment is zero, offsets opaque: under a condition -- also as a
+  // select behind a clamped address -- hipcc put each of these 2 S4 loads in a branch of its own with an
+  // s_waitcnt vmcnt(0) behind it: up to 96 L2 round trips in a row at the head of every launch; round 5)
   float bf[S4][2];
+  {
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, K * p.ldr * 4, 0x00020000);
 #pragma unroll
-  for (int s = 0; s < S4; ++s)
+    for (int s = 0; s < S4; ++s)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int k = kcol0 + 16 * nt + l15, e = 4 * s + q;
-      const float v = p.Wp[(int64_t)min(k, K - 1) * p.ldr + min(e, p.ldr - 1)];
-      bf[s][nt] = (k < K && e < ckk) ? v : 0.0f;
-    }
+      for (int nt = 0; nt < 2; ++nt) {
+        const int k = kcol0 + 16 * nt + l15, e = 4 * s + q;
+        unsigned o = (k < K && e < ckk) ? (unsigned)(k * p.ldr + e) * 4u : 0xfffffff0u;
+        asm volatile("" : "+v"(o));
+        bf[s][nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, o, 0, 0));
+      }
+  }
   for (int e = tid; e < 4 * S4; e += 256) {
     int off = 0;
     if (e < ckk) {

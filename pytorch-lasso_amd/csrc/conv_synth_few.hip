@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 #include "lasso_kernels.h"
 
 namespace lasso {
@@ -42,7 +43,7 @@ struct ConvSynthFew {
 // (lane-linear: one conflict-free ds_read_b32 per MFMA) instead of NT * 4 KQ registers -- the combinations whose
 // fragments do not fit beside the rest (16 NT KQ / 4 > ~100 of the 256 registers of two waves per SIMD)
 template <int NT, int KQ, bool BLDS>
-__global__ __launch_bounds__(kSfThreads) void conv_synth_few_kernel(const ConvSynthFew p) {
+__global__ __launch_bounds__(kSfThreads, (NT * KQ <= 4 && !BLDS) ? 4 : 2) void conv_synth_few_kernel(const ConvSynthFew p) {
   constexpr int PITCH = 16 * NT + 1;           // odd: the gather's lanes walk consecutive pixels
   extern __shared__ __attribute__((aligned(16))) float sf_smem[];
   lds_f32* const cols = (lds_f32*)sf_smem;     // [kSfChunk][PITCH]
@@ -51,24 +52,40 @@ __global__ __launch_bounds__(kSfThreads) void conv_synth_few_kernel(const ConvSy
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int ckk = g.C * g.kh * g.kw;
 
-  // B fragments: bf[c][4 t + e] = W[k = 16 t + 4 q + e][tap = 16 c + l15]   (zero beyond K / the taps)
+  // B fragments: bf[c][4 t + e] = W[k = 16 t + 4 q + e][tap = 16 c + l15]   (zero beyond K / the taps).  Buffer loads
+  // whose offset is out of range where the fragment is zero (opaque offsets, no condition on the load or its use):
+  // under a condition hipcc put every 4-byte load in a branch of its own with an s_waitcnt vmcnt(0) behind it -- 32 to
+  // 64 L2 round trips in a row at the head of every launch (round 5: ~20 us of the 94 us launch at 3 x 5 x 5 taps, 128
+  // atoms)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, g.K * ckk * 4, 0x00020000);
+  auto w_at = [&](int k, int tap) {
+    unsigned o = (tap < ckk && k < g.K) ? (unsigned)(k * ckk + tap) * 4u : 0xfffffff0u;
+    asm volatile("" : "+v"(o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, o, 0, 0));
+  };
   float bf[BLDS ? 1 : NT][BLDS ? 1 : 4 * KQ];
+  if constexpr (BLDS) {
+    // the LDS copy [4 t + e][c][lane], one entry per thread and step
+    constexpr int total = 4 * KQ * NT * 64, steps = (total + kSfThreads - 1) / kSfThreads;
+    float tmp[steps];
 #pragma unroll
-  for (int c0 = 0; c0 < NT; ++c0) {
-    const int c = c0;
-    if (BLDS && (c0 % kSfWaves) != wid) continue;      // (LDS copy: the column blocks are shared out over the waves)
-    const int tap = 16 * c + l15;
+    for (int j = 0; j < steps; ++j) {
+      const int idx = min(tid + kSfThreads * j, total - 1);
+      const int ln = idx & 63, rest = idx >> 6, c = rest % NT, te = rest / NT;
+      tmp[j] = w_at(16 * (te >> 2) + 4 * (ln >> 4) + (te & 3), 16 * c + (ln & 15));
+    }
 #pragma unroll
-    for (int t = 0; t < KQ; ++t)
+    for (int j = 0; j < steps; ++j)
+      if (tid + kSfThreads * j < total) bl[tid + kSfThreads * j] = tmp[j];
+    __syncthreads();
+  } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = 16 * t + 4 * q + e;
-        const float v = (tap < ckk && k < g.K) ? p.W[(int64_t)k * ckk + tap] : 0.0f;
-        if constexpr (BLDS) bl[((4 * t + e) * NT + c) * 64 + lane] = v;
-        else bf[c][4 * t + e] = v;
-      }
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int t = 0; t < KQ; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf[c][4 * t + e] = w_at(16 * t + 4 * q + e, 16 * c + l15);
   }
-  if constexpr (BLDS) __syncthreads();
 
   const int outs = g.C * p.rb * g.W;           // outputs of a band (<= kSfMaxOut * kSfThreads)
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
@@ -145,14 +162,41 @@ __global__ __launch_bounds__(kSfThreads) void conv_synth_few_kernel(const ConvSy
         acc[m] = s;
       }
     }
-    // ---- the band is complete: subtract x, store ----
+    // ---- the band is complete: subtract x, store.  Through buffer descriptors of image n (an offset out of range where
+    // the thread has no output: reads 0, store dropped), so that nothing sits under a branch: one load, its wait and
+    // the store per output in a branch of its own were up to eight dependent HBM round trips per band, and hipcc
+    // closed every such branch with an s_waitcnt vmcnt(0) that also waited for the previous store ----
+    {
+      const int chw = g.C * g.H * g.W;
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(p.R + (int64_t)n * chw, 0, chw * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x ? p.x : p.R) + (int64_t)n * chw, 0,
+                                                                           p.x ? chw * 4 : 0, 0x00020000);
+      // MCT = slots that can hold an output of this band (1, 2, 4 or 8): an out-of-range buffer operation still costs
+      // its issue slot, and small images have one output per thread, not eight
+      auto finish = [&](auto mc_tag) {
+        constexpr int MCT = decltype(mc_tag)::value, B4 = MCT < 4 ? MCT : 4;
 #pragma unroll
-    for (int m = 0; m < kSfMaxOut; ++m) {
-      if (oinfo[m] < 0) continue;
-      const int v = oinfo[m] & 0xfff, u = u0 + ((oinfo[m] >> 12) & 0xfff), ch = oinfo[m] >> 24;
-      if (u >= g.H) continue;
-      const int64_t idx = (((int64_t)n * g.C + ch) * g.H + u) * g.W + v;
-      p.R[idx] = acc[m] - (p.x ? p.x[idx] : 0.0f);
+        for (int m0 = 0; m0 < MCT; m0 += B4) {        // (batches of four: eight live offsets and values more would cost the
+          unsigned ooff[B4];                          // small instantiations their second workgroup per CU -- 128 registers)
+          float xv[B4];
+#pragma unroll
+          for (int j = 0; j < B4; ++j) {
+            const int oi = oinfo[m0 + j];
+            const int v = oi & 0xfff, u = u0 + ((oi >> 12) & 0xfff), ch = oi >> 24;
+            ooff[j] = (oi >= 0 && u < g.H) ? (unsigned)((ch * g.H + u) * g.W + v) * 4u : 0xfffffff0u;
+            asm volatile("" : "+v"(ooff[j]));
+            xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ooff[j], 0, 0));
+          }
+#pragma unroll
+          for (int j = 0; j < B4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[m0 + j] - xv[j]), rrs, ooff[j], 0, 0);
+        }
+      };
+      const int mcount = (outs + kSfThreads - 1) / kSfThreads;
+      if (mcount <= 1) finish(std::integral_constant<int, 1>{});
+      else if (mcount <= 2) finish(std::integral_constant<int, 2>{});
+      else if (mcount <= 4) finish(std::integral_constant<int, 4>{});
+      else finish(std::integral_constant<int, kSfMaxOut>{});
     }
     __syncthreads();                                               // cols is rewritten by the next item
   }
@@ -191,7 +235,8 @@ hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x
   const int ckk = g.C * g.kh * g.kw;
   if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 128 || ckk > 128 || (((uintptr_t)Ym) & 15)) return hipSuccess;
   if ((int64_t)g.C * g.W > kSfMaxOut * kSfThreads || g.W >= 4096 || cus <= 0) return hipSuccess;   // (12-bit fields)
-  if ((int64_t)g.N * g.Hz * g.Wz * g.K >= INT32_MAX) return hipSuccess;
+  if ((int64_t)g.N * g.Hz * g.Wz * g.K >= INT32_MAX || (int64_t)g.C * g.H * g.W * 4 >= INT32_MAX ||
+      (int64_t)g.K * g.C * g.kh * g.kw * 4 >= INT32_MAX) return hipSuccess;       // (32-bit buffer offsets inside an image / W)
   ConvSynthFew p;
   p.Ym = Ym; p.W = w; p.x = x; p.R = r; p.g = g;
   // band height: as tall as eight outputs per thread allow, but enough bands to fill the chip (a band re-reads
