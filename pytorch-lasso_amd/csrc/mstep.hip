@@ -730,17 +730,24 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
     float* const sAn = smem;                                 // [2][32][34]
     __shared__ int sh_dead;
     if (tid == 0) sh_dead = 0;
+    // (through a buffer descriptor, offset out of range where the element is padding, offsets opaque: behind a select
+    // hipcc moved each of these 32 loads under the condition, a branch of its own with an s_waitcnt vmcnt(0) -- 32 memory
+    // round trips in a row before a worker could take its first deltas; round 5)
     f32x4 acc[2][4];
+    {
+      const __amdgpu_buffer_rsrc_t usrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, (int)((int64_t)p.k * p.ldu * 4), 0x00020000);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int row = JB * r + 16 * mt + 4 * q + rg;
-          const float v = p.U[(int64_t)min(row, kl) * p.ldu + 64 * w + 16 * nt + l15];
-          acc[mt][nt][rg] = (row < p.k && 64 * w + 16 * nt + l15 < p.d) ? v : 0.0f;   // (the padding is never read)
-        }
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = JB * r + 16 * mt + 4 * q + rg, col = 64 * w + 16 * nt + l15;
+            unsigned o = (row < p.k && col < p.d) ? (unsigned)(row * (int)p.ldu + col) * 4u : 0xfffffff0u;   // (the padding is never read)
+            asm volatile("" : "+v"(o));
+            acc[mt][nt][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(usrc, o, 0, 0));
+          }
+    }
     load_an(sAn, r, 0, tid, 256);
     // The deltas arrive in groups of 8 atoms (flags[0] counts the groups): the worker of the block next in
     // line has consumed three quarters of the newest block's deltas when its last group is published.
