@@ -170,28 +170,31 @@ constexpr int cgp_occ(int s4) { return s4 == 16 ? LASSO_CGP_OCC16 : LASSO_CGP_OC
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 // The receptive field of a tile, C x RH x RW residual values (zero outside the image), into LDS: H independent
-// loads in flight per thread.
+// loads in flight per thread.  No lane-dependent control flow: the loads go through a buffer descriptor of image n's
+// residual with the offset out of range outside the image (reads 0), surplus lanes store to the spare word S[region].
+// With loads and stores under lane masks hipcc lost count of what was in flight at the join and closed the tile's
+// prologue with s_waitcnt vmcnt(0) -- which also waited for the z / y pieces requested behind the field on purpose.
 template <int H>
-__device__ __forceinline__ void cgp_stage_field(float* __restrict__ S, const float* __restrict__ Rn, const ConvGradProx& p,
+__device__ __forceinline__ void cgp_stage_field(float* __restrict__ S, const __amdgpu_buffer_rsrc_t rrs, const ConvGradProx& p,
                                                 int t0, int region, int plane, int i0, int j0) {
   const ConvGeom& g = p.g;
-  for (int e0 = t0; e0 < region; e0 += 256 * H) {
+  for (int base = 0; base < region; base += 256 * H) {
     float sv[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      const int e = min(e0 + 256 * h, region - 1);
+      const int e = min(base + t0 + 256 * h, region - 1);
       // e = (c, rr, cc): floor((e + 1/2) / d) in fp32 is exact for e < 2^14 (the distance to the next integer
       // is at least 1/(2d), the rounding error below 2e-3/d) -- two runtime integer divisions per element were
       // a third of this kernel's instructions
       const int c = (int)(((float)e + 0.5f) * p.inv_plane), rem = e - c * plane;
       const int rr = (int)(((float)rem + 0.5f) * p.inv_rw), cc = rem - rr * p.RW;
       const int i = i0 + rr, j = j0 + cc;
-      const float v = Rn[((int64_t)c * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)];
-      sv[h] = v * ((i >= 0 && i < g.H && j >= 0 && j < g.W) ? 1.0f : 0.0f);
+      unsigned o = (i >= 0 && i < g.H && j >= 0 && j < g.W) ? (unsigned)((c * g.H + i) * g.W + j) * 4u : 0xfffffff0u;
+      asm volatile("" : "+v"(o));
+      sv[h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, o, 0, 0));
     }
 #pragma unroll
-    for (int h = 0; h < H; ++h)
-      if (e0 + 256 * h < region) S[e0 + 256 * h] = sv[h];
+    for (int h = 0; h < H; ++h) S[min(base + t0 + 256 * h, region)] = sv[h];
   }
 }
 
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float cg_smem[];
   float* const Gt = cg_smem;                                // [TP][KW + 4]
   int* const toff = (int*)(Gt + TP * kCgpGtLd);             // [4 * S4]
-  float* const S = (float*)(toff + 4 * S4);                 // [C][RH][RW]
+  float* const S = (float*)(toff + 4 * S4);                 // [C][RH][RW] + one spare word
   __shared__ float red[256];
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -258,7 +261,8 @@ __global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const 
     const int n = tile / tiles_img, tt = tile - n * tiles_img;
     const int u0 = (tt / p.tiles_v) * p.TU, v0 = (tt % p.tiles_v) * p.TV;
     const int i0 = u0 * g.sh - g.ph, j0 = v0 * g.sw - g.pw;
-    const float* const Rn = p.R + (int64_t)n * g.C * g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R) + (int64_t)n * g.C * g.H * g.W, 0,
+                                                                         g.C * g.H * g.W * 4, 0x00020000);
     // (opaque per trip: otherwise hipcc hoists the index arithmetic of the unrolled staging and
     // epilogue loops out of the tile loop and spills it)
     int tdyn = tid;
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(256, cgp_occ(S4)) void conv_grad_prox_kernel(const 
     asm volatile("" : "+v"(bp[0]), "+v"(bp[1]), "+v"(bp[2]), "+v"(bp[3]));
     // receptive fields of at most 512 values (one image channel, small kernels) take two loads per thread instead
     // of eight: the index arithmetic of the six idle slots was a quarter of the kernel's vector instructions there
-    if (S4 <= 24 && region <= 512) cgp_stage_field<2>(S, Rn, p, tdyn, region, plane, i0, j0);
-    else cgp_stage_field<8>(S, Rn, p, tdyn, region, plane, i0, j0);
+    if (S4 <= 24 && region <= 512) cgp_stage_field<2>(S, rrs, p, tdyn, region, plane, i0, j0);
+    else cgp_stage_field<8>(S, rrs, p, tdyn, region, plane, i0, j0);
     // z, y of the tile do not depend on g: fetched now, so that the HBM latency runs under the MFMAs
     f32x4 yo[8];                                              // (z is fetched in the epilogue: registers)
     unsigned zoff[8];                                         // byte offset of this thread's pieces (~0u: outside -> reads 0, writes dropped)
@@ -587,7 +591,8 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   p.tv_shift = p.TV == 64 ? 6 : p.TV == 32 ? 5 : p.TV == 16 ? 4 : 3;
   p.inv_plane = 1.0f / (float)(p.RH * p.RW);
   p.inv_rw = 1.0f / (float)p.RW;
-  if ((int64_t)g.N * g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31)) return hipSuccess;   // 32-bit row offsets in the kernel
+  if ((int64_t)g.N * g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31) || (int64_t)g.C * g.H * g.W * 4 >= ((int64_t)1 << 31))
+    return hipSuccess;                                                                // 32-bit offsets in the kernel
   p.tiles_u = (g.Hz + p.TU - 1) / p.TU;
   p.tiles_v = (g.Wz + p.TV - 1) / p.TV;
   p.R = r; p.Wp = Wp; p.ldr = ldr; p.Zm = Zm; p.Ym = Ym; p.lr = lr; p.lam = lam; p.coef = coef; p.dpart = dpart; p.g = g;
@@ -596,7 +601,7 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   const int s4 = ckk <= 64 ? 16 : ckk <= 96 ? 24 : ckk <= 144 ? 36 : 48;
   if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
   const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, cgp_occ(s4) * cus / gy)));
-  const size_t lds = (size_t)(tp * (kw + 4) + 4 * s4 + g.C * p.RH * p.RW) * 4;
+  const size_t lds = (size_t)(tp * (kw + 4) + 4 * s4 + g.C * p.RH * p.RW + 1) * 4;
   const dim3 grid(gx, gy);
   const bool skip = ckk <= 4 * s4 - 4;
 #define LASSO_CGP_CASE2(S4_, KW_, SK_)                                                                       \
