@@ -2,7 +2,7 @@
 """bench.py -- BASELINE's metric on MI355X: FISTA iterations/sec (+ time-to-tol) on
 n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em|c3] [--scaling strong|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em|c3|conv] [--scaling strong|weak]
                     [--shape c4|c5] [--dtype bf16|f32] [--rows R] [--backend nccl|gloo] [--share-gpu]
 
 --workload fista (default): a "step" is one sparse_encode solve of --iters FISTA iterations
@@ -26,6 +26,9 @@ n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU
   lr0=1, 10 outer iterations, --dtype bf16 (default, config 3 as named) or f32 tensors; a "step" is one solve;
   value = outer iterations/s; FLOPs as executed = (4 per outer iteration + 2 per trial) n d k.  N > 1: the rows
   sharded, every F <= Q decision on sums all-reduced over the ranks (lasso_fista_solve_sharded).
+--workload conv: convolutional FISTA on one of tools/bench_conv.py's geometries (--conv-case gray | rgb |
+  c16), 20 iterations per solve, fixed step, no stop rule; a "step" is one solve; value = iterations/s; the roofline is
+  HBM (the code and its momentum copy are streamed every iteration); N > 1: the images sharded, no collective.
 --backend gloo --share-gpu: every rank on cuda:0, collectives over gloo (host-staged) -- how the multi-rank
   code paths of this file are executed on a ONE-GPU box (tests/test_bench_gpu.py); never a performance figure.
 
@@ -633,6 +636,71 @@ def run_c3(args, ranks):
     return out
 
 
+CONV_CASES = {   # tools/bench_conv.py's geometries: N, C, K, kernel size, padding, code height = width
+    "gray": (256, 1, 64, 7, 0, 26), "rgb": (64, 3, 128, 5, 2, 64), "c16": (32, 16, 256, 3, 1, 64)}
+CONV_ITERS = 20
+
+
+def run_conv(args, ranks):
+    """convolutional FISTA (lasso/conv2d/ista.py:7-49) on one of tools/bench_conv.py's geometries; a
+    step = one solve of 20 iterations with a fixed step size and no stop rule.  The batch of images is split over the
+    ranks (images are independent: no collective).  Roofline: HBM -- the code z and its momentum copy y, [N, K, Hz, Wz]
+    fp32 each, are streamed every iteration (y read by the synthesis and by the gradient step, z read, both written):
+    9.8 flop per byte at 1 x 7 x 7 taps and 64 atoms, below the fp32-MFMA ridge."""
+    import torch
+    from lasso_amd.conv2d import ista_conv2d
+    from lasso_amd import _native as nat
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    N_all, C, Kc, ks, pd, Hz = CONV_CASES[args.conv_case]
+    if args.rows:
+        N_all = args.rows
+    if N_all % world:
+        raise SystemExit("bench.py: %d images do not split over %d ranks" % (N_all, world))
+    N = N_all // world
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(Kc, C, ks, ks, generator=g) / ks
+    H = (Hz - 1) - 2 * pd + ks
+    x = torch.randn(N_all, C, H, H, generator=g)[rank * N:(rank + 1) * N]
+    lr = 0.5 / w.pow(2).sum().item()
+    xg, wg, zg = x.to(dev), w.to(dev), torch.zeros(N, Kc, Hz, Hz, device=dev)
+
+    def solve():
+        return ista_conv2d(xg, zg, wg, 0.1, stride=1, padding=pd, maxiter=CONV_ITERS, lr=lr, tol=0.0)
+    elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
+    z = solve()
+    nnz = torch.tensor([float((z != 0).sum())], device=dev, dtype=torch.float64)
+    ranks.sum_(nnz)
+    if rank != 0:
+        return None
+    code_bytes = 4.0 * N * Kc * Hz * Hz
+    # per iteration: y read twice (synthesis, gradient step), z read, z and y written, x read; per solve: z0 -> rows
+    # (read, z and y written) and rows -> z (read, written)
+    alg = CONV_ITERS * (5.0 * code_bytes + 4.0 * N * C * H * H) + 5.0 * code_bytes
+    flop = CONV_ITERS * 4.0 * N * Hz * Hz * C * ks * ks * Kc
+    gbps = alg / (kern_ms[0] * 1e-3) / 1e9
+    name = nat.lib().lasso_conv_ista_kernel_name(N, C, H, H, Kc, Hz, Hz, ks, ks, 1, 1, pd, pd)
+    return {
+        "metric": "conv_fista_iterations_per_sec (N=%d %dx%dx%d images, %d %dx%d atoms, fp32, fixed step)" % (N_all, C, H, H, Kc, ks, ks),
+        "value": args.steps * CONV_ITERS / elapsed, "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "convolutional FISTA (ista_conv2d), N=%d images %dx%dx%d, %d atoms %dx%d, padding %d, code "
+                               "%dx%d, alpha=0.1, %d iterations per solve, tol=0; step = one solve"
+                               % (N_all, C, H, H, Kc, ks, ks, pd, Hz, Hz, CONV_ITERS),
+                   "images_per_gpu": N, "images_total": N_all, "parallelism": "images sharded x%d (no collective)" % world},
+        "roofline": with_traffic(
+            {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+             "kernel": name.decode() if name else None,
+             "bytes_per_launch": alg, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
+             "bytes_note": "algorithmic: per iteration y read twice, z read, z and y written (4 N K Hz Wz bytes each) + x; "
+                           "per solve the two layout changes (5 code-sized passes)",
+             "avg_launch_note": "HIP events around the K timed solves / K",
+             "tflops": flop / (kern_ms[0] * 1e-3) / 1e12, "mfma_frac": flop / (kern_ms[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            ("conv_%s" % args.conv_case) if (world == 1 and not args.rows) else None, kern_ms[0], algorithmic_bytes=alg),
+        "nonzeros": int(nnz.item()),
+    }
+
+
 def run_launcher_selftest(args, ranks):
     """No compute: the launcher / barrier / max-over-ranks protocol only (CPU, gloo)."""
     def step():
@@ -652,7 +720,10 @@ def parser():
     ap.add_argument("--steps", type=int, default=100)    # 0.32 s timed at the headline shape
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100, help="FISTA iterations per step (solve)")
-    ap.add_argument("--workload", choices=["fista", "em", "c3", "launcher-selftest"], default="fista")
+    ap.add_argument("--workload", choices=["fista", "em", "c3", "conv", "launcher-selftest"], default="fista")
+    ap.add_argument("--conv-case", choices=sorted(CONV_CASES), default="gray",
+                    help="conv workload: N=256 1x32x32 images with 64 7x7 atoms (gray), N=64 3x64x64 with 128 5x5 (rgb), "
+                         "N=32 16x64x64 with 256 3x3 (c16)")
     ap.add_argument("--shape", choices=sorted(EM_SHAPES), default="c4", help="em workload: config 4 or config 5's shape")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="c3 workload: tensor dtype")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -706,7 +777,7 @@ def main():
             raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(gpu)
         ranks = Ranks(rank, world, torch.device("cuda", gpu), args.backend, force=args.force_dist)
-        out = {"em": run_em, "c3": run_c3, "fista": run_fista}[args.workload](args, ranks)
+        out = {"em": run_em, "c3": run_c3, "fista": run_fista, "conv": run_conv}[args.workload](args, ranks)
         if out is not None and ranks.sharded:
             out["backend"] = args.backend + (" (all ranks share cuda:0: a code-path run, not a performance figure)"
                                              if args.share_gpu else

@@ -488,7 +488,7 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
     pl->BR = (g.Hz + want - 1) / want;
     pl->bands = (g.Hz + pl->BR - 1) / pl->BR;
     if (pl->bands < 2 || 10 * (pl->BR + 2 * (g.kh - 1)) > 16 * pl->BR) return false;
-    // measured (profiles/r05/ab_conv_fused.txt): N=64 3x64x64 images in four bands, 64 atoms 105 against 123 us per
+    // measured (profiles/r05_conv/ab_conv_fused.txt): N=64 3x64x64 images in four bands, 64 atoms 105 against 123 us per
     // iteration of the two-kernel form, 128 atoms 224 against 211 -- the synthesis in two halves does not carry the halo
     if (pl->KQ > 4) return false;
     if (const char* e = getenv("LASSO_CONV_FUSED_BANDS"); e && e[0] == '0') return false;

@@ -5,7 +5,7 @@
 # profiles/.  The steps divisor of the traffic pass = the solves / EM steps the command executes (--warmup 0).
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ALL="fista c3_bf16 c3_f32 em_c4 em_c4_shard em_c5 em_c5_shard"
+ALL="fista c3_bf16 c3_f32 em_c4 em_c4_shard em_c5 em_c5_shard conv_gray conv_rgb conv_c16"
 TAGS=${@:-$ALL}
 cd /tmp && export TMPDIR=/tmp
 for tag in $TAGS; do
@@ -17,6 +17,9 @@ for tag in $TAGS; do
     em_c4_shard) ARGS="--workload em --rows 8192 --steps 40"; PARGS="--workload em --rows 8192 --steps 40 --warmup 0"; DIV=40 ;;
     em_c5)       ARGS="--workload em --shape c5 --steps 40"; PARGS="--workload em --shape c5 --steps 40 --warmup 0"; DIV=40 ;;
     em_c5_shard) ARGS="--workload em --shape c5 --rows 8192 --steps 40"; PARGS="--workload em --shape c5 --rows 8192 --steps 40 --warmup 0"; DIV=40 ;;
+    conv_gray)   ARGS="--workload conv --conv-case gray --steps 40"; PARGS="--workload conv --conv-case gray --steps 40 --warmup 0"; DIV=41 ;;
+    conv_rgb)    ARGS="--workload conv --conv-case rgb --steps 20"; PARGS="--workload conv --conv-case rgb --steps 20 --warmup 0"; DIV=21 ;;
+    conv_c16)    ARGS="--workload conv --conv-case c16 --steps 20"; PARGS="--workload conv --conv-case c16 --steps 20 --warmup 0"; DIV=21 ;;
     *) echo "unknown tag $tag"; continue ;;
   esac
   D=$O/r05_$tag
