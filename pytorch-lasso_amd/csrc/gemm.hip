@@ -13,6 +13,8 @@
 // than 64 x 64 ones and are used whenever they still fill the chip.
 // Roofline: MFMA-bound, 2*m*nn*kk flop (measured numbers: DESIGN.md 3.3).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <algorithm>
 #include "lasso_kernels.h"
@@ -98,11 +100,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
   // staging map: thread -> chunk (tid & 7) of rows (tid >> 3) + 32 h
   const int srow = tid >> 3, sch = tid & 7;
   f32x4 ga[PA], gb[PB];
+  // (VEC: 16-byte buffer loads from descriptors of the block's rows of A and B, the offset out of range beyond the rows /
+  // beyond kk -- reads 0 --, offsets opaque: no branch per chunk, the batch leaves as a batch; the launcher checks
+  // ld BM 4 < 2^31)
+  const int rows_a = min(BM, m - i0), rows_b = min(BN, nn - j0);
+  auto rows_rsrc = [&](const float* base, int64_t ld, int r0, int rows) {
+    const int64_t bytes = (int64_t)rows * ld * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)r0 * ld), 0,
+                                             (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ars = rows_rsrc(A, lda, i0, rows_a), brs = rows_rsrc(B, ldb, j0, rows_b);
   auto fetch = [&](int k0) {
+    if constexpr (VEC) {
+      const int kc = k0 + 4 * sch;
 #pragma unroll
-    for (int h = 0; h < PA; ++h) ga[h] = load_chunk4<VEC>(A, lda, i0 + srow + 32 * h, m, k0 + 4 * sch, kk);
+      for (int h = 0; h < PA; ++h) {
+        unsigned o = (srow + 32 * h < rows_a && kc < kk) ? (unsigned)((srow + 32 * h) * (int)lda + kc) * 4u : 0xfffffff0u;
+        asm volatile("" : "+v"(o));
+        ga[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, o, 0, 0));
+      }
 #pragma unroll
-    for (int h = 0; h < PB; ++h) gb[h] = load_chunk4<VEC>(B, ldb, j0 + srow + 32 * h, nn, k0 + 4 * sch, kk);
+      for (int h = 0; h < PB; ++h) {
+        unsigned o = (srow + 32 * h < rows_b && kc < kk) ? (unsigned)((srow + 32 * h) * (int)ldb + kc) * 4u : 0xfffffff0u;
+        asm volatile("" : "+v"(o));
+        gb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, o, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < PA; ++h) ga[h] = load_chunk4<VEC>(A, lda, i0 + srow + 32 * h, m, k0 + 4 * sch, kk);
+#pragma unroll
+      for (int h = 0; h < PB; ++h) gb[h] = load_chunk4<VEC>(B, ldb, j0 + srow + 32 * h, nn, k0 + 4 * sch, kk);
+    }
   };
   auto stash = [&](int buf) {
 #pragma unroll
@@ -175,34 +203,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     __syncthreads();
     buf ^= 1;
   }
+  // Both epilogues through buffer descriptors of the tile's rows (offset out of range beyond m / nn: reads 0, store
+  // dropped; offsets opaque): with the bounds as branches hipcc gave every element a branch of its own, each load its
+  // s_waitcnt vmcnt(0) and -- at the joins of those lane-masked branches -- every STORE one too, so that a lane's 64 to
+  // 128 stores each waited for the previous one's acknowledgement (round 5; the launcher checks ld BM 4 < 2^31).
+  const int rows_valid = min(BM, m - i0);
+  auto tile_rsrc = [&](const float* base, int64_t ld) {
+    const int64_t bytes = base ? (int64_t)rows_valid * ld * 4 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base + (int64_t)i0 * ld : C), 0,
+                                             (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+  };
+  auto tile_off = [&](int rl, int cc, int64_t ld) {
+    unsigned o = (rl < rows_valid && cc < nn) ? (unsigned)(rl * (int)ld + cc) * 4u : 0xfffffff0u;
+    asm volatile("" : "+v"(o));
+    return o;
+  };
   if constexpr (EPI) {
+    const __amdgpu_buffer_rsrc_t zrs = tile_rsrc(ep.Z, ep.ldz), yrs = tile_rsrc(ep.Y, ep.ldy);
     float dsum = 0.0f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       // all of a row block's z, y values in flight before the first is used
       float zo[NJ][4], yo[NJ][4];
+      unsigned oz[NJ][4], oy[NJ][4];
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
-          const bool in = r < m && cc < nn;
-          zo[nj][rg] = in ? ep.Z[(int64_t)r * ep.ldz + cc] : 0.0f;
-          yo[nj][rg] = in ? ep.Y[(int64_t)r * ep.ldy + cc] : 0.0f;
+          const int rl = (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+          oz[nj][rg] = tile_off(rl, cc, ep.ldz);
+          oy[nj][rg] = tile_off(rl, cc, ep.ldy);
+          zo[nj][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrs, oz[nj][rg], 0, 0));
+          yo[nj][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, oy[nj][rg], 0, 0));
         }
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
-          if (r < m && cc < nn) {
-            const float g = 0.0f - acc[mi][nj][rg];
-            const float v = __fsub_rn(yo[nj][rg], __fmul_rn(ep.lr, g));
-            const float zn = __fsub_rn(v, __builtin_amdgcn_fmed3f(v, -ep.lam, ep.lam));
-            dsum += __builtin_fabsf(__fsub_rn(zo[nj][rg], zn));
-            ep.Y[(int64_t)r * ep.ldy + cc] = __fadd_rn(zn, __fmul_rn(ep.coef, __fsub_rn(zn, zo[nj][rg])));
-            ep.Z[(int64_t)r * ep.ldz + cc] = zn;
-          }
+          const float g = 0.0f - acc[mi][nj][rg];
+          const float v = __fsub_rn(yo[nj][rg], __fmul_rn(ep.lr, g));
+          const float zn = __fsub_rn(v, __builtin_amdgcn_fmed3f(v, -ep.lam, ep.lam));
+          dsum += oz[nj][rg] != 0xfffffff0u ? __builtin_fabsf(__fsub_rn(zo[nj][rg], zn)) : 0.0f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__fadd_rn(zn, __fmul_rn(ep.coef, __fsub_rn(zn, zo[nj][rg])))),
+                                                yrs, oy[nj][rg], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zn), zrs, oz[nj][rg], 0, 0);
         }
     }
     // block sum in a fixed order: lanes (butterfly over the wave), then the four waves
@@ -214,18 +258,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     __syncthreads();
     if (tid == 0) ep.dpart[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   } else {
+    const __amdgpu_buffer_rsrc_t c0rs = tile_rsrc(C0, ldc0), crs = tile_rsrc(C, ldc);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      float c0[NJ][4];
+      unsigned oc[NJ][4];
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int r = i0 + (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
-          if (r < m && cc < nn) {
-            const float c0 = C0 ? C0[(int64_t)r * ldc0 + cc] : 0.0f;
-            C[(int64_t)r * ldc + cc] = add ? c0 + acc[mi][nj][rg] : c0 - acc[mi][nj][rg];
-          }
+          const int rl = (BM / 2) * wr + 16 * mi + 4 * q + rg, cc = j0 + (BN / 2) * wc + 16 * nj + l15;
+          oc[nj][rg] = tile_off(rl, cc, ldc);
+          c0[nj][rg] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, tile_off(rl, cc, ldc0), 0, 0));   // (no C0: 0 records, reads 0)
         }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(add ? c0[nj][rg] + acc[mi][nj][rg] : c0[nj][rg] - acc[mi][nj][rg]),
+                                                crs, oc[nj][rg], 0, 0);
+    }
   }
 }
 
@@ -330,6 +382,11 @@ static void prox_blocks(int m, int nn, int* bm_out, int* bn_out) {
   (void)m; (void)nn;
   *bm_out = 64;
   *bn_out = 64;
+  if (const char* e = getenv("LASSO_PROX_BLOCKS")) {        // A/B knob: "128x128", "128x64", "64x128", "64x64", "auto"
+    int a = 0, b = 0;
+    if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128)) { *bm_out = a; *bn_out = b; }
+    else if (e[0] == 'a') gemm_blocks(m, nn, bm_out, bn_out);
+  }
 }
 
 int gemm_nt_prox_parts(int m, int nn) {
@@ -343,6 +400,8 @@ hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int6
                                float* Y, int64_t ldy, int m, int nn, int kk, float lr, float lam, float coef,
                                float* dpart, hipStream_t stream) {
   if (m <= 0 || nn <= 0) return hipSuccess;
+  // (32-bit buffer offsets inside a block's 128 rows of every operand)
+  if (std::max(std::max(lda, ldb), std::max(ldz, ldy)) * 128 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
   int bm, bn;
@@ -364,6 +423,7 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
                               int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk,
                               hipStream_t stream, int add, int* zero_words, int nzero) {
   if (m <= 0 || nn <= 0) return hipSuccess;
+  if (std::max(std::max(lda, ldb), std::max(ldc, C0 ? ldc0 : (int64_t)0)) * 128 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
   int bm, bn;
