@@ -223,28 +223,44 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         if (a0 + e < p.k) v[e] = (float)src[e];
     }
   };
-  // the same 8 values, still packed (exact: they are bf16 in memory)
-  auto load_z8p = [&](const __bf16* base, int64_t ld, bool vec, int j) -> u32x4 {
+  // the same 8 values, still packed (exact: they are bf16 in memory).  Aligned rows (vec) go through a buffer descriptor
+  // of the tile's rows with the offset out of range where the thread has nothing to read (reads 0), the offset opaque:
+  // with `if (row in range) load` hipcc gave every one of these loads a branch of its own and an s_waitcnt vmcnt(0)
+  // behind it -- the accept step's "all loads in flight together" was a chain of 8 memory round trips per batch (round 5)
+  const int rows_here = min((int)kRows, p.n - row0);
+  auto z_rsrc = [&](const __bf16* base, int64_t ld) {
+    const int64_t bytes = base ? (int64_t)rows_here * ld * 2 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base ? base + (int64_t)row0 * ld : Zg), 0,
+                                             (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t z0rs = z_rsrc(Z0g, p.ldz0), zrs = z_rsrc(Zg, p.ldz);
+  auto z_off = [&](int64_t ld, int j, int tok) {
+    const int a0 = kPass * j + 8 * ec8;
+    unsigned o = (erow_ok && a0 < p.k) ? (unsigned)((erow * (int)ld + a0) * 2 + tok) : 0xfffffff0u;
+    asm volatile("" : "+v"(o));
+    return o;
+  };
+  auto load_z8p = [&](const __bf16* base, const __amdgpu_buffer_rsrc_t rs, int64_t ld, bool vec, int j, int tok = 0) -> u32x4 {
+    if (vec) return __builtin_amdgcn_raw_buffer_load_b128(rs, z_off(ld, j, tok), 0, 0);
     const int a0 = kPass * j + 8 * ec8;
     if (!base || !erow_ok || a0 >= p.k) return (u32x4){0u, 0u, 0u, 0u};
     const __bf16* src = base + (int64_t)(row0 + erow) * ld + a0;
-    if (vec) return *reinterpret_cast<const u32x4*>(src);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (a0 + e < p.k) ? (float)src[e] : 0.0f;
     return pack8(v);
   };
   auto store_z8 = [&](int j, const float (&v)[8]) {
+    if (zvec) {
+      __builtin_amdgcn_raw_buffer_store_b128(pack8(v), zrs, z_off(p.ldz, j, 0), 0, 0);
+      return;
+    }
     const int a0 = kPass * j + 8 * ec8;
     if (!erow_ok || a0 >= p.k) return;
     __bf16* dst = Zg + (int64_t)(row0 + erow) * p.ldz + a0;
-    if (zvec) {
-      *reinterpret_cast<u32x4*>(dst) = pack8(v);
-    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (a0 + e < p.k) dst[e] = (__bf16)v[e];
-    }
+    for (int e = 0; e < 8; ++e)
+      if (a0 + e < p.k) dst[e] = (__bf16)v[e];
   };
   // g rows are padded to whole tiles in the workspace, so every thread's row exists
   const __bf16* const grow = Gg + (int64_t)(row0 + erow) * K + 8 * ec8;   // + kPass * j
@@ -721,9 +737,18 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
         constexpr int b = decltype(b_c)::value;
 #pragma unroll
         for (int u = 0; u < AB2; ++u) gq[b][u] = *reinterpret_cast<const u32x4*>(grow + kPass * (AB2 * b + u) + tok);
+        {
+          const bool first = it == 0;
+          const __amdgpu_buffer_rsrc_t rsel = first ? z0rs : zrs;
+          const int64_t ldsel = first ? p.ldz0 : p.ldz;
+          if (first ? z0vec : zvec) {
 #pragma unroll
-        for (int u = 0; u < AB2; ++u)
-          zq[b][u] = it == 0 ? load_z8p(Z0g + tok, p.ldz0, z0vec, AB2 * b + u) : load_z8p(Zg + tok, p.ldz, zvec, AB2 * b + u);
+            for (int u = 0; u < AB2; ++u) zq[b][u] = __builtin_amdgcn_raw_buffer_load_b128(rsel, z_off(ldsel, AB2 * b + u, tok), 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < AB2; ++u) zq[b][u] = load_z8p(first ? Z0g : Zg, rsel, ldsel, false, AB2 * b + u, tok);
+          }
+        }
       };
       issue(std::integral_constant<int, 0>{});
       if constexpr (NBT > 1) issue(std::integral_constant<int, 1>{});
@@ -745,8 +770,20 @@ __global__ __launch_bounds__(kThreads, 2) void bt16_persist_kernel(const Bt16Per
       u32x4 gq[AB], zq[AB];
 #pragma unroll
       for (int u = 0; u < AB; ++u) gq[u] = load_g8(jb + u);
+      // (the uniform choices -- first iteration reads z0, aligned rows or not -- OUTSIDE the batch: a branch round each
+      // load, uniform or not, ends in its own s_waitcnt vmcnt(0))
+      {
+        const bool first = it == 0;
+        const __amdgpu_buffer_rsrc_t rsel = first ? z0rs : zrs;
+        const int64_t ldsel = first ? p.ldz0 : p.ldz;
+        if (first ? z0vec : zvec) {
 #pragma unroll
-      for (int u = 0; u < AB; ++u) zq[u] = it == 0 ? load_z8p(Z0g, p.ldz0, z0vec, jb + u) : load_z8p(Zg, p.ldz, zvec, jb + u);
+          for (int u = 0; u < AB; ++u) zq[u] = __builtin_amdgcn_raw_buffer_load_b128(rsel, z_off(ldsel, jb + u, 0), 0, 0);
+        } else {
+#pragma unroll
+          for (int u = 0; u < AB; ++u) zq[u] = load_z8p(first ? Z0g : Zg, rsel, ldsel, false, jb + u);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < AB; ++u) {
         const int j = jb + u;
