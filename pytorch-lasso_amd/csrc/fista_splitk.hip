@@ -70,6 +70,19 @@ constexpr size_t lds_bytes(int T) {
 }
 
 // STOP: compile the in-kernel global stop rule in (needs every tile in a resident group slot).
+// Descriptor of `rows` rows of a row-major matrix from row0 on (null base or rows <= 0: nothing, every read 0) and a
+// 4-byte load at (r, cc) through it -- r >= rows is out of range by the record count, `col_ok` false by the offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rows_rsrc(const float* base, int64_t ld, int row0, int rows) {
+  const int64_t bytes = (base && rows > 0) ? (int64_t)rows * ld * 4 : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base + (int64_t)row0 * ld : base), 0,
+                                           (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+}
+__device__ __forceinline__ float tile_rows_load(const __amdgpu_buffer_rsrc_t rs, int64_t ld, int r, int cc, bool col_ok) {
+  unsigned o = col_ok ? (unsigned)(r * (int)ld + cc) * 4u : 0xfffffff0u;
+  asm volatile("" : "+v"(o));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+}
+
 template <int K, int T, bool STOP>
 __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const FistaTileParams p) {
   // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
@@ -197,22 +210,29 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_kernel(const Fi
       const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
+      // (through buffer descriptors of the tile's rows, offset out of range where there is nothing to read, offsets
+      // opaque: as `in ? load : 0` every one of these 16 loads sat in a branch of its own with an s_waitcnt vmcnt(0)
+      // behind it -- 16 to 24 memory round trips in a row at the head of every tile round; round 5)
+      const int trows = (t < nt) ? min((int)kTileM, p.n - row0) : 0;
+      const __amdgpu_buffer_rsrc_t zsrc = tile_rows_rsrc(p.z_in, p.ldz_in, row0, trows);
+      const __amdgpu_buffer_rsrc_t ysc = tile_rows_rsrc(ysrc, ldy, row0, trows);
+      const __amdgpu_buffer_rsrc_t xsc = tile_rows_rsrc(mem == 0 ? p.X : nullptr, p.ldx, row0, trows);
+      float yv[4];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int r = 4 * q + rg, cc = col0 + n;
-        const bool in = t < nt && (row0 + r) < p.n && cc < p.k;
-        zreg[t][rg] = (p.z_in && in) ? p.z_in[(int64_t)(row0 + r) * p.ldz_in + cc] : 0.0f;
-        const float yv = (ysrc && in) ? ysrc[(int64_t)(row0 + r) * ldy + cc] : 0.0f;
-        *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n)) = yv;
+        zreg[t][rg] = tile_rows_load(zsrc, p.ldz_in, r, cc, cc < p.k);
+        yv[rg] = tile_rows_load(ysc, ldy, r, cc, cc < p.k);
       }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n)) = yv[rg];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         f32x4 xn;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
-          float v = 0.0f;
-          if (mem == 0 && t < nt && (row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+          const float v = tile_rows_load(xsc, p.ldx, r, cc, cc < p.d);
           xn[rg] = -v;                                   // members > 0 start their chain at 0
         }
         *(lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16) = xn;
@@ -646,22 +666,29 @@ __global__ __launch_bounds__(kFistaThreads, 2) void fista_splitk_rs_kernel(const
       const int row0 = (grp + p.groups * (T * round + t)) * kTileM;
       const float* ysrc = p.y_in ? p.y_in : p.z_in;
       const int64_t ldy = p.y_in ? p.ldy_in : p.ldz_in;
+      // (through buffer descriptors of the tile's rows, offset out of range where there is nothing to read, offsets
+      // opaque: as `in ? load : 0` every one of these 16 loads sat in a branch of its own with an s_waitcnt vmcnt(0)
+      // behind it -- 16 to 24 memory round trips in a row at the head of every tile round; round 5)
+      const int trows = (t < nt) ? min((int)kTileM, p.n - row0) : 0;
+      const __amdgpu_buffer_rsrc_t zsrc = tile_rows_rsrc(p.z_in, p.ldz_in, row0, trows);
+      const __amdgpu_buffer_rsrc_t ysc = tile_rows_rsrc(ysrc, ldy, row0, trows);
+      const __amdgpu_buffer_rsrc_t xsc = tile_rows_rsrc(mem == 0 ? p.X : nullptr, p.ldx, row0, trows);
+      float yv[4];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int r = 4 * q + rg, cc = col0 + n;
-        const bool in = t < nt && (row0 + r) < p.n && cc < p.k;
-        zreg[t][rg] = (p.z_in && in) ? p.z_in[(int64_t)(row0 + r) * p.ldz_in + cc] : 0.0f;
-        const float yv = (ysrc && in) ? ysrc[(int64_t)(row0 + r) * ldy + cc] : 0.0f;
-        *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(r, 16 * wid + n)) = yv;
+        zreg[t][rg] = tile_rows_load(zsrc, p.ldz_in, r, cc, cc < p.k);
+        yv[rg] = tile_rows_load(ysc, ldy, r, cc, cc < p.k);
       }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) *(lds_f32*)(yt + t * YT_BYTES + tile_off<kSlice>(4 * q + rg, 16 * wid + n)) = yv[rg];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         f32x4 xn;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 4 * q + rg, cc = 32 * wid + 16 * cb + n;
-          float v = 0.0f;
-          if (mem == 0 && t < nt && (row0 + r) < p.n && cc < p.d) v = p.X[(int64_t)(row0 + r) * p.ldx + cc];
+          const float v = tile_rows_load(xsc, p.ldx, r, cc, cc < p.d);
           xn[rg] = -v;
         }
         *(lds_f32x4*)(xt + t * RT_BYTES + wid * 2048 + cb * 1024 + lane * 16) = xn;
