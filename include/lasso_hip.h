@@ -393,7 +393,8 @@ size_t lasso_conv_ista_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t 
 /* Name of the device kernel(s) lasso_conv_ista_solve dispatches this geometry to on the current device (the names
  * rocprofv3 --kernel-trace reports): "lasso::conv_fused_kernel<..>" when whole iterations run as one kernel with a
  * workgroup per image -- up to 64 iterations per launch -- or per band of an image (stride 1, fewer than 8 channels,
- * K <= 128, small images; N >= the number of CUs, or K <= 64 and bands whose halo is cheap), else the synthesis kernel +
+ * K <= 128, small images; at least a third as many images as CUs, or K <= 64 and bands whose halo is cheap), else the
+ * synthesis kernel +
  * the gradient/prox kernel of the two-launch form. */
 const char* lasso_conv_ista_kernel_name(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                                         int64_t Hz, int64_t Wz, int kh, int kw, int sh, int sw, int ph, int pw);

@@ -3,8 +3,8 @@
 // adjoint g = conv2d(x_hat - x, W), the proximal step, the momentum step and the iteration's sum |z - z+|, with ONE
 // WORKGROUP PER IMAGE -- images are independent, so a workgroup carries its image through up to 64 iterations of a launch
 // (the stop rule's per-iteration sums are written out per workgroup and added up afterwards: lasso_conv_ista_solve's
-// speculate-and-replay scheme reads them once per chunk).  With fewer images than CUs (and K <= 64) an image is cut into
-// BANDS of code rows, one work item each: a band synthesises the kh - 1 code rows of halo on either side again (only
+// speculate-and-replay scheme reads them once per chunk).  With fewer images than CUs (and K <= 64) an image may be cut
+// into BANDS of code rows, one work item each (fused_plan: whichever of the two forms is cheaper): a band synthesises the kh - 1 code rows of halo on either side again (only
 // while that is <= 60 % more synthesis), reads its neighbours' rows of the OLD y (so y goes from one buffer to another)
 // and the launch boundary is the grid-wide barrier: one iteration per launch.
 // What the two-kernel form (conv_synth_few.hip + conv.hip) pays for and this one does not: the residual never leaves the
@@ -32,7 +32,7 @@
 // taps before the second part's (the `split` case below) -- and the element-wise steps written with the same operations.
 // Only the iteration's sum |z - z+| is added in another (fixed) order.
 // Eligibility (launcher): stride 1, C < 8, K <= 128 a multiple of 4, C kh kw <= 80, kw <= 7, at most 4096 residual values
-// per item, N >= the number of CUs or (K <= 64) bands whose halo costs <= 60 %.
+// per item; whole images from a third of the CUs on, bands (K <= 64, halo <= 60 %) where they are the cheaper form.
 // Roofline: HBM -- z, y read and written once, y read a second time by phase B (+ the bands' halo rows): 9.8 flop per
 // byte at 1 x 7 x 7 taps and 64 atoms, below the fp32 MFMA ridge.
 // Measured and not kept: the gradient blocks of the rows a chunk completes right behind that chunk,
@@ -479,19 +479,28 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   if ((int64_t)g.Hz * g.Wz * g.K * 4 >= ((int64_t)1 << 31) || (int64_t)g.Hz * g.Wz >= 16384 || g.H + g.ph >= 4096 || g.W + g.pw >= 4096) return false;
   pl->NT = (ckk + 15) / 16;
   pl->KQ = g.K <= 16 ? 1 : g.K <= 32 ? 2 : g.K <= 64 ? 4 : 8;
-  // whole images when there is one for every CU; else bands of code rows (each synthesises kh - 1 code rows of halo on
-  // either side again: only while that is at most 60 % more synthesis)
+  // Whole images (a workgroup per image, up to 64 iterations per launch) or bands of code rows (more work items than
+  // images; each band synthesises kh - 1 code rows of halo on either side again -- only while that is at most 60 % more
+  // synthesis and K <= 64 --, one iteration per launch).  With an image for every CU: whole.  Below that the cheaper
+  // of the two by rows of work per workgroup and launch round (synthesis + gradient rows; bands pay ~15 % for their
+  // launch per iteration), whole images only from a third of the CUs on (measured, tools/ab_conv_small_batches.py:
+  // N=255 ... 96 grey-scale 32 x 32 images 47 ... 38 us per iteration against 80 ... 58 of the two-kernel form, a tie
+  // at N=64 where 3 x 32 x 32 images lose, 43 against 34; 3 x 32 x 32: N=200 whole 46 / bands 61, N=128 whole 44 / bands 37).
   pl->bands = 1;
   pl->BR = g.Hz;
   if (g.N < cus) {
+    const bool whole_ok = (int64_t)g.C * g.H * g.W <= kCfMaxOut * kCfThreads && 3 * (int64_t)g.N >= cus;
     const int want = (cus + g.N - 1) / g.N;
-    pl->BR = (g.Hz + want - 1) / want;
-    pl->bands = (g.Hz + pl->BR - 1) / pl->BR;
-    if (pl->bands < 2 || 10 * (pl->BR + 2 * (g.kh - 1)) > 16 * pl->BR) return false;
+    const int br = (g.Hz + want - 1) / want, nb = (g.Hz + br - 1) / br;
+    bool bands_ok = nb >= 2 && 10 * (br + 2 * (g.kh - 1)) <= 16 * br && pl->KQ <= 4 &&
+                    (int64_t)g.C * std::min(g.H, br + g.kh - 1) * g.W <= kCfMaxOut * kCfThreads;
     // measured (profiles/r05_conv/ab_conv_fused.txt): N=64 3x64x64 images in four bands, 64 atoms 105 against 123 us per
     // iteration of the two-kernel form, 128 atoms 224 against 211 -- the synthesis in two halves does not carry the halo
-    if (pl->KQ > 4) return false;
-    if (const char* e = getenv("LASSO_CONV_FUSED_BANDS"); e && e[0] == '0') return false;
+    if (const char* e = getenv("LASSO_CONV_FUSED_BANDS"); e && e[0] == '0') bands_ok = false;
+    const double cost_whole = whole_ok ? 2.0 * g.Hz : 1e300;
+    const double cost_bands = bands_ok ? 1.15 * (2.0 * br + 2.0 * (g.kh - 1)) * (double)(((int64_t)g.N * nb + cus - 1) / cus) : 1e300;
+    if (cost_whole >= 1e300 && cost_bands >= 1e300) return false;
+    if (cost_bands < cost_whole) { pl->BR = br; pl->bands = nb; }
   }
   const int rhb = pl->BR + g.kh - 1;
   pl->outs_max = g.C * std::min(g.H, rhb) * g.W;

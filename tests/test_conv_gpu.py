@@ -190,7 +190,7 @@ def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
 
 @pytest.mark.parametrize("n_spec,C,K,kh,kw,padding,Hz,Wz", [
     # n_spec >= 0: N = CUs + n_spec images (a workgroup per image, up to 64 iterations per launch);
-    # n_spec < 0: N = CUs // -n_spec images, each cut into bands of code rows (one launch per iteration)
+    # n_spec < -1: N = CUs // -n_spec images, each cut into bands of code rows (one launch per iteration)
     # the BASELINE-like geometry: 49 taps in four column blocks, 64 atoms, 26-pixel code rows -- rows 4, 9, 14, ... hold
     # a multiple of 128 code pixels (the two-kernel form's chunk cuts, whose order of the taps the kernel reproduces)
     (0, 1, 64, 7, 7, 0, 12, 26),
@@ -208,7 +208,10 @@ def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
     # the convolution's zero padding), y through two buffers
     (-4, 2, 48, 3, 3, 1, 40, 24),
     # two bands of twenty rows, 7 x 7 taps: the two-kernel form's chunk cuts counted from the first code row of ITS bands
-    (-2, 1, 32, 7, 7, 3, 40, 26)])
+    (-2, 1, 32, 7, 7, 3, 40, 26),
+    # n_spec -1: N = CUs - 37 -- fewer images than CUs but still a workgroup per image (bands would cost 3x the
+    # synthesis); the two-kernel form cuts THESE images into two bands, whose chunk cuts the overlap-add follows per row
+    (-1, 1, 64, 7, 7, 0, 12, 26)])
 def test_many_iterations_per_launch_kernel(n_spec, C, K, kh, kw, padding, Hz, Wz):
     """conv_fused.hip: small few-channel images run whole iterations in one kernel, a workgroup per image (up to 64
     iterations per launch) or per band of an image (one per launch).  Against the oracle (the usual fp32 bound), BITWISE
@@ -219,7 +222,7 @@ def test_many_iterations_per_launch_kernel(n_spec, C, K, kh, kw, padding, Hz, Wz
     from lasso_amd import _native as nat
     ista_conv2d, _, _, _, orc = _mods()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    N = cus + n_spec if n_spec >= 0 else cus // -n_spec
+    N = cus + n_spec if n_spec >= 0 else cus - 37 if n_spec == -1 else cus // -n_spec
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     assert b"conv_fused_kernel" in nat.lib().lasso_conv_ista_kernel_name(*_geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz))
     os.environ["LASSO_CONV_FUSED"] = "0"
