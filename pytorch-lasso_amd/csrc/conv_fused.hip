@@ -17,7 +17,7 @@
 //   phase A  (synthesis)  rows = code pixels, columns = the C kh kw taps, contraction over the K atoms (in two halves
 //            when K > 64): COLS[pixel][tap] = sum_k Ym[pixel][k] W[k][tap] for a chunk of R whole code rows, each wave a
 //            16-pixel MFMA row block at a time, the block stored to LDS at [row][v + kw - 1][tap] (kw - 1 zero columns
-//            either side); then every thread adds the taps that reach its <= 8 output pixels, kept in registers across
+//            either side); then every thread adds the taps that reach its <= 16 output pixels, kept in registers across
 //            chunks.
 //   phase B  (gradient + prox)  rows = code pixels, columns = the K atoms, contraction over the taps: every wave takes
 //            16-pixel blocks (x all atoms, or x a half / a quarter of them when K > 32) on its own (no barrier): the
@@ -31,8 +31,8 @@
 // 128-pixel chunks (counted from the first code row of ITS band of image rows) cut a code row in two, the first part's
 // taps before the second part's (the `split` case below) -- and the element-wise steps written with the same operations.
 // Only the iteration's sum |z - z+| is added in another (fixed) order.
-// Eligibility (launcher): stride 1, C < 8, K <= 128 a multiple of 4, C kh kw <= 80, kw <= 7, at most 4096 residual values
-// per item; whole images from a third of the CUs on, bands (K <= 64, halo <= 60 %) where they are the cheaper form.
+// Eligibility (launcher): stride 1, C < 8, K <= 128 a multiple of 4, C kh kw <= 80, kw <= 7, at most 8192 residual values
+// per item (2, 8 or 16 per thread); whole images from a third of the CUs on, bands (K <= 64, halo <= 60 %) where they are the cheaper form.
 // Roofline: HBM -- z, y read and written once, y read a second time by phase B (+ the bands' halo rows): 9.8 flop per
 // byte at 1 x 7 x 7 taps and 64 atoms, below the fp32 MFMA ridge.
 // Measured and not kept: the gradient blocks of the rows a chunk completes right behind that chunk,
@@ -69,7 +69,8 @@ typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
-constexpr int kCfWaves = 8, kCfThreads = 64 * kCfWaves, kCfMaxOut = 8, kCfMaxKw = 7, kCfMaxIters = 64;
+constexpr int kCfWaves = 8, kCfThreads = 64 * kCfWaves, kCfMaxOut = 16, kCfMaxKw = 7, kCfMaxIters = 64;
+constexpr int kSynthFewOuts = 8 * 512;       // conv_synth_few_kernel's outputs per band (kSfMaxOut kSfThreads): its band height
 constexpr unsigned kCfOor = 0xfffffff0u;       // buffer offset beyond every image: reads 0, stores dropped
 
 struct ConvFused {
@@ -488,6 +489,13 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   // at N=64 where 3 x 32 x 32 images lose, 43 against 34; 3 x 32 x 32: N=200 whole 46 / bands 61, N=128 whole 44 / bands 37).
   pl->bands = 1;
   pl->BR = g.Hz;
+  if (g.N > cus) {
+    // more images than CUs: rounds of a workgroup per image; a thin last round on LARGE images costs more than the
+    // two-kernel form's finer tiles (N=300 2x60x60 images, 32 3x3 atoms: 249 against 220 us per iteration; with 20x20
+    // code grids 31 against 60)
+    const int64_t rounds = (g.N + cus - 1) / cus;
+    if ((double)g.N < 0.7 * (double)(rounds * cus) && (double)g.Hz * g.Wz * g.K * ckk > 1e6) return false;
+  }
   if (g.N < cus) {
     const bool whole_ok = (int64_t)g.C * g.H * g.W <= kCfMaxOut * kCfThreads && 3 * (int64_t)g.N >= cus;
     const int want = (cus + g.N - 1) / g.N;
@@ -507,7 +515,7 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   if (pl->outs_max > kCfMaxOut * kCfThreads) return false;
   // conv_synth_few_kernel's bands of image rows for this problem (launch_conv_synth_few): the order of its overlap-add
   {
-    int rb = std::min(g.H, (kCfMaxOut * kCfThreads) / (g.C * g.W));
+    int rb = std::min(g.H, kSynthFewOuts / (g.C * g.W));
     const int want = (cus + g.N - 1) / g.N;
     if (want > 1) rb = std::min(rb, std::max(std::min(g.kh, g.H), (g.H + want - 1) / want));
     pl->old_rb = std::max(rb, 1);
@@ -543,6 +551,7 @@ hipError_t fused_launch(const ConvFused& p, int grid, size_t lds, hipStream_t st
 template <int NT, int KQ>
 hipError_t fused_launch_mc(int outs, const ConvFused& p, int grid, size_t lds, hipStream_t stream) {
   if (outs <= 2 * kCfThreads) return fused_launch<NT, KQ, 2>(p, grid, lds, stream);
+  if (outs <= 8 * kCfThreads) return fused_launch<NT, KQ, 8>(p, grid, lds, stream);
   return fused_launch<NT, KQ, kCfMaxOut>(p, grid, lds, stream);
 }
 
@@ -594,7 +603,7 @@ const char* conv_fused_kernel_name(const ConvGeom& g, int cus) {
   FusedPlan pl;
   if (!fused_plan(g, cus, &pl)) return nullptr;
   static thread_local char name[64];
-  snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ, pl.outs_max <= 2 * kCfThreads ? 2 : kCfMaxOut);
+  snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ, pl.outs_max <= 2 * kCfThreads ? 2 : pl.outs_max <= 8 * kCfThreads ? 8 : kCfMaxOut);
   return name;
 }
 

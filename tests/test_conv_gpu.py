@@ -209,6 +209,9 @@ def _geom_args(N, C, K, kh, kw, ph, pw, Hz, Wz):
     (-4, 2, 48, 3, 3, 1, 40, 24),
     # two bands of twenty rows, 7 x 7 taps: the two-kernel form's chunk cuts counted from the first code row of ITS bands
     (-2, 1, 32, 7, 7, 3, 40, 26),
+    # more than 4096 residual values per image: sixteen outputs per thread (the two-kernel form cuts such images into
+    # bands even at N = CUs)
+    (0, 3, 24, 5, 5, 2, 40, 38),
     # n_spec -1: N = CUs - 37 -- fewer images than CUs but still a workgroup per image (bands would cost 3x the
     # synthesis); the two-kernel form cuts THESE images into two bands, whose chunk cuts the overlap-add follows per row
     (-1, 1, 64, 7, 7, 0, 12, 26)])

@@ -13,7 +13,9 @@ if os.environ.get("AB_CONV_CASES") == "fused":     # geometries of the one-launc
              (256, 3, 32, 5, 1, 2, 32), (300, 2, 48, 3, 1, 1, 20), (256, 1, 64, 7, 1, 3, 32), (777, 1, 24, 5, 1, 1, 13),
              (256, 4, 12, 3, 1, 0, 30), (1024, 1, 40, 7, 1, 2, 16),
              # K = 128 (atoms contracted in two halves), and N < CUs: bands of code rows with their halos, one launch per iteration
-             (256, 3, 128, 5, 1, 2, 32), (300, 1, 128, 7, 1, 0, 20), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (96, 2, 48, 3, 1, 1, 20)]
+             (256, 3, 128, 5, 1, 2, 32), (300, 1, 128, 7, 1, 0, 20), (64, 3, 128, 5, 1, 2, 64), (64, 3, 64, 5, 1, 2, 64), (96, 2, 48, 3, 1, 1, 20),
+             # more than 4096 residual values per image (16 outputs per thread), N below and above the number of CUs
+             (256, 3, 24, 5, 1, 2, 40), (256, 1, 64, 7, 1, 0, 64), (256, 3, 64, 5, 1, 2, 44), (200, 1, 64, 7, 1, 0, 26), (128, 1, 16, 3, 1, 1, 8)]
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd")]
     import hashlib, time, torch

@@ -11,6 +11,9 @@ python tools/bench_conv_fused.py > $O/conv_fused.json 2> $O/conv_fused.err
 { echo "# tools/ab_conv.py env:LASSO_CONV_FUSED=0 (us per iteration at 20 iterations, tol = 0; product = the dispatch, other side = the two-kernel form)";
   python tools/ab_conv.py env:LASSO_CONV_FUSED=0; echo "# AB_CONV_CASES=fused"; AB_CONV_CASES=fused python tools/ab_conv.py env:LASSO_CONV_FUSED=0; } > $O/ab_conv_fused.txt 2>&1
 python tools/conv_fused_timeline.py > $O/conv_fused_timeline.txt 2>&1
+python tools/ab_conv_small_batches.py 2>&1 | grep -v amdgpu.ids > $O/ab_conv_small_batches.txt
+python tools/stress_conv_fused.py 400 2>&1 | grep -v amdgpu.ids > $O/stress_conv_fused.txt
+python tools/stress_conv.py 150 2>&1 | grep -v amdgpu.ids > $O/stress_conv.txt
 bash tools/ab_conv_fused_phases.sh run > $O/ab_conv_fused_phases.txt 2>&1
 rm -f $O/pmc_fused.txt
 bash tools/pmc_counters.sh gpurun_out/r05_conv/pmc_fused.txt "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" conv_fused_kernel tools/bench_conv.py --no-cpu --case 0 > /dev/null

@@ -25,8 +25,8 @@ for trial in range(trials):
     kh, kw = (ks, ks) if ri(0, 4) else (ks, max(1, ks - 2))
     ph, pw = ri(0, kh - 1), ri(0, kw - 1)
     banded = ri(0, 2) == 0
-    Hz, Wz = (ri(8, 48), ri(4, 40)) if banded else (ri(1, 30), ri(1, 34))
-    N = [cus // 2, cus // 3, cus // 4, cus - 1][ri(0, 3)] if banded else cus + ri(0, 40)
+    Hz, Wz = (ri(8, 48), ri(4, 40)) if banded else (ri(1, 30), ri(1, 34)) if ri(0, 3) else (ri(20, 64), ri(20, 64))
+    N = [cus // 2, cus // 3, cus // 4, cus - 1][ri(0, 3)] if banded else cus + ri(0, 40) if ri(0, 2) else cus - ri(1, 160)
     H, W_ = (Hz - 1) - 2 * ph + kh, (Wz - 1) - 2 * pw + kw
     if H < 1 or W_ < 1:
         continue
