@@ -60,6 +60,11 @@ extern "C" int lasso_debug_cf_stamps(unsigned long long* host_out) {
 #define CF_STAMP_WAVE(slot) do { } while (0)
 #endif
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load / store in flight
+// (vmcnt(0)) -- the next chunk's A operands and the next gradient block's z, y pieces are requested early precisely so
+// that they stay in flight across these barriers
+#define CF_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 namespace lasso {
 namespace {
 
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         for (int t = 0; t < KQ; ++t) av[t] = an[t];
       }
       load_a(i_c + p.R, wid, av);                                              // the next chunk's first block: in flight under the taps
-      __syncthreads();
+      CF_LDS_BARRIER();
       CF_STAMP(3 + 3 * ((i_c - s0) / p.R));
       // ---- overlap-add: code rows ascending, taps b ascending (rr = kw - 1 - b descending) ----
       // KW = the kernel width when it is 3, 5 or 7 (no per-tap masks), else 0: widths up to 7 behind masks
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
         case 7: add_taps(std::integral_constant<int, 7>{}); break;
         default: add_taps(std::integral_constant<int, 0>{}); break;
       }
-      __syncthreads();
+      CF_LDS_BARRIER();
       CF_STAMP(4 + 3 * ((i_c - s0) / p.R));
     }
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(kCfThreads) void conv_fused_kernel(const ConvFused 
       const int pr = oi & 0xfff, jb = (oi >> 12) & 0xfff, ch = oi >> 24;
       rimg[(ch * p.RHB + pr - c0) * p.RW + jb] = acc[m] - xr[m];
     }
-    __syncthreads();
+    CF_LDS_BARRIER();
     CF_STAMP(26);
 
     // ======================= phase B: gradient, prox, momentum of the band's code rows =======================

@@ -22,6 +22,10 @@
 #include <type_traits>
 #include "lasso_kernels.h"
 
+// workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every global operation in flight: the
+// next chunk's A operands are requested before the barriers so that they arrive under the stores and the overlap-add)
+#define SF_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 namespace lasso {
 namespace {
 
@@ -134,12 +138,12 @@ __global__ __launch_bounds__(kSfThreads, (NT * KQ <= 4 && !BLDS) ? 4 : 2) void c
             cacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], b, cacc[c], 0, 0, 0);
           }
       if (chunk + 1 < nchunks) load_a(chunk + 1, av);              // in flight during the stores and the gather
-      __syncthreads();                                             // the previous chunk's gather is done
+      SF_LDS_BARRIER();                                             // the previous chunk's gather is done
 #pragma unroll
       for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) cols[(16 * wid + 4 * q + rg) * PITCH + 16 * c + l15] = cacc[c][rg];
-      __syncthreads();
+      SF_LDS_BARRIER();
       // ---- gather: code rows of this chunk, ascending; taps b ascending ----
       const int f_lo = kSfChunk * chunk, f_hi = min(f_lo + kSfChunk, npx) - 1;
       const int ia = i_lo + f_lo / g.Wz, ib = i_lo + f_hi / g.Wz, lim = f_hi - f_lo;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kSfThreads, (NT * KQ <= 4 && !BLDS) ? 4 : 2) void c
       else if (mcount <= 4) finish(std::integral_constant<int, 4>{});
       else finish(std::integral_constant<int, kSfMaxOut>{});
     }
-    __syncthreads();                                               // cols is rewritten by the next item
+    SF_LDS_BARRIER();                                               // cols is rewritten by the next item
   }
 }
 
