@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LASSO_HIP_ABI_VERSION 6
+#define LASSO_HIP_ABI_VERSION 7
 
 typedef enum {
   LASSO_OK = 0,
@@ -47,11 +47,14 @@ typedef enum {
   LASSO_ERR_HIP = 4,          /* HIP runtime error (no device, launch failure, ...)    */
   LASSO_WARN_LINESEARCH = 5,  /* backtracking failed, reverted to lr0 (ista.py:48-52)  */
   LASSO_PENDING = 6,          /* LASSO_SOLVE_ASYNC: enqueued; call lasso_fista_solve_finish */
-  LASSO_WARN_ABORTED = 7      /* lasso_fista_solve_finish: the asynchronous solve must be repeated
+  LASSO_WARN_ABORTED = 7,     /* lasso_fista_solve_finish: the asynchronous solve must be repeated
                                  with LASSO_STOP_GLOBAL_CHUNKED -- the in-kernel stop rule gave up
                                  (a workgroup was not resident; z_out untouched), or the rule fired
                                  before the end of an asynchronously enqueued chunk (z_out holds a
                                  later iterate)                                            */
+  LASSO_PENDING_MAPPED = 8    /* LASSO_SOLVE_ASYNC | LASSO_SOLVE_STATUS_MAPPED: enqueued, and the verdict's
+                                 four words will be written to the caller's mapped host buffer by the
+                                 verdict kernel itself -- no lasso_fista_solve_collect needed          */
 } lasso_status;
 
 typedef enum { LASSO_F32 = 0, LASSO_BF16 = 1 } lasso_dtype;
@@ -108,6 +111,15 @@ typedef enum {
  * pays when it stops a long solve early).  Same words from lasso_fista_solve_finish / _collect; when the rule
  * does fire early they say "redo" (LASSO_WARN_ABORTED) exactly as for any other one-chunk solve. */
 #define LASSO_SOLVE_ONE_CHUNK 0x10000
+/* OR into stop_mode together with LASSO_SOLVE_ASYNC: `iters_out` is not a plain host int but FOUR int32 words of
+ * device-writable host memory (pinned and mapped, e.g. hipHostMalloc / torch pin_memory()).  When the solve is
+ * enqueued as one chunk judged on the device (always with LASSO_SOLVE_ONE_CHUNK; otherwise when the batch has more
+ * tiles than resident workgroups) the verdict kernel writes {iterations, last delta (float bits), redo, 0} there
+ * itself and the call returns LASSO_PENDING_MAPPED: the words are valid once an event recorded behind the call has
+ * completed -- no copy launch, no collect call on the step's dependent chain (round 6: the copy and the idle gap
+ * behind it were ~10 us of every EM step).  A solve that takes the in-kernel rule returns LASSO_PENDING as before
+ * (the buffer is then not written; collect as usual). */
+#define LASSO_SOLVE_STATUS_MAPPED 0x20000
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
  * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device
  * memory -- no host round trip; other paths synchronise once to fetch it. */
@@ -260,6 +272,65 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
                      int32_t* degenerate_dev, int32_t* ndeg_out,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 int32_t* lasso_dict_sweep_count(int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes);
+
+/* lasso_dict_sweep without a host wait (ABI 7): the count of degenerate atoms is written by the sweep's last kernel to
+ * `ndeg_mapped`, ONE int32 of device-writable host memory (pinned, mapped) -- valid once an event recorded behind the
+ * call has completed.  Replaces the copy of lasso_dict_sweep_count()'s word on the EM step's dependent chain. */
+int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd,
+                           int64_t d, int64_t k, int dtype, double eps, int positive,
+                           const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
+                           int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+
+/* ---- Pipelined constrained M-step (ABI 7; dict_learning.py:44-45,82-101 in Gram form) -------------
+ * The sweep of atom block b needs rows b of A = Z^T Z and of U = B - A D^T only, and walks the blocks far slower
+ * than the chip produces them.  For d == 256, k a multiple of 256 (512 ... 4096) the M-step therefore exists in a
+ * form that overlaps the two: [A | B] is produced in STAGES of whole block rows (256 atoms each) into ONE matrix
+ * ab [k][k + d] (A in columns 0 .. k-1, B behind it, row pitch ldab >= k + d); stage 0 (the head: the first half of
+ * the block rows) before the sweep starts, the others on a SECOND stream while the sweep runs -- its workgroups wait,
+ * block by block, for the rows they need.  Per EM step, with `stages = lasso_mstep_pipe_stages(n, d, k)` (0: no
+ * pipelined form, use lasso_gram_accumulate + lasso_dict_sweep) and stage s covering rows
+ * lasso_mstep_pipe_stage_rows(s) of ab:
+ *     stream M:  pipe_gram(0) [all-reduce the head's rows of ab] pipe_rows(0, seq)                pipe_sweep ... pipe_finish
+ *     stream S:  pipe_wait(seq)   for s = 1 .. stages-1: pipe_gram(s) [all-reduce stage s' rows] pipe_rows(s)
+ * with everything of stream S ENQUEUED before pipe_sweep (if the two streams ever share a hardware queue the sweep
+ * then simply runs behind its producers) and pipe_finish -- the only call that changes the dictionary -- after
+ * whatever still reads the old one.  A stage's rows of ab are contiguous: one collective per stage, the first on the
+ * critical chain, the others hidden behind the sweep.  All calls of one step take the SAME workspace
+ * (lasso_mstep_pipe_workspace_bytes; caller-owned, shared by both streams, ZEROED once before its first use).
+ * Results: the dictionary of lasso_dict_sweep on the same (A, B) bit for bit -- the same products in the same order --;
+ * A and B themselves differ from lasso_gram_accumulate's in the last bits (other sample splits, hence another
+ * summation order). */
+int lasso_mstep_pipe_stages(int64_t n, int64_t d, int64_t k);
+int lasso_mstep_pipe_stage_rows(int64_t n, int64_t d, int64_t k, int stage, int64_t* row_lo, int64_t* row_hi);
+size_t lasso_mstep_pipe_workspace_bytes(int64_t n, int64_t d, int64_t k);
+/* the stage's rows of [A | B] from this process's n samples: per block row R the columns >= 256 R computed and folded,
+ * the blocks right of the diagonal also written transposed into the rows below (after the stages 0 .. s the rows of
+ * stage s are complete).  Stage 0 also resets the sweep's flag words. */
+int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n, int64_t d,
+                          int64_t k, int dtype, float* ab_dev, int64_t ldab, int stage, void* workspace_dev,
+                          size_t workspace_bytes, void* stream);
+/* "after the head" for stream S without an event record on stream M (an event between two kernels of a stream costs
+ * ~5 us there): pipe_rows(0, seq) leaves `seq` (any value that differs from the previous step's) in a word of the
+ * workspace when its last workgroup finishes; this call enqueues ONE wave that returns when it reads `seq` there (or
+ * after ~0.1 s: the ordering is a scheduling matter -- launches of the later stages in front of the head's would only
+ * take compute units from it -- no data depends on it). */
+int lasso_mstep_pipe_wait(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+/* U rows of the stage (B - A D^T with the dictionary as it is BEFORE the sweep); its last workgroup raises the
+ * "complete" words of the stage's block rows for the running sweep (stage 0: writes `seq` for lasso_mstep_pipe_wait). */
+int lasso_mstep_pipe_rows(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
+                          int64_t k, int dtype, int stage, int seq, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+/* the sweep (one launch of co-operating workgroups + its stand-by); new atoms stay in the workspace, d_dev is only read */
+int lasso_mstep_pipe_sweep(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
+                           int64_t k, int dtype, double eps, int positive, int32_t* degenerate_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+/* writes the new dictionary (degenerate atoms re-drawn from the counter-based generator, flagged in degenerate_dev as
+ * by lasso_dict_sweep); `ndeg_mapped` (nullable): device-writable host word for the count, as lasso_dict_sweep_async */
+int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
+                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+                            void* stream);
 int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
                                const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
                                int64_t pool_ld, int positive, void* stream);
@@ -311,6 +382,11 @@ float* lasso_fista_solve_deltas(int64_t n, int64_t d, int64_t k, int dtype, int 
 int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter,
                               double tol, const float* sums_dev, void* workspace_dev, size_t workspace_bytes,
                               void* stream);
+/* lasso_fista_solve_verdict + the four words written to `status_mapped` (device-writable host memory, as
+ * LASSO_SOLVE_STATUS_MAPPED) by the verdict kernel: no lasso_fista_solve_collect behind it (ABI 7). */
+int lasso_fista_solve_verdict_mapped(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter,
+                                     double tol, const float* sums_dev, int32_t* status_mapped, void* workspace_dev,
+                                     size_t workspace_bytes, void* stream);
 int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                              int32_t* iters_out, float* last_delta_out, void* workspace_dev,
                              size_t workspace_bytes, void* stream);

@@ -274,9 +274,18 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 // reduce_partial_sets_kernel for `iters` rows and chunk_verdict_kernel behind it in ONE workgroup (the asynchronous
 // E-step of an EM loop: one launch less on the step's dependent chain).  Every delta[i] is the same sum in the
 // same order as reduce_partials_kernel's.
-struct ChunkVerdict { float budget; int* out; };
+struct ChunkVerdict { float budget; int* out; int* mirror; };
+// the verdict's four words a second time, into a device-writable HOST buffer (pinned, mapped; LASSO_SOLVE_STATUS_MAPPED):
+// the caller's one host read per EM step then needs no copy launch behind the verdict
+__device__ __forceinline__ void mirror_status(int* mirror, int w0, int w1, int w2) {
+  if (!mirror) return;
+  __hip_atomic_store(mirror + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(mirror + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(mirror + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(mirror + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
-                                                              float budget, int* __restrict__ out) {
+                                                              float budget, int* __restrict__ out, int* mirror) {
   // One WAVE per row, rows w, w + 16, ... (16 waves: the 10 rows of an EM step's chunk in one pass): lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
   // (their strided sums), the first two levels of its tree are then this lane's (a0 + a2) + (a1 + a3), the last six
   // the shuffles below -- no barrier per row.
@@ -312,12 +321,14 @@ __global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets 
     out[1] = __float_as_int(last);
     out[2] = (hit >= 0 && hit + 1 < iters) ? 1 : 0;
     out[3] = 0;
+    mirror_status(mirror, out[0], out[1], out[2]);
   }
 }
 
 // the stop rule over one chunk's per-iteration deltas (ista.py:93-95): out = {iterations, last delta, redo, 0};
 // redo = the rule fired before the chunk's last iteration
-__global__ void chunk_verdict_kernel(const float* __restrict__ delta, int c, float budget, int* __restrict__ out) {
+__global__ void chunk_verdict_kernel(const float* __restrict__ delta, int c, float budget, int* __restrict__ out,
+                                     int* mirror) {
   int hit = -1;
   float last = delta[c - 1];
   for (int i = 0; i < c; ++i)
@@ -326,6 +337,7 @@ __global__ void chunk_verdict_kernel(const float* __restrict__ delta, int c, flo
   out[1] = __float_as_int(last);
   out[2] = (hit >= 0 && hit + 1 < c) ? 1 : 0;
   out[3] = 0;
+  mirror_status(mirror, out[0], out[1], out[2]);
 }
 
 int device_cus() {
@@ -611,7 +623,8 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     else if (tail) ps = {split_rows, nparts, nparts, ws.partials + main_tiles, tail, ntiles, ws.stop_out + 2,
                          ws.partials, main_tiles, ntiles};
     if (verdict && iters <= 64)
-      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(1024), 0, stream, ps, delta, iters, verdict->budget, verdict->out);
+      hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(1024), 0, stream, ps, delta, iters, verdict->budget, verdict->out,
+                         verdict->mirror);
     else
       hipLaunchKernelGGL(reduce_partial_sets_kernel, dim3(iters), dim3(256), 0, stream, ps, delta);
     LASSO_HIP_TRY(hipGetLastError());
@@ -1705,7 +1718,20 @@ const char* lasso_fista_kernel_name(int64_t n, int64_t d, int64_t k, int dtype, 
                                                                             : "lasso::bt16_persist_kernel<256>";
     return backtrack ? "lasso::bt16_grad_kernel / bt16_trial_kernel" : "lasso::bt16_grad_kernel + lasso::generic_prox_kernel";
   }
-  if (backtrack) return "lasso::bt_grad_kernel / bt_trial_kernel";
+  if (backtrack) {
+    // what run_bt() dispatches for fp32 tensors in one process (row pitch == k, 16-byte-aligned state as torch and
+    // hipMalloc hand it out): ONE bt_iter_kernel launch per outer iteration (accept + gradient + the first trials per
+    // tile; the first launch of a solve is the <K, false> instantiation: nothing to accept) + ONE bt_iter_decide_kernel;
+    // k not a multiple of 4 takes the multi-launch kernels of backtrack.hip
+    const int kpb = pad_k(k);
+    if ((k & 3) == 0 && k >= 4) {
+      static thread_local char bname[160];
+      snprintf(bname, sizeof(bname), "lasso::bt_iter_kernel<%d, true> / bt_iter_kernel<%d, false> + lasso::bt_iter_decide_kernel",
+               kpb, kpb);
+      return bname;
+    }
+    return "lasso::bt_grad_kernel / bt_trial_kernel";
+  }
   const SolveGeom geom = solve_geometry(n, d, k);
   const NarrowTiles narrow(geom.narrow);
   const int kp = geom.kp, dpad = pad_d(d, kp);
@@ -1800,7 +1826,8 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       int32_t* iters_out, float* last_delta_out, int32_t* trials_out,
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
-                      const double* lip_dev = nullptr, bool sharded = false, bool one_chunk = false) {
+                      const double* lip_dev = nullptr, bool sharded = false, bool one_chunk = false,
+                      int32_t* status_mapped = nullptr) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1991,15 +2018,16 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // repeats the solve synchronously, exactly like after an aborted handshake.  The E-step of an EM loop
   // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
   if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
-    const ChunkVerdict cv{budget, ws.stop_out};
+    const ChunkVerdict cv{budget, ws.stop_out, status_mapped};
     if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev, &cv))
       return s;
     if (maxiter > 64 || n == 0) {
-      hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out);
+      hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, st, ws.delta, maxiter, budget, ws.stop_out,
+                         status_mapped);
       LASSO_HIP_TRY(hipGetLastError());
     }
-    return LASSO_PENDING;
+    return status_mapped ? LASSO_PENDING_MAPPED : LASSO_PENDING;
   }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
   // replay the chunk up to the stopping iteration if one fired ----------
@@ -2078,7 +2106,13 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const bool async = (stop_mode & LASSO_SOLVE_ASYNC) != 0;
   const bool sharded = (stop_mode & LASSO_SOLVE_SHARDED) != 0;
   const bool one_chunk = (stop_mode & LASSO_SOLVE_ONE_CHUNK) != 0;
-  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK);
+  int32_t* status_mapped = nullptr;
+  if (stop_mode & LASSO_SOLVE_STATUS_MAPPED) {      // iters_out is a device-writable host buffer of four words
+    if (!async || !iters_out) return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_STATUS_MAPPED needs LASSO_SOLVE_ASYNC and iters_out");
+    status_mapped = iters_out;
+    iters_out = nullptr; last_delta_out = nullptr;
+  }
+  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK | LASSO_SOLVE_STATUS_MAPPED);
   if (sharded && !(async && tol > 0.0 && maxiter > 0 && n > 0 && fused_shape(d, k)))
     return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: asynchronous fp32 solves with tol > 0 on the fused shapes only");
   if (async && (objective_out || backtrack || dtype != LASSO_F32))
@@ -2115,7 +2149,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk);
+                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
@@ -2204,8 +2238,9 @@ float* lasso_fista_solve_deltas(int64_t n, int64_t d, int64_t k, int dtype, int 
   return workspace_bytes < ws.bytes ? nullptr : ws.delta;
 }
 
-int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
-                              const float* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+static int solve_verdict_impl(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                              const float* sums_dev, int32_t* status_mapped, void* workspace_dev, size_t workspace_bytes,
+                              void* stream) {
   if (dtype != LASSO_F32 || !fused_shape(d, k) || n <= 0 || n_global < n || maxiter <= 0 || maxiter > kChunkMax ||
       !(tol > 0.0))
     return fail(LASSO_ERR_BAD_ARG, "no pending sharded solve of this shape");
@@ -2213,9 +2248,23 @@ int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k,
   if (!workspace_dev || workspace_bytes < ws.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", ws.bytes);
   const float budget = (float)((double)n_global * (double)k * tol);   // ista.py:64 on the whole batch
   hipLaunchKernelGGL(chunk_verdict_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums_dev ? sums_dev : ws.delta,
-                     maxiter, budget, ws.stop_out);
+                     maxiter, budget, ws.stop_out, status_mapped);
   LASSO_HIP_TRY(hipGetLastError());
   return LASSO_OK;
+}
+
+int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                              const float* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return solve_verdict_impl(n, n_global, d, k, dtype, maxiter, tol, sums_dev, nullptr, workspace_dev, workspace_bytes, stream);
+}
+
+// the same verdict, its four words ALSO written to `status_mapped` (device-writable host memory): no collect call
+int lasso_fista_solve_verdict_mapped(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
+                                     const float* sums_dev, int32_t* status_mapped, void* workspace_dev,
+                                     size_t workspace_bytes, void* stream) {
+  if (!status_mapped) return fail(LASSO_ERR_BAD_ARG, "status_mapped is NULL");
+  return solve_verdict_impl(n, n_global, d, k, dtype, maxiter, tol, sums_dev, status_mapped, workspace_dev, workspace_bytes,
+                            stream);
 }
 
 // the synchronous form: collect, wait, decode
@@ -2377,10 +2426,11 @@ size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k) {
          (dp == 256 ? align_up(sweep_persist_extra_bytes((int)k)) : 0);
 }
 
-int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
-                     int64_t k, int dtype, double eps, int positive, const float* pool_dev,
-                     int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
-                     int32_t* ndeg_out, void* workspace_dev, size_t workspace_bytes, void* stream) {
+static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
+                           int64_t k, int dtype, double eps, int positive, const float* pool_dev,
+                           int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
+                           int32_t* ndeg_out, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+                           void* stream) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!a_dev || !b_dev || !d_dev || !degenerate_dev || !workspace_dev || d <= 0 || k <= 0 || ldd < k)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
@@ -2417,7 +2467,7 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
   p.Dout = direct ? D : nullptr; p.ldo = ldd;
   p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
-  p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg;
+  p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg; p.ndeg_mirror = ndeg_mapped;
   p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
   float* dt_new = Dt;
   LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
@@ -2427,6 +2477,168 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
   }
+  return LASSO_OK;
+}
+
+int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
+                     int64_t k, int dtype, double eps, int positive, const float* pool_dev,
+                     int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
+                     int32_t* ndeg_out, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return dict_sweep_impl(a_dev, b_dev, d_dev, ldd, d, k, dtype, eps, positive, pool_dev, pool_rows, pool_ld, seed,
+                         degenerate_dev, ndeg_out, nullptr, workspace_dev, workspace_bytes, stream);
+}
+
+// the same sweep without a host wait: the count of degenerate atoms goes to `ndeg_mapped`, a device-writable HOST word
+// (pinned, mapped), written by the sweep's last kernel -- valid once an event recorded behind this call has completed
+int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
+                           int64_t k, int dtype, double eps, int positive, const float* pool_dev,
+                           int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
+                           int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!ndeg_mapped) return fail(LASSO_ERR_BAD_ARG, "ndeg_mapped is NULL");
+  return dict_sweep_impl(a_dev, b_dev, d_dev, ldd, d, k, dtype, eps, positive, pool_dev, pool_rows, pool_ld, seed,
+                         degenerate_dev, nullptr, ndeg_mapped, workspace_dev, workspace_bytes, stream);
+}
+
+// ---- pipelined constrained M-step (ABI 7) -------------------------------------------------------
+// workspace = [the sweep's workspace (lasso_dict_sweep_workspace_bytes) | the Gram partial sums of every block row]
+namespace {
+struct PipeWs { SweepParams p; void* extra; float* gram; MstepPipePlan plan; size_t bytes; };
+// the SweepParams of every call of one pipelined M-step (the same carve of the same workspace each time)
+bool pipe_carve(int64_t n, int64_t d, int64_t k, void* workspace_dev, PipeWs* w) {
+  const int cus = device_cus();
+  w->plan = mstep_pipe_plan(n, d, k, cus);
+  if (w->plan.nstages == 0) return false;
+  const size_t sweep = align_up(lasso_dict_sweep_workspace_bytes(d, k));
+  w->bytes = sweep + w->plan.scratch_bytes + 256;
+  const int dp = 256;
+  char* base = (char*)workspace_dev;
+  float* U = (float*)base;
+  float* Dt = (float*)(base + align_up((size_t)k * dp * 4));
+  float* dD = (float*)((char*)Dt + align_up((size_t)k * dp * 4));
+  int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * dp * 4));
+  w->extra = (void*)((char*)ndeg + 256);
+  w->gram = (float*)(base + sweep);
+  SweepParams& p = w->p;
+  p.flags_cleared = 1;
+  p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
+  p.pool = nullptr; p.pool_rows = 0; p.pool_ld = 0; p.seed = 0;
+  p.ndeg_in_out = ndeg; p.ndeg_mirror = nullptr;
+  p.k = (int)k; p.d = (int)d;
+  return true;
+}
+}  // namespace
+
+int lasso_mstep_pipe_stages(int64_t n, int64_t d, int64_t k) {
+  if (n <= 0 || d <= 0 || k <= 0) return 0;
+  return mstep_pipe_plan(n, d, k, device_cus()).nstages;
+}
+
+int lasso_mstep_pipe_stage_rows(int64_t n, int64_t d, int64_t k, int stage, int64_t* row_lo, int64_t* row_hi) {
+  if (n <= 0 || d <= 0 || k <= 0 || !row_lo || !row_hi) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  const MstepPipePlan pl = mstep_pipe_plan(n, d, k, device_cus());
+  if (stage < 0 || stage >= pl.nstages) return fail(LASSO_ERR_BAD_ARG, "stage %d of %d", stage, pl.nstages);
+  *row_lo = 256 * (int64_t)pl.lo[stage];
+  *row_hi = 256 * (int64_t)pl.hi[stage];
+  return LASSO_OK;
+}
+
+size_t lasso_mstep_pipe_workspace_bytes(int64_t n, int64_t d, int64_t k) {
+  PipeWs w;
+  if (n <= 0 || d <= 0 || k <= 0 || !pipe_carve(n, d, k, nullptr, &w)) return 0;
+  return w.bytes;
+}
+
+int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n, int64_t d,
+                          int64_t k, int dtype, float* ab_dev, int64_t ldab, int stage, void* workspace_dev,
+                          size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  PipeWs w;
+  if (!z_dev || !x_dev || !ab_dev || !workspace_dev || n <= 0 || ldz < k || ldx < d || ldab < k + d)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for n=%lld d=%lld k=%lld",
+                                                           (long long)n, (long long)d, (long long)k);
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  if (stage < 0 || stage >= w.plan.nstages) return fail(LASSO_ERR_BAD_ARG, "stage %d of %d", stage, w.plan.nstages);
+  if ((ldab & 3) || ((uintptr_t)ab_dev & 15)) return fail(LASSO_ERR_BAD_ARG, "[A | B] must be 16-byte aligned, pitch a multiple of 4");
+  // the head's launch also clears the sweep's flag words: it sits in front of every launch that sets or reads them
+  int* const flags = stage == 0 ? sweep_persist_flags(w.extra, (int)k) : nullptr;
+  LASSO_HIP_TRY(launch_gram_rows((const float*)z_dev, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, ab_dev, ldab,
+                                 stage, w.plan, w.gram, flags, flags ? 1024 : 0, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+int lasso_mstep_pipe_wait(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
+                          void* stream) {
+  PipeWs w;
+  if (!workspace_dev) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  LASSO_HIP_TRY(launch_wait_word(sweep_pipe_words(w.extra, (int)k) + 1, seq, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+int lasso_mstep_pipe_rows(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
+                          int64_t k, int dtype, int stage, int seq, void* workspace_dev, size_t workspace_bytes,
+                          void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  PipeWs w;
+  if (!ab_dev || !d_dev || !workspace_dev || ldd < k || ldab < k + d) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  if (stage < 0 || stage >= w.plan.nstages) return fail(LASSO_ERR_BAD_ARG, "stage %d of %d", stage, w.plan.nstages);
+  hipStream_t st = (hipStream_t)stream;
+  const int lo = w.plan.lo[stage], hi = w.plan.hi[stage];
+  const int64_t r0 = 256 * (int64_t)lo;
+  // U[j] = B[j] - sum_i A[j][i] D[:, i]   for the rows j of the block (dict_learning.py:82 in Gram form)
+  // (uprod_rows_kernel: bitwise launch_gemm_nt_sub's product; its last workgroup raises the block row's flag)
+  if ((ldab & 3) || (ldd & 3) || ((uintptr_t)ab_dev & 15) || ((uintptr_t)d_dev & 15))
+    return fail(LASSO_ERR_BAD_ARG, "[A | B] and the dictionary must be 16-byte aligned, pitches multiples of 4");
+  // (the head: `seq` into the word lasso_mstep_pipe_wait watches -- the head of the chain is through; the other
+  // stages: the flags of their block rows for the running sweep)
+  int* const words = sweep_pipe_words(w.extra, (int)k);
+  int* const flag = stage > 0 ? sweep_persist_flags(w.extra, (int)k) + kSweepRowFlag + lo : words + 1;
+  LASSO_HIP_TRY(launch_uprod_rows(ab_dev + r0 * ldab, ldab, (const float*)d_dev, ldd, ab_dev + r0 * ldab + k, ldab,
+                                  w.p.U + r0 * 256, 256, 256 * (hi - lo), (int)k, words + 8 + stage, flag,
+                                  stage > 0 ? hi - lo : 1, stage > 0 ? 1 : seq, st));
+  return LASSO_OK;
+}
+
+int lasso_mstep_pipe_sweep(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
+                           int64_t k, int dtype, double eps, int positive, int32_t* degenerate_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  PipeWs w;
+  if (!ab_dev || !d_dev || !degenerate_dev || !workspace_dev || ldd < k || ldab < k + d)
+    return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  if ((k & 3) || (ldd & 3) || ((uintptr_t)d_dev & 15)) return fail(LASSO_ERR_BAD_ARG, "the dictionary must be 16-byte aligned, pitch a multiple of 4");
+  SweepParams& p = w.p;
+  p.A = ab_dev; p.lda = ldab;
+  p.Dsrc = (const float*)d_dev; p.ldd = ldd;
+  p.Dout = (float*)const_cast<void*>(d_dev); p.ldo = ldd;      // (only launch_sweep_fixup writes it: lasso_mstep_pipe_finish)
+  p.degenerate = degenerate_dev; p.eps = (float)eps; p.positive = positive;
+  float* dt_new = nullptr;
+  LASSO_HIP_TRY(launch_sweep_gated(p, w.extra, 256 / kSweepBlock, w.plan.hi[0], &dt_new, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
+                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+                            void* stream) {
+  if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
+  PipeWs w;
+  if (!d_dev || !degenerate_dev || !workspace_dev || ldd < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  SweepParams& p = w.p;
+  p.A = nullptr; p.lda = 0;
+  p.Dsrc = (const float*)d_dev; p.ldd = ldd;
+  p.Dout = (float*)d_dev; p.ldo = ldd;
+  p.degenerate = degenerate_dev; p.eps = (float)eps; p.positive = positive;
+  p.ndeg_mirror = ndeg_mapped;
+  p.Dt = (float*)w.extra;                      // the single-launch sweep's new atoms (SweepPersist::DtN)
+  LASSO_HIP_TRY(launch_sweep_fixup(p, (hipStream_t)stream));
   return LASSO_OK;
 }
 

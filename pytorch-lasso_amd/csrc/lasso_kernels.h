@@ -86,6 +86,8 @@ struct SweepParams {
   int64_t pool_ld; unsigned long long seed;
   int* degenerate;                       // [k] out: 1 where the atom was re-initialised
   int* ndeg_in_out;                      // [1] running count of degenerate atoms
+  int* ndeg_mirror;                      // nullable: a second, device-writable HOST word (pinned, mapped) that receives the
+                                         //   final count as well -- the caller's one host read per EM step then needs no copy
   int k, d;
   float eps; int positive;
   int flags_cleared;                     // the caller had the single-launch sweep's flag words cleared (by the launch in front)
@@ -262,6 +264,34 @@ size_t sweep_persist_extra_bytes(int k);
 int* sweep_persist_flags(void* persist_extra, int k);      // the 1024 flag words inside `persist_extra`
 hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* persist_extra = nullptr,
                              float** dt_out = nullptr);
+// ---- pipelined constrained M-step (round 6; mstep.hip): [A | B] = Z^T [Z | X] by block rows of 256 atoms, the sweep
+// launched once the first block row's U rows exist and gated on the others
+constexpr int kPipeMaxBlocks = 16;     // k <= 4096
+struct MstepPipePlan {
+  int nstages;                          // 0: this shape has no pipelined form
+  int lo[kPipeMaxBlocks], hi[kPipeMaxBlocks];   // stage s produces block rows lo .. hi - 1 (256 atoms each)
+  int blocks[kPipeMaxBlocks];           // 256 x 256 output blocks of the stage's Gram launch
+  int splits[kPipeMaxBlocks];           // its sample splits
+  int rps[kPipeMaxBlocks];              // samples per split
+  size_t scratch_off[kPipeMaxBlocks];   // byte offset of the stage's partial sums inside the Gram scratch
+  size_t scratch_bytes;
+};
+MstepPipePlan mstep_pipe_plan(int64_t n, int64_t d, int64_t k, int cus);
+hipError_t launch_gram_rows(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* AB,
+                            int64_t ldab, int stage, const MstepPipePlan& plan, float* scratch, int* clear_words, int nclear,
+                            hipStream_t stream);
+hipError_t launch_set_flag(int* flag, int value, hipStream_t stream);
+hipError_t launch_wait_word(const int* word, int seq, hipStream_t stream);
+hipError_t launch_uprod_rows(const float* A, int64_t lda, const float* Bm, int64_t ldb, const float* C0, int64_t ldc0,
+                             float* U, int64_t ldu, int rows, int kk, int* ticket, int* flag, int nflags, int flag_value,
+                             hipStream_t stream);
+// the pipeline's own words behind the sweep's flags and debug stamps (never cleared by a launch: the caller zeroes the
+// workspace once): [0] ticket of block row 0's Gram launch, [1] its "finished" sequence number, [8 + R] ticket of
+// block row R's U product
+int* sweep_pipe_words(void* persist_extra, int k);
+hipError_t launch_sweep_gated(const SweepParams& p, void* persist_extra, int gate, int gate0, float** dt_out, hipStream_t stream);
+hipError_t launch_sweep_fixup(const SweepParams& p, hipStream_t stream);
+constexpr int kSweepRowFlag = 192;     // word R of the sweep's flags from here: block row R of [A | U] is complete
 // unconstrained M-step (ridge.hip): V [d][k] = ((A + lam I)^-1 B)^T by blocked Cholesky, k <= 4096
 size_t ridge_workspace_bytes(int64_t d, int64_t k);
 hipError_t launch_ridge_solve(const float* A, const float* B, float* V, int64_t ldv, int d, int k, float lam,

@@ -326,12 +326,28 @@ __global__ __launch_bounds__(256) void sum_splits_sym_kernel(const float* __rest
 // ---------------------------------------------------------------------------
 constexpr int kG3B = 256, kG3S = 32, kG3Ld = 272;
 
+// GramRows (the pipelined M-step, round 6): only the blocks of ONE block row `bi` -- A's (bi, bi .. nb-1), then B's --
+// with the partials of a split holding that block row alone ([256][k + d] per split), so that a row block can use
+// as many sample splits as fill the chip on its own; `clear`: words the first workgroup zeroes (the single-launch
+// sweep's flags: the launch sits in front of everything that sets or reads them).
+struct GramRows {
+  int bi; int bi_hi;                   // block rows bi .. bi_hi - 1 (bi < 0: the whole product, the partials' usual layout)
+  int* clear; int nclear;
+  int* ticket; int* done; int seq;     // nullable: the workgroup that finishes last writes `seq` to *done (and resets the ticket)
+};
 __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict__ Z, int64_t ldz, int k,
                                                          const float* __restrict__ X, int64_t ldx, int d, int n,
-                                                         float* __restrict__ part, int rows_per_split) {
+                                                         float* __restrict__ part, int rows_per_split, const GramRows gr) {
   const int nb = k / kG3B, nsym = nb * (nb + 1) / 2;
+  if (gr.clear && blockIdx.x == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < gr.nclear; i += 512) gr.clear[i] = 0;
   int bi, bj;                                     // bj < nb: A block (bj >= bi);  bj >= nb: B block, X columns 256 (bj - nb)
-  if ((int)blockIdx.x < nsym) {
+  if (gr.bi >= 0) {
+    int rem = blockIdx.x;                         // block row bi has nb - bi blocks of A and d / 256 of B
+    bi = gr.bi;
+    while (rem >= nb - bi + d / kG3B) { rem -= nb - bi + d / kG3B; ++bi; }
+    bj = bi + rem;                                // (rem >= nb - bi: the B blocks)
+  } else if ((int)blockIdx.x < nsym) {
     int rem = blockIdx.x;
     bi = 0;
     while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
@@ -347,7 +363,8 @@ __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict
   const float* const Q = bj < nb ? Z + (int64_t)n_lo * ldz + kG3B * bj : X + (int64_t)n_lo * ldx + kG3B * (bj - nb);
   const int64_t ldq = bj < nb ? ldz : ldx;
   const int64_t ldc = k + d;
-  float* const C = part + (int64_t)blockIdx.z * k * ldc + (int64_t)(kG3B * bi) * ldc + kG3B * bj;   // (bj >= nb lands behind column k)
+  float* const C = gr.bi >= 0 ? part + ((int64_t)blockIdx.z * (gr.bi_hi - gr.bi) + (bi - gr.bi)) * kG3B * ldc + kG3B * bj
+                              : part + (int64_t)blockIdx.z * k * ldc + (int64_t)(kG3B * bi) * ldc + kG3B * bj;
   extern __shared__ __attribute__((aligned(16))) float g3_smem[];
   float* const sp = g3_smem;                               // [2][32][272]
   float* const sq = g3_smem + 2 * kG3S * kG3Ld;
@@ -409,6 +426,18 @@ __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
         C[(int64_t)(64 * wr + 16 * mi + 4 * q + rg) * ldc + 128 * wc + 16 * nj + l15] = acc[mi][nj][rg];
+  if (gr.ticket) {
+    // "this launch has finished" for a launch on ANOTHER stream that should not start before (pipelined M-step: the
+    // later block rows would only take CUs from this one) -- a performance hint, nothing reads data on its strength
+    __syncthreads();
+    if (tid == 0) {
+      const int total = (int)(gridDim.x * gridDim.z);
+      if (__hip_atomic_fetch_add(gr.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+        __hip_atomic_store(gr.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gr.done, gr.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // Both folds of gram_ab256_kernel's partials in one launch: workgroups [0, nsym) are sum_splits_sym_kernel's on
@@ -425,6 +454,121 @@ __global__ __launch_bounds__(256) void sum_splits_ab_kernel(const float* __restr
   if (idx >= (int64_t)k * d) return;
   const int64_t r = idx / d, c = idx - r * d;
   B[r * d + c] = ordered_split_sum(part + k + r * ldpart + c, split_stride, splits);
+}
+
+// Fold of ONE block row of gram_ab256_kernel's row mode into AB [k][k + d] (A | B side by side, row pitch ldab):
+// one workgroup per 32 x 32 tile of the block row's columns 256 bi .. k + d; tiles of A below the diagonal (inside
+// the diagonal block) are left to their mirror images, tiles of A right of it are also written transposed into the
+// block rows below -- after the folds of block rows 0 .. R the rows of block R are complete.  Sums in split order.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ part, int splits, int64_t split_stride,
+                                                        int64_t ldpart, int k, int d, int bi_lo, float* __restrict__ AB,
+                                                        int64_t ldab) {
+  __shared__ float t[32][33];
+  int bi = bi_lo, rem = blockIdx.x;                        // block row bi has 8 tile rows of (k - 256 bi + d) / 32 tiles
+  while (rem >= 8 * ((k - kG3B * bi + d) / 32)) { rem -= 8 * ((k - kG3B * bi + d) / 32); ++bi; }
+  const int tcols = (k - kG3B * bi + d) / 32;              // tiles per tile row
+  const int ti = rem / tcols, tj = rem - ti * tcols;
+  const int r0 = 32 * ti, c0 = kG3B * bi + 32 * tj;        // row inside the block row, column of [A | B]
+  part += (int64_t)(bi - bi_lo) * kG3B * ldpart;           // this block row's rows inside a split's partial
+  const bool isA = c0 < k;
+  if (isA && c0 < kG3B * bi + r0) return;                  // below the diagonal: written as a mirror image
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < splits; s0 += kFoldBatch) {
+    float v[4][kFoldBatch];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int u = 0; u < kFoldBatch; ++u)
+        v[a][u] = part[(int64_t)min(s0 + u, splits - 1) * split_stride + (int64_t)(r0 + ty + 8 * a) * ldpart + c0 + tx];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int u = 0; u < kFoldBatch; ++u)
+        if (s0 + u < splits) acc[a] += v[a][u];
+  }
+  const int gr0 = kG3B * bi + r0;                          // global row of the tile
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = ty + 8 * a;
+    t[i][tx] = acc[a];
+    AB[(int64_t)(gr0 + i) * ldab + c0 + tx] = acc[a];
+  }
+  if (!isA) return;
+  __syncthreads();
+  if (c0 != gr0)      // (a diagonal tile is its own mirror image: the same products in the same order on both sides)
+    for (int i = ty; i < 32; i += 8) AB[(int64_t)(c0 + i) * ldab + gr0 + tx] = t[tx][i];   // the mirror tile
+}
+
+// one word, written through at agent scope: "the rows of block R of [A | U] are complete" (pipelined M-step)
+__global__ void set_flag_kernel(int* flag, int value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave that returns once *word == seq (or after ~0.1 s): stream order behind it then means "after that launch of
+// another stream" without an event record on the other stream (~5 us between two of its kernels).
+__global__ void wait_word_kernel(const int* word, int seq) {
+  for (int spins = 0; spins < (1 << 20); ++spins) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+// U rows of one block row of the pipelined M-step:  U[256][256] = C0 - A Bm^T,  A = rows of [A | B] (K = k atoms),
+// Bm = the dictionary [256 features][k], C0 = the B part of the same rows.  ONE WAVE per 16 x 16 output block, the
+// operands straight from global memory as 16-byte pieces (lane (l15, q) takes K = 16 c + 4 q .. + 3 of row l15: the
+// fragment gemm_nt_kernel reads from its LDS image), ONE accumulator chain over K ascending -- bitwise the product of
+// gemm_nt_kernel (launch_gemm_nt_sub), without its staging barriers: the launch is latency, not throughput (256 x 256
+// outputs), and it sits on the EM step's dependent chain for block row 0.  The workgroup that finishes last publishes
+// the block row's flag (nullable) for the running sweep.
+__global__ __launch_bounds__(64) void uprod_rows_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+                                                        int64_t ldb, const float* __restrict__ C0, int64_t ldc0,
+                                                        float* __restrict__ U, int64_t ldu, int kk, int* ticket, int* flag,
+                                                        int nflags, int flag_value) {
+  const int lane = threadIdx.x, l15 = lane & 15, q = lane >> 4;
+  const int ti = blockIdx.x >> 4, tj = blockIdx.x & 15;          // 16 x 16 tiles of the 256 x 256 block
+  const float* const ap = A + (int64_t)(16 * ti + l15) * lda + 4 * q;
+  const float* const bp = Bm + (int64_t)(16 * tj + l15) * ldb + 4 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int kBatch = 8;                                        // 16-float pieces per operand in flight (2 x 8 x 4 VGPRs), double buffered
+  f32x4 a[2][kBatch], b[2][kBatch];
+  const int npiece = kk / 16;
+  auto fetch = [&](int buf, int c0) {
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int c = min(c0 + i, npiece - 1);
+      a[buf][i] = *(const f32x4*)(ap + 16 * c);
+      b[buf][i] = *(const f32x4*)(bp + 16 * c);
+    }
+  };
+  fetch(0, 0);
+  for (int c0 = 0; c0 < npiece; c0 += 2 * kBatch) {
+    fetch(1, c0 + kBatch);
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][i][j], b[0][i][j], acc, 0, 0, 0);
+    if (c0 + 2 * kBatch < npiece) fetch(0, c0 + 2 * kBatch);
+    if (c0 + kBatch < npiece) {
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][i][j], b[1][i][j], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int r = 16 * ti + 4 * q + rg, c = 16 * tj + l15;
+    U[(int64_t)r * ldu + c] = C0[(int64_t)r * ldc0 + c] - acc[rg];
+  }
+  if (flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < nflags; ++i) __hip_atomic_store(flag + i, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // C[r][c] = sum_s part[s][r][c]  (fixed order)
@@ -690,7 +834,12 @@ struct SweepPersist {
   int solo;            // 1: one workgroup, no workers
   int wg_stride;       // worker i is workgroup i * wg_stride (8: every worker on the sweeper's XCD)
   const int* run_if;   // nullable: run only if *run_if != 0 (the stand-by launch)
+  int gate0;           // first group of rows that is NOT complete when the launch starts (see gate)
+  int gate;            // > 0 (pipelined M-step): the rows of [A | U] arrive in groups of `gate` blocks while the sweep runs;
+                       //   flags[kSpRowFlag + R] != 0 once the rows of blocks gate R .. gate R + gate - 1 are complete
+                       //   (the groups below gate0 are complete before the launch)
 };
+constexpr int kSpRowFlag = 192;     // (below the debug stamps at word 256)
 constexpr int kSpSelf = 1;      // newest deltas the sweeper applies itself
 static_assert(kSpSelf == 1, "the LDS delta buffers are shared with the next block's old atoms");
 
@@ -730,6 +879,15 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
     float* const sAn = smem;                                 // [2][32][34]
     __shared__ int sh_dead;
     if (tid == 0) sh_dead = 0;
+    if (x.gate > 0 && r / x.gate >= x.gate0) {
+      // pipelined M-step: this block's rows of A and U are still being produced (another stream) when the launch
+      // starts -- wait for their group's word, then make this CU read them afresh
+      __syncthreads();
+      if (tid == 0 && !spin_until(x.flags + kSpRowFlag + r / x.gate, 1, f_abort)) sh_dead = 1;
+      __syncthreads();
+      if (sh_dead) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // (through a buffer descriptor, offset out of range where the element is padding, offsets opaque: behind a select
     // hipcc moved each of these 32 loads under the condition, a branch of its own with an s_waitcnt vmcnt(0) -- 32 memory
     // round trips in a row before a worker could take its first deltas; round 5)
@@ -1078,6 +1236,12 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
         if (!solo && lane == 0) __hip_atomic_store(f_pub, 4 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (nb < nblk) {
+        if (x.gate > 0 && nb % x.gate == 0 && nb / x.gate >= x.gate0) {   // first block of a group of rows that arrive while we run
+          bool ok = true;
+          if (lane == 0) ok = spin_until(x.flags + kSpRowFlag + nb / x.gate, 1, f_abort);
+          if (__builtin_amdgcn_readfirstlane((int)ok) == 0) sh_abort = 1;   // (a_staged still advances: nobody hangs)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         stage_a(nb, par ^ 1, tdyn & 63, I64{});
         a_staged = nb;                                       // (behind the tile's writes: LDS keeps a wave's order)
       }
@@ -1106,6 +1270,12 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
         if (w == 2) SP_STAMP(7);
         bool ok = true;
         const bool from_worker = !solo && nb > kSpSelf;
+        if (!from_worker && x.gate > 0 && nb / x.gate >= x.gate0) {
+          // (gated solo sweep: U rows straight from the product -- wave 1 has seen their group's word)
+          while (a_staged < nb) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (sh_abort) ok = false;
+        }
         if (from_worker) {
           if (lane == 0) ok = spin_until(f_rows + nb, 1, f_abort);
           ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
@@ -1456,6 +1626,7 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const SweepParams p) {
         if (s_deg[jj]) s_idx[c++] = jj;
     s_count = c;
     p.ndeg_in_out[0] = c;
+    if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   if (s_count) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1505,6 +1676,7 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
     for (int t = 0; t < 256; ++t) { const int v = s_cnt[t]; s_cnt[t] = c; c += v; }
     s_count = c;
     p.ndeg_in_out[0] = c;
+    if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   if (mine) {
@@ -1572,7 +1744,10 @@ __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams 
   __syncthreads();
   if (tid == 0) {
     const int b = s_bsum, t = s_tsum;
-    if (blockIdx.x == 0) p.ndeg_in_out[0] = t;
+    if (blockIdx.x == 0) {
+      p.ndeg_in_out[0] = t;
+      if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     int n = 0;
     if (t)
       for (int a = 0; a < nb_at; ++a)
@@ -1755,7 +1930,8 @@ bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t 
   const int sp = (n + rps - 1) / rps;
   const size_t lds = (size_t)4 * kG3S * kG3Ld * 4;
   if ((*err = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_ab256_kernel), lds)) != hipSuccess) return true;
-  hipLaunchKernelGGL(gram_ab256_kernel, dim3(blocks, 1, sp), dim3(512), lds, stream, Z, ldz, k, X, ldx, d, n, scratch, rps);
+  hipLaunchKernelGGL(gram_ab256_kernel, dim3(blocks, 1, sp), dim3(512), lds, stream, Z, ldz, k, X, ldx, d, n, scratch, rps,
+                     GramRows{-1, -1, nullptr, 0, nullptr, nullptr, 0});
   const int64_t stride = (int64_t)k * (k + d);
   const int nt = (k + 31) / 32;
   const int nsym = nt * (nt + 1) / 2;
@@ -1866,7 +2042,12 @@ static hipError_t sweep_blocks(const SweepParams& p, hipStream_t stream) {
 
 size_t sweep_persist_extra_bytes(int k) {
   const size_t nblk = (size_t)(k + kSweepBlock - 1) / kSweepBlock;
-  return 3 * nblk * kSweepBlock * 256 * 4 + 4096 + nblk * 128;   // DtN, dDg, Uw, flags (+ debug time stamps)
+  return 3 * nblk * kSweepBlock * 256 * 4 + 4096 + nblk * 128 + 256;   // DtN, dDg, Uw, flags (+ debug time stamps), pipeline words
+}
+
+int* sweep_pipe_words(void* persist_extra, int k) {
+  const size_t nblk = (size_t)(k + kSweepBlock - 1) / kSweepBlock;
+  return (int*)((char*)persist_extra + 3 * nblk * kSweepBlock * 256 * 4 + 4096 + nblk * 128);
 }
 
 int* sweep_persist_flags(void* persist_extra, int k) {
@@ -1876,7 +2057,8 @@ int* sweep_persist_flags(void* persist_extra, int k) {
 
 // dp == 256: the single-launch sweep (+ its stand-by).  `extra` = sweep_persist_extra_bytes(k)
 // bytes; on return *dt_out is where the new atoms are (rows of length 256).
-static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt_out, hipStream_t stream) {
+static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt_out, hipStream_t stream, int gate = 0,
+                                   int gate0 = 1) {
   const int nblk = (p.k + kSweepBlock - 1) / kSweepBlock;
   const size_t rows = (size_t)nblk * kSweepBlock * 256;
   SweepPersist x;
@@ -1897,6 +2079,12 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
 #define LASSO_SWEEP_WG_STRIDE 8
 #endif
   x.wg_stride = LASSO_SWEEP_WG_STRIDE;
+  x.gate = gate;
+  x.gate0 = gate0;
+  // gated (pipelined M-step): other launches run beside the sweep and must find room on EVERY XCD (a launch's
+  // workgroups go round the XCDs; a workgroup of the sweep takes a CU's whole LDS): workers on consecutive
+  // workgroups -- four CUs per XCD instead of all 32 of one
+  if (gate > 0) x.wg_stride = 1;
   const int grid = x.solo ? 1 : (nblk - kSpSelf - 1) * x.wg_stride + 1;
   hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(256), lds, stream, p, x);
   if (!x.solo) {            // stand-by: runs only if the grid gave up (a workgroup was not resident)
@@ -1907,6 +2095,93 @@ static hipError_t sweep_persistent(const SweepParams& p, void* extra, float** dt
   }
   *dt_out = x.DtN;
   return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined M-step (round 6).  The sweep of atom block b needs rows b of A and of U = B - A D^T only, and it walks
+// the blocks at ~8 us each -- far slower than the chip produces them.  So [A | B] is produced by BLOCK ROWS of 256
+// atoms (gram_ab256_kernel's row mode: every block row with as many sample splits as fill the chip by itself, folded
+// by fold_rows_kernel, mirrored into the rows below), the sweep is launched as soon as block row 0's U rows exist, and
+// the later block rows are produced on a second stream while it runs, each announced by one flag word the sweep's
+// workers / staging wave wait for.  The caller (lasso_amd/parallel.py) owns the two streams and the all-reduce of a
+// block row between its fold and its U rows.
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(kSweepRowFlag == kSpRowFlag, "one definition of the row flags' place");
+MstepPipePlan mstep_pipe_plan(int64_t n, int64_t d, int64_t k, int cus) {
+  MstepPipePlan pl;
+  pl.nstages = 0; pl.scratch_bytes = 0;
+  if (d != kG3B || k % kG3B || k < 2 * kG3B || k > kSweepMaxK || k / kG3B > kPipeMaxBlocks || n < 1 || n > INT32_MAX / 2 ||
+      cus < 64)
+    return pl;
+  // Stages: the HEAD (the first half of the block rows, produced before the sweep starts) and then one block row per
+  // stage beside the sweep.  Why not the first block row alone: a worker of the sweep cannot start catching up on the
+  // deltas of the blocks in front of it before its rows of A and U exist (~2.3 us per block of deltas, measured), so the
+  // rows of block r are needed ~6 r us after the sweep starts, and row-mode production (more splits, more partial sums,
+  // three launches per stage) delivers 256 rows per ~75 us: with a one-block-row head the sweep stalled 43 + 36 us at
+  // the group boundaries (profiles/r06/pipe_stamps_4stage.txt).
+  const int nb = (int)(k / kG3B), workers = (int)(k / kSweepBlock);
+  const int head = (nb + 1) / 2;
+  size_t off = 0;
+  int lo = 0;
+  while (lo < nb) {
+    const int hi = lo == 0 ? head : lo + 1, s = pl.nstages++;
+    // the head runs before the sweep; the others beside it (the sweep holds one CU per worker), with a margin, so that
+    // every workgroup of a launch finds a CU at once (one workgroup per CU: LDS and registers)
+    const int avail = lo == 0 ? cus : std::max(cus - workers - 8, cus / 2);
+    int blocks = 0;
+    for (int r = lo; r < hi; ++r) blocks += nb - r + (int)(d / kG3B);
+    int splits = std::max(1, std::min(avail / blocks, kGramAbMaxSplits));
+    int rps = (int)(((n + splits - 1) / splits + kG3S - 1) / kG3S * kG3S);
+    rps = std::max(rps, 2 * kG3S);
+    splits = (int)((n + rps - 1) / rps);
+    pl.lo[s] = lo; pl.hi[s] = hi; pl.blocks[s] = blocks;
+    pl.splits[s] = splits; pl.rps[s] = rps; pl.scratch_off[s] = off;
+    off += ((size_t)splits * (hi - lo) * kG3B * (size_t)(k + d) * 4 + 255) & ~(size_t)255;
+    lo = hi;
+  }
+  pl.scratch_bytes = off;
+  return pl;
+}
+
+hipError_t launch_gram_rows(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* AB,
+                            int64_t ldab, int stage, const MstepPipePlan& plan, float* scratch, int* clear_words, int nclear,
+                            hipStream_t stream) {
+  if (stage < 0 || stage >= plan.nstages || (ldz & 3) || (ldx & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)X & 15)) return hipErrorInvalidValue;
+  const int lo = plan.lo[stage], hi = plan.hi[stage];
+  float* const part = (float*)((char*)scratch + plan.scratch_off[stage]);
+  const size_t lds = (size_t)4 * kG3S * kG3Ld * 4;
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_ab256_kernel), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(gram_ab256_kernel, dim3(plan.blocks[stage], 1, plan.splits[stage]), dim3(512), lds, stream, Z, ldz, k, X,
+                     ldx, d, n, part, plan.rps[stage], GramRows{lo, hi, clear_words, nclear, nullptr, nullptr, 0});
+  int tiles = 0;
+  for (int r = lo; r < hi; ++r) tiles += (kG3B / 32) * ((k - kG3B * r + d) / 32);
+  hipLaunchKernelGGL(fold_rows_kernel, dim3(tiles), dim3(256), 0, stream, part, plan.splits[stage],
+                     (int64_t)(hi - lo) * kG3B * (k + d), (int64_t)(k + d), k, d, lo, AB, ldab);
+  return hipGetLastError();
+}
+
+hipError_t launch_set_flag(int* flag, int value, hipStream_t stream) {
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, stream, flag, value);
+  return hipGetLastError();
+}
+
+hipError_t launch_wait_word(const int* word, int seq, hipStream_t stream) {
+  hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(1), 0, stream, word, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_uprod_rows(const float* A, int64_t lda, const float* Bm, int64_t ldb, const float* C0, int64_t ldc0,
+                             float* U, int64_t ldu, int rows, int kk, int* ticket, int* flag, int nflags, int flag_value,
+                             hipStream_t stream) {
+  if (rows % 16 || kk % 256 || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(uprod_rows_kernel, dim3(rows), dim3(64), 0, stream, A, lda, Bm, ldb, C0, ldc0, U, ldu, kk, ticket, flag,
+                     nflags, flag_value);
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_gated(const SweepParams& p, void* persist_extra, int gate, int gate0, float** dt_out, hipStream_t stream) {
+  if (p.dp != 256 || !persist_extra || !dt_out || !p.Dsrc || !p.Dout) return hipErrorInvalidValue;
+  return sweep_persistent(p, persist_extra, dt_out, stream, gate, gate0);
 }
 
 #ifndef LASSO_SWEEP_WAVES256
@@ -1940,6 +2215,14 @@ hipError_t launch_dict_sweep(const SweepParams& p, hipStream_t stream, void* per
   }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(degenerate_fixup_kernel, dim3(1), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+// last launch of the single-launch sweep, on its own (pipelined M-step: the caller decides when D may change):
+// repairs the degenerate atoms and writes the dictionary from the new atoms at p.Dt
+hipError_t launch_sweep_fixup(const SweepParams& p, hipStream_t stream) {
+  if (!p.Dout || p.dp != 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fixup_transpose_kernel, dim3((p.k + kSweepBlock - 1) / kSweepBlock), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -14,14 +14,15 @@ import torch
 
 LASSO_OK, LASSO_ERR_BAD_ARG, LASSO_ERR_UNSUPPORTED = 0, 1, 2
 LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
-LASSO_PENDING, LASSO_WARN_ABORTED = 6, 7
+LASSO_PENDING, LASSO_WARN_ABORTED, LASSO_PENDING_MAPPED = 6, 7, 8
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 KERNEL_AUTO, KERNEL_TILE, KERNEL_SPLITK = 0, 0x100, 0x200
 SOLVE_ASYNC = 0x4000
 SOLVE_ONE_CHUNK = 0x10000
 SOLVE_SHARDED = 0x8000
+SOLVE_STATUS_MAPPED = 0x20000       # iters_out = four words of pinned (device-writable) host memory
 LR_AUTO = -1.0
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -93,6 +94,27 @@ def _declare(lib):
     lib.lasso_dict_sweep.restype = i32
     lib.lasso_dict_sweep.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                      C.c_uint64, vp, C.POINTER(C.c_int32), vp, sz, vp]
+    lib.lasso_dict_sweep_async.restype = i32
+    lib.lasso_dict_sweep_async.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
+                                           C.c_uint64, vp, vp, vp, sz, vp]
+    lib.lasso_mstep_pipe_stages.restype = i32
+    lib.lasso_mstep_pipe_stages.argtypes = [i64, i64, i64]
+    lib.lasso_mstep_pipe_stage_rows.restype = i32
+    lib.lasso_mstep_pipe_stage_rows.argtypes = [i64, i64, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    lib.lasso_mstep_pipe_workspace_bytes.restype = sz
+    lib.lasso_mstep_pipe_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.lasso_mstep_pipe_gram.restype = i32
+    lib.lasso_mstep_pipe_gram.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, i64, i32, vp, sz, vp]
+    lib.lasso_mstep_pipe_wait.restype = i32
+    lib.lasso_mstep_pipe_wait.argtypes = [i64, i64, i64, i32, vp, sz, vp]
+    lib.lasso_mstep_pipe_rows.restype = i32
+    lib.lasso_mstep_pipe_rows.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]
+    lib.lasso_mstep_pipe_sweep.restype = i32
+    lib.lasso_mstep_pipe_sweep.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32, vp, vp, sz, vp]
+    lib.lasso_mstep_pipe_finish.restype = i32
+    lib.lasso_mstep_pipe_finish.argtypes = [vp, i64, i64, i64, i64, i32, dbl, i32, vp, vp, vp, sz, vp]
+    lib.lasso_fista_solve_verdict_mapped.restype = i32
+    lib.lasso_fista_solve_verdict_mapped.argtypes = [i64, i64, i64, i64, i32, i32, dbl, vp, vp, vp, sz, vp]
     lib.lasso_dict_sweep_count.restype = vp
     lib.lasso_dict_sweep_count.argtypes = [i64, i64, vp, sz]
     lib.lasso_fista_solve_sharded.restype = i32

@@ -139,18 +139,86 @@ class HipEngine:
         with torch.cuda.device(self.device):
             ws = self._ws(L.lasso_dict_sweep_workspace_bytes(d, k), "sweep")
             mask = torch.empty(k, dtype=torch.int32, device=self.device)     # the sweep writes every flag
-            nat.check(L.lasso_dict_sweep(
+            # the count goes straight into a pinned host word, written by the sweep's last kernel (no copy launch)
+            host = self._ndeg_word()
+            nat.check(L.lasso_dict_sweep_async(
                 nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
-                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), None, nat.ptr(ws), ws.numel(), self._stream()))
-            if getattr(self, "_ndeg_host", None) is None:
-                self._ndeg_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            host = self._ndeg_host
-            # the count the sweep's last kernel left in its workspace: 4 bytes to the host, no reduction launch
-            cptr = L.lasso_dict_sweep_count(d, k, nat.ptr(ws), ws.numel())
-            if not cptr:
-                raise nat.NativeError("lasso_dict_sweep_count: no count for d=%d k=%d" % (d, k))
-            off = int(cptr) - ws.data_ptr()
-            host.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.data_ptr(), nat.ptr(ws), ws.numel(),
+                self._stream()))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+
+        def result():
+            ev.synchronize()
+            return mask, int(host[0])
+        return result
+
+    def _ndeg_word(self):
+        """One int32 of pinned (device-writable) host memory from a small ring: a word is reused only after
+        several later sweeps have been enqueued."""
+        ring = getattr(self, "_ndeg_ring", None)
+        if ring is None:
+            ring = self._ndeg_ring = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)]
+        ring.append(ring.pop(0))
+        return ring[-1]
+
+    # -- pipelined constrained M-step (lasso_mstep_pipe_*, DESIGN.md 3.3g) -------------------------------------
+    def mstep_pipe_stages(self, d, k):
+        """Row ranges [(lo, hi), ...] of [A | B] that the stages of the pipelined M-step produce ([]: this dictionary
+        shape has no pipelined form).  Depends on d and k only -- every rank of an EM loop reaches the same answer."""
+        L = self.lib
+        out = []
+        for s_ in range(int(L.lasso_mstep_pipe_stages(1, d, k))):
+            lo, hi = C.c_int64(0), C.c_int64(0)
+            nat.check(L.lasso_mstep_pipe_stage_rows(1, d, k, s_, C.byref(lo), C.byref(hi)))
+            out.append((lo.value, hi.value))
+        return out
+
+    def mstep_pipe_workspace(self, n, d, k):
+        with torch.cuda.device(self.device):
+            nbytes = self.lib.lasso_mstep_pipe_workspace_bytes(max(int(n), 1), d, k)
+            return torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)   # (zeroed once: the tickets)
+
+    def pipe_gram(self, Z, X, AB, R, ws):
+        n, k = Z.shape
+        d = X.shape[1]
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_mstep_pipe_gram(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0), n, d, k,
+                                                     nat.LASSO_F32, nat.ptr(AB), AB.stride(0), int(R),
+                                                     nat.ptr(ws), ws.numel(), self._stream()))
+
+    def pipe_wait(self, n, d, k, seq, ws):
+        """(on the side stream) one wave that returns once block row 0's Gram launch of step `seq` has finished"""
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_mstep_pipe_wait(max(int(n), 1), d, k, int(seq), nat.ptr(ws), ws.numel(),
+                                                     self._stream()))
+
+    def pipe_rows(self, AB, D, n, R, ws, seq=0):
+        d, k = D.shape
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_mstep_pipe_rows(nat.ptr(AB), AB.stride(0), nat.ptr(D), D.stride(0), max(int(n), 1),
+                                                     d, k, nat.LASSO_F32, int(R), int(seq), nat.ptr(ws), ws.numel(),
+                                                     self._stream()))
+
+    def pipe_sweep(self, AB, D, n, eps, positive, ws):
+        """The gated sweep; returns the mask tensor its kernels fill.  D is only read."""
+        d, k = D.shape
+        with torch.cuda.device(self.device):
+            mask = torch.empty(k, dtype=torch.int32, device=self.device)
+            nat.check(self.lib.lasso_mstep_pipe_sweep(nat.ptr(AB), AB.stride(0), nat.ptr(D), D.stride(0),
+                                                      max(int(n), 1), d, k, nat.LASSO_F32, float(eps),
+                                                      int(bool(positive)), nat.ptr(mask), nat.ptr(ws), ws.numel(),
+                                                      self._stream()))
+        return mask
+
+    def pipe_finish(self, D, n, eps, positive, mask, ws):
+        """Writes the new dictionary; returns a callable giving (mask, ndeg) that waits for this launch only."""
+        d, k = D.shape
+        with torch.cuda.device(self.device):
+            host = self._ndeg_word()
+            nat.check(self.lib.lasso_mstep_pipe_finish(nat.ptr(D), D.stride(0), max(int(n), 1), d, k, nat.LASSO_F32,
+                                                       float(eps), int(bool(positive)), nat.ptr(mask),
+                                                       host.data_ptr(), nat.ptr(ws), ws.numel(), self._stream()))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
 

@@ -324,6 +324,9 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
         iters = C.c_int32(0)
         last = C.c_float(float('nan'))
         want_host = bool(return_info) or bool(verbose)
+        # asynchronous solves: the verdict kernel writes its four words straight into pinned host memory
+        # (LASSO_SOLVE_STATUS_MAPPED) -- no copy launch behind it on the EM step's dependent chain
+        status = _pinned_status(dev) if want_async and not shard else None
         want_trace = bool(backtrack) and bool(return_info)
         trials = (C.c_int32 * max(int(maxiter), 1))() if want_trace else None
         acc_lr = (C.c_float * max(int(maxiter), 1))() if want_trace else None
@@ -333,9 +336,10 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0) if zg is not None else 0,
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
             int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0) |
-            (nat.SOLVE_SHARDED if shard else 0),
+            (nat.SOLVE_SHARDED if shard else 0) | (nat.SOLVE_STATUS_MAPPED if status is not None else 0),
             int(bool(backtrack)), float(eta_backtrack),
-            C.byref(iters) if want_host else None, C.byref(last) if want_host else None, trials, acc_lr, acc_f,
+            C.cast(status.data_ptr(), C.POINTER(C.c_int32)) if status is not None else
+            (C.byref(iters) if want_host else None), C.byref(last) if want_host else None, trials, acc_lr, acc_f,
             C.byref(obj) if obj is not None else None, nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         pending = None
         if st == nat.LASSO_PENDING and shard:
@@ -349,16 +353,18 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
             def judge(reduced, n_global, ws=ws, shape=shape, dev=dev):
                 with torch.cuda.device(dev):
                     status = _pinned_status(dev)
-                    nat.check(L.lasso_fista_solve_verdict(shape[0], n_global, *shape[1:], nat.ptr(reduced), nat.ptr(ws),
-                                                          ws.numel(), nat.stream_ptr(dev)))
-                    nat.check(L.lasso_fista_solve_collect(*shape, status.data_ptr(), nat.ptr(ws), ws.numel(),
-                                                          nat.stream_ptr(dev)))
+                    nat.check(L.lasso_fista_solve_verdict_mapped(shape[0], n_global, *shape[1:], nat.ptr(reduced),
+                                                                 status.data_ptr(), nat.ptr(ws), ws.numel(),
+                                                                 nat.stream_ptr(dev)))
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(dev))
                 return status, ev
             pending = PendingShardedSolve(deltas, judge)
+        elif st == nat.LASSO_PENDING_MAPPED:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            pending = PendingSolve(status, ev)
         elif st == nat.LASSO_PENDING:
-            status = _pinned_status(dev)
             nat.check(L.lasso_fista_solve_collect(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
                                                   status.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))
             ev = torch.cuda.Event()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     L = _native.lib()
-    assert L.lasso_hip_abi_version() == 6
+    assert L.lasso_hip_abi_version() == 7
     assert L.lasso_hip_status_string(0) == b"ok"
     assert L.lasso_fista_workspace_bytes(4096, 256, 1024, 0, 100, 0.0, 0, 0) > 2 * 1024 * 1024
     assert L.lasso_fista_workspace_bytes(4096, 256, 4096, 0, 100, 0.0, 0, 0) > 0    # unfused path
