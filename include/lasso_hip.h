@@ -115,9 +115,10 @@ typedef enum {
  * device-writable host memory (pinned and mapped, e.g. hipHostMalloc / torch pin_memory()).  When the solve is
  * enqueued as one chunk judged on the device (always with LASSO_SOLVE_ONE_CHUNK; otherwise when the batch has more
  * tiles than resident workgroups) the verdict kernel writes {iterations, last delta (float bits), redo, 0} there
- * itself and the call returns LASSO_PENDING_MAPPED: the words are valid once an event recorded behind the call has
- * completed -- no copy launch, no collect call on the step's dependent chain (round 6: the copy and the idle gap
- * behind it were ~10 us of every EM step).  A solve that takes the in-kernel rule returns LASSO_PENDING as before
+ * itself -- the fourth word, "valid" = 1, last and released -- and the call returns LASSO_PENDING_MAPPED: a host that
+ * zeroed word 3 before the call POLLS it (or waits for an event recorded behind the call).  No copy launch, no
+ * collect call and no event record on the step's dependent chain (round 6: copy + event cost ~10 us of every EM step;
+ * an event record between two kernels of a stream is ~5 us by itself).  A solve that takes the in-kernel rule returns LASSO_PENDING as before
  * (the buffer is then not written; collect as usual). */
 #define LASSO_SOLVE_STATUS_MAPPED 0x20000
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
@@ -274,13 +275,19 @@ int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_
 int32_t* lasso_dict_sweep_count(int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes);
 
 /* lasso_dict_sweep without a host wait (ABI 7): the count of degenerate atoms is written by the sweep's last kernel to
- * `ndeg_mapped`, ONE int32 of device-writable host memory (pinned, mapped) -- valid once an event recorded behind the
- * call has completed.  Replaces the copy of lasso_dict_sweep_count()'s word on the EM step's dependent chain. */
+ * `ndeg_mapped`, TWO int32 words of device-writable host memory (pinned, mapped): {count, 1}, the second written last
+ * and released -- a host that zeroed it before the call polls it (or waits for an event recorded behind the call).  Replaces the copy of lasso_dict_sweep_count()'s word on the EM step's dependent chain. */
 int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd,
                            int64_t d, int64_t k, int dtype, double eps, int positive,
                            const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
+
+/* One wave on `stream` that returns when *word == value (or after ~0.1 s; host_memory != 0: `word` is pinned host
+ * memory, e.g. the "valid" word of a LASSO_SOLVE_STATUS_MAPPED buffer): "after that kernel of ANOTHER stream" for the
+ * launches behind it without an event record on the other stream.  A scheduling tool: use it only where a late or
+ * early start costs time, never where data depends on the order. */
+int lasso_stream_wait_word(const int32_t* word, int32_t value, int host_memory, void* stream);
 
 /* ---- Pipelined constrained M-step (ABI 7; dict_learning.py:44-45,82-101 in Gram form) -------------
  * The sweep of atom block b needs rows b of A = Z^T Z and of U = B - A D^T only, and walks the blocks far slower
@@ -326,11 +333,19 @@ int lasso_mstep_pipe_rows(const float* ab_dev, int64_t ldab, const void* d_dev, 
 int lasso_mstep_pipe_sweep(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
                            int64_t k, int dtype, double eps, int positive, int32_t* degenerate_dev, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
-/* writes the new dictionary (degenerate atoms re-drawn from the counter-based generator, flagged in degenerate_dev as
- * by lasso_dict_sweep); `ndeg_mapped` (nullable): device-writable host word for the count, as lasso_dict_sweep_async */
-int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
-                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+/* (on stream S, behind its last launch that reads the old dictionary) one thread that writes `seq` to the workspace
+ * word lasso_mstep_pipe_finish(wait_seq = seq) waits for */
+int lasso_mstep_pipe_signal(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
                             void* stream);
+/* writes the new dictionary (degenerate atoms re-drawn from the counter-based generator, flagged in degenerate_dev as
+ * by lasso_dict_sweep); `ndeg_mapped` (nullable): {count, valid} in device-writable host memory, as
+ * lasso_dict_sweep_async.  wait_seq != 0: the kernel itself waits (up to ~0.3 s) for lasso_mstep_pipe_signal(wait_seq)
+ * before it touches the dictionary -- instead of a cross-stream event wait in front of the launch (6-10 us on the
+ * step's chain); if the word never arrives the count comes back as -1 and the caller must treat the step as failed.
+ * wait_seq == 0: the caller has ordered the launch behind stream S itself. */
+int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
+                            int32_t* degenerate_dev, int32_t* ndeg_mapped, int wait_seq, void* workspace_dev,
+                            size_t workspace_bytes, void* stream);
 int lasso_dict_fill_degenerate(void* d_dev, int64_t ldd, int64_t d, int64_t k, int dtype,
                                const int32_t* degenerate_dev, const float* pool_dev, int64_t pool_rows,
                                int64_t pool_ld, int positive, void* stream);

@@ -57,7 +57,13 @@ namespace sp {
 // multiplies residual columns that are exactly zero with rows of W^T that are exactly zero, so leaving it out drops
 // only +-0 terms: d = 64 on the 128-wide tiles runs 2 of 4 chunks, d = 192 on the flagship tile 6 of 8.  The default
 // instantiations (DS = 0) are the code they were.
-template <int K, int M, bool STOP, int NW = kFistaWaves, int DS = 0>
+// ZS ("zero start", round 6): instantiations for launches from an all-zero code (z_in == y_in == NULL) that leave out
+// the first iteration's GEMM-1 -- see the loop below.  A separate instantiation because the branch costs the loop
+// body ~1 % (measured on the 100-iteration headline solve: 31.73 against 31.95 k it/s although it does 0.5 % less
+// work), which a short solve wins back five times over (10 iterations: 5 % of the MFMA work gone) and a long one does
+// not: launch_k() takes it for zero starts of at most kZeroStartIters iterations.
+constexpr int kZeroStartIters = 32;
+template <int K, int M, bool STOP, int NW = kFistaWaves, int DS = 0, bool ZS = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_tile_sp_kernel(const FistaTileParams p) {
   // step size and threshold: launch arguments, or device memory (lr = LASSO_LR_AUTO)
   const float lr_ = p.lr_dev ? p.lr_dev[0] : p.lr, lam_ = p.lr_dev ? p.lr_dev[1] : p.lam;
@@ -158,6 +164,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
 
       // ======================= GEMM-1: r = y W^T - x =========================
       f32x4 acc[2] = {xneg[0], xneg[1]};
+      // Round 6 (ZS instantiations): the first iteration of an ALL-ZERO start (z_in == y_in == NULL: the E-step of an
+      // EM loop, sparse_encode's default) has y = 0, so r = -x exactly -- every product of this GEMM is 0 w and the chain
+      // returns what it started from (the sign of a zero residual of a zero feature aside).  It is left out: the wave
+      // drops the two W steps it has in flight and primes its ring with the first three steps of W^T instead (two DMA
+      // latencies against 16 us of MFMAs: 5 % of a 10-iteration E-step).  Codes bitwise those of the full iteration.
+      const bool skip1 = ZS && it == 0;
+      unsigned long long gr[4] = {0ull, 0ull, 0ull, 0ull};
+      const bool check = STOP && p.stop_on && it > 0;
+      const unsigned long long* const grow =
+          p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * p.ntiles : nullptr;
+      if (skip1) {
+        LASSO_WAIT_VMCNT(0);                         // W steps 1, 2 have landed (unused)
+        dma_step(c.w2, c.voff2, slot0);              // W^T steps 0, 1 (step U = pass U/T2, d-chunk U%T2)
+        dma_step(c.w2 + (size_t)(32 * (1 / T2)) * D + 32 * (1 % T2), c.voff2, slot1);
+        LASSO_WAIT_VMCNT(4);
+        load_b(c, X, slot0);
+        LASSO_WAIT_LGKM0();
+        dma_step(c.w2 + (size_t)(32 * (2 / T2)) * D + 32 * (2 % T2), c.voff2, slot0);
+        // now X.b = B fragments of GEMM-2 step 0; slot1 <- W^T step 1, slot0 <- W^T step 2 (the invariant below)
+      } else {
       load_a(c, X, yrow, 0);                       // A fragments of step 0 (y is final now)
       // one trip = steps s = 2*s2 (on X) and s+1 (on Y).  srcE/srcO: DMA refills issued
       // in the even/odd step (steps s+3 / s+4 of the stream).
@@ -180,10 +206,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
       // in-kernel stop rule: wave 0 fetches the previous iteration's per-tile |dz| granules
       // a quarter into GEMM-1 (every workgroup has published them by then) and looks at
       // them when GEMM-1 is done -- the L2 round trip hides behind the MFMAs.
-      unsigned long long gr[4] = {0ull, 0ull, 0ull, 0ull};
-      const bool check = STOP && p.stop_on && it > 0;
-      const unsigned long long* const grow =
-          p.stop_gran ? p.stop_gran + (size_t)((it - 1) & (kStopRing - 1)) * p.ntiles : nullptr;
       // The contraction over the atoms is summed in SLICES of 128 atoms (two trips): the MFMA
       // chain restarts from 0 at every slice boundary and the slice totals are added left to
       // right, r = ((p_0 + p_1) + p_2) + ... with p_0's chain starting from -x.  This is the
@@ -233,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) acc[cb][rg] = __fadd_rn(run[cb][rg], acc[cb][rg]);   // + the last slice
+      }   // (!skip1)
 
       if (STOP && check && wid == 0) {
         // every granule must carry tag == it (iteration it-1 published as it-1+1); re-poll the
@@ -446,15 +469,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && K > 512) ? 1 : 2) void fista_t
   LASSO_WAIT_VMCNT(0);
 }
 
-template <int K, int M, bool STOP, int NW, int DS = 0>
+template <int K, int M, bool STOP, int NW, int DS = 0, bool ZS = false>
 static hipError_t launch_ks(const FistaTileParams& p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)M * K * 4 + (size_t)512 * NW * 4 + (size_t)NW * kRingBytesPerWave + 64;
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP, NW, DS>), lds);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fista_tile_sp_kernel<K, M, STOP, NW, DS, ZS>), lds);
       e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP, NW, DS>), dim3(grid), dim3(64 * NW), lds, stream, p);
+  hipLaunchKernelGGL((fista_tile_sp_kernel<K, M, STOP, NW, DS, ZS>), dim3(grid), dim3(64 * NW), lds, stream, p);
   return hipGetLastError();
 }
+
+// the ZS instantiation of the fixed-iteration kernel (defined and instantiated in fista_tile_sp_zs.hip: its own
+// translation unit, so that it builds beside the others)
+template <int K, int M, int NW>
+hipError_t launch_zero_start(const FistaTileParams& p, int grid, hipStream_t stream);
 
 template <int K, int M, int NW = kFistaWaves>
 static hipError_t occupancy_k(int* blocks_per_cu) {
@@ -466,7 +494,11 @@ static hipError_t occupancy_k(int* blocks_per_cu) {
 
 template <int K, int M, int NW = kFistaWaves>
 static hipError_t launch_k(const FistaTileParams& p, int grid, hipStream_t stream) {
-  return p.stop_on ? launch_ks<K, M, true, NW>(p, grid, stream) : launch_ks<K, M, false, NW>(p, grid, stream);
+  if (p.stop_on) return launch_ks<K, M, true, NW>(p, grid, stream);
+  static const bool zs_off = getenv("LASSO_NO_ZERO_START") != nullptr;        // (A/B)
+  if (!p.z_in && !p.y_in && p.iters > 0 && p.iters <= kZeroStartIters && !zs_off)
+    return launch_zero_start<K, M, NW>(p, grid, stream);
+  return launch_ks<K, M, false, NW>(p, grid, stream);
 }
 
 }  // namespace sp

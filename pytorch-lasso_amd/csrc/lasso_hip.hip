@@ -282,7 +282,9 @@ __device__ __forceinline__ void mirror_status(int* mirror, int w0, int w1, int w
   __hip_atomic_store(mirror + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(mirror + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(mirror + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(mirror + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // word 3 = "valid", written last and released: a host that has zeroed it before the call may POLL it instead of
+  // recording an event behind the launch (an event record costs the stream ~5 us between two kernels)
+  __hip_atomic_store(mirror + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
                                                               float budget, int* __restrict__ out, int* mirror) {
@@ -2371,7 +2373,9 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
   const int cus = device_cus();
   if (cus <= 0) return fail(LASSO_ERR_HIP, "no HIP device");
   if (n > 0) {
-    LASSO_HIP_TRY(launch_objective(p, kp, std::min(ntiles, cus), alpha, (double)n,
+    int grid = std::min(ntiles, cus);
+    if (const char* g = getenv("LASSO_OBJ_GRID")) grid = std::max(1, std::min(grid, atoi(g)));   // A/B knob (round 6)
+    LASSO_HIP_TRY(launch_objective(p, kp, grid, alpha, (double)n,
                                    sums_dev ? sums_dev : sums, loss_dev, st));
   }
   return LASSO_OK;
@@ -2468,6 +2472,7 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
   p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg; p.ndeg_mirror = ndeg_mapped;
+  p.wait_word = nullptr; p.wait_value = 0;
   p.k = (int)k; p.d = (int)d; p.eps = (float)eps; p.positive = positive;
   float* dt_new = Dt;
   LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
@@ -2523,6 +2528,7 @@ bool pipe_carve(int64_t n, int64_t d, int64_t k, void* workspace_dev, PipeWs* w)
   p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = nullptr; p.pool_rows = 0; p.pool_ld = 0; p.seed = 0;
   p.ndeg_in_out = ndeg; p.ndeg_mirror = nullptr;
+  p.wait_word = nullptr; p.wait_value = 0;
   p.k = (int)k; p.d = (int)d;
   return true;
 }
@@ -2567,13 +2573,19 @@ int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int
   return LASSO_OK;
 }
 
+int lasso_stream_wait_word(const int32_t* word, int32_t value, int host_memory, void* stream) {
+  if (!word) return fail(LASSO_ERR_BAD_ARG, "word is NULL");
+  LASSO_HIP_TRY(launch_wait_word(word, value, host_memory, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
 int lasso_mstep_pipe_wait(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
                           void* stream) {
   PipeWs w;
   if (!workspace_dev) return fail(LASSO_ERR_BAD_ARG, "bad argument");
   if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
   if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
-  LASSO_HIP_TRY(launch_wait_word(sweep_pipe_words(w.extra, (int)k) + 1, seq, (hipStream_t)stream));
+  LASSO_HIP_TRY(launch_wait_word(sweep_pipe_words(w.extra, (int)k) + 1, seq, 0, (hipStream_t)stream));
   return LASSO_OK;
 }
 
@@ -2623,9 +2635,19 @@ int lasso_mstep_pipe_sweep(const float* ab_dev, int64_t ldab, const void* d_dev,
   return LASSO_OK;
 }
 
-int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
-                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+int lasso_mstep_pipe_signal(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
                             void* stream) {
+  PipeWs w;
+  if (!workspace_dev) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for this shape");
+  if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
+  LASSO_HIP_TRY(launch_set_flag(sweep_pipe_words(w.extra, (int)k) + 2, seq, (hipStream_t)stream));
+  return LASSO_OK;
+}
+
+int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int64_t k, int dtype, double eps, int positive,
+                            int32_t* degenerate_dev, int32_t* ndeg_mapped, int wait_seq, void* workspace_dev,
+                            size_t workspace_bytes, void* stream) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   PipeWs w;
   if (!d_dev || !degenerate_dev || !workspace_dev || ldd < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
@@ -2637,6 +2659,7 @@ int lasso_mstep_pipe_finish(void* d_dev, int64_t ldd, int64_t n, int64_t d, int6
   p.Dout = (float*)d_dev; p.ldo = ldd;
   p.degenerate = degenerate_dev; p.eps = (float)eps; p.positive = positive;
   p.ndeg_mirror = ndeg_mapped;
+  if (wait_seq != 0) { p.wait_word = sweep_pipe_words(w.extra, (int)k) + 2; p.wait_value = wait_seq; }
   p.Dt = (float*)w.extra;                      // the single-launch sweep's new atoms (SweepPersist::DtN)
   LASSO_HIP_TRY(launch_sweep_fixup(p, (hipStream_t)stream));
   return LASSO_OK;

@@ -86,8 +86,11 @@ struct SweepParams {
   int64_t pool_ld; unsigned long long seed;
   int* degenerate;                       // [k] out: 1 where the atom was re-initialised
   int* ndeg_in_out;                      // [1] running count of degenerate atoms
-  int* ndeg_mirror;                      // nullable: a second, device-writable HOST word (pinned, mapped) that receives the
-                                         //   final count as well -- the caller's one host read per EM step then needs no copy
+  int* ndeg_mirror;                      // nullable: TWO device-writable HOST words (pinned, mapped): {the final count, 1} -- the
+                                         //   second written last and released, so a host that zeroed it may poll it: the caller's one
+                                         //   host read per EM step needs neither a copy nor an event record behind the sweep
+  const int* wait_word; int wait_value;  // nullable (fixup_transpose_kernel, pipelined M-step): do not touch the dictionary before
+                                         //   *wait_word == wait_value -- a word another STREAM raises when it has read the old one
   int k, d;
   float eps; int positive;
   int flags_cleared;                     // the caller had the single-launch sweep's flag words cleared (by the launch in front)
@@ -281,7 +284,7 @@ hipError_t launch_gram_rows(const float* Z, int64_t ldz, int k, const float* X, 
                             int64_t ldab, int stage, const MstepPipePlan& plan, float* scratch, int* clear_words, int nclear,
                             hipStream_t stream);
 hipError_t launch_set_flag(int* flag, int value, hipStream_t stream);
-hipError_t launch_wait_word(const int* word, int seq, hipStream_t stream);
+hipError_t launch_wait_word(const int* word, int seq, int host_memory, hipStream_t stream);
 hipError_t launch_uprod_rows(const float* A, int64_t lda, const float* Bm, int64_t ldb, const float* C0, int64_t ldc0,
                              float* U, int64_t ldu, int rows, int kk, int* ticket, int* flag, int nflags, int flag_value,
                              hipStream_t stream);

@@ -507,7 +507,14 @@ __global__ void set_flag_kernel(int* flag, int value) {
 
 // One wave that returns once *word == seq (or after ~0.1 s): stream order behind it then means "after that launch of
 // another stream" without an event record on the other stream (~5 us between two of its kernels).
-__global__ void wait_word_kernel(const int* word, int seq) {
+__global__ void wait_word_kernel(const int* word, int seq, int host_memory) {
+  if (host_memory) {                     // a word of pinned host memory (e.g. a verdict's "valid" word): one bus read per poll
+    for (int spins = 0; spins < (1 << 16); ++spins) {
+      if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    return;
+  }
   for (int spins = 0; spins < (1 << 20); ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;
     __builtin_amdgcn_s_sleep(8);
@@ -1626,7 +1633,10 @@ __global__ __launch_bounds__(256) void sweep_small_kernel(const SweepParams p) {
         if (s_deg[jj]) s_idx[c++] = jj;
     s_count = c;
     p.ndeg_in_out[0] = c;
-    if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.ndeg_mirror) {                                   // {count, valid}: the host may poll word 1 (zeroed before the call)
+      __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(p.ndeg_mirror + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
   if (s_count) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1676,7 +1686,10 @@ __global__ __launch_bounds__(256) void degenerate_fixup_kernel(const SweepParams
     for (int t = 0; t < 256; ++t) { const int v = s_cnt[t]; s_cnt[t] = c; c += v; }
     s_count = c;
     p.ndeg_in_out[0] = c;
-    if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.ndeg_mirror) {                                   // {count, valid}: the host may poll word 1 (zeroed before the call)
+      __hip_atomic_store(p.ndeg_mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(p.ndeg_mirror + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
   if (mine) {
@@ -1724,7 +1737,19 @@ __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams 
   const int tid = threadIdx.x, j0 = JB * blockIdx.x, nb_at = min(JB, p.k - j0);
   const int per = (p.k + 255) / 256;
   const int lo = min(tid * per, p.k), hi = min(lo + per, p.k);
-  if (tid == 0) { s_bsum = 0; s_tsum = 0; }
+  __shared__ int s_late;
+  if (tid == 0) {
+    s_bsum = 0; s_tsum = 0; s_late = 0;
+    if (p.wait_word) {
+      // the other stream of the pipelined M-step (objective, U rows of the later stages) still reads the OLD dictionary:
+      // wait for its word instead of a cross-stream event in front of this launch (~6-10 us on the step's chain)
+      int spins = 0;
+      while (__hip_atomic_load(p.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.wait_value &&
+             ++spins < (1 << 20))
+        __builtin_amdgcn_s_sleep(8);
+      s_late = spins >= (1 << 20);       // ~0.3 s: reported through the count of degenerate atoms (-1), never silently
+    }
+  }
   __syncthreads();
   int before = 0, total = 0;
   for (int j = lo; j < hi; ++j) {
@@ -1745,8 +1770,11 @@ __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams 
   if (tid == 0) {
     const int b = s_bsum, t = s_tsum;
     if (blockIdx.x == 0) {
-      p.ndeg_in_out[0] = t;
-      if (p.ndeg_mirror) __hip_atomic_store(p.ndeg_mirror, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      p.ndeg_in_out[0] = s_late ? -1 : t;
+      if (p.ndeg_mirror) {
+        __hip_atomic_store(p.ndeg_mirror, s_late ? -1 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.ndeg_mirror + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     int n = 0;
     if (t)
@@ -2127,7 +2155,9 @@ MstepPipePlan mstep_pipe_plan(int64_t n, int64_t d, int64_t k, int cus) {
     const int hi = lo == 0 ? head : lo + 1, s = pl.nstages++;
     // the head runs before the sweep; the others beside it (the sweep holds one CU per worker), with a margin, so that
     // every workgroup of a launch finds a CU at once (one workgroup per CU: LDS and registers)
-    const int avail = lo == 0 ? cus : std::max(cus - workers - 8, cus / 2);
+    int avail = lo == 0 ? cus : std::max(cus - workers - 8, cus / 2);
+    if (lo > 0)
+      if (const char* g = getenv("LASSO_PIPE_AVAIL")) avail = std::max(16, std::min(avail, atoi(g)));   // A/B knob (round 6)
     int blocks = 0;
     for (int r = lo; r < hi; ++r) blocks += nb - r + (int)(d / kG3B);
     int splits = std::max(1, std::min(avail / blocks, kGramAbMaxSplits));
@@ -2165,8 +2195,8 @@ hipError_t launch_set_flag(int* flag, int value, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_wait_word(const int* word, int seq, hipStream_t stream) {
-  hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(1), 0, stream, word, seq);
+hipError_t launch_wait_word(const int* word, int seq, int host_memory, hipStream_t stream) {
+  hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(1), 0, stream, word, seq, host_memory);
   return hipGetLastError();
 }
 

@@ -97,6 +97,8 @@ def _declare(lib):
     lib.lasso_dict_sweep_async.restype = i32
     lib.lasso_dict_sweep_async.argtypes = [vp, vp, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
                                            C.c_uint64, vp, vp, vp, sz, vp]
+    lib.lasso_stream_wait_word.restype = i32
+    lib.lasso_stream_wait_word.argtypes = [vp, i32, i32, vp]
     lib.lasso_mstep_pipe_stages.restype = i32
     lib.lasso_mstep_pipe_stages.argtypes = [i64, i64, i64]
     lib.lasso_mstep_pipe_stage_rows.restype = i32
@@ -112,7 +114,9 @@ def _declare(lib):
     lib.lasso_mstep_pipe_sweep.restype = i32
     lib.lasso_mstep_pipe_sweep.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, dbl, i32, vp, vp, sz, vp]
     lib.lasso_mstep_pipe_finish.restype = i32
-    lib.lasso_mstep_pipe_finish.argtypes = [vp, i64, i64, i64, i64, i32, dbl, i32, vp, vp, vp, sz, vp]
+    lib.lasso_mstep_pipe_finish.argtypes = [vp, i64, i64, i64, i64, i32, dbl, i32, vp, vp, i32, vp, sz, vp]
+    lib.lasso_mstep_pipe_signal.restype = i32
+    lib.lasso_mstep_pipe_signal.argtypes = [i64, i64, i64, i32, vp, sz, vp]
     lib.lasso_fista_solve_verdict_mapped.restype = i32
     lib.lasso_fista_solve_verdict_mapped.argtypes = [i64, i64, i64, i64, i32, i32, dbl, vp, vp, vp, sz, vp]
     lib.lasso_dict_sweep_count.restype = vp
@@ -231,6 +235,37 @@ def stream_ptr(device):
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HostWords:
+    """A few int32 words of pinned (device-writable) host memory whose LAST word a kernel sets to 1, released, after it
+    has written the others (LASSO_SOLVE_STATUS_MAPPED, lasso_dict_sweep_async, lasso_mstep_pipe_finish).  ``arm()``
+    zeroes that word before the launch; ``wait()`` polls it -- the result needs neither a copy launch nor an event
+    record behind the kernel (an event record between two kernels of a stream costs ~5 us on that stream)."""
+
+    def __init__(self, count):
+        self.tensor = torch.zeros(count, dtype=torch.int32).pin_memory()
+        self.view = self.tensor.numpy()              # shares the pinned pages
+
+    def arm(self):
+        self.view[-1] = 0
+        return self.tensor.data_ptr()
+
+    def ready(self):
+        return self.view[-1] != 0
+
+    def wait(self, timeout=120.0):
+        import time
+        view, spins, t0 = self.view, 0, None
+        while view[-1] == 0:
+            spins += 1
+            if (spins & 0x3FFF) == 0:
+                now = time.monotonic()
+                if t0 is None:
+                    t0 = now
+                elif now - t0 > timeout:
+                    raise NativeError("lasso_amd: no result from the GPU after %.0f s (kernel fault or hang)" % timeout)
+        return view
 
 
 _WS = collections.OrderedDict()       # key -> buffer, least recently used first

@@ -143,24 +143,34 @@ class HipEngine:
             host = self._ndeg_word()
             nat.check(L.lasso_dict_sweep_async(
                 nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
-                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.data_ptr(), nat.ptr(ws), ws.numel(),
+                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(), nat.ptr(ws), ws.numel(),
                 self._stream()))
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
 
-        def result():
-            ev.synchronize()
-            return mask, int(host[0])
+        def result():        # (polls the word the sweep's last kernel raises: no event record behind the sweep)
+            return mask, int(host.wait()[0])
         return result
 
     def _ndeg_word(self):
-        """One int32 of pinned (device-writable) host memory from a small ring: a word is reused only after
-        several later sweeps have been enqueued."""
+        """{count, valid}: two int32 words of pinned (device-writable) host memory from a small ring: a slot is
+        reused only after several later sweeps have been enqueued."""
         ring = getattr(self, "_ndeg_ring", None)
         if ring is None:
-            ring = self._ndeg_ring = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)]
+            ring = self._ndeg_ring = [nat.HostWords(2) for _ in range(4)]
         ring.append(ring.pop(0))
         return ring[-1]
+
+    def side_stream(self):
+        """The engine's second stream (the EM loop's objective and the later stages of the pipelined M-step)."""
+        st = getattr(self, "_side", None)
+        if st is None:
+            st = self._side = torch.cuda.Stream(self.device)
+        return st
+
+    def stream_wait_word(self, address, value, host_memory):
+        """(on the current stream) one wave that returns when the int32 at `address` equals `value`"""
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_stream_wait_word(C.c_void_p(int(address)), int(value), int(bool(host_memory)),
+                                                      self._stream()))
 
     # -- pipelined constrained M-step (lasso_mstep_pipe_*, DESIGN.md 3.3g) -------------------------------------
     def mstep_pipe_stages(self, d, k):
@@ -211,20 +221,28 @@ class HipEngine:
                                                       self._stream()))
         return mask
 
-    def pipe_finish(self, D, n, eps, positive, mask, ws):
+    def pipe_signal(self, n, d, k, seq, ws):
+        """(on the side stream, last) raises the word pipe_finish(wait_seq=seq) waits for"""
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.lasso_mstep_pipe_signal(max(int(n), 1), d, k, int(seq), nat.ptr(ws), ws.numel(),
+                                                       self._stream()))
+
+    def pipe_finish(self, D, n, eps, positive, mask, ws, wait_seq=0):
         """Writes the new dictionary; returns a callable giving (mask, ndeg) that waits for this launch only."""
         d, k = D.shape
         with torch.cuda.device(self.device):
             host = self._ndeg_word()
             nat.check(self.lib.lasso_mstep_pipe_finish(nat.ptr(D), D.stride(0), max(int(n), 1), d, k, nat.LASSO_F32,
                                                        float(eps), int(bool(positive)), nat.ptr(mask),
-                                                       host.data_ptr(), nat.ptr(ws), ws.numel(), self._stream()))
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+                                                       host.arm(), int(wait_seq), nat.ptr(ws), ws.numel(),
+                                                       self._stream()))
 
         def result():
-            ev.synchronize()
-            return mask, int(host[0])
+            ndeg = int(host.wait()[0])
+            if ndeg < 0:
+                raise nat.NativeError("lasso_amd: the pipelined M-step's side stream did not finish in time "
+                                      "(GPU shared with other work?); set LASSO_EM_PIPELINE=0")
+            return mask, ndeg
         return result
 
     def lipschitz(self, W):

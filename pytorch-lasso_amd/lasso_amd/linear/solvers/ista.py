@@ -121,16 +121,25 @@ class PendingSolve:
     iteration (z then holds a later iterate).  ``iterations`` / ``last_delta`` are valid after a True call."""
 
     def __init__(self, status, event):
+        # status: a _native.HostWords of 4 words; event: a torch event behind the copy of the words (the in-kernel
+        # rule's path), or None when the verdict kernel writes them itself and raises the "valid" word (polled)
         self._status, self._event = status, event
         self.iterations, self.last_delta = None, None
 
+    def status_word(self):
+        """address of the "valid" word (pinned host memory), for lasso_stream_wait_word; None on the event path"""
+        return None if self._event is not None or self._status is None else self._status.tensor.data_ptr() + 12
+
     def __call__(self):
-        self._event.synchronize()
-        st = self._status
+        if self._event is not None:
+            self._event.synchronize()
+            st = self._status.view
+        else:
+            st = self._status.wait()
         if int(st[2]) != 0:
             return False
         self.iterations = int(st[0])
-        self.last_delta = float(st[1:2].view(torch.float32)[0])
+        self.last_delta = float(st[1:2].view('float32')[0])
         return True
 
 
@@ -159,7 +168,7 @@ def _pinned_status(dev):
     slots = _PINNED.setdefault(key, [])
     # a small ring: a slot is reused only after several later solves on the same stream
     if len(slots) < 4:
-        slots.append(torch.zeros(4, dtype=torch.int32).pin_memory())
+        slots.append(nat.HostWords(4))
         return slots[-1]
     slots.append(slots.pop(0))
     return slots[-1]
@@ -338,7 +347,7 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
             int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0) |
             (nat.SOLVE_SHARDED if shard else 0) | (nat.SOLVE_STATUS_MAPPED if status is not None else 0),
             int(bool(backtrack)), float(eta_backtrack),
-            C.cast(status.data_ptr(), C.POINTER(C.c_int32)) if status is not None else
+            C.cast(status.arm(), C.POINTER(C.c_int32)) if status is not None else
             (C.byref(iters) if want_host else None), C.byref(last) if want_host else None, trials, acc_lr, acc_f,
             C.byref(obj) if obj is not None else None, nat.ptr(ws), ws.numel(), nat.stream_ptr(dev))
         pending = None
@@ -354,19 +363,15 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
                 with torch.cuda.device(dev):
                     status = _pinned_status(dev)
                     nat.check(L.lasso_fista_solve_verdict_mapped(shape[0], n_global, *shape[1:], nat.ptr(reduced),
-                                                                 status.data_ptr(), nat.ptr(ws), ws.numel(),
+                                                                 status.arm(), nat.ptr(ws), ws.numel(),
                                                                  nat.stream_ptr(dev)))
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
-                return status, ev
+                return status, None
             pending = PendingShardedSolve(deltas, judge)
         elif st == nat.LASSO_PENDING_MAPPED:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            pending = PendingSolve(status, ev)
+            pending = PendingSolve(status, None)      # the verdict kernel raises the buffer's "valid" word itself
         elif st == nat.LASSO_PENDING:
             nat.check(L.lasso_fista_solve_collect(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
-                                                  status.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))
+                                                  status.tensor.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             pending = PendingSolve(status, ev)

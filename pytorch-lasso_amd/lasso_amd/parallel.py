@@ -220,8 +220,14 @@ class _EmptyShardPending:
 
     def judge(self, reduced, n_global):
         self._reduced, self._n_global = reduced, n_global
+        self._ev = None
+        if reduced.is_cuda:      # (the two-stream loop reduces on its side stream: wait for THAT stream's work)
+            self._ev = torch.cuda.Event()
+            self._ev.record(torch.cuda.current_stream(reduced.device))
 
     def __call__(self):
+        if getattr(self, '_ev', None) is not None:
+            self._ev.synchronize()
         budget = torch.tensor(float(self._n_global) * self._k * self._tol, dtype=torch.float32).item()
         h = self._reduced.tolist()
         hit = next((i for i, v in enumerate(h) if v <= budget), -1)
@@ -307,6 +313,16 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     if ('stop_mode' not in begin_kwargs and begin_kwargs.get('algorithm', 'ista') == 'ista'
             and 0 < int(begin_kwargs.get('maxiter', 10)) <= 64):
         begin_kwargs['stop_mode'] = 'one-chunk'
+    # Round 6: the constrained loop on TWO streams -- the objective (and, for d == 256 and k a multiple of 256, the later
+    # stages of the pipelined M-step) beside the atom sweep, host results polled instead of waited for through events.
+    # Decided from rank-invariant inputs only (every rank takes the same path).
+    import os
+    if (constrained and defer and X.is_cuda and hasattr(engine, 'side_stream') and tol > 0
+            and (overlap or (shard_async and ndelta > 0)) and os.environ.get("LASSO_EM_SIDE_STREAM", "1") != "0"
+            and os.environ.get("LASSO_EM_PIPELINE", "1") != "0" and hasattr(engine, 'mstep_pipe_stages')
+            and (len(engine.mstep_pipe_stages(d, k)) > 0 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")):
+        return _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group,
+                                    n_total, ndelta, losses, stats)
     i, Zlast = 0, None
     while i < steps:
         pending, sharded = None, False
@@ -380,6 +396,224 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             bar.set_postfix(loss=losses[i].item())                                        # :50
             bar.update(1)
         i += 1
+    if deferred is not None:
+        mask, ndeg = deferred()
+        if ndeg:
+            repair(mask, ndeg, Zlast)
+    if bar is not None:
+        bar.close()
+    return weight, losses
+
+
+def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group, n_total,
+                         ndelta, losses, stats):
+    """The constrained EM loop (dict_learning.py:35-53) on two streams -- see em_loop for the one-stream form, which
+    this one reproduces step for step (same kernels on the same operands; only [A | B] of the pipelined M-step has
+    another summation order).  Per step, stream M (the caller's): E-step, the head of the M-step (Gram product of the
+    first block rows, its all-reduce, its U rows), the sweep, the new dictionary; stream S (the engine's): the later
+    stages of the M-step (Gram, all-reduce, U rows -- each announced to the running sweep by a flag word), the stop
+    rule's verdict on the reduced sums, and the objective (dict_learning.py:39) -- so the step's dependent chain is
+    E-step -> head -> sweep -> Lipschitz, and the chain carries no event record and no copy: S is started by a wave
+    that polls a word (the head's U rows / the verdict's "valid" word), M waits for S's event only before it changes
+    the dictionary (S reads the old one), and the host POLLS the verdict's and the sweep's words in pinned memory at
+    its one wait per step.  With several ranks the objective's two sums ride in the NEXT step's message (one small
+    all-reduce flushes the last step's): a message per stage, the first on the critical chain.  Shapes without a
+    pipelined M-step (e.g. 8 x 8 patches: d = 64) keep lasso_gram_accumulate + lasso_dict_sweep on M and only move
+    the objective to S."""
+    import torch as _t
+    world, rank = _world(group)
+    multi = _sharded(group)
+    n_local, d = X.shape
+    k = weight.shape[1]
+    dev = X.device
+    tol = float(solver_kwargs.get('tol', 1e-5))
+    M = _t.cuda.current_stream(dev)
+    S = engine.side_stream()
+    import os
+    stages = engine.mstep_pipe_stages(d, k) if (hasattr(engine, 'mstep_pipe_stages')
+                                                and os.environ.get("LASSO_EM_PIPELINE", "1") != "0") else []
+    pipe = len(stages) > 0
+    # ONE buffer per step's messages: [A | B] (pipelined: one matrix [k][k + d]; else A [k][k] then B [k][d]) and the
+    # tail [sum r^2, sum |z| of the PREVIOUS step | this step's stop-rule sums]
+    buf = _t.zeros(k * (k + d) + 2 + ndelta, dtype=_t.float32, device=dev)
+    tail = buf[k * (k + d):k * (k + d) + 2]
+    dtail = buf[k * (k + d) + 2:]
+    AB = buf[:k * (k + d)].view(k, k + d) if pipe else None
+    ws = engine.mstep_pipe_workspace(n_local, d, k) if pipe else None
+    ev_S = _t.cuda.Event()
+    state = {"seq": 0, "prev_sums": None, "prev_index": -1}
+    Z0, Zlast, deferred = None, None, None
+
+    def repair(mask, ndeg, Zprev):
+        cand = draw_directions(d, ndeg).to(weight.device)       # every rank advances its generator alike
+        if multi:
+            _broadcast(cand, group)                              # ... and uses rank 0's directions
+        engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
+        if Zprev is not None and Zprev.shape[0] > 0:
+            engine.zero_columns(Zprev, mask)                                              # :98
+
+    def fill_tail(pending):
+        """(on the stream of the message that carries the tail) the previous step's objective sums, this step's deltas"""
+        if state["prev_sums"] is not None:
+            tail.copy_(state["prev_sums"])
+        else:
+            tail.zero_()
+        if ndelta:
+            if pending is not None:
+                dtail.copy_(pending.deltas)
+            else:
+                dtail.zero_()
+
+    def after_tail(i):
+        """(behind the all-reduce of the tail) the previous step's loss from the summed pair"""
+        j = state["prev_index"]
+        if j >= 0:
+            losses[j] = (0.5 * tail[0] + alpha * tail[1]) / n_total
+
+    def objective(Z, i):
+        """(on S) dict_learning.py:39 for this step's code with the OLD dictionary"""
+        if n_local == 0:
+            sums = _t.zeros(2, dtype=_t.float64, device=dev)
+        elif multi:
+            _, sums = engine.objective_sums(X, Z, weight, alpha)
+        else:
+            engine.objective_sums(X, Z, weight, alpha, loss_out=losses[i])
+            sums = None
+        state["next_sums"] = sums
+
+    def produce(Z, pending, i, start_word):
+        """Enqueue everything of step i between the E-step and the new dictionary.  Returns the sweep's handle: a
+        callable (mask -> deferred result) to be called once the host has seen the verdict."""
+        sharded = multi and pending is not None
+        if pipe:
+            state["seq"] += 1
+            seq = state["seq"]
+            last = len(stages) - 1
+
+            def stage(s_):
+                lo, hi = stages[s_]
+                if n_local > 0:
+                    engine.pipe_gram(Z, X, AB, s_, ws)
+                else:
+                    AB[lo:hi].zero_()
+                if multi:
+                    if s_ == last:
+                        fill_tail(pending)
+                        _all_reduce(buf[lo * (k + d):], group)           # the last stage's rows + the tail: contiguous
+                        after_tail(i)
+                    else:
+                        _all_reduce(buf[lo * (k + d):hi * (k + d)], group)
+                engine.pipe_rows(AB, weight, n_local, s_, ws, seq=seq)
+
+            stage(0)                                                     # the head: on the step's dependent chain
+            with _t.cuda.stream(S):
+                engine.pipe_wait(n_local, d, k, seq, ws)                 # (a wave that polls the head's word: no event on M)
+                for s_ in range(1, last + 1):
+                    stage(s_)
+                if sharded:
+                    pending.judge(dtail, n_total)                        # the verdict, mirrored into pinned memory
+                objective(Z, i)
+                engine.pipe_signal(n_local, d, k, seq, ws)               # "S has read the old dictionary"
+                ev_S.record(S)
+            mask = engine.pipe_sweep(AB, weight, n_local, 1e-10, False, ws)
+
+            def finish():
+                # (the kernel that writes the dictionary waits for S's word itself: no cross-stream event on M's chain)
+                return engine.pipe_finish(weight, n_local, 1e-10, False, mask, ws, wait_seq=seq)
+            return finish
+        # no pipelined form: the objective alone moves to S (started by the verdict's word: no event on M)
+        with _t.cuda.stream(S):
+            if start_word is not None:
+                engine.stream_wait_word(start_word, 1, True)
+            else:
+                ev = _t.cuda.Event()
+                ev.record(M)
+                S.wait_event(ev)
+            objective(Z, i)
+            ev_S.record(S)
+        A = buf[:k * k].view(k, k)
+        B = buf[k * k:k * k + k * d].view(k, d)
+        if n_local > 0:
+            engine.gram(Z, X, buf)
+        else:
+            buf[:k * (k + d)].zero_()
+        if multi:
+            fill_tail(pending)
+            _all_reduce(buf, group)
+            after_tail(i)
+            if sharded:
+                pending.judge(dtail, n_total)
+
+        def finish():
+            M.wait_event(ev_S)                                           # the sweep writes the dictionary S reads
+            return engine.sweep_begin(A, B, weight, 1e-10, False)
+        return finish
+
+    def encode_sync():
+        return sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
+
+    i = 0
+    while i < steps:
+        # ---- E-step (dict_learning.py:38), enqueued without a wait
+        start_word = None
+        if not multi:
+            Z, pending = engine.encode_begin(X, weight, alpha, Z0, **begin_kwargs)
+            if pending is not None and hasattr(pending, 'status_word'):
+                start_word = pending.status_word()
+        elif n_local == 0:
+            Z = Z0 if Z0 is not None else X.new_zeros(0, k)
+            pending = _EmptyShardPending(ndelta, k, tol, dev)
+        else:
+            if Z0 is not None and Z0.device != dev:
+                Z0 = Z0.to(dev)
+            began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs)
+            if began is None:
+                raise RuntimeError("encode_begin_sharded refused arguments sharded_async_ok accepted")
+            Z, pending = began
+        if stats is not None:
+            stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
+        finish = produce(Z, pending, i, start_word)
+        # ---- the step's ONE host wait: the previous sweep's count of degenerate atoms, this E-step's verdict
+        if deferred is not None:
+            mask, ndeg = deferred()
+            deferred = None
+            if ndeg:     # rare: an atom degenerated in the previous sweep -- repair, redo this step
+                if pending is not None:
+                    pending()
+                M.wait_event(ev_S)
+                _t.cuda.current_stream(dev).synchronize()
+                repair(mask, ndeg, Zlast)
+                continue
+        if pending is not None and not pending():
+            # the stop rule fired before the last iteration (or the in-kernel rule gave up): the same rule on the
+            # chunked path, then the step's products once more for the right code.  Nothing of the speculated step
+            # has touched the dictionary (finish() was not called).
+            M.wait_event(ev_S)
+            _t.cuda.current_stream(dev).synchronize()
+            if multi:
+                Z = encode_sync()
+            else:
+                Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
+            finish = produce(Z, None, i, None)
+            if stats is not None:
+                stats['replayed_steps'] = stats.get('replayed_steps', 0) + 1
+        if multi:
+            state["prev_sums"], state["prev_index"] = state["next_sums"], i
+        if persist:
+            Z0 = Z                                                                        # :40-41
+        deferred = finish()                                                               # :44-45
+        Zlast = Z
+        if bar is not None:
+            ev_S.synchronize()
+            j = i if not multi else state["prev_index"] - 1            # (several ranks: a loss is known a step later)
+            bar.set_postfix(loss=losses[j].item() if j >= 0 else float('nan'))            # :50
+            bar.update(1)
+        i += 1
+    M.wait_event(ev_S)
+    if multi and state["prev_index"] >= 0:           # flush: the last step's objective sums
+        t2 = state["prev_sums"].to(_t.float32).clone()
+        _all_reduce(t2, group)
+        losses[state["prev_index"]] = (0.5 * t2[0] + alpha * t2[1]) / n_total
     if deferred is not None:
         mask, ndeg = deferred()
         if ndeg:
