@@ -521,7 +521,14 @@ def run_em(args, ranks):
         parallel._all_reduce = real_all_reduce
     out = None
     if rank == 0:
-        ar = sorted(a.elapsed_time(b) for a, b, _ in comm_ms[-args.steps:]) if comm_ms else []
+        # messages per EM step: one ([A | B | tail]), or -- pipelined M-step (d = 256, k a multiple of 256) -- one per
+        # STAGE of block rows, the first on the step's dependent chain, the others behind the running sweep
+        per_step = len(comm_ms) // args.steps if comm_ms else 0
+        msgs = comm_ms[-args.steps * per_step:] if per_step else []
+        step_ms = sorted(sum(a.elapsed_time(b) for a, b, _ in msgs[i * per_step:(i + 1) * per_step])
+                         for i in range(args.steps)) if per_step else []
+        head_ms = sorted(msgs[i * per_step][0].elapsed_time(msgs[i * per_step][1]) for i in range(args.steps)) if per_step else []
+        ar = step_ms
         # E-step flops dominate: 10 iterations x 4 n d k per rank, + Gram 2nk^2 + 2nkd + objective 2ndk
         flop = (10 * 4.0 + 2.0 + 2.0) * rows * d * k + 2.0 * rows * k * k
         ms = 1e3 * elapsed / args.steps
@@ -535,14 +542,19 @@ def run_em(args, ranks):
             "config": {"workload": "%s: dict_learning EM step, n=%d d=%d k=%d alpha=%g, FISTA E-step "
                                    "(lr='auto', maxiter=10, tol=1e-5) + constrained M-step" % (cfg, n_all, d, k, alpha),
                        "rows_per_gpu": rows, "rows_total": n_all,
-                       "parallelism": "row-sharded x%d, one all-reduce of [A|B|sums] per step" % world},
+                       "parallelism": "row-sharded x%d, all-reduce of [A|B|sums] per step (one message per stage of the "
+                                      "pipelined M-step)" % world},
             "all_reduce_ms": {"median": ar[len(ar) // 2] if ar else 0.0, "max": ar[-1] if ar else 0.0,
+                              "median_first_message": head_ms[len(head_ms) // 2] if head_ms else 0.0,
                               "bytes": 4 * (k * k + k * d + 2 + 10),
                               "bytes_sent": sorted({nb for _, _, nb in comm_ms}),
+                              "bytes_per_step": sum(nb for _, _, nb in msgs) // args.steps if msgs else 0,
                               "per_step": len(comm_ms) / float(args.steps),
-                              "note": "device time of the one RCCL all-reduce "
-                              "per EM step -- [A | B | objective sums | the E-step's 10 stop-rule sums] -- (0 at N=1: "
-                              "no collective)"},
+                              "note": "device time of the RCCL all-reduces of one EM step, summed -- [A | B | objective "
+                              "sums of the previous step | the E-step's 10 stop-rule sums]: ONE message, or with the "
+                              "pipelined M-step one per stage of block rows (`per_step` of them, `bytes_per_step` in "
+                              "all; only the first -- median_first_message -- sits on the step's dependent chain, the "
+                              "others travel behind the running sweep) -- (0 at N=1: no collective)"},
             "roofline": with_traffic(
                 {"bound": "mfma", "achieved": flop / (dev_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,

@@ -313,7 +313,8 @@ int lasso_mstep_pipe_stage_rows(int64_t n, int64_t d, int64_t k, int stage, int6
 size_t lasso_mstep_pipe_workspace_bytes(int64_t n, int64_t d, int64_t k);
 /* the stage's rows of [A | B] from this process's n samples: per block row R the columns >= 256 R computed and folded,
  * the blocks right of the diagonal also written transposed into the rows below (after the stages 0 .. s the rows of
- * stage s are complete).  Stage 0 also resets the sweep's flag words. */
+ * stage s are complete).  Stage 0 also resets the sweep's flag words.  n == 0 (a rank without rows, which still runs the
+ * identical sweep on the all-reduced matrix): the stage's rows are zeroed, the flag words reset all the same. */
 int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n, int64_t d,
                           int64_t k, int dtype, float* ab_dev, int64_t ldab, int stage, void* workspace_dev,
                           size_t workspace_bytes, void* stream);

@@ -2559,15 +2559,24 @@ int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int
                           size_t workspace_bytes, void* stream) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   PipeWs w;
-  if (!z_dev || !x_dev || !ab_dev || !workspace_dev || n <= 0 || ldz < k || ldx < d || ldab < k + d)
+  if (!ab_dev || !workspace_dev || n < 0 || (n > 0 && (!z_dev || !x_dev || ldz < k || ldx < d)) || ldab < k + d)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
-  if (!pipe_carve(n, d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for n=%lld d=%lld k=%lld",
+  if (!pipe_carve(std::max<int64_t>(n, 1), d, k, workspace_dev, &w)) return fail(LASSO_ERR_UNSUPPORTED, "no pipelined M-step for n=%lld d=%lld k=%lld",
                                                            (long long)n, (long long)d, (long long)k);
   if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
   if (stage < 0 || stage >= w.plan.nstages) return fail(LASSO_ERR_BAD_ARG, "stage %d of %d", stage, w.plan.nstages);
   if ((ldab & 3) || ((uintptr_t)ab_dev & 15)) return fail(LASSO_ERR_BAD_ARG, "[A | B] must be 16-byte aligned, pitch a multiple of 4");
   // the head's launch also clears the sweep's flag words: it sits in front of every launch that sets or reads them
   int* const flags = stage == 0 ? sweep_persist_flags(w.extra, (int)k) : nullptr;
+  if (n == 0) {
+    // a rank without rows (it still runs the identical sweep on the all-reduced [A | B]): zero contributions, and the
+    // flag words cleared all the same -- stale "rows complete" words would let the gated sweep run ahead of its rows
+    const int lo = w.plan.lo[stage], hi = w.plan.hi[stage];
+    LASSO_HIP_TRY(hipMemset2DAsync(ab_dev + (int64_t)256 * lo * ldab, ldab * 4, 0, (size_t)(k + d) * 4, (size_t)256 * (hi - lo),
+                                   (hipStream_t)stream));
+    if (flags) LASSO_HIP_TRY(hipMemsetAsync(flags, 0, 4096, (hipStream_t)stream));
+    return LASSO_OK;
+  }
   LASSO_HIP_TRY(launch_gram_rows((const float*)z_dev, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, ab_dev, ldab,
                                  stage, w.plan, w.gram, flags, flags ? 1024 : 0, (hipStream_t)stream));
   return LASSO_OK;

@@ -193,7 +193,8 @@ class HipEngine:
         n, k = Z.shape
         d = X.shape[1]
         with torch.cuda.device(self.device):
-            nat.check(self.lib.lasso_mstep_pipe_gram(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0), n, d, k,
+            nat.check(self.lib.lasso_mstep_pipe_gram(nat.ptr(Z) if n else None, Z.stride(0), nat.ptr(X) if n else None,
+                                                     X.stride(0), n, d, k,
                                                      nat.LASSO_F32, nat.ptr(AB), AB.stride(0), int(R),
                                                      nat.ptr(ws), ws.numel(), self._stream()))
 

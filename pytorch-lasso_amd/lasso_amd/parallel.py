@@ -492,10 +492,7 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
 
             def stage(s_):
                 lo, hi = stages[s_]
-                if n_local > 0:
-                    engine.pipe_gram(Z, X, AB, s_, ws)
-                else:
-                    AB[lo:hi].zero_()
+                engine.pipe_gram(Z, X, AB, s_, ws)               # (a rank without rows: zeros, and the flag words cleared)
                 if multi:
                     if s_ == last:
                         fill_tail(pending)
@@ -572,6 +569,8 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             Z, pending = began
         if stats is not None:
             stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
+            if pipe:
+                stats['pipelined_steps'] = stats.get('pipelined_steps', 0) + 1
         finish = produce(Z, pending, i, start_word)
         # ---- the step's ONE host wait: the previous sweep's count of degenerate atoms, this E-step's verdict
         if deferred is not None:

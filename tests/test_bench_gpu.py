@@ -42,12 +42,15 @@ def test_two_rank_fista_line_and_global_time_to_tol():
     assert out["roofline"]["frac"] > 0 and "gloo" in out["backend"]
 
 
-def test_two_rank_em_line_has_one_message_per_step():
+def test_two_rank_em_line_has_one_message_per_stage():
     out = _bench(SHARED + ["--workload", "em"])
     assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 32768
     ar = out["all_reduce_ms"]
     assert ar["bytes"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
-    assert ar["bytes_sent"] == [ar["bytes"]] and ar["per_step"] == 1.0       # ONE collective per EM step, that size
+    # the pipelined M-step: one message per STAGE of block rows of [A | B] (the head: 512 rows; then 256 each, the last
+    # with the 12-word tail) -- the same bytes in all as the one message of the plain M-step, no other collective
+    assert ar["bytes_sent"] == [4 * 256 * 1280, 4 * (256 * 1280 + 12), 4 * 512 * 1280] and ar["per_step"] == 3.0
+    assert ar["bytes_per_step"] == ar["bytes"]
     assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
     # the first EM steps of config 4 on the whole batch: losses[2] of the reference's run (tests/golden/g4_c4_em.npz)
     import numpy as np
@@ -104,7 +107,8 @@ def test_one_rank_rccl_group_em_line():
     plain = _bench(["--workload", "em", "--steps", "2", "--warmup", "1"])
     out = _bench(FORCED + ["--workload", "em"])
     ar = out["all_reduce_ms"]
-    assert ar["per_step"] == 1.0 and ar["bytes_sent"] == [4 * (1024 * 1024 + 1024 * 256 + 12)]   # ONE RCCL message per EM step
+    # one RCCL message per stage of the pipelined M-step, [A | B | tail] in all
+    assert ar["per_step"] == 3.0 and ar["bytes_per_step"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
     assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
     assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
     assert plain["all_reduce_ms"]["per_step"] == 0.0

@@ -570,3 +570,76 @@ def test_em_steps_whose_stop_rule_fires_early():
     assert info["iterations"] < 10, info
     for w, l in outs[1:]:
         assert torch.equal(w, outs[0][0]) and torch.equal(l, outs[0][1])
+
+
+# ---- round 6: the pipelined M-step and the two-stream EM loop ---------------------------------------------------------
+@pytest.mark.parametrize("n,k", [(8192, 1024), (300, 512), (4097, 768), (2048, 2048)])
+def test_pipelined_mstep_against_the_plain_one(n, k):
+    """lasso_mstep_pipe_*: [A | B] by stages of block rows (against an fp64 product), the gated sweep fed by a second
+    stream while it runs -- the dictionary of lasso_dict_sweep on the SAME [A | B] bit for bit (same kernels, same
+    order), and that of lasso_gram_accumulate + lasso_dict_sweep up to the other summation order of the Gram product."""
+    from lasso_amd.engine import HipEngine
+    d = 256
+    eng = HipEngine()
+    g = torch.Generator().manual_seed(n + k)
+    X = torch.randn(n, d, generator=g).cuda()
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)).cuda()
+    D0 = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+    stages = eng.mstep_pipe_stages(d, k)
+    assert len(stages) >= 2 and stages[0][0] == 0 and stages[-1][1] == k
+    buf = torch.zeros(k * k + k * d, device="cuda")
+    A, B = eng.gram(Z, X, buf)
+    Dp = D0.clone()
+    eng.sweep(A, B, Dp, None, 1e-10, False)
+    ws = eng.mstep_pipe_workspace(n, d, k)
+    AB = torch.full((k, k + d), float("nan"), device="cuda")
+    M, S = torch.cuda.current_stream(), eng.side_stream()
+    for rep in range(3):
+        D = D0.clone()
+        AB.fill_(float("nan"))
+        eng.pipe_gram(Z, X, AB, 0, ws)
+        eng.pipe_rows(AB, D, n, 0, ws, seq=rep + 1)
+        with torch.cuda.stream(S):
+            eng.pipe_wait(n, d, k, rep + 1, ws)
+            for s_ in range(1, len(stages)):
+                eng.pipe_gram(Z, X, AB, s_, ws)
+                eng.pipe_rows(AB, D, n, s_, ws)
+            eng.pipe_signal(n, d, k, rep + 1, ws)
+        mask = eng.pipe_sweep(AB, D, n, 1e-10, False, ws)
+        _, ndeg = eng.pipe_finish(D, n, 1e-10, False, mask, ws, wait_seq=rep + 1)()
+        torch.cuda.synchronize()
+        A64, B64 = Z.double().T @ Z.double(), Z.double().T @ X.double()
+        scale = A64.abs().max().item()
+        assert (AB[:, :k].double() - A64).abs().max().item() <= 2e-6 * scale
+        assert (AB[:, k:].double() - B64).abs().max().item() <= 2e-6 * B64.abs().max().item()
+        assert torch.equal(AB[:, :k], AB[:, :k].T)                                        # mirrored, not recomputed
+        Dq = D0.clone()
+        eng.sweep(AB[:, :k].contiguous(), AB[:, k:].contiguous(), Dq, None, 1e-10, False)
+        assert torch.equal(D, Dq) and ndeg == 0
+        assert (D - Dp).abs().max().item() <= 5e-6
+
+
+def test_two_stream_em_loop_against_the_one_stream_loop_and_degenerate_atoms(monkeypatch):
+    """dict_learning at a pipelined shape: the two-stream loop (default) against the one-stream loop
+    (LASSO_EM_SIDE_STREAM=0) -- same kernels but for the Gram product's summation order -- and, with fewer samples than
+    atoms, through degenerate atoms: the speculated step is discarded, the atom re-drawn with the reference's RNG
+    (dict_learning.py:92-98) and the step redone; against the oracle with the same seed."""
+    from lasso_amd.linear import dict_learning
+    orc = _orc()
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(3000, 256, generator=g)
+    D0 = torch.nn.functional.normalize(torch.randn(256, 512, generator=g), dim=0)
+    two = dict_learning(X.cuda(), 512, alpha=0.4, steps=4, init_weight=D0, progbar=False, device="cuda")
+    monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
+    one = dict_learning(X.cuda(), 512, alpha=0.4, steps=4, init_weight=D0, progbar=False, device="cuda")
+    monkeypatch.delenv("LASSO_EM_SIDE_STREAM")
+    assert (two[1] - one[1]).abs().max().item() <= 2e-6 * one[1].abs().max().item()
+    assert (two[0] - one[0]).abs().max().item() <= 5e-6
+    # degenerate atoms: 40 samples, 512 atoms, a large penalty -- most atoms are never used
+    Xs = X[:40]
+    torch.manual_seed(11)
+    Dref, lref = orc.dict_learning(Xs, 512, alpha=1.5, steps=3, init_weight=D0, progbar=False)
+    torch.manual_seed(11)
+    D, losses = dict_learning(Xs.cuda(), 512, alpha=1.5, steps=3, init_weight=D0, progbar=False, device="cuda")
+    assert (losses.cpu() - lref).abs().max().item() <= 1e-5 * lref.abs().max().item()
+    assert (D.cpu() - Dref).abs().max().item() <= 2e-5

@@ -107,6 +107,86 @@ def test_two_ranks_on_the_hip_engine(tmp_path):
     record_margins("two_ranks_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
 
 
+# ---- the PIPELINED M-step on two ranks (d = 256, k a multiple of 256: em_loop's two-stream form) ------------------
+PN, PD, PK, PSPLIT = 900, 256, 512, 333
+PCASES = {"auto": dict(maxiter=10),                                        # lr='auto', default tol: one message per stage
+          "tol_short": dict(lr=0.05, maxiter=40, tol=2e-2),                 # the rule fires early: speculated step discarded, replay
+          "persist": dict(persist=True, lr=0.05, maxiter=8, tol=1e-7)}
+
+
+def _pipe_problem():
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(PN, PD, generator=g)
+    D0 = torch.nn.functional.normalize(torch.randn(PD, PK, generator=g), dim=0)
+    return X, D0
+
+
+def _pipe_worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from lasso_amd import parallel
+    from lasso_amd.engine import HipEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, D0 = _pipe_problem()
+    out = {}
+    sent = []
+    real = parallel._all_reduce
+
+    def counting(t, group):
+        sent.append(t.numel())
+        return real(t, group)
+    parallel._all_reduce = counting
+    for empty in (False, True):
+        lo, hi = ((0, PSPLIT) if rank == 0 else (PSPLIT, PN)) if not empty else ((0, PN) if rank == 0 else (PN, PN))
+        for tag, kw in PCASES.items():
+            if empty and tag != "auto":
+                continue
+            torch.manual_seed(1)
+            eng = HipEngine()
+            eng.em_stats = {}
+            del sent[:]
+            Dl, losses = parallel.dict_learning_sharded(X[lo:hi], PK, alpha=0.3, steps=4, init_weight=D0, engine=eng, **kw)
+            key = ("empty_" if empty else "") + tag
+            out[key + "_D"], out[key + "_l"] = Dl.cpu().numpy(), losses.cpu().numpy()
+            out[key + "_stats"] = np.array([eng.em_stats.get("pipelined_steps", 0), eng.em_stats.get("replayed_steps", 0)])
+            out[key + "_sent"] = np.array(sent)
+    np.savez(os.path.join(tmp, "pipe%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_mstep_on_two_ranks(tmp_path):
+    """d = 256, k = 512: em_loop takes its two-stream form -- [A | B] all-reduced per STAGE of block rows (head on the
+    step's chain, the rest behind the running sweep), the objective's sums riding in the next step's message.  Ragged
+    shards, a rank without rows, a stop rule that fires early (replay) and persist=True: both ranks bit for bit, and the
+    reference's arithmetic on the whole batch (oracle) within the two-rank margins of the plain form."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lasso_oracle as orc
+    port = 33500 + (os.getpid() % 2000)
+    mp.start_processes(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "pipe0.npz"), np.load(tmp_path / "pipe1.npz")
+    X, D0 = _pipe_problem()
+    stage_rows = 256 * (PK + PD)
+    margins = {}
+    for key in [k[:-2] for k in r0.files if k.endswith("_D")]:
+        tag = key.replace("empty_", "")
+        assert np.array_equal(r0[key + "_D"], r1[key + "_D"]) and np.array_equal(r0[key + "_l"], r1[key + "_l"]), key
+        assert np.array_equal(r0[key + "_stats"], r1[key + "_stats"]) and np.array_equal(r0[key + "_sent"], r1[key + "_sent"]), key
+        assert int(r0[key + "_stats"][0]) >= 4, (key, r0[key + "_stats"])                  # every step on the pipelined form
+        assert (int(r0[key + "_stats"][1]) >= 1) == (tag == "tol_short"), (key, r0[key + "_stats"])
+        big = [int(v) for v in r0[key + "_sent"] if v >= 1024]
+        # every large message is a stage of [A | B]: 256 rows, the last one with the tail (2 sums + maxiter stop-rule sums)
+        assert set(big) <= {stage_rows, stage_rows + 2 + PCASES[tag].get("maxiter", 10)}, (key, sorted(set(big)))
+        torch.manual_seed(1)
+        Do, lo_ = orc.dict_learning(X, PK, alpha=0.3, steps=4, init_weight=D0, **PCASES[tag])
+        margins[key] = (float(np.abs(r0[key + "_l"] - lo_.numpy()).max()), float(np.abs(r0[key + "_D"] - Do.numpy()).max()))
+        assert margins[key][0] <= 1e-5 and margins[key][1] <= 2e-5, (key, margins[key])
+    record_margins("two_ranks_pipelined_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
+
+
 # ---- row-sharded line search (ista.py:23-52 on two ranks) -------------------------------------
 BT = dict(n=700, d=64, k=200, split=263, alpha=0.25, lr=0.6, maxiter=8, eta=1.5)
 
