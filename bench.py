@@ -2,7 +2,7 @@
 """bench.py -- BASELINE's metric on MI355X: FISTA iterations/sec (+ time-to-tol) on
 n=4096 d=256 k=1024 fp32, fixed step 1/L, through the C ABI, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em|c3|conv] [--scaling strong|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fista|em|c3|conv|cd] [--scaling strong|weak]
                     [--shape c4|c5] [--dtype bf16|f32] [--rows R] [--backend nccl|gloo] [--share-gpu]
 
 --workload fista (default): a "step" is one sparse_encode solve of --iters FISTA iterations
@@ -186,6 +186,19 @@ def cpu_baseline(X, W, lr, budget_s=12.0):
 # --------------------------------------------------------------------------------------
 # launcher
 # --------------------------------------------------------------------------------------
+def nat_kernel_name(rows, d, k, dtype=None, backtrack=0):
+    from lasso_amd import _native as nat
+    return nat.lib().lasso_fista_kernel_name(rows, d, k, nat.LASSO_F32 if dtype is None else dtype, backtrack).decode()
+
+
+def kernel_tokens(name):
+    """the kernel names a `roofline.kernel` string mentions, each cut in front of its closing '>' (so that a name given
+    with its leading template arguments matches the full instantiation in a trace): what tests/test_bench_gpu.py looks
+    for in the rocprofv3 kernel trace of the same command"""
+    import re
+    return [t.rstrip(">") for t in re.findall(r"[A-Za-z_0-9]+_kernel(?:<[^<>]*>?)?", name or "")]
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -558,8 +571,8 @@ def run_em(args, ranks):
             "roofline": with_traffic(
                 {"bound": "mfma", "achieved": flop / (dev_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                 "kernel": "whole EM step (E-step kernel dominates; the Lipschitz squarings "
-                           "and the atom sweep are latency chains)",
+                 "kernel": "whole EM step: %s (E-step; dominates) + the Gram product, the atom sweep and the Lipschitz "
+                           "squarings (latency chains)" % nat_kernel_name(rows, d, k),
                  "flop_per_launch": flop, "per": "GPU (rank 0)", "avg_launch_ms": dev_ms,
                  "avg_launch_note": "HIP events around the K timed EM steps / K"},
                 ("em_%s%s" % (args.shape, "" if n_all == n_default else "_shard"))
@@ -713,6 +726,73 @@ def run_conv(args, ranks):
     }
 
 
+CD_STEPS = 1000
+
+
+def run_cd(args, ranks):
+    """greedy coordinate descent (lasso/linear/solvers/coordinate_descent.py:5-54) at BASELINE config
+    2's shape; a step = one solve of 1000 coordinate steps per row (tol = 1e-6 k: no row of this problem converges
+    earlier).  Rows are independent: sharded over the ranks, no collective.  Roofline: neither MFMA nor HBM -- every
+    row-step reads one row of S = I - W^T W (4 K bytes) out of L2 / MALL (S is 4 MiB) behind a dependent chain
+    argmax -> address -> load -> update: the block reports achieved L2 bytes against the L2 peak of
+    MI355X_MICROARCH.md (34.5 TB/s) and says so in `bound`."""
+    import torch
+    from lasso_amd.linear.solvers import coord_descent
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    n_all = args.rows or N_ROWS
+    if n_all % world:
+        raise SystemExit("bench.py: %d rows do not split over %d ranks" % (n_all, world))
+    rows = n_all // world
+    X, W = recipe(n_all)
+    Xg, Wg = X[rank * rows:(rank + 1) * rows].to(dev), W.to(dev)
+
+    def solve():
+        return coord_descent(Xg, Wg, None, ALPHA, maxiter=CD_STEPS)
+    elapsed, kern_ms = timed_steps(ranks, solve, args.steps, args.warmup)
+    z, info = coord_descent(Xg, Wg, None, ALPHA, maxiter=CD_STEPS, return_info=True)
+    # the objective of the returned codes, all-reduced (dict_learning.py:10-13 on all rows)
+    from lasso_amd.engine import HipEngine
+    _, sums = HipEngine(dev).objective_sums(Xg, z, Wg, ALPHA)
+    ranks.sum_(sums)
+    if rank != 0:
+        return None
+    row_steps = float(rows) * CD_STEPS                     # per rank and solve
+    l2_bytes = row_steps * 4.0 * K
+    gbps = l2_bytes / (kern_ms[0] * 1e-3) / 1e9
+    out = {
+        "metric": "coord_descent_row_steps_per_sec (n=%d d=%d k=%d fp32, %d steps per row)" % (n_all, D, K, CD_STEPS),
+        "value": args.steps * float(n_all) * CD_STEPS / elapsed, "unit": "row-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "greedy coordinate descent (algorithm='cd') at BASELINE config 2's shape: n=%d d=%d k=%d "
+                               "alpha=%g, maxiter=%d, tol=1e-6 (no row stops earlier); step = one solve"
+                               % (n_all, D, K, ALPHA, CD_STEPS),
+                   "rows_per_gpu": rows, "rows_total": n_all, "parallelism": "rows sharded x%d (no collective)" % world},
+        "roofline": with_traffic(
+            {"bound": "l2", "achieved": gbps, "peak": 34500.0, "unit": "GB/s", "frac": gbps / 34500.0,
+             "kernel": "lasso::cd_rows_kernel<%d>" % (K // 256),
+             "bytes_per_launch": l2_bytes, "per": "GPU (rank 0)", "avg_launch_ms": kern_ms[0],
+             "bytes_note": "algorithmic: one row of S = I - W^T W (4 k bytes) per row-step, served by L2 / MALL (S is 4 MiB); "
+                           "peak = the aggregate L2 bandwidth of MI355X_MICROARCH.md.  The step is a dependent chain "
+                           "(argmax -> address -> load -> k multiply-adds): latency-bound at the occupancy n allows",
+             "avg_launch_note": "HIP events around the K timed solves / K (set-up GEMMs b = xW, S = I - W^T W included)"},
+            "cd" if (world == 1 and not args.rows) else None, kern_ms[0], algorithmic_bytes=4.0 * (rows * D + D * K + rows * K)),
+        "max_steps": info["max_steps"], "n_active": info["n_active"],
+        "objective": float((0.5 * sums[0] + ALPHA * sums[1]) / n_all),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import lasso_oracle as orc
+        sample = 256
+        orc.coordinate_descent(X[:8], W, None, ALPHA, maxiter=10)
+        t0 = time.perf_counter()
+        orc.coordinate_descent(X[:sample], W, None, ALPHA, maxiter=CD_STEPS)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": sample * CD_STEPS / dt, "unit": "row-steps/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": "%d rows x %d steps of oracle/lasso_oracle.py coordinate_descent, "
+                               "%.1f s, os.cpu_count()=%s" % (sample, CD_STEPS, dt, os.cpu_count())}
+    return out
+
+
 def run_launcher_selftest(args, ranks):
     """No compute: the launcher / barrier / max-over-ranks protocol only (CPU, gloo)."""
     def step():
@@ -732,7 +812,7 @@ def parser():
     ap.add_argument("--steps", type=int, default=100)    # 0.32 s timed at the headline shape
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100, help="FISTA iterations per step (solve)")
-    ap.add_argument("--workload", choices=["fista", "em", "c3", "conv", "launcher-selftest"], default="fista")
+    ap.add_argument("--workload", choices=["fista", "em", "c3", "conv", "cd", "launcher-selftest"], default="fista")
     ap.add_argument("--conv-case", choices=sorted(CONV_CASES), default="gray",
                     help="conv workload: N=256 1x32x32 images with 64 7x7 atoms (gray), N=64 3x64x64 with 128 5x5 (rgb), "
                          "N=32 16x64x64 with 256 3x3 (c16)")
@@ -789,7 +869,7 @@ def main():
             raise SystemExit("bench.py: rank %d has no GPU (visible: %d)" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(gpu)
         ranks = Ranks(rank, world, torch.device("cuda", gpu), args.backend, force=args.force_dist)
-        out = {"em": run_em, "c3": run_c3, "fista": run_fista, "conv": run_conv}[args.workload](args, ranks)
+        out = {"em": run_em, "c3": run_c3, "fista": run_fista, "conv": run_conv, "cd": run_cd}[args.workload](args, ranks)
         if out is not None and ranks.sharded:
             out["backend"] = args.backend + (" (all ranks share cuda:0: a code-path run, not a performance figure)"
                                              if args.share_gpu else

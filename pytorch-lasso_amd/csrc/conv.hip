@@ -564,7 +564,7 @@ hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int 
 // the caller has to take the explicit path.
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int dry) {
   *count = 0;
   const int ckk = g.C * g.kh * g.kw;
   if (ckk > 192) return hipSuccess;
@@ -602,6 +602,10 @@ hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float
   if (gy > dpart_cap || ntiles <= 0 || ntiles > INT32_MAX) return hipSuccess;
   const int gx = (int)std::min<int64_t>(ntiles, std::min(dpart_cap / gy, std::max(1, cgp_occ(s4) * cus / gy)));
   const size_t lds = (size_t)(tp * (kw + 4) + 4 * s4 + g.C * p.RH * p.RW + 1) * 4;
+  if (dry) {                                     // (no launch: lasso_conv_ista_kernel_name asks whether the geometry is covered)
+    *count = gx * gy;
+    return hipSuccess;
+  }
   const dim3 grid(gx, gy);
   const bool skip = ckk <= 4 * s4 - 4;
 #define LASSO_CGP_CASE2(S4_, KW_, SK_)                                                                       \

@@ -223,8 +223,9 @@ hipError_t synth_launch(const ConvSynth& p, int cus, hipStream_t stream) {
 
 // *done = false when the geometry is not covered (stride > 1, C > 16, K not a multiple of 4, a
 // kernel size / atom count without an instantiation): the caller takes the explicit path.
+// dry != 0: no launch -- *done says whether this geometry is covered (lasso_conv_ista_kernel_name)
 hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
-                             bool* done, hipStream_t stream) {
+                             bool* done, hipStream_t stream, int dry) {
   *done = false;
   // (C is padded to the 16 columns of an MFMA block: below 8 channels the explicit path does less work)
   if (g.sh != 1 || g.sw != 1 || g.C > 16 || g.C < 8 || g.K < 4 || (g.K & 3) || g.kh != g.kw || (((uintptr_t)Ym) & 15)) return hipSuccess;
@@ -237,6 +238,10 @@ hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, fl
   p.ntiles = (int)nt;
   const int ks = g.kh, K = g.K;
   hipError_t e = hipSuccess;
+  if (dry) {
+    *done = (ks == 3 && K <= 256) || (ks == 5 && K <= 128) || (ks == 7 && K <= 64);
+    return hipSuccess;
+  }
   *done = true;
   if (ks == 3 && K <= 32) e = synth_launch<3, 3, 1, 1>(p, cus, stream);
   else if (ks == 3 && K <= 64) e = synth_launch<3, 3, 2, 1>(p, cus, stream);

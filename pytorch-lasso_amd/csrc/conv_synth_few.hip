@@ -234,7 +234,7 @@ hipError_t few_launch_nt(int nt, const ConvSynthFew& p, int cus, hipStream_t str
 // *done = false when the geometry is not covered (stride > 1, C >= 8: conv_synth.hip's range, K > 128 or not a
 // multiple of 4, more than 128 taps, an image row too wide for eight outputs per thread): the caller goes on.
 hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
-                                 bool* done, hipStream_t stream) {
+                                 bool* done, hipStream_t stream, int dry) {
   *done = false;
   const int ckk = g.C * g.kh * g.kw;
   if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 128 || ckk > 128 || (((uintptr_t)Ym) & 15)) return hipSuccess;
@@ -254,6 +254,10 @@ hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x
   if (items <= 0 || items > INT32_MAX) return hipSuccess;
   p.items = (int)items;
   const int nt = (ckk + 15) / 16;
+  if (dry) {                                       // (no launch: is the geometry covered?)
+    *done = nt <= 8;
+    return hipSuccess;
+  }
   if (g.K <= 32) return few_launch_nt<2>(nt, p, cus, stream, done);
   if (g.K <= 64) return few_launch_nt<4>(nt, p, cus, stream, done);
   return few_launch_nt<8>(nt, p, cus, stream, done);

@@ -315,11 +315,11 @@ hipError_t launch_conv_residual(const float* Ym, const float* Wt, const float* w
 // conv_synth.hip: the same residual as one implicit-GEMM kernel (stride 1, C <= 16, square kernels 3/5/7 with
 // an instantiated atom count); *done = false -> not covered
 hipError_t launch_conv_synth(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
-                             bool* done, hipStream_t stream);
+                             bool* done, hipStream_t stream, int dry = 0);
 // conv_synth_few.hip: the same for C < 8 channels (columns = the taps, overlap-add in LDS); stride 1, K <= 128 a multiple
 // of 4, C kh kw <= 128
 hipError_t launch_conv_synth_few(const float* Ym, const float* w, const float* x, float* r, const ConvGeom& g, int cus,
-                                 bool* done, hipStream_t stream);
+                                 bool* done, hipStream_t stream, int dry = 0);
 // conv_fused.hip: synthesis + gradient + prox of up to 64 iterations in ONE launch, a workgroup per image or band of an
 // image (stride 1, C < 8, K <= 128, small images or bands); `tables` = conv_fused_table_bytes() of workspace filled once per solve by
 // launch_conv_fused_pack (*covered = false -> not covered, use the two-kernel form)
@@ -338,7 +338,7 @@ hipError_t launch_conv_fused(const void* tables, const float* x, float* Zm, cons
                              const ConvGeom& g, int cus, hipStream_t stream);
 hipError_t launch_conv_grad_prox(const float* r, const float* Wp, int ldr, float* Zm, float* Ym, float lr, float lam,
                                  float coef, float* dpart, int dpart_cap, const ConvGeom& g, int cus, int* count,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int dry = 0);
 hipError_t launch_conv_gradient(const float* r, const float* Wp, float* rc, int ldr, float* G, const ConvGeom& g,
                                 hipStream_t stream);
 hipError_t launch_patches_extract(const float* img, float* out, int64_t ld, float* means, const ConvGeom& g,

@@ -134,3 +134,45 @@ def test_conv_lines_one_and_two_ranks():
     assert one["nonzeros"] > 0 and abs(one["nonzeros"] - two["nonzeros"]) <= 1e-5 * one["nonzeros"]
     rgb = _bench(["--workload", "conv", "--conv-case", "rgb", "--steps", "2", "--warmup", "1"])
     assert rgb["config"]["images_total"] == 64 and rgb["value"] > 0 and rgb["roofline"]["bound"] == "hbm"
+
+
+# ---- every roofline block names kernels that its own command dispatches (a stale name survived a round) ----
+TRACED = [["--workload", "fista", "--no-cpu-baseline", "--no-shards", "--no-extras"],
+          ["--workload", "c3", "--dtype", "f32"], ["--workload", "c3", "--dtype", "bf16"],
+          ["--workload", "em", "--rows", "8192"], ["--workload", "em", "--shape", "c5", "--rows", "8192"],
+          ["--workload", "conv"], ["--workload", "conv", "--conv-case", "rgb"],
+          ["--workload", "cd", "--no-cpu-baseline"]]
+
+
+@pytest.mark.parametrize("args", TRACED, ids=lambda a: "-".join(x.strip("-") for x in a if x != "--workload"))
+def test_roofline_kernel_occurs_in_the_dispatch(args, tmp_path):
+    """`roofline.kernel` of a bench line against the rocprofv3 kernel trace of the SAME command: every kernel the
+    string names (bench.kernel_tokens) must have been dispatched."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        pytest.skip("rocprofv3 not on this box")
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = str(tmp_path)
+    cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", str(tmp_path / "t"), "-o", "k", "--",
+           sys.executable, BENCH] + args + ["--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    traces = glob.glob(str(tmp_path / "t" / "**" / "*kernel_trace.csv"), recursive=True)
+    assert traces, "no kernel trace written"
+    names = set()
+    for t in traces:
+        with open(t) as f:
+            names |= {row["Kernel_Name"] for row in csv.DictReader(f)}
+    tokens = bench.kernel_tokens(out["roofline"]["kernel"])
+    assert tokens, out["roofline"]["kernel"]
+    flat = [n.replace(" ", "") for n in names]
+    for tok in tokens:
+        assert any(tok.replace(" ", "") in n for n in flat), (tok, sorted(names)[:40])
