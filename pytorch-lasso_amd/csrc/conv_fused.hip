@@ -476,8 +476,37 @@ __global__ __launch_bounds__(256) void conv_fused_sums_kernel(const float* __res
 
 struct FusedPlan { int NT, KQ, R, BR, bands, old_rb, outs_max; size_t lds; };
 
+// The plan of ONE solve is computed ONCE: launch_conv_fused_pack() -- the first call of a solve -- plans
+// afresh (environment switches included) and leaves the plan in this thread's slot; the iteration count, the y-buffer
+// question and every launch of the same solve read it back instead of re-deriving it (a switch flipped in between can
+// no longer make the pack and the launches disagree, and band mode no longer calls getenv once per iteration).
+struct PlanSlot { bool valid; ConvGeom g; int cus; bool covered; FusedPlan pl; };
+static thread_local PlanSlot tl_plan = {false, {}, 0, false, {}};
+static bool same_geom(const ConvGeom& a, const ConvGeom& b) {
+  return a.N == b.N && a.C == b.C && a.H == b.H && a.W == b.W && a.K == b.K && a.Hz == b.Hz && a.Wz == b.Wz &&
+         a.kh == b.kh && a.kw == b.kw && a.sh == b.sh && a.sw == b.sw && a.ph == b.ph && a.pw == b.pw;
+}
+static bool fused_plan_fresh(const ConvGeom& g, int cus, FusedPlan* pl);
 // false when the geometry is not covered
-bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
+bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl, bool fresh = false) {
+  if (!fresh && tl_plan.valid && tl_plan.cus == cus && same_geom(tl_plan.g, g)) {
+    *pl = tl_plan.pl;
+    return tl_plan.covered;
+  }
+  tl_plan.covered = fused_plan_fresh(g, cus, pl);
+  tl_plan.valid = true; tl_plan.g = g; tl_plan.cus = cus; tl_plan.pl = *pl;
+  return tl_plan.covered;
+}
+
+// LDS a workgroup may ask for on this device (the plan below budgets 150 KB of gfx950's 160 KB)
+static size_t device_lds_limit() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+  return (size_t)std::max(v, 0);
+}
+
+static bool fused_plan_fresh(const ConvGeom& g, int cus, FusedPlan* pl) {
   if (const char* e = getenv("LASSO_CONV_FUSED"); e && e[0] == '0') return false;      // A/B and test switch: the two-kernel form
   const int ckk = g.C * g.kh * g.kw;
   if (g.sh != 1 || g.sw != 1 || g.C >= 8 || g.K < 4 || (g.K & 3) || g.K > 128 || ckk > 80 || g.kw > kCfMaxKw) return false;
@@ -529,6 +558,10 @@ bool fused_plan(const ConvGeom& g, int cus, FusedPlan* pl) {
   const size_t fixed = (size_t)(pl->NT * pl->KQ * 256 + 4 * pl->NT * 64 * ntp + 16 * pl->NT +
                                 ((g.C * rhb * (g.W + 2 * g.pw) + 3) & ~3) + kCfMaxKw * pitch) * 4;
   const size_t budget = 150 * 1024;
+  // a part with less LDS per workgroup, or with more CUs than the partial-sum buffer of a 64-iteration launch holds
+  // (kConvDpart words: lasso_hip.hip's kConvDpart): the two-kernel form, not a failed launch
+  if (device_lds_limit() < budget) return false;
+  if ((int64_t)std::min<int64_t>((int64_t)g.N * pl->bands, cus) * (pl->bands > 1 ? 1 : kCfMaxIters) > kConvDpart) return false;
   if (fixed + (size_t)wp * pitch * 4 > budget) return false;
   const int srows = std::min(g.Hz, pl->BR + (pl->bands > 1 ? 2 * (g.kh - 1) : 0));      // code rows a band synthesises
   const int rmax = (int)std::min<size_t>((budget - fixed) / ((size_t)wp * pitch * 4), (size_t)srows);
@@ -577,7 +610,7 @@ size_t conv_fused_table_bytes() { return (size_t)(5 * 8 * 256 + 4 * 5 * 64 * 8 +
 hipError_t launch_conv_fused_pack(const float* w, void* tables, const ConvGeom& g, int cus, bool* covered,
                                   hipStream_t stream) {
   FusedPlan pl;
-  *covered = fused_plan(g, cus, &pl);
+  *covered = fused_plan(g, cus, &pl, /*fresh=*/true);          // the solve's plan: every later call reads it back
   if (!*covered) return hipSuccess;
   const int ntp = pl.KQ > 4 ? 8 : 4;
   float* wf1 = (float*)tables;
@@ -606,7 +639,7 @@ int conv_fused_two_y_buffers(const ConvGeom& g, int cus) {
 // the instantiation launch_conv_fused would run for this geometry (the name rocprofv3 reports), or null
 const char* conv_fused_kernel_name(const ConvGeom& g, int cus) {
   FusedPlan pl;
-  if (!fused_plan(g, cus, &pl)) return nullptr;
+  if (!fused_plan(g, cus, &pl, /*fresh=*/true)) return nullptr;
   static thread_local char name[64];
   snprintf(name, sizeof(name), "lasso::conv_fused_kernel<%d, %d, %d>", pl.NT, pl.KQ, pl.outs_max <= 2 * kCfThreads ? 2 : pl.outs_max <= 8 * kCfThreads ? 8 : kCfMaxOut);
   return name;

@@ -400,12 +400,15 @@ hipError_t launch_gemm_nt_prox(const float* A, int64_t lda, const float* B, int6
                                float* Y, int64_t ldy, int m, int nn, int kk, float lr, float lam, float coef,
                                float* dpart, hipStream_t stream) {
   if (m <= 0 || nn <= 0) return hipSuccess;
-  // (32-bit buffer offsets inside a block's 128 rows of every operand)
-  if (std::max(std::max(lda, ldb), std::max(ldz, ldy)) * 128 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
   int bm, bn;
   prox_blocks(m, nn, &bm, &bn);
+  // (32-bit buffer offsets inside a block's rows of every operand: a very wide row pitch takes the smaller blocks --
+  // 64 rows reach a pitch of 2^23 floats -- before the launch is refused)
+  const int64_t ldmax = std::max(std::max(lda, ldb), std::max(ldz, ldy));
+  if (ldmax * 128 * 4 >= ((int64_t)1 << 31)) { bm = 64; bn = 64; }
+  if (ldmax * 64 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   const ProxEpilogue ep = {Z, ldz, Y, ldy, lr, lam, coef, dpart};
 #define LASSO_PROX_CASE(BM_, BN_)                                                                 \
   if (bm == BM_ && bn == BN_)                                                                      \
@@ -423,11 +426,16 @@ hipError_t launch_gemm_nt_sub(const float* A, int64_t lda, const float* B, int64
                               int64_t ldc0, float* C, int64_t ldc, int m, int nn, int kk,
                               hipStream_t stream, int add, int* zero_words, int nzero) {
   if (m <= 0 || nn <= 0) return hipSuccess;
-  if (std::max(std::max(lda, ldb), std::max(ldc, C0 ? ldc0 : (int64_t)0)) * 128 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   const bool vec = kk % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)B & 15) == 0;
   int bm, bn;
   gemm_blocks(m, nn, &bm, &bn);
+  // (32-bit buffer offsets inside a block's rows: a very wide row pitch takes blocks of fewer rows -- 32 rows reach a
+  // pitch of 2^24 floats -- before the launch is refused)
+  const int64_t ldmax = std::max(std::max(lda, ldb), std::max(ldc, C0 ? ldc0 : (int64_t)0));
+  if (ldmax * 128 * 4 >= ((int64_t)1 << 31)) { bm = std::min(bm, 64); bn = std::min(bn, 64); }
+  if (ldmax * 64 * 4 >= ((int64_t)1 << 31)) { bm = 32; bn = 32; }
+  if (ldmax * 32 * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   // Small products (U = B - A D^T of the M-step: 1024 x 256 outputs = 64 blocks of 64 x 64 on 256 CUs): 32-wide
   // sides until every CU has a workgroup.
   if (bm == 64 && bn == 64) {

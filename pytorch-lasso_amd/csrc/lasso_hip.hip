@@ -9,6 +9,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 #include <vector>
@@ -560,7 +561,10 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   // inputs, which must still be there
   const bool in_place = (z_in && z_in == z_out) || (y_in && y_in == y_out) || (y_in && y_in == z_out) ||
                         (z_in && y_out && z_in == y_out);
-  KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, in_place ? LASSO_KERNEL_TILE : hint);
+  // (the split-k kernel reads a tile's 16 rows of x / z / y through 32-bit buffer offsets: a row pitch of 2^31 / 64 floats
+  // or more keeps the tile kernel, whose loads are 64-bit addressed -- ADVICE r05: the descriptor clamped silently)
+  const bool wide_pitch = std::max(std::max(ldx, ldz_in), std::max(ldy_in, std::max(ldz_out, ldy_out))) * 64 >= ((int64_t)1 << 31);
+  KernelPlan plan = plan_kernel(kp, dpad, ntiles, p.stop_on != 0, (in_place || wide_pitch) ? LASSO_KERNEL_TILE : hint);
   float* const split_rows = ws.partials + (size_t)kChunkMax * ntiles;    // behind the tile kernel's rows
   // ---- ragged batches (round 4): the tile kernel runs ceil(ntiles / #CUs) rounds, so 257 tiles cost what 512 do.
   // The LAST, partly filled round goes to the split-k kernel instead when the cost model says so: the full rounds on
@@ -568,7 +572,7 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
   // stream; rows are independent and a row's code is bitwise the same from either kernel).  n = 5000 at k = 1024:
   // 63 -> 42 us per iteration.
   KernelPlan tplan = {false, 0, 1, 0.0};
-  const int tail = (in_place || p.stop_on) ? 0 : ragged_tail(kp, dpad, ntiles, tp.waves, hint, plan, &tplan);
+  const int tail = (in_place || wide_pitch || p.stop_on) ? 0 : ragged_tail(kp, dpad, ntiles, tp.waves, hint, plan, &tplan);
   if (tail) plan.split = false;                  // (the hybrid beats the split-k kernel on the whole batch as well)
   // the split-k kernel on the tiles of `q` (+ its stand-by): returns the partial sums per row of that launch
   auto launch_split = [&](FistaTileParams q, const KernelPlan& pl, float* standby_partials, int* nparts_out) -> int {
@@ -888,6 +892,7 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
   while (it < maxiter) {
   if (can_async && fusedit) {
     const int win0 = it, wlen = std::min(kBtWindow, maxiter - it);
+    const int n_first_used = n_first;
     LASSO_HIP_TRY(hipMemsetAsync(ws.flags, 0, (size_t)kBtWindow * 4 * sizeof(int), st));
     LASSO_HIP_TRY(hipMemsetAsync(ws.ctl, 0, 4 * sizeof(int), st));
     BtIterParams q;
@@ -967,6 +972,9 @@ int solve_backtracking(const void* x_any, int64_t ldx, const void* w_any, int64_
       // the next window computes as many trials per tile as this one's longest search took (every computed trial costs
       // its GEMM whether it is needed or not; a search that outgrows the guess costs one synchronous iteration)
       n_first = std::min(kBtBatch, std::max(2, most));
+      // a whole window without a search beyond its first batch: the second trial batch and its decision leave the
+      // windows again (two launches per iteration that did nothing; ADVICE r05: `safety` was never cleared)
+      if (hctl[0] != 2 && most <= n_first_used) safety = false;
     }
     it = done;
     if (hctl[0] == 1) break;     // the stop rule fired at iteration `done` (:93-95)
@@ -1560,7 +1568,7 @@ int check_cd(int64_t n, int64_t d, int64_t k, int dtype) {
 // ---------------------------------------------------------------------------
 // convolutional ISTA (conv.hip)
 // ---------------------------------------------------------------------------
-constexpr int kConvDpart = 64 * 1024;      // partial sums |z - z+|: 64 iterations per launch x up to 1024 workgroups (conv_fused.hip)
+// (kConvDpart, lasso_kernels.h: partial sums |z - z+|: 64 iterations per launch x up to 1024 workgroups, conv_fused.hip)
 struct ConvWorkspace { float* Wt; float* Wp; void* Wf; float* Zm; float* Ym; float* G; float* PT; float* R; float* dpart; float* delta; double* sums;
                        float* Zc; float* Yc;      // (z, y) at the head of a speculated chunk of iterations (stop rule, below)
                        size_t bytes; };
@@ -1621,15 +1629,18 @@ ConvGeom make_geom(int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_
 
 namespace lasso {
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  // (kernel, device) -> the largest size set so far: kernels whose LDS size depends on the geometry (the convolutional
+  // kernels) raise the attribute again when a later call needs more (the cache ignored the byte count)
   static std::mutex mu;
-  static std::set<std::pair<const void*, int>> done;
+  static std::map<std::pair<const void*, int>, size_t> done;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lock(mu);
-  if (done.count({kernel, dev})) return hipSuccess;
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) done.insert({kernel, dev});
+  if (e == hipSuccess) done[{kernel, dev}] = bytes;
   return e;
 }
 }  // namespace lasso

@@ -146,6 +146,8 @@ struct CdParams {
 };
 
 // convolutional ISTA (conv.hip): x [N][C][H][W], weight [K][C][kh][kw], code z [N][K][Hz][Wz]
+constexpr int kConvDpart = 64 * 1024;      // words of the convolutional solver's partial-sum buffer (lasso_hip.hip carves it;
+                                           // conv_fused.hip plans against it: 64 iterations per launch x up to 1024 workgroups)
 struct ConvGeom {
   int N, C, H, W, K, Hz, Wz, kh, kw, sh, sw, ph, pw;
 };

@@ -270,6 +270,57 @@ def test_many_iterations_per_launch_kernel(n_spec, C, K, kh, kw, padding, Hz, Wz
     assert abs(info1["last_delta"] - info2["last_delta"]) <= 1e-5 * abs(info2["last_delta"]) or info1["iterations"] != info2["iterations"]
 
 
+@pytest.mark.parametrize("form", ["fused", "bands", "two-kernel"])
+def test_stop_rule_count_pinned_exactly_against_the_oracle(form):
+    """ista.py:44-46 with an explicit step: the iteration at which the rule fires is the ORACLE's, exactly -- not +-1 --
+    on the one-launch kernel (a workgroup per image), on its banded form and on the two-kernel form.  The budget is
+    placed where the oracle's sums leave room: at least 1 % away from the sum of the iteration that fires and from
+    every earlier one, far beyond the 1e-6-level differences of the summation orders (the three
+    `<= 1` tolerances elsewhere in this file stay for lr='auto' and for budgets placed ON a sum)."""
+    import math
+    import os
+    from lasso_amd import _native as nat
+    ista_conv2d, _, _, _, orc = _mods()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if form == "bands":
+        N, C, K, ks, pd, Hz = max(cus // 4, 8), 1, 8, 3, 1, 32         # fewer images than a third of the CUs: bands of code rows
+    else:
+        N, C, K, ks, pd, Hz = cus, 1, 8, 3, 1, 12                      # an image per CU
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(K, C, ks, ks, generator=g) / ks
+    H = (Hz - 1) - 2 * pd + ks
+    x = torch.randn(N, C, H, H, generator=g)
+    z0 = torch.zeros(N, K, Hz, Hz)
+    lr = 0.5 / w.pow(2).sum().item()
+    # the oracle's sum of every iteration (one run per length: the loop is deterministic)
+    sums = [orc.conv_fista(x, z0, w, 0.1, padding=pd, maxiter=m, lr=lr, tol=0.0, return_info=True)[1]["last_delta"]
+            for m in range(1, 31)]
+    # an iteration m whose sum is the first below a budget with >= 1 % of room on both sides
+    pick = None
+    for m in range(8, 30):
+        lo, hi = sums[m - 1], min(sums[:m - 1])
+        if lo < hi and hi / lo >= 1.03:
+            pick, budget = m, math.sqrt(lo * hi)
+            break
+    assert pick is not None, sums
+    tol = budget / z0.numel()
+    _, rinfo = orc.conv_fista(x, z0, w, 0.1, padding=pd, maxiter=200, lr=lr, tol=tol, return_info=True)
+    assert rinfo["iterations"] == pick
+    args = _geom_args(N, C, K, ks, ks, pd, pd, Hz, Hz)
+    if form == "two-kernel":
+        os.environ["LASSO_CONV_FUSED"] = "0"
+    try:
+        name = nat.lib().lasso_conv_ista_kernel_name(*args)
+        assert (b"conv_fused_kernel" in name) == (form != "two-kernel"), name
+        got, info = ista_conv2d(x.cuda(), z0.cuda(), w.cuda(), 0.1, padding=pd, maxiter=200, lr=lr, tol=tol,
+                                return_info=True)
+    finally:
+        os.environ.pop("LASSO_CONV_FUSED", None)
+    assert info["iterations"] == pick, (form, info, rinfo, sums[pick - 2:pick + 1])
+    ref = orc.conv_fista(x, z0, w, 0.1, padding=pd, maxiter=pick, lr=lr, tol=0.0)
+    assert (got.cpu() - ref).abs().max().item() <= Z_ATOL
+
+
 def test_errors_and_edge_cases():
     ista_conv2d, _, _, _, _ = _mods()
     w = torch.randn(4, 2, 3, 3, device="cuda")
