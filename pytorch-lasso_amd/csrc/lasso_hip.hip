@@ -1988,7 +1988,9 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
       return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_SHARDED needs LASSO_SOLVE_ASYNC | LASSO_STOP_GLOBAL");
     if (maxiter > kChunkMax)
       return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: maxiter=%d > %d", maxiter, kChunkMax);
-    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+    // (y_out = NULL: the one chunk is the whole solve -- a verdict of "redo" repeats it from its start, nothing
+    // continues from its momentum point; round 6: the kernel no longer writes the n x k tile of y nobody reads)
+    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev))
       return s;
     return LASSO_PENDING;
@@ -2032,7 +2034,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
   if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
     const ChunkVerdict cv{budget, ws.stop_out, status_mapped};
-    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, ws.state[1], k, n, d, k,
+    if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev, &cv))
       return s;
     if (maxiter > 64 || n == 0) {
@@ -2422,6 +2424,14 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
     hipError_t e = hipSuccess;
     if (launch_gram_ab(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, a_dev, b_dev, scratch,
                        workspace_bytes - 256, cus, st, &e)) {
+      LASSO_HIP_TRY(e);
+      return LASSO_OK;
+    }
+  }
+  if (scratch && !getenv("LASSO_GRAM_TWO_LAUNCHES")) {      // small dictionaries: one product launch, one fold (A/B: the env switch)
+    hipError_t e = hipSuccess;
+    if (launch_gram_ab128(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, a_dev, b_dev, scratch,
+                          workspace_bytes - 256, cus, gram_max_splits(d, k), st, &e)) {
       LASSO_HIP_TRY(e);
       return LASSO_OK;
     }

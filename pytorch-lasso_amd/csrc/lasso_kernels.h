@@ -247,6 +247,9 @@ constexpr int kGramAbMaxSplits = 128;
 size_t gram_ab_scratch_bytes(int64_t d, int64_t k);
 bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
                     float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err);
+// small dictionaries (k >= 128, d <= 128): A = Z^T Z and B = Z^T X in one product launch + one fold launch
+bool launch_gram_ab128(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
+                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err);
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
                           int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
                           hipStream_t stream);

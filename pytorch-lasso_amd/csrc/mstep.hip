@@ -132,12 +132,21 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const float* __restrict__ 
 #define LASSO_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 constexpr int kG2B = 128, kG2S = 32, kG2Ld = 144;
 
+// Gram2 (round 6): a SECOND right operand whose blocks ride in the same launch -- B = P^T Q2 behind the sym product
+// A = P^T P (the M-step's two products of a small dictionary: d <= 128 is one column block, half of it padding for
+// d = 64 -- still cheaper than a launch of its own on the EM step's chain).  Its partials go to C2 (pitch ldc2).
+struct Gram2 { const float* Q2; int64_t ldq2; int qc2; float* C2; int64_t ldc2; int64_t split_stride2; int first; };
 __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restrict__ P, int64_t ldp, int pc,
                                                             const float* __restrict__ Q, int64_t ldq, int qc, int n,
                                                             float* __restrict__ C, int64_t ldc, int sym,
-                                                            int rows_per_split, int64_t split_stride) {
+                                                            int rows_per_split, int64_t split_stride, const Gram2 g2) {
   int bi, bj;
-  if (sym) {                                   // blockIdx.x -> (bi, bj), bj >= bi, row by row
+  if (g2.Q2 && (int)blockIdx.x >= g2.first) {  // a block of the second product: row block bi of P, column block bj of Q2
+    const int e = blockIdx.x - g2.first, nbq = (g2.qc2 + kG2B - 1) / kG2B;
+    bi = e / nbq;
+    bj = e - bi * nbq;
+    Q = g2.Q2; ldq = g2.ldq2; qc = g2.qc2; C = g2.C2; ldc = g2.ldc2; split_stride = g2.split_stride2;
+  } else if (sym) {                            // blockIdx.x -> (bi, bj), bj >= bi, row by row
     const int nb = (pc + kG2B - 1) / kG2B;
     int rem = blockIdx.x;
     bi = 0;
@@ -292,6 +301,32 @@ __device__ __forceinline__ void sum_splits_sym_body(int block, const float* __re
 __global__ __launch_bounds__(256) void sum_splits_sym4_kernel(const float* __restrict__ part, int splits,
                                                               int64_t split_stride, int64_t ldpart, int pc,
                                                               float* __restrict__ C, int64_t ldc) {
+  const int nt = (pc + 31) / 32;
+  int rem = blockIdx.x >> 2, tr = 0;
+  while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
+  const int tc = tr + rem, a = blockIdx.x & 3;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r = 32 * tr + ty + 8 * a, c = 32 * tc + tx;
+  const float v = ordered_split_sum(part + (int64_t)min(r, pc - 1) * ldpart + min(c, pc - 1), split_stride, splits);
+  if (r < pc && c < pc) {
+    C[(int64_t)r * ldc + c] = v;
+    if (tr != tc) C[(int64_t)c * ldc + r] = v;
+  }
+}
+
+// sum_splits_sym4_kernel on A and the element-wise fold of a second product B in ONE launch (small dictionaries: the two
+// folds of an EM step's Gram products; the same sums in the same order as the separate kernels)
+__global__ __launch_bounds__(256) void sum_splits_sym4_b_kernel(const float* __restrict__ part, int splits,
+                                                                int64_t split_stride, int64_t ldpart, int pc,
+                                                                float* __restrict__ C, int64_t ldc, int nsym4,
+                                                                const float* __restrict__ part2, int64_t split_stride2,
+                                                                int rows2, int cols2, float* __restrict__ C2, int64_t ldc2) {
+  if ((int)blockIdx.x >= nsym4) {
+    const int64_t idx = (int64_t)(blockIdx.x - nsym4) * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows2 * cols2) return;
+    C2[(idx / cols2) * ldc2 + idx % cols2] = ordered_split_sum(part2 + idx, split_stride2, splits);
+    return;
+  }
   const int nt = (pc + 31) / 32;
   int rem = blockIdx.x >> 2, tr = 0;
   while (rem >= nt - tr) { rem -= nt - tr; ++tr; }
@@ -1969,6 +2004,41 @@ bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t 
   return true;
 }
 
+#ifndef LASSO_GRAM_MIN_ROWS
+#define LASSO_GRAM_MIN_ROWS 128
+#endif
+constexpr int kGramMinRowsC = LASSO_GRAM_MIN_ROWS;      // (== kGramMinRows below)
+// A = Z^T Z (k x k, sym) and B = Z^T X (k x d) of a SMALL dictionary in one product launch + one fold launch (round 6:
+// the EM step of 8 x 8 patches -- d = 64, k = 256 -- spent four launches here).  false: not applicable (the caller takes
+// the two products one after the other).  Scratch: [splits][k][k] for A, then [splits][k][d] for B.
+bool launch_gram_ab128(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
+                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err) {
+  *err = hipSuccess;
+  if (k < kG2B || d > kG2B || (k & 3) || (d & 3) || (ldz & 3) || (ldx & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)X & 15) ||
+      !scratch || n <= 0)
+    return false;
+  const int nbp = (k + kG2B - 1) / kG2B, nsym = nbp * (nbp + 1) / 2, nb2 = nbp;         // B: one column block per row block
+  if (nsym >= 128) return false;                                                          // (the few-tiles fold below)
+  int splits = std::max(1, 2 * cus / std::max(nsym + nb2, 1));
+  splits = std::min(splits, std::max(n / kGramMinRowsC, 1));
+  splits = std::max(1, std::min(splits, max_splits));
+  const int rps = ((n + splits - 1) / splits + kG2S - 1) / kG2S * kG2S;
+  const int sp = std::max(1, (n + rps - 1) / std::max(rps, 1));
+  const int64_t strideA = (int64_t)k * k, strideB = (int64_t)k * d;
+  if ((size_t)sp * (size_t)(strideA + strideB) * 4 > scratch_bytes) return false;
+  float* const partA = scratch;
+  float* const partB = scratch + (size_t)sp * strideA;
+  const size_t lds = (size_t)4 * kG2S * kG2Ld * 4;
+  if ((*err = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_tn128_kernel), lds)) != hipSuccess) return true;
+  hipLaunchKernelGGL(gram_tn128_kernel, dim3(nsym + nb2, 1, sp), dim3(256), lds, stream, Z, ldz, k, Z, ldz, k, n, partA,
+                     (int64_t)k, 1, rps, strideA, Gram2{X, ldx, d, partB, (int64_t)d, strideB, nsym});
+  const int nt = (k + 31) / 32, ntiles = nt * (nt + 1) / 2;
+  hipLaunchKernelGGL(sum_splits_sym4_b_kernel, dim3(4 * ntiles + (unsigned)((strideB + 255) / 256)), dim3(256), 0, stream,
+                     partA, sp, strideA, (int64_t)k, k, A, (int64_t)k, 4 * ntiles, partB, strideB, k, d, B, (int64_t)d);
+  *err = hipGetLastError();
+  return true;
+}
+
 static bool gram_use128(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc) {
   return pc >= kG2B && qc >= kG2B && pc % 4 == 0 && qc % 4 == 0 && ldp % 4 == 0 && ldq % 4 == 0 &&
          ((uintptr_t)P & 15) == 0 && ((uintptr_t)Q & 15) == 0;
@@ -2010,7 +2080,7 @@ hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, i
     float* const out = to_scratch ? scratch : C;
     const int64_t old_ = to_scratch ? qc : ldc, stride128 = (int64_t)pc * qc;
     hipLaunchKernelGGL(gram_tn128_kernel, dim3(blocks, 1, sp), dim3(256), lds, stream, P, ldp, pc, Q, ldq, qc, n, out,
-                       old_, sym, rps, stride128);
+                       old_, sym, rps, stride128, Gram2{nullptr, 0, 0, nullptr, 0, 0, 0});
     if (sym) {
       const int nt = (pc + 31) / 32, ntiles = nt * (nt + 1) / 2;
       if (ntiles < 128)
