@@ -320,7 +320,11 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     if (constrained and defer and X.is_cuda and hasattr(engine, 'side_stream') and tol > 0
             and (overlap or (shard_async and ndelta > 0)) and os.environ.get("LASSO_EM_SIDE_STREAM", "1") != "0"
             and os.environ.get("LASSO_EM_PIPELINE", "1") != "0" and hasattr(engine, 'mstep_pipe_stages')
-            and (len(engine.mstep_pipe_stages(d, k)) > 0 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")):
+            and (len(engine.mstep_pipe_stages(d, k)) > 0 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")
+            # measured (tools/r6_em_rows.sh, k = 1024): 4096 rows per rank -4.4 %, 8192 -3.5 %, 16384 -2.3 %, 32768 -0.3 %,
+            # 65536 +0.6 % -- at that size the Gram product and the objective are HBM-bound and gain nothing from running
+            # beside each other.  (The average row count: the same number on every rank.)
+            and (n_total / max(world, 1) <= 32768 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")):
         return _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group,
                                     n_total, ndelta, losses, stats)
     i, Zlast = 0, None
