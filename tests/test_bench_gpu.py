@@ -104,14 +104,19 @@ def test_one_rank_rccl_group_fista_line():
 
 
 def test_one_rank_rccl_group_em_line():
-    plain = _bench(["--workload", "em", "--steps", "2", "--warmup", "1"])
+    # up to 32768 rows per rank: the two-stream loop, one RCCL message per stage of the pipelined M-step
+    plain = _bench(["--workload", "em", "--rows", "16384", "--steps", "2", "--warmup", "1"])
+    out = _bench(FORCED + ["--workload", "em", "--rows", "16384"])
+    ar = out["all_reduce_ms"]
+    assert ar["per_step"] == 3.0 and ar["bytes_per_step"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
+    assert out["em_path"].get("pipelined_steps") == 2 and not out["em_path"].get("replayed_steps")
+    assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
+    assert plain["all_reduce_ms"]["per_step"] == 0.0 and plain["em_path"].get("pipelined_steps") == 2
+    # beyond: the one-stream loop, ONE message [A | B | tail] per EM step
     out = _bench(FORCED + ["--workload", "em"])
     ar = out["all_reduce_ms"]
-    # one RCCL message per stage of the pipelined M-step, [A | B | tail] in all
-    assert ar["per_step"] == 3.0 and ar["bytes_per_step"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
-    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
-    assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
-    assert plain["all_reduce_ms"]["per_step"] == 0.0
+    assert ar["per_step"] == 1.0 and ar["bytes_sent"] == [4 * (1024 * 1024 + 1024 * 256 + 12)]
+    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("pipelined_steps")
 
 
 def test_one_rank_rccl_group_line_search_line():
