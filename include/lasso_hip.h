@@ -235,6 +235,12 @@ int lasso_objective(const void* x_dev, int64_t ldx, const void* w_dev, int64_t l
                     const void* z_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype,
                     double alpha, float* loss_dev, double* sums_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
+/* lasso_objective on at most `max_workgroups` workgroups of the fused kernel (0 = no cap): for callers that run it
+ * beside latency-bound work of another stream (ABI 7; the EM loop's objective beside the atom sweep). */
+int lasso_objective_throttled(const void* x_dev, int64_t ldx, const void* w_dev, int64_t ldw,
+                              const void* z_dev, int64_t ldz, int64_t n, int64_t d, int64_t k, int dtype,
+                              double alpha, float* loss_dev, double* sums_dev, int max_workgroups,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- constrained M-step in Gram form: replaces update_dict, dict_learning.py:56-103 --
  * lasso_gram_accumulate: A = Z^T Z [k][k] (ld k), B = Z^T X [k][d] (ld d) of this row

@@ -85,6 +85,9 @@ def _declare(lib):
     lib.lasso_objective.restype = i32
     lib.lasso_objective.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, vp, vp,
                                     vp, sz, vp]
+    lib.lasso_objective_throttled.restype = i32
+    lib.lasso_objective_throttled.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, dbl, vp, vp, i32,
+                                              vp, sz, vp]
     lib.lasso_gram_accumulate.restype = i32
     lib.lasso_gram_workspace_bytes.restype = sz
     lib.lasso_gram_workspace_bytes.argtypes = [i64, i64, i64]

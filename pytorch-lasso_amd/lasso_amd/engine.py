@@ -323,7 +323,7 @@ class HipEngine:
     # -- objective ---------------------------------------------------------------
     objective_loss_out = True      # objective_sums(..., loss_out=) exists (parallel.em_loop)
 
-    def objective_sums(self, X, Z, W, alpha, loss_out=None):
+    def objective_sums(self, X, Z, W, alpha, loss_out=None, max_workgroups=0):
         """-> (loss_local 0-d float tensor, sums double[2] = {sum r^2, sum |z|}) on device.
         ``loss_out``: an optional 0-d fp32 device tensor (e.g. one slot of a loss history) the loss is
         written to directly."""
@@ -334,10 +334,10 @@ class HipEngine:
             ws = self._ws(L.lasso_objective_workspace_bytes(n, d, k), "obj")
             loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=self.device)
             sums = torch.empty(2, dtype=torch.float64, device=self.device)
-            nat.check(L.lasso_objective(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0),
-                                        nat.ptr(Z), Z.stride(0), n, d, k, nat.LASSO_F32, float(alpha),
-                                        nat.ptr(loss), nat.ptr(sums), nat.ptr(ws), ws.numel(),
-                                        self._stream()))
+            nat.check(L.lasso_objective_throttled(nat.ptr(X), X.stride(0), nat.ptr(W), W.stride(0),
+                                                  nat.ptr(Z), Z.stride(0), n, d, k, nat.LASSO_F32, float(alpha),
+                                                  nat.ptr(loss), nat.ptr(sums), int(max_workgroups), nat.ptr(ws),
+                                                  ws.numel(), self._stream()))
         return loss, sums
 
     # -- M-step --------------------------------------------------------------------
