@@ -126,8 +126,9 @@ def hbm_traffic_for(tag):
         top = ", ".join("%s %.1f MB" % (r["kernel"].replace("lasso::", "")[:48], r["hbm_bytes_per_step"] / 1e6)
                         for r in rec.get("kernels", [])[:3])
         return rec["hbm_bytes_per_step"], ("%s/hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE of `%s`, all "
-                                           "dispatches / %g steps; not collected in this run; largest: %s)"
-                                           % (c, rec.get("command", "?"), rec.get("steps_divisor", 0), top))
+                                           "dispatches / %g steps; not collected in this run; largest: %s)%s"
+                                           % (c, rec.get("command", "?"), rec.get("steps_divisor", 0), top,
+                                              ("; " + rec["conditions"]) if rec.get("conditions") else ""))
     return None, why
 
 

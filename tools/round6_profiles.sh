@@ -30,8 +30,13 @@ for tag in $TAGS; do
   python $R/tools/summarize_prof.py /tmp/pp_$tag > $D/kernel_stats.txt 2>&1
   # EM workloads: the launch timeline of the last steps, both streams (the overlap of the two-stream loop)
   case $tag in em_*) f=$(find /tmp/pp_$tag -name '*kernel_trace.csv' | head -1); python $R/tools/step_timeline.py $f 70 > $D/timeline.txt 2>&1 ;; esac
+  # PMC passes serialise the kernels of a process: the two-stream EM loop cannot run under them (the sweep and the side
+  # stream's launches wait for each other on the device) -- the counter passes of the em workloads run the ONE-stream
+  # loop (LASSO_EM_SIDE_STREAM=0: Gram product by lasso_gram_accumulate, objective on the main stream) and say so
+  case $tag in em_*) export LASSO_EM_SIDE_STREAM=0; export LASSO_HBM_NOTE="counter passes ran the one-stream EM loop (LASSO_EM_SIDE_STREAM=0): PMC collection serialises kernels, under which the two-stream loop's device-side waits cannot be met" ;; *) unset LASSO_EM_SIDE_STREAM; unset LASSO_HBM_NOTE ;; esac
   bash $R/tools/pmc_mfma_busy.sh $D/mfma_busy.txt $R/bench.py $ARGS > /dev/null 2>&1
   bash $R/tools/prof_hbm.sh $D $DIV $PARGS > $D/hbm.log 2>&1
+  unset LASSO_EM_SIDE_STREAM
   # the bench line LAST: it then finds this build's hbm_traffic.json beside it (gpurun_out/r06_<tag>/ is looked at first)
   python $R/bench.py $ARGS > $D/bench.json 2> $D/bench.err
   echo "== $tag"; head -c 600 $D/bench.json; echo; head -4 $D/kernel_stats.txt; tail -7 $D/hbm.log
