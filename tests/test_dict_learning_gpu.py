@@ -643,3 +643,60 @@ def test_two_stream_em_loop_against_the_one_stream_loop_and_degenerate_atoms(mon
     D, losses = dict_learning(Xs.cuda(), 512, alpha=1.5, steps=3, init_weight=D0, progbar=False, device="cuda")
     assert (losses.cpu() - lref).abs().max().item() <= 1e-5 * lref.abs().max().item()
     assert (D.cpu() - Dref).abs().max().item() <= 2e-5
+
+
+def _pipe_once(eng, Z, X, D0, AB, ws, seq):
+    """one pipelined M-step on two streams; returns (D, ndeg)"""
+    n, k = Z.shape
+    d = X.shape[1]
+    stages = eng.mstep_pipe_stages(d, k)
+    S = eng.side_stream()
+    D = D0.clone()
+    eng.pipe_gram(Z, X, AB, 0, ws)
+    eng.pipe_rows(AB, D, n, 0, ws, seq=seq)
+    with torch.cuda.stream(S):
+        eng.pipe_wait(n, d, k, seq, ws)
+        for s_ in range(1, len(stages)):
+            eng.pipe_gram(Z, X, AB, s_, ws)
+            eng.pipe_rows(AB, D, n, s_, ws)
+        eng.pipe_signal(n, d, k, seq, ws)
+    mask = eng.pipe_sweep(AB, D, n, 1e-10, False, ws)
+    _, ndeg = eng.pipe_finish(D, n, 1e-10, False, mask, ws, wait_seq=seq)()
+    torch.cuda.synchronize()
+    return D, ndeg
+
+
+def test_pipelined_mstep_standby_form_and_busy_gpu():
+    """The GATED sweep's one-workgroup stand-by form (lasso_debug_force_standby: every row straight from the product,
+    each stage's rows waited for by the staging waves) returns the co-operative form's dictionary bit for bit; and with a
+    third stream holding the CUs -- the hand-offs between the two streams and inside the sweep under uneven load -- twenty
+    pipelined M-steps in a row return that dictionary every time, no error, no hang."""
+    from lasso_amd import _native as nat
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine()
+    lib = nat.lib()
+    n, d, k = 4096, 256, 1024
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(n, d, generator=g).cuda()
+    Z = (torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.2)).cuda()
+    D0 = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+    ws = eng.mstep_pipe_workspace(n, d, k)
+    AB = torch.zeros(k, k + d, device="cuda")
+    Dref, ndeg = _pipe_once(eng, Z, X, D0, AB, ws, 1)
+    assert ndeg == 0
+    assert lib.lasso_debug_force_standby(1) == 0
+    try:
+        Dsolo, _ = _pipe_once(eng, Z, X, D0, AB, ws, 2)
+    finally:
+        assert lib.lasso_debug_force_standby(0) == 1
+    assert torch.equal(Dsolo, Dref)
+    busy = torch.cuda.Stream()
+    a = torch.randn(6144, 6144, device="cuda")
+    b = torch.randn(6144, 6144, device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(20):
+        with torch.cuda.stream(busy):
+            for _ in range(1 + trial % 4):
+                a = torch.mm(a, b) * 1e-2
+        D, ndeg = _pipe_once(eng, Z, X, D0, AB, ws, 3 + trial)
+        assert ndeg == 0 and torch.equal(D, Dref), trial
