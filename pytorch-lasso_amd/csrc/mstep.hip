@@ -812,8 +812,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ bool spin_until(const int* flag, int want, int* abort_flag) {
-  for (int spins = 0; spins < kStopSpinLimit; ++spins) {
+// The waits of the GATED sweep (pipelined M-step) for rows that another stream is still producing: that stream's work
+// includes the caller's collectives (RCCL all-reduces of a stage; the first ones of a process set up connections for
+// hundreds of milliseconds), so their bound is ~30 s, not the ~0.2 s that says "a co-operating workgroup is not resident".
+constexpr int kGateSpinLimit = 1 << 24;
+__device__ __forceinline__ bool spin_until(const int* flag, int want, int* abort_flag, int limit = kStopSpinLimit) {
+  for (int spins = 0; spins < limit; ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     __builtin_amdgcn_s_sleep(2);
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       // pipelined M-step: this block's rows of A and U are still being produced (another stream) when the launch
       // starts -- wait for their group's word, then make this CU read them afresh
       __syncthreads();
-      if (tid == 0 && !spin_until(x.flags + kSpRowFlag + r / x.gate, 1, f_abort)) sh_dead = 1;
+      if (tid == 0 && !spin_until(x.flags + kSpRowFlag + r / x.gate, 1, f_abort, kGateSpinLimit)) sh_dead = 1;
       __syncthreads();
       if (sh_dead) return;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -960,7 +964,8 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       if (b + 1 <= r - kSpSelf - 1) load_an(sAn + ((b + 1) & 1) * JB * kSpLdA, r, b + 1, tid, 256);
       for (int g = 0; g < 4 && alive; ++g) {
         bool ok = true;
-        if (lane == 0) ok = spin_until(f_pub, 4 * b + g + 1, f_abort);
+        // (gated: the sweeper may itself be waiting for a stage of rows -- its deltas then take as long as that stage)
+        if (lane == 0) ok = spin_until(f_pub, 4 * b + g + 1, f_abort, x.gate > 0 ? kGateSpinLimit : kStopSpinLimit);
         alive = __builtin_amdgcn_readfirstlane((int)ok) != 0;
         if (alive) sp_mma_group<4>(acc, cur, dd_global(b), g, l15, q);
       }
@@ -1280,7 +1285,7 @@ __global__ __launch_bounds__(256) void sweep_persist_kernel(const SweepParams p,
       if (nb < nblk) {
         if (x.gate > 0 && nb % x.gate == 0 && nb / x.gate >= x.gate0) {   // first block of a group of rows that arrive while we run
           bool ok = true;
-          if (lane == 0) ok = spin_until(x.flags + kSpRowFlag + nb / x.gate, 1, f_abort);
+          if (lane == 0) ok = spin_until(x.flags + kSpRowFlag + nb / x.gate, 1, f_abort, kGateSpinLimit);
           if (__builtin_amdgcn_readfirstlane((int)ok) == 0) sh_abort = 1;   // (a_staged still advances: nobody hangs)
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -1780,9 +1785,10 @@ __global__ __launch_bounds__(256) void fixup_transpose_kernel(const SweepParams 
       // wait for its word instead of a cross-stream event in front of this launch (~6-10 us on the step's chain)
       int spins = 0;
       while (__hip_atomic_load(p.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.wait_value &&
-             ++spins < (1 << 20))
-        __builtin_amdgcn_s_sleep(8);
-      s_late = spins >= (1 << 20);       // ~0.3 s: reported through the count of degenerate atoms (-1), never silently
+             ++spins < kGateSpinLimit)
+        __builtin_amdgcn_s_sleep(16);
+      s_late = spins >= kGateSpinLimit;  // ~30 s (the other stream's work includes the caller's collectives): reported
+                                         // through the count of degenerate atoms (-1), never silently
     }
   }
   __syncthreads();
