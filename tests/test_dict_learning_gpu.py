@@ -700,3 +700,25 @@ def test_pipelined_mstep_standby_form_and_busy_gpu():
                 a = torch.mm(a, b) * 1e-2
         D, ndeg = _pipe_once(eng, Z, X, D0, AB, ws, 3 + trial)
         assert ndeg == 0 and torch.equal(D, Dref), trial
+
+
+@pytest.mark.parametrize("n,k,kw", [(10, 512, dict(steps=3)), (700, 768, dict(steps=3, persist=True)),
+                                    (515, 1024, dict(steps=1)), (900, 2048, dict(steps=2, lr=0.05, maxiter=6)),
+                                    (600, 512, dict(steps=3, progbar=True))])
+def test_two_stream_em_loop_corner_cases(n, k, kw, monkeypatch):
+    """The two-stream loop on the shapes and arguments around its default: fewer samples than a split, every pipelined
+    dictionary size (2, 3, 4 and 8 block rows), persist=True (the previous code as the start: no zero-start kernel), one
+    step, an explicit step size, the progress bar (a host read of a loss the side stream writes) -- against the
+    one-stream loop on the same inputs (same kernels but the Gram product's summation order)."""
+    from lasso_amd.linear import dict_learning
+    g = torch.Generator().manual_seed(n + k)
+    X = torch.randn(n, 256, generator=g).cuda()
+    D0 = torch.nn.functional.normalize(torch.randn(256, k, generator=g), dim=0)
+    torch.manual_seed(4)
+    two = dict_learning(X, k, alpha=0.3, init_weight=D0, device="cuda", **dict(dict(progbar=False), **kw))
+    monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
+    torch.manual_seed(4)
+    one = dict_learning(X, k, alpha=0.3, init_weight=D0, device="cuda", **dict(dict(progbar=False), **kw))
+    assert torch.isfinite(two[0]).all() and torch.isfinite(two[1]).all()
+    assert (two[1] - one[1]).abs().max().item() <= 5e-6 * one[1].abs().max().item()
+    assert (two[0] - one[0]).abs().max().item() <= 2e-5
