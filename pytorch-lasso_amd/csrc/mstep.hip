@@ -2232,8 +2232,8 @@ MstepPipePlan mstep_pipe_plan(int64_t n, int64_t d, int64_t k, int cus) {
     // the head runs before the sweep; the others beside it (the sweep holds one CU per worker), with a margin, so that
     // every workgroup of a launch finds a CU at once (one workgroup per CU: LDS and registers)
     int avail = lo == 0 ? cus : std::max(cus - workers - 8, cus / 2);
-    if (lo > 0)
-      if (const char* g = getenv("LASSO_PIPE_AVAIL")) avail = std::max(16, std::min(avail, atoi(g)));   // A/B knob (round 6)
+    static const int avail_knob = [] { const char* g = getenv("LASSO_PIPE_AVAIL"); return g ? atoi(g) : 0; }();   // A/B knob, read once
+    if (lo > 0 && avail_knob > 0) avail = std::max(16, std::min(avail, avail_knob));
     int blocks = 0;
     for (int r = lo; r < hi; ++r) blocks += nb - r + (int)(d / kG3B);
     int splits = std::max(1, std::min(avail / blocks, kGramAbMaxSplits));
