@@ -289,6 +289,18 @@ int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, 
                            int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
 
+/* lasso_dict_sweep_async with the new dictionary written to ANOTHER buffer (d_out_dev, pitch ldo >= k, not overlapping
+ * d_dev): d_dev is only read.  The call may then be enqueued BEFORE the host knows whether the EM step it belongs to
+ * stands (the E-step's verdict, the previous sweep's count of degenerate atoms) -- a step that is repeated keeps d_dev
+ * and ignores d_out_dev, degenerate_dev and ndeg_mapped -- and launches on another stream may keep reading d_dev beside
+ * it (the objective of dict_learning.py:39).  Same kernels, same arithmetic: bitwise the dictionary of lasso_dict_sweep.
+ * Replaces the in-place update of dict_learning.py:83-91 where the caller double-buffers the dictionary. */
+int lasso_dict_sweep_async_to(const float* a_dev, const float* b_dev, const void* d_dev, int64_t ldd,
+                              void* d_out_dev, int64_t ldo, int64_t d, int64_t k, int dtype, double eps, int positive,
+                              const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
+                              int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev,
+                              size_t workspace_bytes, void* stream);
+
 /* One wave on `stream` that returns when *word == value (or after ~0.1 s; host_memory != 0: `word` is pinned host
  * memory, e.g. the "valid" word of a LASSO_SOLVE_STATUS_MAPPED buffer): "after that kernel of ANOTHER stream" for the
  * launches behind it without an event record on the other stream.  A scheduling tool: use it only where a late or

@@ -2471,14 +2471,23 @@ size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k) {
          (dp == 256 ? align_up(sweep_persist_extra_bytes((int)k)) : 0);
 }
 
+// d_out_dev (pitch ldo): where the new dictionary goes -- d_dev itself (in place), or another buffer: d_dev is then only
+// read (lasso_dict_sweep_async_to)
 static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd, int64_t d,
                            int64_t k, int dtype, double eps, int positive, const float* pool_dev,
                            int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
                            int32_t* ndeg_out, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
-                           void* stream) {
+                           void* stream, void* d_out_dev = nullptr, int64_t ldo = 0) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!a_dev || !b_dev || !d_dev || !degenerate_dev || !workspace_dev || d <= 0 || k <= 0 || ldd < k)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (!d_out_dev) { d_out_dev = d_dev; ldo = ldd; }
+  if (ldo < k) return fail(LASSO_ERR_BAD_ARG, "bad argument");
+  if (d_out_dev != d_dev) {         // two buffers: they must not overlap (the old atoms are read while the new ones land)
+    const char* a0 = (const char*)d_dev, * a1 = a0 + ((size_t)(d - 1) * ldd + k) * 4;
+    const char* b0 = (const char*)d_out_dev, * b1 = b0 + ((size_t)(d - 1) * ldo + k) * 4;
+    if (a0 < b1 && b0 < a1) return fail(LASSO_ERR_BAD_ARG, "d_out_dev overlaps d_dev");
+  }
   if (d > kSweepMaxD || k > kSweepMaxK)
     return fail(LASSO_ERR_UNSUPPORTED, "atom sweep: d=%lld k=%lld (d <= %d, k <= %d)", (long long)d,
                 (long long)k, kSweepMaxD, kSweepMaxK);
@@ -2493,11 +2502,13 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
   float* dD = (float*)((char*)Dt + align_up((size_t)k * dp * 4));
   int* ndeg = (int*)((char*)dD + align_up((size_t)kSweepBlock * dp * 4));
   float* D = (float*)d_dev;
+  float* Dnew = (float*)d_out_dev;
   // (ndeg is written by degenerate_fixup_kernel on every path: no clearing launch in front)
   // U[j][dd] = B[j][dd] - sum_i A[j][i] D[dd][i]          (k x d, zero padded to dp columns)
   // The single-launch sweep (dp == 256) reads its old atoms from D itself, never reads the padding of U, and its
   // last launch writes the new dictionary: no transposed copies, no clearing of U (four launches off the chain).
-  const bool direct = dp == 256 && k % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)D & 15) == 0;
+  const bool direct = dp == 256 && k % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)D & 15) == 0 && ldo % 4 == 0 &&
+                      ((uintptr_t)Dnew & 15) == 0;
   if (dp != d && !direct) LASSO_HIP_TRY(hipMemsetAsync(U, 0, (size_t)k * dp * 4, st));   // (d == dp: the product writes every column)
   void* const extra = dp == 256 ? (void*)((char*)ndeg + 256) : nullptr;
   // (the product's first workgroup also clears the single-launch sweep's flag words: no fill launch between them)
@@ -2509,7 +2520,7 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
   SweepParams p;
   p.flags_cleared = flag_words != nullptr;
   p.Dsrc = direct ? D : nullptr; p.ldd = ldd;
-  p.Dout = direct ? D : nullptr; p.ldo = ldd;
+  p.Dout = direct ? Dnew : nullptr; p.ldo = ldo;
   p.A = a_dev; p.lda = k; p.U = U; p.ldu = dp; p.Dt = Dt; p.dD = dD; p.dp = dp;
   p.pool = pool_dev; p.pool_rows = (int)pool_rows; p.pool_ld = pool_ld; p.seed = seed;
   p.degenerate = degenerate_dev; p.ndeg_in_out = ndeg; p.ndeg_mirror = ndeg_mapped;
@@ -2518,7 +2529,7 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
   float* dt_new = Dt;
   LASSO_HIP_TRY(launch_dict_sweep(p, st, extra, &dt_new));
   // D[dd][j] = Dt[j][dd]
-  if (!direct) LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, D, ldd, (int)d, (int)k, st));
+  if (!direct) LASSO_HIP_TRY(launch_transpose_pad(dt_new, dp, (int)k, (int)d, Dnew, ldo, (int)d, (int)k, st));
   if (ndeg_out) {
     LASSO_HIP_TRY(hipMemcpyAsync(ndeg_out, ndeg, sizeof(int), hipMemcpyDeviceToHost, st));
     LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -2543,6 +2554,21 @@ int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, 
   if (!ndeg_mapped) return fail(LASSO_ERR_BAD_ARG, "ndeg_mapped is NULL");
   return dict_sweep_impl(a_dev, b_dev, d_dev, ldd, d, k, dtype, eps, positive, pool_dev, pool_rows, pool_ld, seed,
                          degenerate_dev, nullptr, ndeg_mapped, workspace_dev, workspace_bytes, stream);
+}
+
+// lasso_dict_sweep_async with the new dictionary written to ANOTHER buffer: d_dev is only read, so the call may be
+// enqueued before the host knows whether the step it belongs to stands (an EM loop's E-step verdict, the previous sweep's
+// count of degenerate atoms: a step that has to be repeated simply keeps d_dev), and work on another stream may go on
+// reading the old dictionary beside it (the objective of dict_learning.py:39) -- DESIGN.md 3.3h
+int lasso_dict_sweep_async_to(const float* a_dev, const float* b_dev, const void* d_dev, int64_t ldd, void* d_out_dev,
+                              int64_t ldo, int64_t d, int64_t k, int dtype, double eps, int positive,
+                              const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
+                              int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
+                              void* stream) {
+  if (!ndeg_mapped) return fail(LASSO_ERR_BAD_ARG, "ndeg_mapped is NULL");
+  if (!d_out_dev || d_out_dev == d_dev) return fail(LASSO_ERR_BAD_ARG, "d_out_dev must be another buffer");
+  return dict_sweep_impl(a_dev, b_dev, const_cast<void*>(d_dev), ldd, d, k, dtype, eps, positive, pool_dev, pool_rows, pool_ld,
+                         seed, degenerate_dev, nullptr, ndeg_mapped, workspace_dev, workspace_bytes, stream, d_out_dev, ldo);
 }
 
 // ---- pipelined constrained M-step (ABI 7) -------------------------------------------------------

@@ -131,9 +131,13 @@ class HipEngine:
         return z, dict(iterations=it, last_delta=last.value, trials=list(trials[:it]),
                        accepted_lr=list(acc_lr[:it]), accepted_f=list(acc_f[:it]))
 
-    def sweep_begin(self, A, B, D, eps, positive):
+    sweep_out_of_place = True        # sweep_begin(out=...): lasso_dict_sweep_async_to
+
+    def sweep_begin(self, A, B, D, eps, positive, out=None):
         """The atom sweep without the host round trip for the number of degenerate atoms: returns
-        a callable giving (mask, ndeg) that waits only for the sweep itself."""
+        a callable giving (mask, ndeg) that waits only for the sweep itself.  ``out``: another [d, k] tensor that
+        receives the new dictionary -- D is then only read (lasso_dict_sweep_async_to: the call may be enqueued before
+        the host knows whether the step stands, and another stream may keep reading D)."""
         d, k = D.shape
         L = self.lib
         with torch.cuda.device(self.device):
@@ -141,10 +145,18 @@ class HipEngine:
             mask = torch.empty(k, dtype=torch.int32, device=self.device)     # the sweep writes every flag
             # the count goes straight into a pinned host word, written by the sweep's last kernel (no copy launch)
             host = self._ndeg_word()
-            nat.check(L.lasso_dict_sweep_async(
-                nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
-                int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(), nat.ptr(ws), ws.numel(),
-                self._stream()))
+            if out is None:
+                nat.check(L.lasso_dict_sweep_async(
+                    nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), d, k, nat.LASSO_F32, float(eps),
+                    int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(), nat.ptr(ws), ws.numel(),
+                    self._stream()))
+            else:
+                if tuple(out.shape) != (d, k) or out.dtype != D.dtype or out.stride(1) != 1:
+                    raise RuntimeError("sweep_begin: `out` must be a [d, k] tensor like D")
+                nat.check(L.lasso_dict_sweep_async_to(
+                    nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), nat.ptr(out), out.stride(0), d, k, nat.LASSO_F32,
+                    float(eps), int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(), nat.ptr(ws), ws.numel(),
+                    self._stream()))
 
         def result():        # (polls the word the sweep's last kernel raises: no event record behind the sweep)
             return mask, int(host.wait()[0])
@@ -155,7 +167,7 @@ class HipEngine:
         reused only after several later sweeps have been enqueued."""
         ring = getattr(self, "_ndeg_ring", None)
         if ring is None:
-            ring = self._ndeg_ring = [nat.HostWords(2) for _ in range(4)]
+            ring = self._ndeg_ring = [nat.HostWords(2) for _ in range(8)]
         ring.append(ring.pop(0))
         return ring[-1]
 

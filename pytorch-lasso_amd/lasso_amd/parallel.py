@@ -313,20 +313,28 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
     if ('stop_mode' not in begin_kwargs and begin_kwargs.get('algorithm', 'ista') == 'ista'
             and 0 < int(begin_kwargs.get('maxiter', 10)) <= 64):
         begin_kwargs['stop_mode'] = 'one-chunk'
-    # Round 6: the constrained loop on TWO streams -- the objective (and, for d == 256 and k a multiple of 256, the later
-    # stages of the pipelined M-step) beside the atom sweep, host results polled instead of waited for through events.
-    # Decided from rank-invariant inputs only (every rank takes the same path).
+    # Round 6: the constrained loop on TWO streams -- the objective beside the M-step instead of in front of it, host
+    # results polled instead of waited for through events.  Two forms: d == 256 and k a multiple
+    # of 256 pipeline the M-step (later stages + objective beside the atom sweep); small dictionaries (d <= 64, k <= 256:
+    # the one-workgroup sweep) double-buffer the dictionary, which lets the sweep be enqueued before the step's host wait
+    # and the objective after it, on the other stream.  Decided from rank-invariant inputs only (every rank takes the
+    # same path).
     import os
+    side = os.environ.get("LASSO_EM_SIDE_STREAM", "1")
     if (constrained and defer and X.is_cuda and hasattr(engine, 'side_stream') and tol > 0
-            and (overlap or (shard_async and ndelta > 0)) and os.environ.get("LASSO_EM_SIDE_STREAM", "1") != "0"
-            and os.environ.get("LASSO_EM_PIPELINE", "1") != "0" and hasattr(engine, 'mstep_pipe_stages')
-            and (len(engine.mstep_pipe_stages(d, k)) > 0 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")
-            # measured (tools/r6_em_rows.sh, k = 1024): 4096 rows per rank -4.4 %, 8192 -3.5 %, 16384 -2.3 %, 32768 -0.3 %,
-            # 65536 +0.6 % -- at that size the Gram product and the objective are HBM-bound and gain nothing from running
-            # beside each other.  (The average row count: the same number on every rank.)
-            and (n_total / max(world, 1) <= 32768 or os.environ.get("LASSO_EM_SIDE_STREAM", "1") == "force")):
-        return _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group,
-                                    n_total, ndelta, losses, stats)
+            and (overlap or (shard_async and ndelta > 0)) and side != "0"):
+        piped = (os.environ.get("LASSO_EM_PIPELINE", "1") != "0" and hasattr(engine, 'mstep_pipe_stages')
+                 and len(engine.mstep_pipe_stages(d, k)) > 0)
+        # measured (tools/r6_em_rows.sh, k = 1024): 4096 rows per rank -4.4 %, 8192 -3.5 %, 16384 -2.3 %, 32768 -0.3 %,
+        # 65536 +0.6 % -- at that size the Gram product and the objective are HBM-bound and gain nothing from running
+        # beside each other.  (The average row count: the same number on every rank.)
+        if piped:
+            use = n_total / max(world, 1) <= 32768
+        else:
+            use = getattr(engine, 'sweep_out_of_place', False) and d <= 64 and k <= 256
+        if use or (side == "force" and (piped or getattr(engine, 'sweep_out_of_place', False))):
+            return _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group,
+                                        n_total, ndelta, losses, stats)
     i, Zlast = 0, None
     while i < steps:
         pending, sharded = None, False
@@ -422,8 +430,12 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     the dictionary (S reads the old one), and the host POLLS the verdict's and the sweep's words in pinned memory at
     its one wait per step.  With several ranks the objective's two sums ride in the NEXT step's message (one small
     all-reduce flushes the last step's): a message per stage, the first on the critical chain.  Shapes without a
-    pipelined M-step (e.g. 8 x 8 patches: d = 64) keep lasso_gram_accumulate + lasso_dict_sweep on M and only move
-    the objective to S."""
+    pipelined M-step (e.g. 8 x 8 patches: d = 64) keep lasso_gram_accumulate + the sweep on M, with the dictionary
+    DOUBLE-BUFFERED: the sweep writes the new dictionary into the other buffer (lasso_dict_sweep_async_to), so it is
+    enqueued BEFORE the step's host wait (a step that has to be repeated keeps the old buffer and drops the other), and
+    the objective is enqueued on S right AFTER that wait -- the host has then seen the E-step's verdict, so S needs no
+    device-side start signal, and nothing on M waits for it: the old dictionary it reads is only overwritten by the
+    NEXT step's sweep."""
     import torch as _t
     world, rank = _world(group)
     multi = _sharded(group)
@@ -445,14 +457,16 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     AB = buf[:k * (k + d)].view(k, k + d) if pipe else None
     ws = engine.mstep_pipe_workspace(n_local, d, k) if pipe else None
     ev_S = _t.cuda.Event()
-    state = {"seq": 0, "prev_sums": None, "prev_index": -1}
+    # "cur": the dictionary in force; "alt" (shapes without a pipelined M-step): the buffer the running step's sweep fills
+    state = {"seq": 0, "prev_sums": None, "prev_index": -1, "cur": weight,
+             "alt": None if pipe else _t.empty_like(weight)}
     Z0, Zlast, deferred = None, None, None
 
     def repair(mask, ndeg, Zprev):
         cand = draw_directions(d, ndeg).to(weight.device)       # every rank advances its generator alike
         if multi:
             _broadcast(cand, group)                              # ... and uses rank 0's directions
-        engine.fill_degenerate(weight, mask, cand, False)                                 # :93-96
+        engine.fill_degenerate(state["cur"], mask, cand, False)                           # :93-96
         if Zprev is not None and Zprev.shape[0] > 0:
             engine.zero_columns(Zprev, mask)                                              # :98
 
@@ -483,15 +497,16 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         if n_local == 0:
             sums = _t.zeros(2, dtype=_t.float64, device=dev)
         elif multi:
-            _, sums = engine.objective_sums(X, Z, weight, alpha, max_workgroups=cap)
+            _, sums = engine.objective_sums(X, Z, state["cur"], alpha, max_workgroups=cap)
         else:
-            engine.objective_sums(X, Z, weight, alpha, loss_out=losses[i], max_workgroups=cap)
+            engine.objective_sums(X, Z, state["cur"], alpha, loss_out=losses[i], max_workgroups=cap)
             sums = None
         state["next_sums"] = sums
 
-    def produce(Z, pending, i, start_word):
-        """Enqueue everything of step i between the E-step and the new dictionary.  Returns the sweep's handle: a
-        callable (mask -> deferred result) to be called once the host has seen the verdict."""
+    def produce(Z, pending, i):
+        """Enqueue everything of step i between the E-step and the new dictionary.  Returns a callable to be called once
+        the host has seen the verdict; it gives the sweep's handle (() -> (mask, ndeg)).  Pipelined: that call enqueues
+        the launch that writes the dictionary.  Otherwise the sweep has been enqueued already, into state["alt"]."""
         sharded = multi and pending is not None
         if pipe:
             state["seq"] += 1
@@ -526,52 +541,42 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
                 # (the kernel that writes the dictionary waits for S's word itself: no cross-stream event on M's chain)
                 return engine.pipe_finish(weight, n_local, 1e-10, False, mask, ws, wait_seq=seq)
             return finish
-        # no pipelined form: the objective alone moves to S (started by the verdict's word: no event on M)
-        with _t.cuda.stream(S):
-            if start_word is not None:
-                engine.stream_wait_word(start_word, 1, True)
-            else:
-                ev = _t.cuda.Event()
-                ev.record(M)
-                S.wait_event(ev)
-            objective(Z, i)
-            ev_S.record(S)
+        # no pipelined form: Gram product and message on M, then the sweep into the OTHER dictionary buffer -- enqueued here,
+        # before the host has seen the verdict (the objective follows on S after the host wait, see the loop)
         A = buf[:k * k].view(k, k)
         B = buf[k * k:k * k + k * d].view(k, d)
         if n_local > 0:
             engine.gram(Z, X, buf)
         else:
             buf[:k * (k + d)].zero_()
+        # S's last objective (enqueued a step ago: long complete) wrote the sums this message carries and read the buffer
+        # this sweep overwrites
+        M.wait_event(ev_S)
         if multi:
             fill_tail(pending)
             _all_reduce(buf, group)
             after_tail(i)
             if sharded:
                 pending.judge(dtail, n_total)
-
-        def finish():
-            M.wait_event(ev_S)                                           # the sweep writes the dictionary S reads
-            return engine.sweep_begin(A, B, weight, 1e-10, False)
-        return finish
+        handle = engine.sweep_begin(A, B, state["cur"], 1e-10, False, out=state["alt"])
+        return lambda: handle
 
     def encode_sync():
-        return sharded_encode(engine, X, weight, alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
+        return sharded_encode(engine, X, state["cur"], alpha, Z0, group=group, n_global=n_total, **solver_kwargs)
 
     i = 0
     while i < steps:
         # ---- E-step (dict_learning.py:38), enqueued without a wait
-        start_word = None
+        D = state["cur"]
         if not multi:
-            Z, pending = engine.encode_begin(X, weight, alpha, Z0, **begin_kwargs)
-            if pending is not None and hasattr(pending, 'status_word'):
-                start_word = pending.status_word()
+            Z, pending = engine.encode_begin(X, D, alpha, Z0, **begin_kwargs)
         elif n_local == 0:
             Z = Z0 if Z0 is not None else X.new_zeros(0, k)
             pending = _EmptyShardPending(ndelta, k, tol, dev)
         else:
             if Z0 is not None and Z0.device != dev:
                 Z0 = Z0.to(dev)
-            began = engine.encode_begin_sharded(X, weight, alpha, Z0, **solver_kwargs)
+            began = engine.encode_begin_sharded(X, D, alpha, Z0, **solver_kwargs)
             if began is None:
                 raise RuntimeError("encode_begin_sharded refused arguments sharded_async_ok accepted")
             Z, pending = began
@@ -579,7 +584,9 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
             if pipe:
                 stats['pipelined_steps'] = stats.get('pipelined_steps', 0) + 1
-        finish = produce(Z, pending, i, start_word)
+            else:
+                stats['speculative_sweeps'] = stats.get('speculative_sweeps', 0) + 1
+        finish = produce(Z, pending, i)
         # ---- the step's ONE host wait: the previous sweep's count of degenerate atoms, this E-step's verdict
         if deferred is not None:
             mask, ndeg = deferred()
@@ -594,21 +601,30 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         if pending is not None and not pending():
             # the stop rule fired before the last iteration (or the in-kernel rule gave up): the same rule on the
             # chunked path, then the step's products once more for the right code.  Nothing of the speculated step
-            # has touched the dictionary (finish() was not called).
+            # has touched the dictionary in force (pipelined: finish() was not called; else the sweep wrote the other
+            # buffer, which the repeated sweep overwrites).
             M.wait_event(ev_S)
             _t.cuda.current_stream(dev).synchronize()
             if multi:
                 Z = encode_sync()
             else:
-                Z = engine.encode(X, weight, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
-            finish = produce(Z, None, i, None)
+                Z = engine.encode(X, D, alpha, Z0, **dict(solver_kwargs, stop_mode='chunked'))
+            finish = produce(Z, None, i)
             if stats is not None:
                 stats['replayed_steps'] = stats.get('replayed_steps', 0) + 1
+        if not pipe:
+            # the host has seen this E-step's verdict: Z is final, and S needs no device-side start signal.  It reads the
+            # dictionary of THIS step, which stays untouched until the next step's sweep (ordered behind ev_S) refills it.
+            with _t.cuda.stream(S):
+                objective(Z, i)
+                ev_S.record(S)
         if multi:
             state["prev_sums"], state["prev_index"] = state["next_sums"], i
         if persist:
             Z0 = Z                                                                        # :40-41
         deferred = finish()                                                               # :44-45
+        if not pipe:
+            state["cur"], state["alt"] = state["alt"], state["cur"]
         Zlast = Z
         if bar is not None:
             ev_S.synchronize()
@@ -625,6 +641,8 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         mask, ndeg = deferred()
         if ndeg:
             repair(mask, ndeg, Zlast)
+    if state["cur"] is not weight:                   # (an odd number of accepted sweeps: the caller's tensor is the other buffer)
+        weight.copy_(state["cur"])
     if bar is not None:
         bar.close()
     return weight, losses

@@ -722,3 +722,93 @@ def test_two_stream_em_loop_corner_cases(n, k, kw, monkeypatch):
     assert torch.isfinite(two[0]).all() and torch.isfinite(two[1]).all()
     assert (two[1] - one[1]).abs().max().item() <= 5e-6 * one[1].abs().max().item()
     assert (two[0] - one[0]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("d,k", [(64, 256), (64, 100), (48, 256), (256, 512), (128, 384), (100, 130), (300, 64)])
+def test_out_of_place_sweep_is_the_in_place_sweep(d, k):
+    """lasso_dict_sweep_async_to (the new dictionary into ANOTHER buffer, the old one only read) against
+    lasso_dict_sweep_async on every form of the sweep -- one workgroup (d <= 64), co-operating workgroups + the launch
+    that transposes (d padded to 256), the multi-launch form (d > 256) -- with degenerate atoms in the product:
+    bitwise the same dictionary, flags and count; the input dictionary untouched; a pitched output; overlap refused."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine(torch.device("cuda"))
+    g = torch.Generator().manual_seed(d + k)
+    n = 3 * k
+    Z = torch.randn(n, k, generator=g) * (torch.rand(n, k, generator=g) < 0.1)
+    Z[:, 3] = 0
+    Z[:, k - 1] = 0                                                                # two atoms no sample uses: degenerate
+    X = torch.randn(n, d, generator=g)
+    D0 = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0).cuda()
+    A = (Z.T @ Z).cuda().contiguous()
+    B = (Z.T @ X).cuda().contiguous()
+    Din = D0.clone()
+    m1, n1 = eng.sweep_begin(A, B, Din, 1e-10, False)()
+    torch.cuda.synchronize()
+    Dsrc = D0.clone()
+    wide = torch.full((d, k + 12), 7.0, device="cuda")
+    out = wide[:, 4:4 + k] if k % 4 == 0 else torch.empty(d, k, device="cuda")    # a view with a pitch (16-byte aligned)
+    m2, n2 = eng.sweep_begin(A, B, Dsrc, 1e-10, False, out=out)()
+    torch.cuda.synchronize()
+    assert n1 == n2 == 2 and torch.equal(m1, m2) and m1[3].item() == 1 and m1[k - 1].item() == 1
+    assert torch.equal(out, Din) and torch.equal(Dsrc, D0)
+    if k % 4 == 0:
+        assert (wide[:, :4] == 7.0).all() and (wide[:, 4 + k:] == 7.0).all()
+    with pytest.raises(Exception):
+        eng.sweep_begin(A, B, Dsrc, 1e-10, False, out=Dsrc)
+    big = torch.empty(2 * d * k + 8, device="cuda")
+    with pytest.raises(Exception):
+        eng.sweep_begin(A, B, big[:d * k].view(d, k), 1e-10, False, out=big[k:k + d * k].view(d, k))
+
+
+@pytest.mark.parametrize("kw", [dict(steps=4), dict(steps=5), dict(steps=3, persist=True), dict(steps=1),
+                                dict(steps=3, progbar=True), dict(steps=3, lr=0.05)])
+def test_double_buffered_em_loop_of_a_small_dictionary(kw, monkeypatch):
+    """dict_learning of 8 x 8 patches (d = 64, k = 256: the default two-stream loop with the double-buffered dictionary --
+    sweep enqueued before the step's host wait, objective on the side stream after it) against the one-stream loop
+    (LASSO_EM_SIDE_STREAM=0): the same kernels on the same operands in the same order per stream, so BITWISE the same
+    dictionary and losses; even and odd numbers of steps (the caller's tensor is one of the two buffers)."""
+    from lasso_amd.linear import dict_learning
+    from lasso_amd import parallel
+    X = recipe_c5(3000).cuda()
+    g = torch.Generator().manual_seed(9)
+    D0 = torch.nn.functional.normalize(torch.randn(64, 256, generator=g), dim=0)
+    calls = []
+    real = parallel._em_loop_two_streams
+    monkeypatch.setattr(parallel, "_em_loop_two_streams", lambda *a, **k2: (calls.append(1), real(*a, **k2))[1])
+    kw = dict(dict(progbar=False), **kw)
+    torch.manual_seed(4)
+    two = dict_learning(X, 256, alpha=0.1, init_weight=D0, device="cuda", **kw)
+    assert calls == [1]
+    monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
+    torch.manual_seed(4)
+    one = dict_learning(X, 256, alpha=0.1, init_weight=D0, device="cuda", **kw)
+    assert calls == [1]
+    assert torch.isfinite(two[1]).all() and torch.equal(two[1], one[1]) and torch.equal(two[0], one[0])
+
+
+def test_double_buffered_em_loop_degenerate_atoms_and_other_sweeps(monkeypatch):
+    """The double-buffered loop through degenerate atoms (the speculated step is dropped, the atom re-drawn with the
+    reference's RNG in the buffer in force, dict_learning.py:92-98, and the step redone) against the oracle with the same
+    seed; and forced (LASSO_EM_SIDE_STREAM=force) on a dictionary whose sweep is the co-operating form (d = 128: the new
+    dictionary written by the transposing launch) against the one-stream loop, bitwise."""
+    from lasso_amd.linear import dict_learning
+    orc = _orc()
+    X = recipe_c5(40)
+    g = torch.Generator().manual_seed(9)
+    D0 = torch.nn.functional.normalize(torch.randn(64, 256, generator=g), dim=0)
+    torch.manual_seed(11)
+    Dref, lref = orc.dict_learning(X, 256, alpha=0.6, steps=4, init_weight=D0, progbar=False)
+    torch.manual_seed(11)
+    D, losses = dict_learning(X.cuda(), 256, alpha=0.6, steps=4, init_weight=D0, progbar=False, device="cuda")
+    assert (losses.cpu() - lref).abs().max().item() <= 1e-5 * lref.abs().max().item()
+    assert (D.cpu() - Dref).abs().max().item() <= 2e-5
+    monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
+    torch.manual_seed(11)
+    D1, l1 = dict_learning(X.cuda(), 256, alpha=0.6, steps=4, init_weight=D0, progbar=False, device="cuda")
+    assert torch.equal(D, D1) and torch.equal(losses, l1)
+    Xb = torch.randn(2000, 128, generator=g).cuda()
+    Db = torch.nn.functional.normalize(torch.randn(128, 384, generator=g), dim=0)
+    one = dict_learning(Xb, 384, alpha=0.3, steps=3, init_weight=Db, progbar=False, device="cuda")
+    monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "force")
+    two = dict_learning(Xb, 384, alpha=0.3, steps=3, init_weight=Db, progbar=False, device="cuda")
+    assert torch.equal(two[0], one[0]) and torch.equal(two[1], one[1])

@@ -114,14 +114,19 @@ PCASES = {"auto": dict(maxiter=10),                                        # lr=
           "persist": dict(persist=True, lr=0.05, maxiter=8, tol=1e-7)}
 
 
-def _pipe_problem():
+# ---- ... and the DOUBLE-BUFFERED loop of a small dictionary (d <= 64, k <= 256: the one-workgroup sweep) ------------
+SN, SD, SK, SSPLIT = 900, 64, 256, 333
+
+
+def _pipe_problem(shape=None):
+    n, d, k, _ = shape or (PN, PD, PK, PSPLIT)
     g = torch.Generator().manual_seed(77)
-    X = torch.randn(PN, PD, generator=g)
-    D0 = torch.nn.functional.normalize(torch.randn(PD, PK, generator=g), dim=0)
+    X = torch.randn(n, d, generator=g)
+    D0 = torch.nn.functional.normalize(torch.randn(d, k, generator=g), dim=0)
     return X, D0
 
 
-def _pipe_worker(rank, world, port, tmp):
+def _pipe_worker(rank, world, port, tmp, shape=None, stat="pipelined_steps", name="pipe"):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     from lasso_amd import parallel
@@ -130,7 +135,8 @@ def _pipe_worker(rank, world, port, tmp):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    X, D0 = _pipe_problem()
+    X, D0 = _pipe_problem(shape)
+    PN, PD, PK, PSPLIT = shape or (globals()["PN"], globals()["PD"], globals()["PK"], globals()["PSPLIT"])
     out = {}
     sent = []
     real = parallel._all_reduce
@@ -151,9 +157,9 @@ def _pipe_worker(rank, world, port, tmp):
             Dl, losses = parallel.dict_learning_sharded(X[lo:hi], PK, alpha=0.3, steps=4, init_weight=D0, engine=eng, **kw)
             key = ("empty_" if empty else "") + tag
             out[key + "_D"], out[key + "_l"] = Dl.cpu().numpy(), losses.cpu().numpy()
-            out[key + "_stats"] = np.array([eng.em_stats.get("pipelined_steps", 0), eng.em_stats.get("replayed_steps", 0)])
+            out[key + "_stats"] = np.array([eng.em_stats.get(stat, 0), eng.em_stats.get("replayed_steps", 0)])
             out[key + "_sent"] = np.array(sent)
-    np.savez(os.path.join(tmp, "pipe%d.npz" % rank), **out)
+    np.savez(os.path.join(tmp, "%s%d.npz" % (name, rank)), **out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -185,6 +191,35 @@ def test_pipelined_mstep_on_two_ranks(tmp_path):
         margins[key] = (float(np.abs(r0[key + "_l"] - lo_.numpy()).max()), float(np.abs(r0[key + "_D"] - Do.numpy()).max()))
         assert margins[key][0] <= 1e-5 and margins[key][1] <= 2e-5, (key, margins[key])
     record_margins("two_ranks_pipelined_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
+
+
+def test_double_buffered_em_loop_on_two_ranks(tmp_path):
+    """d = 64, k = 256 on two ranks: em_loop's two-stream form with the double-buffered dictionary -- ONE message per step
+    ([A | B | the previous step's objective sums | this step's stop-rule sums]), the sweep enqueued before the host wait,
+    the objective on the side stream after it.  Ragged shards, a rank without rows, a stop rule that fires early (the
+    speculated sweep is dropped, replay) and persist=True: both ranks bit for bit, the oracle within the two-rank margins."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lasso_oracle as orc
+    port = 35500 + (os.getpid() % 2000)
+    shape = (SN, SD, SK, SSPLIT)
+    mp.start_processes(_pipe_worker, args=(2, port, str(tmp_path), shape, "speculative_sweeps", "small"), nprocs=2, join=True,
+                       start_method="spawn")
+    r0, r1 = np.load(tmp_path / "small0.npz"), np.load(tmp_path / "small1.npz")
+    X, D0 = _pipe_problem(shape)
+    margins = {}
+    for key in [k[:-2] for k in r0.files if k.endswith("_D")]:
+        tag = key.replace("empty_", "")
+        assert np.array_equal(r0[key + "_D"], r1[key + "_D"]) and np.array_equal(r0[key + "_l"], r1[key + "_l"]), key
+        assert np.array_equal(r0[key + "_stats"], r1[key + "_stats"]) and np.array_equal(r0[key + "_sent"], r1[key + "_sent"]), key
+        assert int(r0[key + "_stats"][0]) >= 4, (key, r0[key + "_stats"])                  # every step on the speculative form
+        assert (int(r0[key + "_stats"][1]) >= 1) == (tag == "tol_short"), (key, r0[key + "_stats"])
+        big = [int(v) for v in r0[key + "_sent"] if v >= 1024]
+        assert set(big) == {SK * (SK + SD) + 2 + PCASES[tag].get("maxiter", 10)}, (key, sorted(set(big)))
+        torch.manual_seed(1)
+        Do, lo_ = orc.dict_learning(X, SK, alpha=0.3, steps=4, init_weight=D0, **PCASES[tag])
+        margins[key] = (float(np.abs(r0[key + "_l"] - lo_.numpy()).max()), float(np.abs(r0[key + "_D"] - Do.numpy()).max()))
+        assert margins[key][0] <= 1e-5 and margins[key][1] <= 2e-5, (key, margins[key])
+    record_margins("two_ranks_double_buffered_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
 
 
 # ---- row-sharded line search (ista.py:23-52 on two ranks) -------------------------------------
