@@ -148,17 +148,8 @@ __global__ void momentum_table_kernel(float* __restrict__ coef, float* __restric
 // ~10 such 5-us launches otherwise): pack W (pack_w_kernel), the momentum table
 // (momentum_table_kernel, by the last block), zero the stop rule's granule ring and result words,
 // and -- lr = LASSO_LR_AUTO -- turn lambda_max into {lr, alpha*lr} (step_from_lipschitz_kernel).
-struct PrepareExtras {
-  unsigned long long* zero_a; int words_a;      // nullable
-  unsigned long long* zero_b; int words_b;      // nullable
-  const double* lip; double alpha; float* lr_slot;   // nullable
-};
-// The momentum coefficients (t_i - 1) / t_{i+1} are a serial recurrence (a double sqrt and two divisions per step):
-// computed by one GPU thread, 100 of them took 17 us -- the whole prepare launch.  The first kCoefHead are the same
-// numbers for every solve: the host computes them once (same IEEE operations, same bits) and hands them over as a
-// launch argument; only a longer schedule continues on the device from t_kCoefHead.
-constexpr int kCoefHead = 256;
-struct CoefHead { float v[kCoefHead]; double t_next; };
+// (PrepareExtras, CoefHead, PrepareJob and the launch's device code: lasso_kernels.h -- the Lipschitz launch of an
+// lr = LASSO_LR_AUTO solve carries the same blocks, csrc/lipschitz.hip)
 static const CoefHead& coef_head() {
   static const CoefHead head = [] {
     CoefHead h;
@@ -173,45 +164,9 @@ static const CoefHead& coef_head() {
   }();
   return head;
 }
-__global__ void prepare_solve_kernel(const float* __restrict__ W, int64_t ldw, int d, int k, int kp,
-                                     float* __restrict__ wp, float* __restrict__ wtp, int dpad, float* __restrict__ coef,
-                                     float* __restrict__ zeros, int count, const PrepareExtras x, const CoefHead head) {
+__global__ void prepare_solve_kernel(const PrepareJob j) {
   __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    const float v = (r < d && c < k) ? W[(int64_t)r * ldw + c] : 0.0f;
-    tile[i][tx] = v;
-    wp[(size_t)r * kp + c] = v;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    wtp[(size_t)c * dpad + r] = tile[tx][i];
-  }
-  const int bid = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y, tid = ty * 32 + tx;
-  for (int i = bid * 256 + tid; i < x.words_a; i += nb * 256) x.zero_a[i] = 0ull;
-  for (int i = bid * 256 + tid; i < x.words_b; i += nb * 256) x.zero_b[i] = 0ull;
-  if (bid == nb - 1)
-    for (int i = tid; i < count && i < kCoefHead; i += 256) { coef[i] = head.v[i]; zeros[i] = 0.0f; }
-  if (tid != 0) return;
-  if (bid == 0 && x.lip) {
-    const double lr = 1.0 / x.lip[0];
-    x.lr_slot[0] = (float)lr;
-    x.lr_slot[1] = (float)(x.alpha * lr);
-  }
-  if (bid == nb - 1) {
-    double t = head.t_next;
-    for (int i = kCoefHead; i < count; ++i) {
-      const double tt = __dmul_rn(t, t);
-      const double s = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(4.0, tt)));
-      const double tn = __ddiv_rn(__dadd_rn(1.0, s), 2.0);
-      coef[i] = (float)__ddiv_rn(__dsub_rn(t, 1.0), tn);
-      zeros[i] = 0.0f;
-      t = tn;
-    }
-  }
+  prepare_block(j, blockIdx.x, blockIdx.y, threadIdx.y * 32 + threadIdx.x, tile);
 }
 
 // delta[i] = sum_t partials[i][t], fixed summation order (deterministic).  `alt` (nullable):
@@ -648,14 +603,42 @@ int splitk_aborted(const Workspace& ws, hipStream_t stream, bool* aborted) {
   return LASSO_OK;
 }
 
+static PrepareJob prepare_job(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k, int coef_cap,
+                              const PrepareExtras* extras) {
+  PrepareJob j;
+  j.W = w; j.ldw = ldw; j.d = (int)d; j.k = (int)k; j.kp = kp;
+  j.wp = ws.wp; j.wtp = ws.wtp; j.dpad = pad_d(d, kp); j.coef = ws.coef; j.zeros = ws.zeros;
+  j.count = std::max(coef_cap, 1);
+  j.x = PrepareExtras{nullptr, 0, nullptr, 0, nullptr, 0.0, nullptr};
+  if (extras) j.x = *extras;
+  j.head = coef_head();
+  j.gx = kp / 32; j.gy = j.dpad / 32;
+  return j;
+}
+
 int prepare_impl(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k,
                  int coef_cap, hipStream_t stream, const PrepareExtras* extras = nullptr) {
-  const int dpad = pad_d(d, kp);
-  PrepareExtras x = {nullptr, 0, nullptr, 0, nullptr, 0.0, nullptr};
-  if (extras) x = *extras;
-  hipLaunchKernelGGL(prepare_solve_kernel, dim3(kp / 32, dpad / 32), dim3(32, 8), 0, stream, w, ldw, (int)d, (int)k, kp,
-                     ws.wp, ws.wtp, dpad, ws.coef, ws.zeros, std::max(coef_cap, 1), x, coef_head());
+  const PrepareJob j = prepare_job(ws, kp, w, ldw, d, k, coef_cap, extras);
+  hipLaunchKernelGGL(prepare_solve_kernel, dim3(j.gx, j.gy), dim3(32, 8), 0, stream, j);
   LASSO_HIP_TRY(hipGetLastError());
+  return LASSO_OK;
+}
+
+// lr = LASSO_LR_AUTO on the fused shapes: the Lipschitz launches and the prepare launch of the solve as ONE sequence --
+// the prepare blocks ride in the Gram launch of the Lipschitz computation (both read only W), and the launch that
+// finishes lambda_max leaves {lr, alpha lr} itself: one launch less on an EM step's dependent chain (round 6)
+int prepare_with_lipschitz(const Workspace& ws, int kp, const float* w, int64_t ldw, int64_t d, int64_t k, int coef_cap,
+                           hipStream_t stream, const PrepareExtras& extras, void* lip_ws) {
+  PrepareExtras x = extras;
+  const LipLr lr{x.lr_slot, x.alpha};
+  x.lip = nullptr; x.lr_slot = nullptr;               // (the step size is the Lipschitz launches' business now)
+  const PrepareJob j = prepare_job(ws, kp, w, ldw, d, k, coef_cap, &x);
+  bool fused = false;
+  LASSO_HIP_TRY(launch_lipschitz(w, ldw, d, k, lip_ws, 20, stream, &j, &fused, lr));
+  if (!fused) {
+    hipLaunchKernelGGL(prepare_solve_kernel, dim3(j.gx, j.gy), dim3(32, 8), 0, stream, j);
+    LASSO_HIP_TRY(hipGetLastError());
+  }
   return LASSO_OK;
 }
 
@@ -1840,7 +1823,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
                       const double* lip_dev = nullptr, bool sharded = false, bool one_chunk = false,
-                      int32_t* status_mapped = nullptr) {
+                      int32_t* status_mapped = nullptr, void* lip_deferred_ws = nullptr) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -1961,7 +1944,10 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     px.zero_a = ws.gran; px.words_a = kStopRing * std::max(tp0.ntiles, kSplitMaxParts);
     px.zero_b = reinterpret_cast<unsigned long long*>(ws.stop_out); px.words_b = 2;
   }
-  if (int s = prepare_impl(ws, kps, (const float*)w_dev, ldw, d, k, maxiter, st, &px)) return s;
+  // (lr = LASSO_LR_AUTO: the Lipschitz launches were left to this point -- their Gram launch carries the prepare blocks)
+  if (lip_deferred_ws) {
+    if (int s = prepare_with_lipschitz(ws, kps, (const float*)w_dev, ldw, d, k, maxiter, st, px, lip_deferred_ws)) return s;
+  } else if (int s = prepare_impl(ws, kps, (const float*)w_dev, ldw, d, k, maxiter, st, &px)) return s;
 
   if (!stop_rule) {
     if (int s = run_impl(ws, kps, x, ldx, z0, ldz0, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
@@ -2134,6 +2120,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_ASYNC: fp32 fixed-step solves without objective_out only");
   const float* lr_dev = nullptr;
   const double* lip_dev = nullptr;
+  void* lip_deferred = nullptr;
   if (lr == LASSO_LR_AUTO) {
     // lr = 1/L, L = lambda_max(W^T W) (ista.py:72-73, :8-14) computed here on the stream.  The fp32
     // fixed-step kernels read {lr, alpha*lr} from device memory -- no host round trip; the other
@@ -2148,13 +2135,14 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
       return fail(LASSO_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, before + lip);
     hipStream_t st = (hipStream_t)stream;
     char* const lip_ws = (char*)workspace_dev + before;
-    LASSO_HIP_TRY(launch_lipschitz((const float*)w_dev, ldw, d, k, lip_ws, 20, st));
     if (fused_shape(d, k) && !backtrack && maxiter > 0 && n > 0) {
       float* const slot = (float*)(lip_ws + align_up(lipschitz_workspace_bytes(d, k)));
-      lip_dev = (const double*)lip_ws;                 // the prepare launch of the solve fills the slot
+      lip_dev = (const double*)lip_ws;                 // solve_impl enqueues the Lipschitz launches with its prepare blocks;
+      lip_deferred = lip_ws;                           //   the launch that finishes lambda_max fills the slot
       lr_dev = slot;
       lr = 1.0;                                        // placeholder, never used by the kernels
     } else {
+      LASSO_HIP_TRY(launch_lipschitz((const float*)w_dev, ldw, d, k, lip_ws, 20, st));
       double L = 0.0;
       LASSO_HIP_TRY(hipMemcpyAsync(&L, lip_ws, sizeof(double), hipMemcpyDeviceToHost, st));
       LASSO_HIP_TRY(hipStreamSynchronize(st));
@@ -2164,7 +2152,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped);
+                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped, lip_deferred);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)

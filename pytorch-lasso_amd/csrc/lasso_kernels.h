@@ -236,9 +236,76 @@ hipError_t launch_generic_trial(const float* P, const float* G, float* Cand, int
 hipError_t launch_bt_finish(float* Z, int64_t ldz, float* Y, const float* Cand, int n, int k,
                             float coef, const int* flags, float* dpart, int grid, hipStream_t stream);
 
+// Everything a solve needs before its persistent launch, in ONE launch (the EM step is made of
+// ~10 such 5-us launches otherwise): pack W (pack_w_kernel), the momentum table
+// (momentum_table_kernel, by the last block), zero the stop rule's granule ring and result words,
+// and -- lr = LASSO_LR_AUTO -- turn lambda_max into {lr, alpha*lr} (step_from_lipschitz_kernel).
+struct PrepareExtras {
+  unsigned long long* zero_a; int words_a;      // nullable
+  unsigned long long* zero_b; int words_b;      // nullable
+  const double* lip; double alpha; float* lr_slot;   // nullable
+};
+// The momentum coefficients (t_i - 1) / t_{i+1} are a serial recurrence (a double sqrt and two divisions per step):
+// computed by one GPU thread, 100 of them took 17 us -- the whole prepare launch.  The first kCoefHead are the same
+// numbers for every solve: the host computes them once (same IEEE operations, same bits) and hands them over as a
+// launch argument; only a longer schedule continues on the device from t_kCoefHead.
+constexpr int kCoefHead = 256;
+struct CoefHead { float v[kCoefHead]; double t_next; };
+// the arguments of the prepare launch: a grid of gx x gy blocks of 256 threads (32 x 8)
+struct PrepareJob {
+  const float* W; int64_t ldw; int d, k, kp;
+  float* wp; float* wtp; int dpad; float* coef; float* zeros; int count;
+  PrepareExtras x; CoefHead head; int gx, gy;
+};
+#ifdef __HIPCC__
+// block (bx, by) of the prepare launch; tid = 32 ty + tx
+__device__ __forceinline__ void prepare_block(const PrepareJob& j, int bx, int by, int tid, float (*tile)[33]) {
+  const int c0 = bx * 32, r0 = by * 32;
+  const int tx = tid & 31, ty = tid >> 5;         // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < j.d && c < j.k) ? j.W[(int64_t)r * j.ldw + c] : 0.0f;
+    tile[i][tx] = v;
+    j.wp[(size_t)r * j.kp + c] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    j.wtp[(size_t)c * j.dpad + r] = tile[tx][i];
+  }
+  const int bid = by * j.gx + bx, nb = j.gx * j.gy;
+  for (int i = bid * 256 + tid; i < j.x.words_a; i += nb * 256) j.x.zero_a[i] = 0ull;
+  for (int i = bid * 256 + tid; i < j.x.words_b; i += nb * 256) j.x.zero_b[i] = 0ull;
+  if (bid == nb - 1)
+    for (int i = tid; i < j.count && i < kCoefHead; i += 256) { j.coef[i] = j.head.v[i]; j.zeros[i] = 0.0f; }
+  if (tid != 0) return;
+  if (bid == 0 && j.x.lip) {
+    const double lr = 1.0 / j.x.lip[0];
+    j.x.lr_slot[0] = (float)lr;
+    j.x.lr_slot[1] = (float)(j.x.alpha * lr);
+  }
+  if (bid == nb - 1) {
+    double t = j.head.t_next;
+    for (int i = kCoefHead; i < j.count; ++i) {
+      const double tt = __dmul_rn(t, t);
+      const double s = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(4.0, tt)));
+      const double tn = __ddiv_rn(__dadd_rn(1.0, s), 2.0);
+      j.coef[i] = (float)__ddiv_rn(__dsub_rn(t, 1.0), tn);
+      j.zeros[i] = 0.0f;
+      t = tn;
+    }
+  }
+}
+#endif
+
 size_t lipschitz_workspace_bytes(int64_t d, int64_t k);
+// {lr, alpha lr} = {1 / lambda_max, alpha / lambda_max} as fp32, written by the launch that finishes lambda_max (slot nullable)
+struct LipLr { float* slot; double alpha; };
+// job (nullable): the blocks of a solve's prepare launch, carried by the Gram launch of this computation where that is the
+// span kernel (*fused = true); otherwise the caller launches them itself
 hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,
-                            int squarings, hipStream_t stream);
+                            int squarings, hipStream_t stream, const PrepareJob* job = nullptr, bool* fused = nullptr,
+                            LipLr lr = LipLr{nullptr, 0.0});
 
 // (max_splits: what the caller's scratch holds -- 16 unless it was sized for more)
 int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits = 16);

@@ -14,6 +14,7 @@
 // FISTA hot loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "lasso_kernels.h"
 
 namespace lasso {
@@ -24,6 +25,15 @@ constexpr int kLipTile = 32;   // output tile per workgroup (256 threads, 2x2 pe
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// {lr, alpha lr} of an lr = LASSO_LR_AUTO solve, left by whichever launch finishes lambda_max (as prepare_block would
+// from the stored double: the same conversions)
+__device__ __forceinline__ void lip_write_lr(const LipLr lr, double lambda_max) {
+  if (!lr.slot) return;
+  const double step = 1.0 / lambda_max;
+  lr.slot[0] = (float)step;
+  lr.slot[1] = (float)(lr.alpha * step);
+}
 
 constexpr int kLipSpan = 256;      // contraction elements whose loads one workgroup keeps in flight together
 constexpr int kLipMaxSplits = 16;  // partial products along the contraction (blockIdx.z)
@@ -191,11 +201,18 @@ __global__ __launch_bounds__(256) void square_f64_kernel(const double* __restric
 // per split as syrk_f64_kernel<float, false> -- bitwise the same partial products.
 // ROWS: elem(i, t) = W[i * ld + t] (G = W W^T), else elem(i, t) = W[t * ld + i] (G = W^T W).
 // Needs m % 4 == 0 or ROWS, len % 4 == 0 or !ROWS, ld % 4 == 0, a 16-byte aligned base.
+// Round 6: the launch also carries the blocks of a solve's prepare launch (job.gx > 0: z slices >= gs; both read only W) --
+// an lr = LASSO_LR_AUTO solve is one launch shorter.
 template <bool ROWS>
 __global__ __launch_bounds__(256) void gram_span_f64_kernel(const float* __restrict__ W, int64_t ld, int m, int len,
-                                                            int mp, double* __restrict__ C) {
+                                                            int mp, double* __restrict__ C, int gs, const PrepareJob job) {
   constexpr int RS = 257;
   extern __shared__ __attribute__((aligned(16))) double gs_smem[];
+  if ((int)blockIdx.z >= gs) {
+    const int id = (((int)blockIdx.z - gs) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (id < job.gx * job.gy) prepare_block(job, id % job.gx, id / job.gx, threadIdx.x, reinterpret_cast<float (*)[33]>(gs_smem));
+    return;
+  }
   double* const sa = gs_smem;                 // [32][RS]
   double* const sb = gs_smem + 32 * RS;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tbase = blockIdx.z * 256;
@@ -287,7 +304,8 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double x) {
 // P_{i+1} = P_i P_i^T / tr(P_i)^2 as before; the sums inside a squaring are taken in another (fixed) order.
 template <int MP>
 __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __restrict__ G, int squarings,
-                                                                double* __restrict__ Pout, double* __restrict__ out) {
+                                                                double* __restrict__ Pout, double* __restrict__ out,
+                                                                const LipLr lr) {
   constexpr int RS = MP + 2, NBK = MP / 16, NBLK = NBK * (NBK + 1) / 2;   // (row pitch = 4 banks mod 64: the operand reads and the mirror writes are conflict-free)
   __shared__ double buf[2][MP * RS];
   __shared__ double trp[2][4];
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(1024) void square_chain_f64_kernel(const double* __
     if (tid < s2) shq[tid] += shq[tid + s2];
     __syncthreads();
   }
-  if (tid == 0) out[0] = shq[0] / tr;
+  if (tid == 0) { const double lam = shq[0] / tr; out[0] = lam; lip_write_lr(lr, lam); }
 }
 
 // C[e] = sum_z part[z][e]  (fixed order)
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const double* __rest
 // out[0] = <G, P>_F / tr(P)   (single block, fixed summation order)
 __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __restrict__ G,
                                                               const double* __restrict__ P, int mp,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, const LipLr lr) {
   __shared__ double sh[1024];
   double tr = 0.0;
   for (int i = threadIdx.x; i < mp; i += 1024) tr += P[(size_t)i * mp + i];
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(1024) void rayleigh_trace_kernel(const double* __re
     if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sh[0] / tr;
+  if (threadIdx.x == 0) { out[0] = sh[0] / tr; lip_write_lr(lr, out[0]); }
 }
 
 // The same quotient in two launches that use the chip: kRayBlocks workgroups each reduce a contiguous chunk of <G, P>_F
@@ -481,19 +499,21 @@ __global__ __launch_bounds__(256) void rayleigh_partial_kernel(const double* __r
   }
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
 }
-__global__ void rayleigh_finish_kernel(const double* __restrict__ part, double* __restrict__ out) {
+__global__ void rayleigh_finish_kernel(const double* __restrict__ part, double* __restrict__ out, const LipLr lr) {
   double num = 0.0, tr = 0.0;
   for (int b = 0; b < kRayBlocks; ++b) { num += part[2 * b]; tr += part[2 * b + 1]; }
   out[0] = num / tr;
+  lip_write_lr(lr, out[0]);
 }
 // `part`: 2 kRayBlocks doubles of scratch (the split-partials region of the workspace is free by then)
-static void launch_rayleigh(const double* G, const double* P, int mp, double* out, double* part, hipStream_t stream) {
+static void launch_rayleigh(const double* G, const double* P, int mp, double* out, double* part, hipStream_t stream,
+                            const LipLr lr) {
   if (mp < 128) {            // small iterates: one block is the shorter path
-    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, P, mp, out);
+    hipLaunchKernelGGL(rayleigh_trace_kernel, dim3(1), dim3(1024), 0, stream, G, P, mp, out, lr);
     return;
   }
   hipLaunchKernelGGL(rayleigh_partial_kernel, dim3(kRayBlocks), dim3(256), 0, stream, G, P, mp, part);
-  hipLaunchKernelGGL(rayleigh_finish_kernel, dim3(1), dim3(1), 0, stream, part, out);
+  hipLaunchKernelGGL(rayleigh_finish_kernel, dim3(1), dim3(1), 0, stream, part, out, lr);
 }
 
 }  // namespace
@@ -517,6 +537,7 @@ struct LipPersist {
   int* flags;          // [0] barrier arrivals, [1] abort, [2] quotient arrivals
   int mp, squarings, solo;
   const int* run_if;   // nullable: run only if *run_if != 0
+  LipLr lr;            // (slot nullable) {lr, alpha lr} next to out[0]
 };
 
 __device__ __forceinline__ bool lip_spin_until(const int* flag, int want, int* abort_flag) {
@@ -668,7 +689,9 @@ __global__ __launch_bounds__(256) void square_persist_f64_kernel(const LipPersis
       if (last) {
         double num = 0.0, tr = 0.0;
         for (int b = 0; b < kRayBlocks; ++b) { num += ld1(rp, 2 * b); tr += ld1(rp, 2 * b + 1); }
-        x.out[0] = num / tr;
+        const double lam = num / tr;
+        x.out[0] = lam;
+        lip_write_lr(x.lr, lam);
       }
     }
   }
@@ -691,7 +714,8 @@ size_t lipschitz_workspace_bytes(int64_t d, int64_t k) {
 
 // Enqueue the whole computation; the result lands in ((double*)workspace)[0].
 hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, void* workspace,
-                            int squarings, hipStream_t stream) {
+                            int squarings, hipStream_t stream, const PrepareJob* job, bool* fused, LipLr lr) {
+  if (fused) *fused = false;
   const bool rows = d <= k;                 // G = W W^T (rows) or W^T W (columns)
   const int m = (int)(rows ? d : k), len = (int)(rows ? k : d);
   const int mp = (m + kLipTile - 1) / kLipTile * kLipTile;
@@ -710,9 +734,13 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
     const size_t lds = (size_t)64 * 257 * sizeof(double);
     const void* fn = rows ? (const void*)&gram_span_f64_kernel<true> : (const void*)&gram_span_f64_kernel<false>;
     if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
-    const dim3 grid(mp / kLipTile, mp / kLipTile, gs);
-    if (rows) hipLaunchKernelGGL(gram_span_f64_kernel<true>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G);
-    else hipLaunchKernelGGL(gram_span_f64_kernel<false>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G);
+    static const PrepareJob no_job = [] { PrepareJob j; memset(&j, 0, sizeof(j)); return j; }();
+    const int per_slice = (mp / kLipTile) * (mp / kLipTile);
+    const int extra = job ? (job->gx * job->gy + per_slice - 1) / per_slice : 0;     // z slices of prepare blocks
+    const dim3 grid(mp / kLipTile, mp / kLipTile, gs + extra);
+    if (rows) hipLaunchKernelGGL(gram_span_f64_kernel<true>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G, gs, job ? *job : no_job);
+    else hipLaunchKernelGGL(gram_span_f64_kernel<false>, grid, dim3(256), lds, stream, W, ldw, m, len, mp, gs > 1 ? part : G, gs, job ? *job : no_job);
+    if (job && fused) *fused = true;
   } else {
     hipLaunchKernelGGL((syrk_f64_kernel<float, false>), dim3(mp / kLipTile, mp / kLipTile, gs), dim3(256), 0, stream,
                        W, rows ? ldw : (int64_t)1, rows ? (int64_t)1 : ldw, m, len, mp, gspans, gs > 1 ? part : G);
@@ -731,7 +759,7 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
     if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return e;
     LipPersist x;
     x.G = G; x.P0 = P[0]; x.P1 = P[1]; x.part = part; x.out = out; x.flags = pflags;
-    x.mp = mp; x.squarings = squarings; x.solo = 0; x.run_if = nullptr;
+    x.mp = mp; x.squarings = squarings; x.solo = 0; x.run_if = nullptr; x.lr = lr;
     LipPersist y = x;
     y.solo = 1; y.run_if = pflags + 1;
     int tiles = (mp / kLipTile) * (mp / kLipTile);
@@ -748,8 +776,8 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
   }
 #endif
   if (mp <= 64 && squarings > 0) {         // small iterate: every squaring in one launch of one workgroup
-    if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out);
-    else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out);
+    if (mp == 64) hipLaunchKernelGGL(square_chain_f64_kernel<64>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out, lr);
+    else hipLaunchKernelGGL(square_chain_f64_kernel<32>, dim3(1), dim3(1024), 0, stream, G, squarings, P[0], out, lr);
     return hipGetLastError();
   }
   if (mp <= 256) {                         // the usual case (d or k <= 256): the low-latency squaring kernel
@@ -769,7 +797,7 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
       }
       src = dst;
     }
-    launch_rayleigh(G, src, mp, out, part, stream);
+    launch_rayleigh(G, src, mp, out, part, stream, lr);
     return hipGetLastError();
   }
   for (int p = 0; p < squarings; ++p) {
@@ -778,7 +806,7 @@ hipError_t launch_lipschitz(const float* W, int64_t ldw, int64_t d, int64_t k, v
     if (ps > 1) hipLaunchKernelGGL(fold_partials_kernel, fold_grid, dim3(256), 0, stream, part, ps, mm, P[p & 1]);
     src = P[p & 1];
   }
-  launch_rayleigh(G, src, mp, out, part, stream);
+  launch_rayleigh(G, src, mp, out, part, stream, lr);
   return hipGetLastError();
 }
 
