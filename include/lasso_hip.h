@@ -52,6 +52,7 @@ typedef enum {
                                  (a workgroup was not resident; z_out untouched), or the rule fired
                                  before the end of an asynchronously enqueued chunk (z_out holds a
                                  later iterate)                                            */
+  LASSO_PENDING_DEFERRED = 9, /* LASSO_SOLVE_DEFER_VERDICT: enqueued WITHOUT the verdict's launch (lasso_fista_solve_verdict_deferred) */
   LASSO_PENDING_MAPPED = 8    /* LASSO_SOLVE_ASYNC | LASSO_SOLVE_STATUS_MAPPED: enqueued, and the verdict's
                                  four words will be written to the caller's mapped host buffer by the
                                  verdict kernel itself -- no lasso_fista_solve_collect needed          */
@@ -121,6 +122,7 @@ typedef enum {
  * an event record between two kernels of a stream is ~5 us by itself).  A solve that takes the in-kernel rule returns LASSO_PENDING as before
  * (the buffer is then not written; collect as usual). */
 #define LASSO_SOLVE_STATUS_MAPPED 0x20000
+#define LASSO_SOLVE_DEFER_VERDICT 0x40000 /* with STATUS_MAPPED | ONE_CHUNK: see lasso_fista_solve_verdict_deferred */
 /* lr: the reference's lr='auto' (ista.py:72-73): 1 / lambda_max(W^T W) computed by the library on
  * the stream (csrc/lipschitz.hip).  The fp32 fixed-step kernels read the step from device
  * memory -- no host round trip; other paths synchronise once to fetch it. */
@@ -272,6 +274,13 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
                           int64_t n, int64_t d, int64_t k, int dtype,
                           float* a_dev, float* b_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream);
+/* lasso_gram_accumulate whose first launch writes *started_word = started_value (device memory) as it STARTS: everything
+ * enqueued on `stream` before the call has completed by then.  A start signal for work on ANOTHER stream
+ * (lasso_stream_wait_word polls the word) that costs this stream nothing -- an event record between two kernels is ~5 us. */
+int lasso_gram_accumulate_signal(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx,
+                                 int64_t n, int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
+                                 void* workspace_dev, size_t workspace_bytes, int32_t* started_word,
+                                 int32_t started_value, void* stream);
 size_t lasso_dict_sweep_workspace_bytes(int64_t d, int64_t k);
 int lasso_dict_sweep(const float* a_dev, const float* b_dev, void* d_dev, int64_t ldd,
                      int64_t d, int64_t k, int dtype, double eps, int positive,
@@ -301,7 +310,7 @@ int lasso_dict_sweep_async_to(const float* a_dev, const float* b_dev, const void
                               int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev,
                               size_t workspace_bytes, void* stream);
 
-/* One wave on `stream` that returns when *word == value (or after ~0.1 s; host_memory != 0: `word` is pinned host
+/* One wave on `stream` that returns when *word == value (or after ~20 s; ~0.1 s for host_memory != 0: `word` is pinned host
  * memory, e.g. the "valid" word of a LASSO_SOLVE_STATUS_MAPPED buffer): "after that kernel of ANOTHER stream" for the
  * launches behind it without an event record on the other stream.  A scheduling tool: use it only where a late or
  * early start costs time, never where data depends on the order. */
@@ -343,6 +352,9 @@ int lasso_mstep_pipe_gram(const void* z_dev, int64_t ldz, const void* x_dev, int
  * take compute units from it -- no data depends on it). */
 int lasso_mstep_pipe_wait(int64_t n, int64_t d, int64_t k, int seq, void* workspace_dev, size_t workspace_bytes,
                           void* stream);
+/* the word lasso_mstep_pipe_wait polls (device memory inside the workspace; NULL if the shape has no pipelined M-step):
+ * for launches behind that wait which must re-check it (the gate of lasso_fista_solve_verdict_deferred) */
+const int32_t* lasso_mstep_pipe_head_word(int64_t n, int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes);
 /* U rows of the stage (B - A D^T with the dictionary as it is BEFORE the sweep); its last workgroup raises the
  * "complete" words of the stage's block rows for the running sweep (stage 0: writes `seq` for lasso_mstep_pipe_wait). */
 int lasso_mstep_pipe_rows(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,
@@ -421,6 +433,19 @@ int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k,
 int lasso_fista_solve_verdict_mapped(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter,
                                      double tol, const float* sums_dev, int32_t* status_mapped, void* workspace_dev,
                                      size_t workspace_bytes, void* stream);
+/* LASSO_SOLVE_DEFER_VERDICT (with LASSO_SOLVE_ASYNC | LASSO_SOLVE_ONE_CHUNK | LASSO_SOLVE_STATUS_MAPPED, not with
+ * LASSO_SOLVE_SHARDED): the solve enqueues its kernels but NOT the launch that reduces the per-iteration sums and judges
+ * the stop rule (ista.py:93-95), and returns LASSO_PENDING_DEFERRED; this call enqueues that launch on `stream`, which the
+ * caller has ordered behind the solve's kernels without touching the solve's stream -- e.g. behind lasso_stream_wait_word
+ * on the word lasso_gram_accumulate_signal raises.  An EM step's dependent chain (E-step -> Gram product -> sweep) is
+ * then one launch shorter; same kernel, same sums, same four words in `status_mapped`.  The arguments are kept per host
+ * thread, one solve at a time: call it from the thread that enqueued the solve, with that solve's workspace, before the
+ * thread's next LASSO_SOLVE_ASYNC solve.  A solve that cannot defer (maxiter > 64) returns LASSO_PENDING_MAPPED as
+ * without the flag.  gate_word (nullable, device memory): the word the stream's wait polled -- the launch re-checks
+ * *gate_word == gate_value and, if the wait ran into its bound instead, reports "repeat the solve" (status word 2 = 1)
+ * rather than judging sums of kernels that may still be running. */
+int lasso_fista_solve_verdict_deferred(void* workspace_dev, int32_t* status_mapped, const int32_t* gate_word,
+                                       int32_t gate_value, void* stream);
 int lasso_fista_solve_finish(int64_t n, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                              int32_t* iters_out, float* last_delta_out, void* workspace_dev,
                              size_t workspace_bytes, void* stream);

@@ -179,6 +179,9 @@ struct PartialSets {
   const int* alt_if;
   const float* base; int base_n, base_stride; // nullable
 };
+struct DeferredVerdict { void* workspace; PartialSets ps; float* delta; int iters; float budget; int* out; bool armed; };
+// the arguments of the verdict launch an asynchronous solve of THIS thread left out (one slot: the EM loop's E-step)
+static thread_local DeferredVerdict t_deferred_verdict = {nullptr, {}, nullptr, 0, 0.0f, nullptr, false};
 __global__ void reduce_partial_sets_kernel(const PartialSets ps, float* __restrict__ delta) {
   __shared__ float sh[256];
   const float* partials = ps.src;
@@ -230,7 +233,10 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 // reduce_partial_sets_kernel for `iters` rows and chunk_verdict_kernel behind it in ONE workgroup (the asynchronous
 // E-step of an EM loop: one launch less on the step's dependent chain).  Every delta[i] is the same sum in the
 // same order as reduce_partials_kernel's.
-struct ChunkVerdict { float budget; int* out; int* mirror; };
+// defer (nullable): do not launch reduce_verdict_kernel -- leave its arguments there (LASSO_SOLVE_DEFER_VERDICT: the caller
+// launches it on another stream, lasso_fista_solve_verdict_deferred)
+struct DeferredVerdict;
+struct ChunkVerdict { float budget; int* out; int* mirror; DeferredVerdict* defer = nullptr; };
 // the verdict's four words a second time, into a device-writable HOST buffer (pinned, mapped; LASSO_SOLVE_STATUS_MAPPED):
 // the caller's one host read per EM step then needs no copy launch behind the verdict
 __device__ __forceinline__ void mirror_status(int* mirror, int w0, int w1, int w2) {
@@ -242,8 +248,19 @@ __device__ __forceinline__ void mirror_status(int* mirror, int w0, int w1, int w
   // recording an event behind the launch (an event record costs the stream ~5 us between two kernels)
   __hip_atomic_store(mirror + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// gate (nullable; the deferred launch on another stream): the word that stream's wait polled -- if it does not hold
+// gate_value the wait ran into its bound and the solve's kernels may still be running: the verdict is then "repeat the
+// solve" (out[2] = 1), never a judgement of unfinished sums.
 __global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
-                                                              float budget, int* __restrict__ out, int* mirror) {
+                                                              float budget, int* __restrict__ out, int* mirror,
+                                                              const int* gate = nullptr, int gate_value = 0) {
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_value) {
+    if (threadIdx.x == 0) {
+      out[0] = 0; out[1] = __float_as_int(NAN); out[2] = 1; out[3] = 0;
+      mirror_status(mirror, out[0], out[1], out[2]);
+    }
+    return;
+  }
   // One WAVE per row, rows w, w + 16, ... (16 waves: the 10 rows of an EM step's chunk in one pass): lane l plays reduce_partials_kernel's threads l, l + 64, l + 128, l + 192
   // (their strided sums), the first two levels of its tree are then this lane's (a0 + a2) + (a1 + a3), the last six
   // the shuffles below -- no barrier per row.
@@ -583,7 +600,10 @@ int run_impl(const Workspace& ws, int kp, const float* x, int64_t ldx, const flo
     if (plan.split) ps = {split_rows, nparts, nparts, ws.partials, ntiles, ntiles, ws.stop_out + 2, nullptr, 0, 0};
     else if (tail) ps = {split_rows, nparts, nparts, ws.partials + main_tiles, tail, ntiles, ws.stop_out + 2,
                          ws.partials, main_tiles, ntiles};
-    if (verdict && iters <= 64)
+    if (verdict && iters <= 64 && verdict->defer) {     // the caller enqueues that launch itself, on another stream
+      DeferredVerdict& dv = *verdict->defer;
+      dv.ps = ps; dv.delta = delta; dv.iters = iters; dv.budget = verdict->budget; dv.out = verdict->out; dv.armed = true;
+    } else if (verdict && iters <= 64)
       hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(1024), 0, stream, ps, delta, iters, verdict->budget, verdict->out,
                          verdict->mirror);
     else
@@ -1823,7 +1843,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                       float* accepted_lr_out, float* accepted_f_out, void* workspace_dev,
                       size_t workspace_bytes, void* stream, const float* lr_dev = nullptr, bool async = false,
                       const double* lip_dev = nullptr, bool sharded = false, bool one_chunk = false,
-                      int32_t* status_mapped = nullptr, void* lip_deferred_ws = nullptr) {
+                      int32_t* status_mapped = nullptr, void* lip_deferred_ws = nullptr, bool defer_verdict = false) {
   // LASSO_BF16 (x, W, z0, z_out all bf16) is native on the fused shapes
   const bool half_any = dtype == LASSO_BF16 && fused_shape(d, k) && maxiter > 0 && n > 0;
   const bool half_bt = half_any && backtrack;
@@ -2019,7 +2039,11 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   // repeats the solve synchronously, exactly like after an aborted handshake.  The E-step of an EM loop
   // (maxiter = 10) practically never stops early, and no longer makes the GPU wait for the host. -------------
   if (async && stop_mode == LASSO_STOP_GLOBAL && maxiter <= kChunkMax && !(z0 && z0 == zout)) {
-    const ChunkVerdict cv{budget, ws.stop_out, status_mapped};
+    // LASSO_SOLVE_DEFER_VERDICT: the verdict launch is left to lasso_fista_solve_verdict_deferred (another stream)
+    const bool defer = defer_verdict && status_mapped && maxiter <= 64 && n > 0;
+    t_deferred_verdict.armed = false;
+    t_deferred_verdict.workspace = workspace_dev;
+    const ChunkVerdict cv{budget, ws.stop_out, status_mapped, defer ? &t_deferred_verdict : nullptr};
     if (int s = run_impl(ws, kps, x, ldx, cur_z, cur_ldz, nullptr, 0, zout, ldz, nullptr, 0, n, d, k,
                          alpha, lr, fast, 0, maxiter, ws.delta, st, -1.0f, hint, nullptr, lr_dev, &cv))
       return s;
@@ -2028,6 +2052,7 @@ static int solve_impl(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                          status_mapped);
       LASSO_HIP_TRY(hipGetLastError());
     }
+    if (defer && t_deferred_verdict.armed) return LASSO_PENDING_DEFERRED;
     return status_mapped ? LASSO_PENDING_MAPPED : LASSO_PENDING;
   }
   // ---- exact global stop rule, chunked: speculate a chunk, read its per-iteration deltas,
@@ -2113,7 +2138,11 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     status_mapped = iters_out;
     iters_out = nullptr; last_delta_out = nullptr;
   }
-  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK | LASSO_SOLVE_STATUS_MAPPED);
+  const bool defer_verdict = (stop_mode & LASSO_SOLVE_DEFER_VERDICT) != 0;
+  if (defer_verdict && !(status_mapped && one_chunk))
+    return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_DEFER_VERDICT needs LASSO_SOLVE_STATUS_MAPPED and LASSO_SOLVE_ONE_CHUNK");
+  stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK | LASSO_SOLVE_STATUS_MAPPED |
+                 LASSO_SOLVE_DEFER_VERDICT);
   if (sharded && !(async && tol > 0.0 && maxiter > 0 && n > 0 && fused_shape(d, k)))
     return fail(LASSO_ERR_UNSUPPORTED, "LASSO_SOLVE_SHARDED: asynchronous fp32 solves with tol > 0 on the fused shapes only");
   if (async && (objective_out || backtrack || dtype != LASSO_F32))
@@ -2152,7 +2181,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
   const int status = solve_impl(x_dev, ldx, w_dev, ldw, z0_dev, ldz0, z_out_dev, ldz, n, d, k, dtype, alpha, lr,
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
-                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped, lip_deferred);
+                                workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped, lip_deferred,
+                                defer_verdict && !sharded);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
@@ -2259,6 +2289,23 @@ static int solve_verdict_impl(int64_t n, int64_t n_global, int64_t d, int64_t k,
 int lasso_fista_solve_verdict(int64_t n, int64_t n_global, int64_t d, int64_t k, int dtype, int maxiter, double tol,
                               const float* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   return solve_verdict_impl(n, n_global, d, k, dtype, maxiter, tol, sums_dev, nullptr, workspace_dev, workspace_bytes, stream);
+}
+
+// The verdict launch an asynchronous LASSO_SOLVE_DEFER_VERDICT solve of this thread left out (it returned
+// LASSO_PENDING_DEFERRED), on `stream` -- which the caller has ordered behind the solve's kernels (the EM loop: its side
+// stream, behind a wave that polls a word the next launch of the solve's stream raises): the stop rule's launch is then
+// off the step's dependent chain.  Same kernel, same sums, same words in `status_mapped` as the solve would have left.
+int lasso_fista_solve_verdict_deferred(void* workspace_dev, int32_t* status_mapped, const int32_t* gate_word,
+                                       int32_t gate_value, void* stream) {
+  DeferredVerdict& dv = t_deferred_verdict;
+  if (!status_mapped) return fail(LASSO_ERR_BAD_ARG, "status_mapped is NULL");
+  if (!dv.armed || dv.workspace != workspace_dev)
+    return fail(LASSO_ERR_BAD_ARG, "no deferred verdict for this workspace (LASSO_SOLVE_DEFER_VERDICT, same thread, one at a time)");
+  dv.armed = false;
+  hipLaunchKernelGGL(reduce_verdict_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dv.ps, dv.delta, dv.iters, dv.budget,
+                     dv.out, status_mapped, gate_word, gate_value);
+  LASSO_HIP_TRY(hipGetLastError());
+  return LASSO_OK;
 }
 
 // the same verdict, its four words ALSO written to `status_mapped` (device-writable host memory): no collect call
@@ -2415,9 +2462,31 @@ size_t lasso_gram_workspace_bytes(int64_t n, int64_t d, int64_t k) {
   return std::max((size_t)gram_max_splits(d, k) * (size_t)k * (size_t)std::max(k, d) * 4, gram_ab_scratch_bytes(d, k)) + 256;
 }
 
+static int gram_accumulate_impl(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
+                                int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream, int32_t* started_word,
+                                int32_t started_value);
 int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
                           int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return gram_accumulate_impl(z_dev, ldz, x_dev, ldx, n, d, k, dtype, a_dev, b_dev, workspace_dev, workspace_bytes, stream,
+                              nullptr, 0);
+}
+// the same products; the first launch raises *started_word = started_value when it STARTS (device memory): "everything
+// enqueued on this stream before the call has completed", for a wave of another stream that polls the word
+// (lasso_stream_wait_word) -- a start signal without an event record on this stream (~5 us between two kernels)
+int lasso_gram_accumulate_signal(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
+                                 int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
+                                 void* workspace_dev, size_t workspace_bytes, int32_t* started_word, int32_t started_value,
+                                 void* stream) {
+  if (!started_word) return fail(LASSO_ERR_BAD_ARG, "started_word is NULL");
+  return gram_accumulate_impl(z_dev, ldz, x_dev, ldx, n, d, k, dtype, a_dev, b_dev, workspace_dev, workspace_bytes, stream,
+                              started_word, started_value);
+}
+static int gram_accumulate_impl(const void* z_dev, int64_t ldz, const void* x_dev, int64_t ldx, int64_t n,
+                                int64_t d, int64_t k, int dtype, float* a_dev, float* b_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream, int32_t* started_word,
+                                int32_t started_value) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!z_dev || !x_dev || !a_dev || !b_dev || n < 0 || d <= 0 || k <= 0 || ldz < k || ldx < d)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
@@ -2431,7 +2500,7 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
   if (scratch) {
     hipError_t e = hipSuccess;
     if (launch_gram_ab(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, a_dev, b_dev, scratch,
-                       workspace_bytes - 256, cus, st, &e)) {
+                       workspace_bytes - 256, cus, st, &e, started_word, started_value)) {
       LASSO_HIP_TRY(e);
       return LASSO_OK;
     }
@@ -2439,11 +2508,13 @@ int lasso_gram_accumulate(const void* z_dev, int64_t ldz, const void* x_dev, int
   if (scratch && !getenv("LASSO_GRAM_TWO_LAUNCHES")) {      // small dictionaries: one product launch, one fold (A/B: the env switch)
     hipError_t e = hipSuccess;
     if (launch_gram_ab128(Z, ldz, (int)k, (const float*)x_dev, ldx, (int)d, (int)n, a_dev, b_dev, scratch,
-                          workspace_bytes - 256, cus, gram_max_splits(d, k), st, &e)) {
+                          workspace_bytes - 256, cus, gram_max_splits(d, k), st, &e, started_word, started_value)) {
       LASSO_HIP_TRY(e);
       return LASSO_OK;
     }
   }
+  // (the other product kernels do not carry the signal: a launch of its own in front of them)
+  if (started_word) LASSO_HIP_TRY(launch_set_flag(started_word, started_value, st));
   const int smax = scratch ? gram_max_splits(d, k) : 1;
   const int sa = gram_splits((int)k, (int)k, (int)n, 1, cus, smax), sb = gram_splits((int)k, (int)d, (int)n, 0, cus, smax);
   LASSO_HIP_TRY(launch_gram_tn(Z, ldz, (int)k, Z, ldz, (int)k, (int)n, a_dev, k, 1, scratch, sa, st));
@@ -2651,6 +2722,14 @@ int lasso_mstep_pipe_wait(int64_t n, int64_t d, int64_t k, int seq, void* worksp
   if (workspace_bytes < w.bytes) return fail(LASSO_ERR_WORKSPACE, "need %zu bytes", w.bytes);
   LASSO_HIP_TRY(launch_wait_word(sweep_pipe_words(w.extra, (int)k) + 1, seq, 0, (hipStream_t)stream));
   return LASSO_OK;
+}
+
+// the word lasso_mstep_pipe_wait polls (device memory inside the workspace; NULL: no pipelined M-step for the shape) --
+// for launches behind the wait that must re-check it themselves (lasso_fista_solve_verdict_deferred's gate)
+const int32_t* lasso_mstep_pipe_head_word(int64_t n, int64_t d, int64_t k, void* workspace_dev, size_t workspace_bytes) {
+  PipeWs w;
+  if (!workspace_dev || !pipe_carve(n, d, k, workspace_dev, &w) || workspace_bytes < w.bytes) return nullptr;
+  return sweep_pipe_words(w.extra, (int)k) + 1;
 }
 
 int lasso_mstep_pipe_rows(const float* ab_dev, int64_t ldab, const void* d_dev, int64_t ldd, int64_t n, int64_t d,

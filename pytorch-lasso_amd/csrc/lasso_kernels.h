@@ -55,6 +55,7 @@ constexpr size_t kSplitkFlagBytes =
 // means part of the grid is not resident (CUs held by another stream / process); the kernels
 // then abort as a whole and the host repeats the solve on a path without handshakes.
 constexpr int kStopSpinLimit = 1 << 17;
+constexpr int kGateSpinLimit = 1 << 24;   // waits for ANOTHER stream's work (may include the caller's collectives): ~20-30 s
 // lasso_debug_force_standby (lasso_hip.h): the co-operative launches of the sweep and the Lipschitz squarings are
 // skipped, their one-workgroup stand-by forms run alone
 extern int g_force_standby;
@@ -313,10 +314,12 @@ int gram_splits(int pc, int qc, int n, int sym, int cus, int max_splits = 16);
 constexpr int kGramAbMaxSplits = 128;
 size_t gram_ab_scratch_bytes(int64_t d, int64_t k);
 bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
-                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err);
+                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err, int* raise = nullptr,
+                    int raise_value = 0);
 // small dictionaries (k >= 128, d <= 128): A = Z^T Z and B = Z^T X in one product launch + one fold launch
 bool launch_gram_ab128(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
-                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err);
+                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err,
+                       int* raise = nullptr, int raise_value = 0);
 hipError_t launch_gram_tn(const float* P, int64_t ldp, int pc, const float* Q, int64_t ldq, int qc,
                           int n, float* C, int64_t ldc, int sym, float* scratch, int splits,
                           hipStream_t stream);

@@ -135,11 +135,14 @@ constexpr int kG2B = 128, kG2S = 32, kG2Ld = 144;
 // Gram2 (round 6): a SECOND right operand whose blocks ride in the same launch -- B = P^T Q2 behind the sym product
 // A = P^T P (the M-step's two products of a small dictionary: d <= 128 is one column block, half of it padding for
 // d = 64 -- still cheaper than a launch of its own on the EM step's chain).  Its partials go to C2 (pitch ldc2).
-struct Gram2 { const float* Q2; int64_t ldq2; int qc2; float* C2; int64_t ldc2; int64_t split_stride2; int first; };
+struct Gram2 { const float* Q2; int64_t ldq2; int qc2; float* C2; int64_t ldc2; int64_t split_stride2; int first;
+               int* raise = nullptr; int raise_value = 0; };   // (raise, nullable: *raise = raise_value as the launch starts)
 __global__ __launch_bounds__(256, 2) void gram_tn128_kernel(const float* __restrict__ P, int64_t ldp, int pc,
                                                             const float* __restrict__ Q, int64_t ldq, int qc, int n,
                                                             float* __restrict__ C, int64_t ldc, int sym,
                                                             int rows_per_split, int64_t split_stride, const Gram2 g2) {
+  if (g2.raise && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_store(g2.raise, g2.raise_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int bi, bj;
   if (g2.Q2 && (int)blockIdx.x >= g2.first) {  // a block of the second product: row block bi of P, column block bj of Q2
     const int e = blockIdx.x - g2.first, nbq = (g2.qc2 + kG2B - 1) / kG2B;
@@ -369,6 +372,7 @@ struct GramRows {
   int bi; int bi_hi;                   // block rows bi .. bi_hi - 1 (bi < 0: the whole product, the partials' usual layout)
   int* clear; int nclear;
   int* ticket; int* done; int seq;     // nullable: the workgroup that finishes last writes `seq` to *done (and resets the ticket)
+  int* raise = nullptr; int raise_value = 0;   // nullable: *raise = raise_value as the launch starts (lasso_gram_accumulate_signal)
 };
 __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict__ Z, int64_t ldz, int k,
                                                          const float* __restrict__ X, int64_t ldx, int d, int n,
@@ -376,6 +380,8 @@ __global__ __launch_bounds__(512) void gram_ab256_kernel(const float* __restrict
   const int nb = k / kG3B, nsym = nb * (nb + 1) / 2;
   if (gr.clear && blockIdx.x == 0 && blockIdx.z == 0)
     for (int i = threadIdx.x; i < gr.nclear; i += 512) gr.clear[i] = 0;
+  if (gr.raise && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_store(gr.raise, gr.raise_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int bi, bj;                                     // bj < nb: A block (bj >= bi);  bj >= nb: B block, X columns 256 (bj - nb)
   if (gr.bi >= 0) {
     int rem = blockIdx.x;                         // block row bi has nb - bi blocks of A and d / 256 of B
@@ -550,7 +556,9 @@ __global__ void wait_word_kernel(const int* word, int seq, int host_memory) {
     }
     return;
   }
-  for (int spins = 0; spins < (1 << 20); ++spins) {
+  // (~30 s: what is waited for may sit behind the caller's collectives or a time-sliced GPU; launches behind this one
+  // that could not tolerate an early return carry their own check of the word)
+  for (int spins = 0; spins < kGateSpinLimit; ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;
     __builtin_amdgcn_s_sleep(8);
   }
@@ -815,7 +823,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The waits of the GATED sweep (pipelined M-step) for rows that another stream is still producing: that stream's work
 // includes the caller's collectives (RCCL all-reduces of a stage; the first ones of a process set up connections for
 // hundreds of milliseconds), so their bound is ~30 s, not the ~0.2 s that says "a co-operating workgroup is not resident".
-constexpr int kGateSpinLimit = 1 << 24;
 __device__ __forceinline__ bool spin_until(const int* flag, int want, int* abort_flag, int limit = kStopSpinLimit) {
   for (int spins = 0; spins < limit; ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
@@ -1973,7 +1980,8 @@ size_t gram_ab_scratch_bytes(int64_t d, int64_t k) {
 }
 
 bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
-                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err) {
+                    float* scratch, size_t scratch_bytes, int cus, hipStream_t stream, hipError_t* err, int* raise,
+                    int raise_value) {
   *err = hipSuccess;
   if (k < kG3B || d < kG3B || k % kG3B || d % kG3B || (ldz & 3) || (ldx & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)X & 15) ||
       !scratch || n < 8 * 512)
@@ -2000,7 +2008,7 @@ bool launch_gram_ab(const float* Z, int64_t ldz, int k, const float* X, int64_t 
   const size_t lds = (size_t)4 * kG3S * kG3Ld * 4;
   if ((*err = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_ab256_kernel), lds)) != hipSuccess) return true;
   hipLaunchKernelGGL(gram_ab256_kernel, dim3(blocks, 1, sp), dim3(512), lds, stream, Z, ldz, k, X, ldx, d, n, scratch, rps,
-                     GramRows{-1, -1, nullptr, 0, nullptr, nullptr, 0});
+                     GramRows{-1, -1, nullptr, 0, nullptr, nullptr, 0, raise, raise_value});
   const int64_t stride = (int64_t)k * (k + d);
   const int nt = (k + 31) / 32;
   const int nsym = nt * (nt + 1) / 2;
@@ -2018,7 +2026,8 @@ constexpr int kGramMinRowsC = LASSO_GRAM_MIN_ROWS;      // (== kGramMinRows belo
 // the EM step of 8 x 8 patches -- d = 64, k = 256 -- spent four launches here).  false: not applicable (the caller takes
 // the two products one after the other).  Scratch: [splits][k][k] for A, then [splits][k][d] for B.
 bool launch_gram_ab128(const float* Z, int64_t ldz, int k, const float* X, int64_t ldx, int d, int n, float* A, float* B,
-                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err) {
+                       float* scratch, size_t scratch_bytes, int cus, int max_splits, hipStream_t stream, hipError_t* err,
+                       int* raise, int raise_value) {
   *err = hipSuccess;
   if (k < kG2B || d > kG2B || (k & 3) || (d & 3) || (ldz & 3) || (ldx & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)X & 15) ||
       !scratch || n <= 0)
@@ -2037,7 +2046,7 @@ bool launch_gram_ab128(const float* Z, int64_t ldz, int k, const float* X, int64
   const size_t lds = (size_t)4 * kG2S * kG2Ld * 4;
   if ((*err = ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_tn128_kernel), lds)) != hipSuccess) return true;
   hipLaunchKernelGGL(gram_tn128_kernel, dim3(nsym + nb2, 1, sp), dim3(256), lds, stream, Z, ldz, k, Z, ldz, k, n, partA,
-                     (int64_t)k, 1, rps, strideA, Gram2{X, ldx, d, partB, (int64_t)d, strideB, nsym});
+                     (int64_t)k, 1, rps, strideA, Gram2{X, ldx, d, partB, (int64_t)d, strideB, nsym, raise, raise_value});
   const int nt = (k + 31) / 32, ntiles = nt * (nt + 1) / 2;
   hipLaunchKernelGGL(sum_splits_sym4_b_kernel, dim3(4 * ntiles + (unsigned)((strideB + 255) / 256)), dim3(256), 0, stream,
                      partA, sp, strideA, (int64_t)k, k, A, (int64_t)k, 4 * ntiles, partB, strideB, k, d, B, (int64_t)d);

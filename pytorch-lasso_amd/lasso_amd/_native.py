@@ -14,7 +14,7 @@ import torch
 
 LASSO_OK, LASSO_ERR_BAD_ARG, LASSO_ERR_UNSUPPORTED = 0, 1, 2
 LASSO_ERR_WORKSPACE, LASSO_ERR_HIP, LASSO_WARN_LINESEARCH = 3, 4, 5
-LASSO_PENDING, LASSO_WARN_ABORTED, LASSO_PENDING_MAPPED = 6, 7, 8
+LASSO_PENDING, LASSO_WARN_ABORTED, LASSO_PENDING_MAPPED, LASSO_PENDING_DEFERRED = 6, 7, 8, 9
 LASSO_F32, LASSO_BF16 = 0, 1
 STOP_GLOBAL, STOP_NONE, STOP_GLOBAL_CHUNKED = 0, 1, 2
 ABI_VERSION = 7
@@ -23,6 +23,7 @@ SOLVE_ASYNC = 0x4000
 SOLVE_ONE_CHUNK = 0x10000
 SOLVE_SHARDED = 0x8000
 SOLVE_STATUS_MAPPED = 0x20000       # iters_out = four words of pinned (device-writable) host memory
+SOLVE_DEFER_VERDICT = 0x40000       # the verdict's launch is left to lasso_fista_solve_verdict_deferred (another stream)
 LR_AUTO = -1.0
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -92,6 +93,11 @@ def _declare(lib):
     lib.lasso_gram_workspace_bytes.restype = sz
     lib.lasso_gram_workspace_bytes.argtypes = [i64, i64, i64]
     lib.lasso_gram_accumulate.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]
+    lib.lasso_gram_accumulate_signal.argtypes = [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp, i32, vp]
+    lib.lasso_fista_solve_verdict_deferred.restype = i32
+    lib.lasso_fista_solve_verdict_deferred.argtypes = [vp, vp, vp, i32, vp]
+    lib.lasso_mstep_pipe_head_word.restype = vp
+    lib.lasso_mstep_pipe_head_word.argtypes = [i64, i64, i64, vp, sz]
     lib.lasso_dict_sweep_workspace_bytes.restype = sz
     lib.lasso_dict_sweep_workspace_bytes.argtypes = [i64, i64]
     lib.lasso_dict_sweep.restype = i32

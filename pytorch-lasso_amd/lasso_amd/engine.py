@@ -73,10 +73,12 @@ class HipEngine:
                     and X.is_cuda and W.is_cuda and d <= 256 and k <= 1024
                     and kw.get('stop_mode', 'global') == 'global' and 0 < maxiter <= 64)
 
-    def encode_begin(self, X, W, alpha, z0, **solver_kwargs):
+    def encode_begin(self, X, W, alpha, z0, defer_verdict=False, **solver_kwargs):
         """sparse_encode that does not wait for the stop rule's outcome: returns (Z, pending);
         ``pending`` is None (complete) or a callable that waits for the solve alone and returns
-        False when it has to be repeated with stop_mode='chunked' (solvers/ista.py PendingSolve)."""
+        False when it has to be repeated with stop_mode='chunked' (solvers/ista.py PendingSolve).
+        ``defer_verdict``: where the solve allows it, the stop rule's launch is left to the caller
+        (``pending.deferred`` -> ``pending.launch_verdict()`` on a stream ordered behind the solve)."""
         from .linear.solvers import ista
         kw = dict(solver_kwargs)
         plain = (kw.pop('algorithm', 'ista') == 'ista' and kw.pop('init', None) is None and not kw.get('verbose')
@@ -87,7 +89,7 @@ class HipEngine:
         if z0 is None:
             from .linear.solvers.ista import lazy_zeros
             z0 = lazy_zeros(X, X.shape[0], W.shape[1])
-        return ista(X, z0, W, alpha, begin=True, **kw)
+        return ista(X, z0, W, alpha, begin='defer' if defer_verdict else True, **kw)
 
     def encode_sharded_backtrack(self, X, W, alpha, z0, lr, fast, maxiter, tol, eta, n_global, all_reduce):
         """ISTA/FISTA with the backtracking line search on this rank's row shard
@@ -195,6 +197,13 @@ class HipEngine:
             nat.check(L.lasso_mstep_pipe_stage_rows(1, d, k, s_, C.byref(lo), C.byref(hi)))
             out.append((lo.value, hi.value))
         return out
+
+    def pipe_head_word(self, n, d, k, ws):
+        """address of the word pipe_wait polls (device memory inside ws)"""
+        p = self.lib.lasso_mstep_pipe_head_word(max(int(n), 1), d, k, nat.ptr(ws), ws.numel())
+        if not p:
+            raise nat.NativeError("lasso_mstep_pipe_head_word: no pipelined M-step for this shape")
+        return int(p)
 
     def mstep_pipe_workspace(self, n, d, k):
         with torch.cuda.device(self.device):
@@ -353,18 +362,25 @@ class HipEngine:
         return loss, sums
 
     # -- M-step --------------------------------------------------------------------
-    def gram(self, Z, X, out):
+    def gram(self, Z, X, out, started=None):
         """out: flat fp32 buffer of k*k + k*d (+extra) floats; A and B are written at its
-        start so one all-reduce covers both."""
+        start so one all-reduce covers both.  ``started``: (int32 device tensor, value) -- the product's first launch
+        writes the value there as it starts (lasso_gram_accumulate_signal: a start signal for another stream)."""
         n, k = Z.shape
         d = X.shape[1]
         A = out[:k * k].view(k, k)
         B = out[k * k:k * k + k * d].view(k, d)
         with torch.cuda.device(self.device):
             ws = self._ws(self.lib.lasso_gram_workspace_bytes(n, d, k), "gram")
-            nat.check(self.lib.lasso_gram_accumulate(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0),
-                                                     n, d, k, nat.LASSO_F32, nat.ptr(A), nat.ptr(B),
-                                                     nat.ptr(ws), ws.numel(), self._stream()))
+            if started is None:
+                nat.check(self.lib.lasso_gram_accumulate(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0),
+                                                         n, d, k, nat.LASSO_F32, nat.ptr(A), nat.ptr(B),
+                                                         nat.ptr(ws), ws.numel(), self._stream()))
+            else:
+                nat.check(self.lib.lasso_gram_accumulate_signal(nat.ptr(Z), Z.stride(0), nat.ptr(X), X.stride(0),
+                                                                n, d, k, nat.LASSO_F32, nat.ptr(A), nat.ptr(B),
+                                                                nat.ptr(ws), ws.numel(), nat.ptr(started[0]), int(started[1]),
+                                                                self._stream()))
         return A, B
 
     def sweep(self, A, B, D, pool, eps, positive, seed=0):

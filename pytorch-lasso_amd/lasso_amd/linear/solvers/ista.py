@@ -120,17 +120,39 @@ class PendingSolve:
     with more tiles than resident workgroups, enqueued as one chunk -- the rule fired before the last
     iteration (z then holds a later iterate).  ``iterations`` / ``last_delta`` are valid after a True call."""
 
-    def __init__(self, status, event):
+    def __init__(self, status, event, deferred=None):
         # status: a _native.HostWords of 4 words; event: a torch event behind the copy of the words (the in-kernel
         # rule's path), or None when the verdict kernel writes them itself and raises the "valid" word (polled)
         self._status, self._event = status, event
         self.iterations, self.last_delta = None, None
+        # deferred: (workspace tensor, device) of a LASSO_SOLVE_DEFER_VERDICT solve whose verdict launch is still owed
+        self._deferred = deferred
+
+    @property
+    def deferred(self):
+        """True while the verdict's launch has not been enqueued (``ista(..., begin='defer')``): call launch_verdict()
+        on a stream ordered behind the solve -- calling the object before that would wait for ever"""
+        return self._deferred is not None
+
+    def launch_verdict(self, gate=None):
+        """(begin='defer') enqueue the stop rule's launch on the CURRENT stream, which the caller has ordered behind the
+        solve's kernels (lasso_fista_solve_verdict_deferred); same host thread as the solve, before its next one.
+        ``gate``: (address of an int32 in device memory, value) -- the word the stream's wait polled; the launch
+        re-checks it and answers "repeat the solve" if the wait gave up instead"""
+        ws, dev = self._deferred
+        self._deferred = None
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().lasso_fista_solve_verdict_deferred(
+                nat.ptr(ws), self._status.tensor.data_ptr(), C.c_void_p(int(gate[0])) if gate else None,
+                int(gate[1]) if gate else 0, nat.stream_ptr(dev)))
 
     def status_word(self):
         """address of the "valid" word (pinned host memory), for lasso_stream_wait_word; None on the event path"""
         return None if self._event is not None or self._status is None else self._status.tensor.data_ptr() + 12
 
     def __call__(self):
+        if self._deferred is not None:
+            raise RuntimeError("PendingSolve: the deferred verdict was never launched (launch_verdict())")
         if self._event is not None:
             self._event.synchronize()
             st = self._status.view
@@ -188,7 +210,9 @@ def ista(x, z0, weight, alpha=1.0, fast=True, lr='auto', maxiter=10,
     'chunked' = the same rule without the in-kernel handshake, 'none' = run maxiter iterations.
     ``kernel`` (extension): 'auto' | 'tile' | 'splitk' -- which fused kernel runs the batch
     (include/lasso_hip.h, LASSO_KERNEL_*); the code is bitwise the same either way.
-    ``begin`` (extension): return ``(z, pending)`` without waiting for the stop rule's outcome;
+    ``begin`` (extension): return ``(z, pending)`` without waiting for the stop rule's outcome
+    (``begin='defer'``, with stop_mode='one-chunk': the rule's launch itself is left to the caller, who enqueues it on
+    another stream -- ``pending.deferred`` / ``pending.launch_verdict()``);
     ``pending`` is a :class:`PendingSolve`, or None when the solve completed inside the call.
     ``shard`` (extension, with ``begin``): x is one rank's row shard of a larger batch -- ``pending`` is a
     :class:`PendingShardedSolve` whose sums the multi-GPU driver all-reduces (lasso_amd/parallel.py).
@@ -345,7 +369,8 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
             nat.ptr(xg), xg.stride(0), nat.ptr(wg), wg.stride(0), nat.ptr(zg), zg.stride(0) if zg is not None else 0,
             nat.ptr(z), z.stride(0), n, d, k, _DT[x.dtype], float(alpha), lr, int(bool(fast)),
             int(maxiter), float(tol), _STOP[stop_mode] | _KERNEL[kernel] | (nat.SOLVE_ASYNC if want_async else 0) |
-            (nat.SOLVE_SHARDED if shard else 0) | (nat.SOLVE_STATUS_MAPPED if status is not None else 0),
+            (nat.SOLVE_SHARDED if shard else 0) | (nat.SOLVE_STATUS_MAPPED if status is not None else 0) |
+            (nat.SOLVE_DEFER_VERDICT if (begin == 'defer' and status is not None and stop_mode == 'one-chunk') else 0),
             int(bool(backtrack)), float(eta_backtrack),
             C.cast(status.arm(), C.POINTER(C.c_int32)) if status is not None else
             (C.byref(iters) if want_host else None), C.byref(last) if want_host else None, trials, acc_lr, acc_f,
@@ -369,6 +394,8 @@ def _solve_native(x, z0, weight, alpha, fast, lr, maxiter, tol, backtrack, eta_b
             pending = PendingShardedSolve(deltas, judge)
         elif st == nat.LASSO_PENDING_MAPPED:
             pending = PendingSolve(status, None)      # the verdict kernel raises the buffer's "valid" word itself
+        elif st == nat.LASSO_PENDING_DEFERRED:
+            pending = PendingSolve(status, None, deferred=(ws, dev))     # ... once the caller has launched it
         elif st == nat.LASSO_PENDING:
             nat.check(L.lasso_fista_solve_collect(n, d, k, _DT[x.dtype], int(maxiter), float(tol),
                                                   status.tensor.data_ptr(), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)))

@@ -457,6 +457,11 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     AB = buf[:k * (k + d)].view(k, k + d) if pipe else None
     ws = engine.mstep_pipe_workspace(n_local, d, k) if pipe else None
     ev_S = _t.cuda.Event()
+    import inspect
+    can_defer = (not multi and os.environ.get("LASSO_EM_DEFER_VERDICT", "1") != "0"
+                 and 'defer_verdict' in inspect.signature(engine.encode_begin).parameters)
+    defer_kw = dict(defer_verdict=True) if can_defer else {}
+    sig = _t.zeros(1, dtype=_t.int32, device=dev) if can_defer and not pipe else None     # raised by the Gram launch
     # "cur": the dictionary in force; "alt" (shapes without a pipelined M-step): the buffer the running step's sweep fills
     state = {"seq": 0, "prev_sums": None, "prev_index": -1, "cur": weight,
              "alt": None if pipe else _t.empty_like(weight)}
@@ -492,16 +497,30 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     # disturbance of the sweep's memory round trips (measured: 64 of 256 workgroups; 32 make the step wait for it)
     cap = 64 if pipe else 0
 
-    def objective(Z, i):
+    def objective(Z, i, D=None):
         """(on S) dict_learning.py:39 for this step's code with the OLD dictionary"""
+        D = state["cur"] if D is None else D
         if n_local == 0:
             sums = _t.zeros(2, dtype=_t.float64, device=dev)
         elif multi:
-            _, sums = engine.objective_sums(X, Z, state["cur"], alpha, max_workgroups=cap)
+            _, sums = engine.objective_sums(X, Z, D, alpha, max_workgroups=cap)
         else:
-            engine.objective_sums(X, Z, state["cur"], alpha, loss_out=losses[i], max_workgroups=cap)
+            engine.objective_sums(X, Z, D, alpha, loss_out=losses[i], max_workgroups=cap)
             sums = None
         state["next_sums"] = sums
+
+    def flush_objective():
+        """(double-buffered form) the objective of the last accepted step, enqueued on S -- the host has seen that step's
+        verdict, so S needs no start signal; it is put off until the NEXT E-step has been enqueued on M (its launches
+        are what the host must get out before the running sweep ends) unless somebody reads the loss first"""
+        job = state.pop("objective_job", None)
+        if job is None:
+            return
+        with _t.cuda.stream(S):
+            objective(*job)
+            ev_S.record(S)
+        if multi:
+            state["prev_sums"], state["prev_index"] = state["next_sums"], job[1]
 
     def produce(Z, pending, i):
         """Enqueue everything of step i between the E-step and the new dictionary.  Returns a callable to be called once
@@ -528,6 +547,10 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             stage(0)                                                     # the head: on the step's dependent chain
             with _t.cuda.stream(S):
                 engine.pipe_wait(n_local, d, k, seq, ws)                 # (a wave that polls the head's word: no event on M)
+                if getattr(pending, 'deferred', False):                  # the E-step's stop rule (its kernels are long done)
+                    pending.launch_verdict(gate=(engine.pipe_head_word(n_local, d, k, ws), seq))
+                    if stats is not None:
+                        stats['deferred_verdicts'] = stats.get('deferred_verdicts', 0) + 1
                 for s_ in range(1, last + 1):
                     stage(s_)
                 if sharded:
@@ -545,7 +568,15 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         # before the host has seen the verdict (the objective follows on S after the host wait, see the loop)
         A = buf[:k * k].view(k, k)
         B = buf[k * k:k * k + k * d].view(k, d)
-        if n_local > 0:
+        if n_local > 0 and getattr(pending, 'deferred', False):
+            state["sig"] = state.get("sig", 0) + 1
+            engine.gram(Z, X, buf, started=(sig, state["sig"]))          # its first launch raises the word as it starts
+            with _t.cuda.stream(S):
+                engine.stream_wait_word(sig.data_ptr(), state["sig"], False)
+                pending.launch_verdict(gate=(sig.data_ptr(), state["sig"]))
+            if stats is not None:
+                stats['deferred_verdicts'] = stats.get('deferred_verdicts', 0) + 1
+        elif n_local > 0:
             engine.gram(Z, X, buf)
         else:
             buf[:k * (k + d)].zero_()
@@ -569,7 +600,9 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         # ---- E-step (dict_learning.py:38), enqueued without a wait
         D = state["cur"]
         if not multi:
-            Z, pending = engine.encode_begin(X, D, alpha, Z0, **begin_kwargs)
+            # (the stop rule's launch goes to S -- behind a wave that polls a word M's next launch raises -- where the
+            # engine can leave it out of the solve: nothing of the step's chain on M needs its outcome)
+            Z, pending = engine.encode_begin(X, D, alpha, Z0, **dict(begin_kwargs, **defer_kw))
         elif n_local == 0:
             Z = Z0 if Z0 is not None else X.new_zeros(0, k)
             pending = _EmptyShardPending(ndelta, k, tol, dev)
@@ -580,6 +613,7 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             if began is None:
                 raise RuntimeError("encode_begin_sharded refused arguments sharded_async_ok accepted")
             Z, pending = began
+        flush_objective()        # (the previous step's; before this step's message, which carries its sums)
         if stats is not None:
             stats['overlapped_steps'] = stats.get('overlapped_steps', 0) + 1
             if pipe:
@@ -613,12 +647,10 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             if stats is not None:
                 stats['replayed_steps'] = stats.get('replayed_steps', 0) + 1
         if not pipe:
-            # the host has seen this E-step's verdict: Z is final, and S needs no device-side start signal.  It reads the
-            # dictionary of THIS step, which stays untouched until the next step's sweep (ordered behind ev_S) refills it.
-            with _t.cuda.stream(S):
-                objective(Z, i)
-                ev_S.record(S)
-        if multi:
+            # the host has seen this E-step's verdict: Z is final.  The objective reads the dictionary of THIS step, which
+            # stays untouched until the next step's sweep (ordered behind ev_S) refills it: see flush_objective()
+            state["objective_job"] = (Z, i, state["cur"])
+        elif multi:
             state["prev_sums"], state["prev_index"] = state["next_sums"], i
         if persist:
             Z0 = Z                                                                        # :40-41
@@ -627,11 +659,13 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             state["cur"], state["alt"] = state["alt"], state["cur"]
         Zlast = Z
         if bar is not None:
+            flush_objective()
             ev_S.synchronize()
             j = i if not multi else state["prev_index"] - 1            # (several ranks: a loss is known a step later)
             bar.set_postfix(loss=losses[j].item() if j >= 0 else float('nan'))            # :50
             bar.update(1)
         i += 1
+    flush_objective()
     M.wait_event(ev_S)
     if multi and state["prev_index"] >= 0:           # flush: the last step's objective sums
         t2 = state["prev_sums"].to(_t.float32).clone()
