@@ -254,7 +254,7 @@ __device__ __forceinline__ void mirror_status(int* mirror, int w0, int w1, int w
 __global__ __launch_bounds__(1024) void reduce_verdict_kernel(const PartialSets ps, float* __restrict__ delta, int iters,
                                                               float budget, int* __restrict__ out, int* mirror,
                                                               const int* gate = nullptr, int gate_value = 0) {
-  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_value) {
+  if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_value) {     // (words count up)
     if (threadIdx.x == 0) {
       out[0] = 0; out[1] = __float_as_int(NAN); out[2] = 1; out[3] = 0;
       mirror_status(mirror, out[0], out[1], out[2]);
@@ -2536,7 +2536,8 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
                            int64_t k, int dtype, double eps, int positive, const float* pool_dev,
                            int64_t pool_rows, int64_t pool_ld, uint64_t seed, int32_t* degenerate_dev,
                            int32_t* ndeg_out, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
-                           void* stream, void* d_out_dev = nullptr, int64_t ldo = 0) {
+                           void* stream, void* d_out_dev = nullptr, int64_t ldo = 0, int32_t* started_word = nullptr,
+                           int32_t started_value = 0) {
   if (dtype != LASSO_F32) return fail(LASSO_ERR_UNSUPPORTED, "dtype %d", dtype);
   if (!a_dev || !b_dev || !d_dev || !degenerate_dev || !workspace_dev || d <= 0 || k <= 0 || ldd < k)
     return fail(LASSO_ERR_BAD_ARG, "bad argument");
@@ -2576,6 +2577,9 @@ static int dict_sweep_impl(const float* a_dev, const float* b_dev, void* d_dev, 
                                    flag_words ? 1024 : 0));
   // Dt[j][dd] = D[dd][j]  (zero padded to dp features)
   if (!direct) LASSO_HIP_TRY(launch_transpose_pad(D, ldd, (int)d, (int)k, Dt, dp, (int)k, dp, st));
+  // "the sweep starts now": a word another stream's wave polls (work that should run BESIDE the sweep, which leaves most
+  // of the chip idle -- the EM loop's objective on large batches); one 4-us launch on this stream
+  if (started_word) LASSO_HIP_TRY(launch_set_flag(started_word, started_value, st));
   SweepParams p;
   p.flags_cleared = flag_words != nullptr;
   p.Dsrc = direct ? D : nullptr; p.ldd = ldd;
@@ -2622,12 +2626,13 @@ int lasso_dict_sweep_async(const float* a_dev, const float* b_dev, void* d_dev, 
 int lasso_dict_sweep_async_to(const float* a_dev, const float* b_dev, const void* d_dev, int64_t ldd, void* d_out_dev,
                               int64_t ldo, int64_t d, int64_t k, int dtype, double eps, int positive,
                               const float* pool_dev, int64_t pool_rows, int64_t pool_ld, uint64_t seed,
-                              int32_t* degenerate_dev, int32_t* ndeg_mapped, void* workspace_dev, size_t workspace_bytes,
-                              void* stream) {
+                              int32_t* degenerate_dev, int32_t* ndeg_mapped, int32_t* started_word,
+                              int32_t started_value, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (!ndeg_mapped) return fail(LASSO_ERR_BAD_ARG, "ndeg_mapped is NULL");
   if (!d_out_dev || d_out_dev == d_dev) return fail(LASSO_ERR_BAD_ARG, "d_out_dev must be another buffer");
   return dict_sweep_impl(a_dev, b_dev, const_cast<void*>(d_dev), ldd, d, k, dtype, eps, positive, pool_dev, pool_rows, pool_ld,
-                         seed, degenerate_dev, nullptr, ndeg_mapped, workspace_dev, workspace_bytes, stream, d_out_dev, ldo);
+                         seed, degenerate_dev, nullptr, ndeg_mapped, workspace_dev, workspace_bytes, stream, d_out_dev, ldo,
+                         started_word, started_value);
 }
 
 // ---- pipelined constrained M-step (ABI 7) -------------------------------------------------------

@@ -559,7 +559,7 @@ __global__ void wait_word_kernel(const int* word, int seq, int host_memory) {
   // (~30 s: what is waited for may sit behind the caller's collectives or a time-sliced GPU; launches behind this one
   // that could not tolerate an early return carry their own check of the word)
   for (int spins = 0; spins < kGateSpinLimit; ++spins) {
-    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;      // (the words count up)
     __builtin_amdgcn_s_sleep(8);
   }
 }

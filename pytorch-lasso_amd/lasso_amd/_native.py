@@ -108,7 +108,7 @@ def _declare(lib):
                                            C.c_uint64, vp, vp, vp, sz, vp]
     lib.lasso_dict_sweep_async_to.restype = i32
     lib.lasso_dict_sweep_async_to.argtypes = [vp, vp, vp, i64, vp, i64, i64, i64, i32, dbl, i32, vp, i64, i64,
-                                              C.c_uint64, vp, vp, vp, sz, vp]
+                                              C.c_uint64, vp, vp, vp, i32, vp, sz, vp]
     lib.lasso_stream_wait_word.restype = i32
     lib.lasso_stream_wait_word.argtypes = [vp, i32, i32, vp]
     lib.lasso_mstep_pipe_stages.restype = i32

@@ -135,11 +135,12 @@ class HipEngine:
 
     sweep_out_of_place = True        # sweep_begin(out=...): lasso_dict_sweep_async_to
 
-    def sweep_begin(self, A, B, D, eps, positive, out=None):
+    def sweep_begin(self, A, B, D, eps, positive, out=None, started=None):
         """The atom sweep without the host round trip for the number of degenerate atoms: returns
         a callable giving (mask, ndeg) that waits only for the sweep itself.  ``out``: another [d, k] tensor that
         receives the new dictionary -- D is then only read (lasso_dict_sweep_async_to: the call may be enqueued before
-        the host knows whether the step stands, and another stream may keep reading D)."""
+        the host knows whether the step stands, and another stream may keep reading D).  ``started`` (with ``out``):
+        (int32 device tensor, value) -- a launch in front of the sweep writes the value: "the sweep starts now"."""
         d, k = D.shape
         L = self.lib
         with torch.cuda.device(self.device):
@@ -157,7 +158,8 @@ class HipEngine:
                     raise RuntimeError("sweep_begin: `out` must be a [d, k] tensor like D")
                 nat.check(L.lasso_dict_sweep_async_to(
                     nat.ptr(A), nat.ptr(B), nat.ptr(D), D.stride(0), nat.ptr(out), out.stride(0), d, k, nat.LASSO_F32,
-                    float(eps), int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(), nat.ptr(ws), ws.numel(),
+                    float(eps), int(bool(positive)), None, 0, 0, 0, nat.ptr(mask), host.arm(),
+                    nat.ptr(started[0]) if started else None, int(started[1]) if started else 0, nat.ptr(ws), ws.numel(),
                     self._stream()))
 
         def result():        # (polls the word the sweep's last kernel raises: no event record behind the sweep)

@@ -325,16 +325,35 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
             and (overlap or (shard_async and ndelta > 0)) and side != "0"):
         piped = (os.environ.get("LASSO_EM_PIPELINE", "1") != "0" and hasattr(engine, 'mstep_pipe_stages')
                  and len(engine.mstep_pipe_stages(d, k)) > 0)
-        # measured (tools/r6_em_rows.sh, k = 1024): 4096 rows per rank -4.4 %, 8192 -3.5 %, 16384 -2.3 %, 32768 -0.3 %,
-        # 65536 +0.6 % -- at that size the Gram product and the objective are HBM-bound and gain nothing from running
-        # beside each other.  (The average row count: the same number on every rank.)
-        if piped:
-            use = n_total / max(world, 1) <= 32768
+        # Which form, by rows per rank (the average: the same number on every rank).  Measured on one MI355X, config 4's
+        # dictionary (tools/r6_em_forms.sh; ms per step: one-stream / pipelined / double-buffered):
+        #    2048: 0.745 / 0.898 / 0.906    the two-stream forms are HOST-bound below ~0.9 ms per step (more calls per step)
+        #    4096: 0.866 / 0.831 / 0.841    8192: 1.260 / 1.202 / 1.207   (equal; the pipelined form has the smaller message
+        #                                                                  on the chain when there are several ranks)
+        #   12288: 1.657 / 1.640 / 1.579   16384: 2.050 / 2.091 / 1.962
+        #   32768: 3.63  / 3.92  / 3.44    65536: 6.80  / 7.66  / 6.50    (the stages of a pipelined M-step then take
+        #                                  longer than the sweep can wait for; the double-buffered form holds the objective
+        #                                  back until the sweep starts instead of letting it fight the Gram product for HBM)
+        # Small dictionaries (the one-workgroup sweep; config 5's shape): double-buffered at every size measured
+        # (2048 rows 0.2025 -> 0.190, 8192 0.2205 -> 0.201, 65536 0.673 -> 0.641).
+        rows = n_total / max(world, 1)
+        oop = getattr(engine, 'sweep_out_of_place', False)
+        if oop and d <= 64 and k <= 256:
+            form = "double-buffer"
+        elif piped and 4096 <= rows <= 8192:
+            form = "pipeline"
+        elif oop and piped and rows > 8192:
+            form = "double-buffer"
+        elif side == "force" and (piped or oop):
+            form = "pipeline" if piped else "double-buffer"
         else:
-            use = getattr(engine, 'sweep_out_of_place', False) and d <= 64 and k <= 256
-        if use or (side == "force" and (piped or getattr(engine, 'sweep_out_of_place', False))):
+            form = None
+        knob = os.environ.get("LASSO_EM_FORM")               # A/B knob (tools/r6_em_forms.sh): pipeline | double-buffer
+        if knob == "pipeline" and piped or knob == "double-buffer" and oop:
+            form = knob
+        if form:
             return _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group,
-                                        n_total, ndelta, losses, stats)
+                                        n_total, ndelta, losses, stats, pipeline=(form == "pipeline"))
     i, Zlast = 0, None
     while i < steps:
         pending, sharded = None, False
@@ -418,7 +437,7 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
 
 
 def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_kwargs, begin_kwargs, group, n_total,
-                         ndelta, losses, stats):
+                         ndelta, losses, stats, pipeline=True):
     """The constrained EM loop (dict_learning.py:35-53) on two streams -- see em_loop for the one-stream form, which
     this one reproduces step for step (same kernels on the same operands; only [A | B] of the pipelined M-step has
     another summation order).  Per step, stream M (the caller's): E-step, the head of the M-step (Gram product of the
@@ -446,7 +465,7 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     M = _t.cuda.current_stream(dev)
     S = engine.side_stream()
     import os
-    stages = engine.mstep_pipe_stages(d, k) if (hasattr(engine, 'mstep_pipe_stages')
+    stages = engine.mstep_pipe_stages(d, k) if (pipeline and hasattr(engine, 'mstep_pipe_stages')
                                                 and os.environ.get("LASSO_EM_PIPELINE", "1") != "0") else []
     pipe = len(stages) > 0
     # ONE buffer per step's messages: [A | B] (pipelined: one matrix [k][k + d]; else A [k][k] then B [k][d]) and the
@@ -462,6 +481,11 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
                  and 'defer_verdict' in inspect.signature(engine.encode_begin).parameters)
     defer_kw = dict(defer_verdict=True) if can_defer else {}
     sig = _t.zeros(1, dtype=_t.int32, device=dev) if can_defer and not pipe else None     # raised by the Gram launch
+    # a sweep of co-operating workgroups (not the one-workgroup sweep of small dictionaries) leaves most of the chip idle
+    # for hundreds of microseconds: the objective is held back until it starts (a word a launch in front of it raises)
+    # instead of running beside the Gram product, with which it competes for HBM
+    gate_obj = not pipe and not (d <= 64 and k <= 256)
+    sig2 = _t.zeros(1, dtype=_t.int32, device=dev) if gate_obj else None
     # "cur": the dictionary in force; "alt" (shapes without a pipelined M-step): the buffer the running step's sweep fills
     state = {"seq": 0, "prev_sums": None, "prev_index": -1, "cur": weight,
              "alt": None if pipe else _t.empty_like(weight)}
@@ -517,7 +541,9 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         if job is None:
             return
         with _t.cuda.stream(S):
-            objective(*job)
+            if job[3]:
+                engine.stream_wait_word(sig2.data_ptr(), job[3], False)      # "that step's sweep has started"
+            objective(*job[:3])
             ev_S.record(S)
         if multi:
             state["prev_sums"], state["prev_index"] = state["next_sums"], job[1]
@@ -589,7 +615,10 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             after_tail(i)
             if sharded:
                 pending.judge(dtail, n_total)
-        handle = engine.sweep_begin(A, B, state["cur"], 1e-10, False, out=state["alt"])
+        if gate_obj:
+            state["sig2"] = state.get("sig2", 0) + 1
+        handle = engine.sweep_begin(A, B, state["cur"], 1e-10, False, out=state["alt"],
+                                    started=(sig2, state["sig2"]) if gate_obj else None)
         return lambda: handle
 
     def encode_sync():
@@ -649,7 +678,7 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         if not pipe:
             # the host has seen this E-step's verdict: Z is final.  The objective reads the dictionary of THIS step, which
             # stays untouched until the next step's sweep (ordered behind ev_S) refills it: see flush_objective()
-            state["objective_job"] = (Z, i, state["cur"])
+            state["objective_job"] = (Z, i, state["cur"], state.get("sig2", 0) if gate_obj else 0)
         elif multi:
             state["prev_sums"], state["prev_index"] = state["next_sums"], i
         if persist:

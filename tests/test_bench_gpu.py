@@ -42,20 +42,26 @@ def test_two_rank_fista_line_and_global_time_to_tol():
     assert out["roofline"]["frac"] > 0 and "gloo" in out["backend"]
 
 
-def test_two_rank_em_line_has_one_message_per_stage():
+def test_two_rank_em_line_has_one_message_per_step_or_stage():
     out = _bench(SHARED + ["--workload", "em"])
     assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 32768
     ar = out["all_reduce_ms"]
     assert ar["bytes"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
-    # the pipelined M-step: one message per STAGE of block rows of [A | B] (the head: 512 rows; then 256 each, the last
-    # with the 12-word tail) -- the same bytes in all as the one message of the plain M-step, no other collective
-    assert ar["bytes_sent"] == [4 * 256 * 1280, 4 * (256 * 1280 + 12), 4 * 512 * 1280] and ar["per_step"] == 3.0
-    assert ar["bytes_per_step"] == ar["bytes"]
-    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("replayed_steps")
+    # beyond 8192 rows per rank: the double-buffered loop, ONE message [A | B | tail] per EM step, no other collective
+    assert ar["bytes_sent"] == [4 * (1024 * 1280 + 12)] and ar["per_step"] == 1.0 and ar["bytes_per_step"] == ar["bytes"]
+    assert out["em_path"].get("overlapped_steps") == 2 and out["em_path"].get("speculative_sweeps") == 2
+    assert not out["em_path"].get("replayed_steps")
     # the first EM steps of config 4 on the whole batch: losses[2] of the reference's run (tests/golden/g4_c4_em.npz)
     import numpy as np
     ref = np.load(os.path.join(ROOT, "tests", "golden", "g4_c4_em.npz"))["c_losses_auto"]
     assert abs(out["objective_last_step"] - float(ref[2])) <= 2e-4
+    # 4096 .. 8192 rows per rank: the pipelined M-step -- one message per STAGE of block rows of [A | B] (the head: 512
+    # rows; then 256 each, the last with the 12-word tail), the same bytes in all
+    out = _bench(SHARED + ["--workload", "em", "--rows", "16384"])
+    ar = out["all_reduce_ms"]
+    assert out["config"]["rows_per_gpu"] == 8192 and out["em_path"].get("pipelined_steps") == 2
+    assert ar["bytes_sent"] == [4 * 256 * 1280, 4 * (256 * 1280 + 12), 4 * 512 * 1280] and ar["per_step"] == 3.0
+    assert ar["bytes_per_step"] == ar["bytes"]
 
 
 def test_two_rank_em_line_at_the_shape_of_config_5():
@@ -104,19 +110,28 @@ def test_one_rank_rccl_group_fista_line():
 
 
 def test_one_rank_rccl_group_em_line():
-    # up to 32768 rows per rank: the two-stream loop, one RCCL message per stage of the pipelined M-step
-    plain = _bench(["--workload", "em", "--rows", "16384", "--steps", "2", "--warmup", "1"])
-    out = _bench(FORCED + ["--workload", "em", "--rows", "16384"])
+    # 4096 .. 8192 rows per rank: the two-stream loop with the PIPELINED M-step, one RCCL message per stage
+    plain = _bench(["--workload", "em", "--rows", "8192", "--steps", "2", "--warmup", "1"])
+    out = _bench(FORCED + ["--workload", "em", "--rows", "8192"])
     ar = out["all_reduce_ms"]
     assert ar["per_step"] == 3.0 and ar["bytes_per_step"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
     assert out["em_path"].get("pipelined_steps") == 2 and not out["em_path"].get("replayed_steps")
     assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
     assert plain["all_reduce_ms"]["per_step"] == 0.0 and plain["em_path"].get("pipelined_steps") == 2
-    # beyond: the one-stream loop, ONE message [A | B | tail] per EM step
+    assert plain["em_path"].get("deferred_verdicts") == 2 and not out["em_path"].get("deferred_verdicts")
+    # beyond: the two-stream loop with the DOUBLE-BUFFERED dictionary, ONE message [A | B | tail] per EM step
+    plain = _bench(["--workload", "em", "--steps", "2", "--warmup", "1"])
     out = _bench(FORCED + ["--workload", "em"])
     ar = out["all_reduce_ms"]
-    assert ar["per_step"] == 1.0 and ar["bytes_sent"] == [4 * (1024 * 1024 + 1024 * 256 + 12)]
-    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("pipelined_steps")
+    assert ar["per_step"] == 1.0 and ar["bytes_per_step"] == 4 * (1024 * 1024 + 1024 * 256 + 12)
+    assert out["em_path"].get("speculative_sweeps") == 2 and not out["em_path"].get("pipelined_steps")
+    assert plain["em_path"].get("speculative_sweeps") == 2 and plain["em_path"].get("deferred_verdicts") == 2
+    assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
+    # below 4096 rows per rank: the one-stream loop (the two-stream forms are host-bound there)
+    out = _bench(FORCED + ["--workload", "em", "--rows", "2048"])
+    assert out["all_reduce_ms"]["per_step"] == 1.0
+    assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("pipelined_steps") \
+        and not out["em_path"].get("speculative_sweeps")
 
 
 def test_one_rank_rccl_group_line_search_line():

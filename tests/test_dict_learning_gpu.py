@@ -629,6 +629,8 @@ def test_two_stream_em_loop_against_the_one_stream_loop_and_degenerate_atoms(mon
     g = torch.Generator().manual_seed(5)
     X = torch.randn(3000, 256, generator=g)
     D0 = torch.nn.functional.normalize(torch.randn(256, 512, generator=g), dim=0)
+    # (the loop takes the pipelined form by itself between 4096 and 8192 rows per rank: asked for here)
+    monkeypatch.setenv("LASSO_EM_FORM", "pipeline")
     two = dict_learning(X.cuda(), 512, alpha=0.4, steps=4, init_weight=D0, progbar=False, device="cuda")
     monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
     one = dict_learning(X.cuda(), 512, alpha=0.4, steps=4, init_weight=D0, progbar=False, device="cuda")
@@ -714,6 +716,7 @@ def test_two_stream_em_loop_corner_cases(n, k, kw, monkeypatch):
     g = torch.Generator().manual_seed(n + k)
     X = torch.randn(n, 256, generator=g).cuda()
     D0 = torch.nn.functional.normalize(torch.randn(256, k, generator=g), dim=0)
+    monkeypatch.setenv("LASSO_EM_FORM", "pipeline")
     torch.manual_seed(4)
     two = dict_learning(X, k, alpha=0.3, init_weight=D0, device="cuda", **dict(dict(progbar=False), **kw))
     monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "0")
@@ -812,3 +815,45 @@ def test_double_buffered_em_loop_degenerate_atoms_and_other_sweeps(monkeypatch):
     monkeypatch.setenv("LASSO_EM_SIDE_STREAM", "force")
     two = dict_learning(Xb, 384, alpha=0.3, steps=3, init_weight=Db, progbar=False, device="cuda")
     assert torch.equal(two[0], one[0]) and torch.equal(two[1], one[1])
+
+
+def test_deferred_verdict_on_another_stream_and_its_gate():
+    """LASSO_SOLVE_DEFER_VERDICT: the asynchronous E-step without its stop-rule launch, that launch enqueued on ANOTHER
+    stream behind a wave polling the word lasso_gram_accumulate_signal's first launch raises -- same code, same verdict
+    words as the plain asynchronous solve; a launch whose gate word does not hold the expected value (its wait gave up)
+    answers "repeat the solve" instead of judging; asking for the outcome before the launch is an error."""
+    from lasso_amd.engine import HipEngine
+    eng = HipEngine(torch.device("cuda"))
+    X = recipe_c5(2000).cuda()
+    g = torch.Generator().manual_seed(3)
+    W = torch.nn.functional.normalize(torch.randn(64, 256, generator=g), dim=0).cuda()
+    kw = dict(maxiter=10, tol=1e-5, stop_mode='one-chunk')
+    Zp, pend = eng.encode_begin(X, W, 0.1, None, **kw)
+    assert pend is not None and not pend.deferred and pend()
+    S = eng.side_stream()
+    sig = torch.zeros(1, dtype=torch.int32, device="cuda")
+    buf = torch.zeros(256 * 256 + 256 * 64, device="cuda")
+    for value, gate_value, expect in [(5, 5, True), (6, 9, False)]:
+        Z, pd = eng.encode_begin(X, W, 0.1, None, defer_verdict=True, **kw)
+        assert pd.deferred
+        with pytest.raises(RuntimeError):
+            pd()
+        A, B = eng.gram(Z, X, buf, started=(sig, value))
+        with torch.cuda.stream(S):
+            eng.stream_wait_word(sig.data_ptr(), value, False)
+            pd.launch_verdict(gate=(sig.data_ptr(), gate_value))
+        assert not pd.deferred
+        assert pd() is expect
+        torch.cuda.synchronize()
+        assert sig.item() == value and torch.equal(Z, Zp)
+        if expect:
+            assert pd.iterations == pend.iterations and pd.last_delta == pend.last_delta
+    A0, B0 = eng.gram(Zp, X, torch.zeros_like(buf))
+    assert torch.equal(A, A0) and torch.equal(B, B0)
+    # a shape whose Gram kernels do not carry the signal (d = 100: a launch of its own in front raises the word)
+    Xo = torch.randn(500, 100, generator=g).cuda()
+    Zo = torch.randn(500, 130, generator=g).cuda()
+    bo = torch.zeros(130 * 130 + 130 * 100, device="cuda")
+    eng.gram(Zo, Xo, bo, started=(sig, 11))
+    torch.cuda.synchronize()
+    assert sig.item() == 11

@@ -137,6 +137,8 @@ def _pipe_worker(rank, world, port, tmp, shape=None, stat="pipelined_steps", nam
     dist.init_process_group("gloo", rank=rank, world_size=world)
     X, D0 = _pipe_problem(shape)
     PN, PD, PK, PSPLIT = shape or (globals()["PN"], globals()["PD"], globals()["PK"], globals()["PSPLIT"])
+    if shape is None:
+        os.environ["LASSO_EM_FORM"] = "pipeline"       # (by itself the loop pipelines between 4096 and 8192 rows per rank)
     out = {}
     sent = []
     real = parallel._all_reduce
