@@ -327,7 +327,9 @@ def em_loop(engine, X, weight, alpha, constrained=True, persist=False, lambd=1e-
                  and len(engine.mstep_pipe_stages(d, k)) > 0)
         # Which form, by rows per rank (the average: the same number on every rank).  Measured on one MI355X, config 4's
         # dictionary (tools/r6_em_forms.sh; ms per step: one-stream / pipelined / double-buffered):
-        #    2048: 0.745 / 0.898 / 0.906    the two-stream forms are HOST-bound below ~0.9 ms per step (more calls per step)
+        #    2048: 0.745 / 0.898 / 0.906    (objective and Gram product are ~20 us each there: less than what running beside
+        #                                   the sweep costs it, and than the fixed launches of a stage; the host is not the
+        #                                   limit -- it spends 0.5 ms per step waiting, cProfile)
         #    4096: 0.866 / 0.831 / 0.841    8192: 1.260 / 1.202 / 1.207   (equal; the pipelined form has the smaller message
         #                                                                  on the chain when there are several ranks)
         #   12288: 1.657 / 1.640 / 1.579   16384: 2.050 / 2.091 / 1.962

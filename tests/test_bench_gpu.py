@@ -127,7 +127,7 @@ def test_one_rank_rccl_group_em_line():
     assert out["em_path"].get("speculative_sweeps") == 2 and not out["em_path"].get("pipelined_steps")
     assert plain["em_path"].get("speculative_sweeps") == 2 and plain["em_path"].get("deferred_verdicts") == 2
     assert abs(out["objective_last_step"] - plain["objective_last_step"]) <= 2e-6 * plain["objective_last_step"]
-    # below 4096 rows per rank: the one-stream loop (the two-stream forms are host-bound there)
+    # below 4096 rows per rank: the one-stream loop (objective and Gram product are too short to pay for a second stream)
     out = _bench(FORCED + ["--workload", "em", "--rows", "2048"])
     assert out["all_reduce_ms"]["per_step"] == 1.0
     assert out["em_path"].get("overlapped_steps") == 2 and not out["em_path"].get("pipelined_steps") \
