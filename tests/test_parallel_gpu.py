@@ -126,7 +126,7 @@ def _pipe_problem(shape=None):
     return X, D0
 
 
-def _pipe_worker(rank, world, port, tmp, shape=None, stat="pipelined_steps", name="pipe"):
+def _pipe_worker(rank, world, port, tmp, shape=None, stat="pipelined_steps", name="pipe", form=None):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-lasso_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     from lasso_amd import parallel
@@ -137,8 +137,8 @@ def _pipe_worker(rank, world, port, tmp, shape=None, stat="pipelined_steps", nam
     dist.init_process_group("gloo", rank=rank, world_size=world)
     X, D0 = _pipe_problem(shape)
     PN, PD, PK, PSPLIT = shape or (globals()["PN"], globals()["PD"], globals()["PK"], globals()["PSPLIT"])
-    if shape is None:
-        os.environ["LASSO_EM_FORM"] = "pipeline"       # (by itself the loop pipelines between 4096 and 8192 rows per rank)
+    if shape is None or form:
+        os.environ["LASSO_EM_FORM"] = form or "pipeline"   # (by itself the loop picks its form from the rows per rank)
     out = {}
     sent = []
     real = parallel._all_reduce
@@ -222,6 +222,32 @@ def test_double_buffered_em_loop_on_two_ranks(tmp_path):
         margins[key] = (float(np.abs(r0[key + "_l"] - lo_.numpy()).max()), float(np.abs(r0[key + "_D"] - Do.numpy()).max()))
         assert margins[key][0] <= 1e-5 and margins[key][1] <= 2e-5, (key, margins[key])
     record_margins("two_ranks_double_buffered_vs_oracle", {t: {"max_dloss": a, "max_dD": b} for t, (a, b) in margins.items()})
+
+
+def test_double_buffered_em_loop_of_a_large_dictionary_on_two_ranks(tmp_path):
+    """d = 256, k = 512 on two ranks in the form em_loop takes beyond 8192 rows per rank (asked for here): double-buffered
+    dictionary, the co-operating sweep written by its transposing launch into the other buffer, the objective on the side
+    stream held back until the sweep starts, ONE message per step.  Both ranks bit for bit, the oracle within the bars."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lasso_oracle as orc
+    port = 37500 + (os.getpid() % 2000)
+    shape = (PN, PD, PK, PSPLIT)
+    mp.start_processes(_pipe_worker, args=(2, port, str(tmp_path), shape, "speculative_sweeps", "large", "double-buffer"),
+                       nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "large0.npz"), np.load(tmp_path / "large1.npz")
+    X, D0 = _pipe_problem(shape)
+    for key in [k[:-2] for k in r0.files if k.endswith("_D")]:
+        tag = key.replace("empty_", "")
+        assert np.array_equal(r0[key + "_D"], r1[key + "_D"]) and np.array_equal(r0[key + "_l"], r1[key + "_l"]), key
+        assert np.array_equal(r0[key + "_stats"], r1[key + "_stats"]) and np.array_equal(r0[key + "_sent"], r1[key + "_sent"]), key
+        assert int(r0[key + "_stats"][0]) >= 4, (key, r0[key + "_stats"])
+        assert (int(r0[key + "_stats"][1]) >= 1) == (tag == "tol_short"), (key, r0[key + "_stats"])
+        big = [int(v) for v in r0[key + "_sent"] if v >= 1024]
+        assert set(big) == {PK * (PK + PD) + 2 + PCASES[tag].get("maxiter", 10)}, (key, sorted(set(big)))
+        torch.manual_seed(1)
+        Do, lo_ = orc.dict_learning(X, PK, alpha=0.3, steps=4, init_weight=D0, **PCASES[tag])
+        dl, dD = float(np.abs(r0[key + "_l"] - lo_.numpy()).max()), float(np.abs(r0[key + "_D"] - Do.numpy()).max())
+        assert dl <= 1e-5 and dD <= 2e-5, (key, dl, dD)
 
 
 # ---- row-sharded line search (ista.py:23-52 on two ranks) -------------------------------------
