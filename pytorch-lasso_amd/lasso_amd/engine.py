@@ -134,6 +134,17 @@ class HipEngine:
                        accepted_lr=list(acc_lr[:it]), accepted_f=list(acc_f[:it]))
 
     sweep_out_of_place = True        # sweep_begin(out=...): lasso_dict_sweep_async_to
+    defer_verdict = True             # encode_begin(defer_verdict=True): LASSO_SOLVE_DEFER_VERDICT
+
+    def signal_words(self):
+        """(int32[2] in device memory, [count0, count1] on the host): words that launches of one stream raise for waves
+        of another to poll (lasso_gram_accumulate_signal, lasso_dict_sweep_async_to's started_word) -- they count up
+        over the engine's lifetime, so a loop neither allocates nor clears them"""
+        w = getattr(self, "_signal_words", None)
+        if w is None:
+            with torch.cuda.device(self.device):
+                w = self._signal_words = (torch.zeros(2, dtype=torch.int32, device=self.device), [0, 0])
+        return w
 
     def sweep_begin(self, A, B, D, eps, positive, out=None, started=None):
         """The atom sweep without the host round trip for the number of degenerate atoms: returns

@@ -478,16 +478,18 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     AB = buf[:k * (k + d)].view(k, k + d) if pipe else None
     ws = engine.mstep_pipe_workspace(n_local, d, k) if pipe else None
     ev_S = _t.cuda.Event()
-    import inspect
     can_defer = (not multi and os.environ.get("LASSO_EM_DEFER_VERDICT", "1") != "0"
-                 and 'defer_verdict' in inspect.signature(engine.encode_begin).parameters)
+                 and getattr(engine, 'defer_verdict', False))
     defer_kw = dict(defer_verdict=True) if can_defer else {}
-    sig = _t.zeros(1, dtype=_t.int32, device=dev) if can_defer and not pipe else None     # raised by the Gram launch
+    # two words in device memory that count up over the engine's lifetime (one allocation, no clearing per loop):
+    # [0] raised by the Gram launch of a step ("the E-step has completed"), [1] by the launch in front of a sweep
+    words, count = engine.signal_words() if hasattr(engine, 'signal_words') else (None, None)
+    sig = words[0:1] if can_defer and not pipe else None
     # a sweep of co-operating workgroups (not the one-workgroup sweep of small dictionaries) leaves most of the chip idle
     # for hundreds of microseconds: the objective is held back until it starts (a word a launch in front of it raises)
     # instead of running beside the Gram product, with which it competes for HBM
-    gate_obj = not pipe and not (d <= 64 and k <= 256)
-    sig2 = _t.zeros(1, dtype=_t.int32, device=dev) if gate_obj else None
+    gate_obj = not pipe and not (d <= 64 and k <= 256) and words is not None
+    sig2 = words[1:2] if gate_obj else None
     # "cur": the dictionary in force; "alt" (shapes without a pipelined M-step): the buffer the running step's sweep fills
     state = {"seq": 0, "prev_sums": None, "prev_index": -1, "cur": weight,
              "alt": None if pipe else _t.empty_like(weight)}
@@ -597,7 +599,8 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
         A = buf[:k * k].view(k, k)
         B = buf[k * k:k * k + k * d].view(k, d)
         if n_local > 0 and getattr(pending, 'deferred', False):
-            state["sig"] = state.get("sig", 0) + 1
+            count[0] += 1
+            state["sig"] = count[0]
             engine.gram(Z, X, buf, started=(sig, state["sig"]))          # its first launch raises the word as it starts
             with _t.cuda.stream(S):
                 engine.stream_wait_word(sig.data_ptr(), state["sig"], False)
@@ -618,7 +621,8 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
             if sharded:
                 pending.judge(dtail, n_total)
         if gate_obj:
-            state["sig2"] = state.get("sig2", 0) + 1
+            count[1] += 1
+            state["sig2"] = count[1]
         handle = engine.sweep_begin(A, B, state["cur"], 1e-10, False, out=state["alt"],
                                     started=(sig2, state["sig2"]) if gate_obj else None)
         return lambda: handle
