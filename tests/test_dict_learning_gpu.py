@@ -857,3 +857,53 @@ def test_deferred_verdict_on_another_stream_and_its_gate():
     eng.gram(Zo, Xo, bo, started=(sig, 11))
     torch.cuda.synchronize()
     assert sig.item() == 11
+
+
+def test_two_stream_em_loops_beside_other_work_on_the_gpu(monkeypatch):
+    """Both two-stream forms of the EM loop while a third stream keeps the GPU busy with GEMMs of varying length (the
+    side stream's waits, the deferred verdict, the gated sweep and the launch that writes the dictionary all meet other
+    timings than in a quiet run): results bitwise those of the quiet run -- ordering by words and events, not by luck."""
+    from lasso_amd.linear import dict_learning
+    g = torch.Generator().manual_seed(23)
+    busy = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device="cuda")
+    b = torch.randn(2048, 2048, device="cuda") * 0.01
+
+    def run(fn, noisy):
+        if not noisy:
+            return fn()
+        import threading
+        stop = threading.Event()
+
+        def noise():
+            torch.cuda.set_device(0)
+            t = 0
+            with torch.cuda.stream(busy):
+                while not stop.is_set():
+                    c = a
+                    for _ in range(1 + t % 5):
+                        c = torch.mm(c, b)
+                    t += 1
+                    if t % 8 == 0:
+                        busy.synchronize()
+        th = threading.Thread(target=noise)
+        th.start()
+        try:
+            return fn()
+        finally:
+            stop.set()
+            th.join()
+            torch.cuda.synchronize()
+    Xs = recipe_c5(3000).cuda()
+    Ds = torch.nn.functional.normalize(torch.randn(64, 256, generator=g), dim=0)
+    Xb = torch.randn(1200, 256, generator=g).cuda()
+    Db = torch.nn.functional.normalize(torch.randn(256, 512, generator=g), dim=0)
+    cases = [("double-buffer", lambda: dict_learning(Xs, 256, alpha=0.1, steps=6, init_weight=Ds, progbar=False, device="cuda")),
+             ("pipeline", lambda: dict_learning(Xb, 512, alpha=0.3, steps=4, init_weight=Db, progbar=False, device="cuda")),
+             ("double-buffer", lambda: dict_learning(Xb, 512, alpha=0.3, steps=4, init_weight=Db, progbar=False, device="cuda"))]
+    for form, fn in cases:
+        monkeypatch.setenv("LASSO_EM_FORM", form)
+        quiet = run(fn, False)
+        for _ in range(2):
+            loud = run(fn, True)
+            assert torch.equal(loud[0], quiet[0]) and torch.equal(loud[1], quiet[1]), form
