@@ -447,16 +447,18 @@ def _em_loop_two_streams(engine, X, weight, alpha, persist, steps, bar, solver_k
     stages of the M-step (Gram, all-reduce, U rows -- each announced to the running sweep by a flag word), the stop
     rule's verdict on the reduced sums, and the objective (dict_learning.py:39) -- so the step's dependent chain is
     E-step -> head -> sweep -> Lipschitz, and the chain carries no event record and no copy: S is started by a wave
-    that polls a word (the head's U rows / the verdict's "valid" word), M waits for S's event only before it changes
-    the dictionary (S reads the old one), and the host POLLS the verdict's and the sweep's words in pinned memory at
-    its one wait per step.  With several ranks the objective's two sums ride in the NEXT step's message (one small
+    that polls a word in device memory (raised by the head's U rows), M is ordered behind S where it changes the
+    dictionary S reads (a word the writing launch waits for itself / an event that completed a step ago), and the host
+    POLLS the verdict's and the sweep's words in pinned memory at its one wait per step.  On one GPU the E-step's stop
+    rule is judged on S too (LASSO_SOLVE_DEFER_VERDICT): nothing on M needs its outcome.  With several ranks the objective's two sums ride in the NEXT step's message (one small
     all-reduce flushes the last step's): a message per stage, the first on the critical chain.  Shapes without a
     pipelined M-step (e.g. 8 x 8 patches: d = 64) keep lasso_gram_accumulate + the sweep on M, with the dictionary
     DOUBLE-BUFFERED: the sweep writes the new dictionary into the other buffer (lasso_dict_sweep_async_to), so it is
     enqueued BEFORE the step's host wait (a step that has to be repeated keeps the old buffer and drops the other), and
-    the objective is enqueued on S right AFTER that wait -- the host has then seen the E-step's verdict, so S needs no
-    device-side start signal, and nothing on M waits for it: the old dictionary it reads is only overwritten by the
-    NEXT step's sweep."""
+    the objective is enqueued on S AFTER that wait (behind the next E-step's launches) -- the host has then seen the
+    E-step's verdict, so S needs no device-side start signal, and nothing on M waits for it: the old dictionary it reads
+    is only overwritten by the NEXT step's sweep.  Batches beyond 8192 rows per rank of a pipelinable dictionary take this
+    form as well (`pipeline=False`), with the objective held back until the sweep has started."""
     import torch as _t
     world, rank = _world(group)
     multi = _sharded(group)
