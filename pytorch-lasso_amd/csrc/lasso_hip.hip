@@ -2139,8 +2139,8 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
     iters_out = nullptr; last_delta_out = nullptr;
   }
   const bool defer_verdict = (stop_mode & LASSO_SOLVE_DEFER_VERDICT) != 0;
-  if (defer_verdict && !(status_mapped && one_chunk))
-    return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_DEFER_VERDICT needs LASSO_SOLVE_STATUS_MAPPED and LASSO_SOLVE_ONE_CHUNK");
+  if (defer_verdict && (!(status_mapped && one_chunk) || sharded))
+    return fail(LASSO_ERR_BAD_ARG, "LASSO_SOLVE_DEFER_VERDICT needs LASSO_SOLVE_STATUS_MAPPED and LASSO_SOLVE_ONE_CHUNK, without LASSO_SOLVE_SHARDED");
   stop_mode &= ~(LASSO_SOLVE_ASYNC | LASSO_SOLVE_SHARDED | LASSO_SOLVE_ONE_CHUNK | LASSO_SOLVE_STATUS_MAPPED |
                  LASSO_SOLVE_DEFER_VERDICT);
   if (sharded && !(async && tol > 0.0 && maxiter > 0 && n > 0 && fused_shape(d, k)))
@@ -2182,7 +2182,7 @@ int lasso_fista_solve(const void* x_dev, int64_t ldx, const void* w_dev, int64_t
                                 fast, maxiter, tol, stop_mode, backtrack, eta_backtrack, iters_out,
                                 last_delta_out, trials_out, accepted_lr_out, accepted_f_out, workspace_dev,
                                 workspace_bytes, stream, lr_dev, async, lip_dev, sharded, one_chunk, status_mapped, lip_deferred,
-                                defer_verdict && !sharded);
+                                defer_verdict);
   if ((status != LASSO_OK && status != LASSO_WARN_LINESEARCH) || !objective_out || n <= 0) return status;
   // objective_out: (0.5*||x - z W^T||^2 + alpha*||z||_1)/n of the RETURNED code, evaluated in fp32
   // (the verbose print of ista.py:66-69,80-81 for the final iterate; dict_learning.py:10-13)
